@@ -1,0 +1,57 @@
+"""ctypes mirror of include/cadrays_hip.h (the C ABI of libcadrays_hip.so).
+
+The struct layouts are the boundary's input contract; the CPU oracle takes the same structs,
+so tests hand identical bytes to both sides.
+"""
+import ctypes as C
+
+OK, E_INVALID, E_DEVICE, E_NOMEM, E_NOTBUILT = 0, -1, -2, -3, -4
+
+FRESNEL_CONSTANT, FRESNEL_CONDUCTOR, FRESNEL_DIELECTRIC = -1.0, -2.0, -3.0
+
+
+class crh_bsdf(C.Structure):
+    _fields_ = [(n, C.c_float * 4) for n in
+                ("Kc", "Kd", "Ks", "Kt", "Le", "Absorption", "FresnelCoat", "FresnelBase")]
+
+
+class crh_light(C.Structure):
+    _fields_ = [("vec", C.c_float * 3), ("is_point", C.c_float),
+                ("emission", C.c_float * 3), ("smoothness", C.c_float)]
+
+
+class crh_camera(C.Structure):
+    _fields_ = [("eye", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3),
+                ("fovy_deg", C.c_float), ("aspect", C.c_float), ("is_ortho", C.c_int32),
+                ("ortho_scale", C.c_float), ("aperture_radius", C.c_float), ("focal_dist", C.c_float)]
+
+
+class crh_params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_depth", C.c_uint32),
+                ("radiance_clamp", C.c_float), ("two_sided", C.c_int32), ("coherent_rng", C.c_int32),
+                ("seed", C.c_uint32), ("tile_size", C.c_uint32), ("tonemap_mode", C.c_int32),
+                ("exposure", C.c_float), ("white_point", C.c_float), ("background", C.c_float * 3),
+                ("env_as_background", C.c_int32), ("scene_epsilon", C.c_float),
+                ("russian_roulette", C.c_int32)]
+
+
+class crh_stats(C.Structure):
+    _fields_ = [("rays_nearest", C.c_uint64), ("rays_any", C.c_uint64), ("nodes_nearest", C.c_uint64),
+                ("tris_nearest", C.c_uint64), ("nodes_any", C.c_uint64), ("tris_any", C.c_uint64), ("shaded_hits", C.c_uint64), ("samples", C.c_uint64),
+                ("seconds", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+assert C.sizeof(crh_bsdf) == 128 and C.sizeof(crh_light) == 32
+
+# every symbol include/cadrays_hip.h declares (tests check the built library exports them all)
+EXPORTS = [
+    "crh_create", "crh_destroy", "crh_last_error", "crh_set_geometry", "crh_set_materials",
+    "crh_set_lights", "crh_set_envmap", "crh_set_camera", "crh_set_params", "crh_build", "crh_reset",
+    "crh_render", "crh_render_tiles", "crh_sync", "crh_read_hdr", "crh_read_ldr",
+    "crh_accum_device_ptr", "crh_enable_counters", "crh_get_stats", "crh_trace_nearest",
+    "crh_trace_any", "crh_get_bvh", "crh_build_bvh_host", "crh_bench_trace", "crh_debug_math", "crh_enable_kernel_timing",
+    "crh_get_kernel_timing",
+]

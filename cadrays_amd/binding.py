@@ -1,0 +1,184 @@
+"""Thin ctypes binding over a library that exports the cadrays_hip.h entry points under a prefix.
+
+The product binds prefix 'crh_' on libcadrays_hip.so (cadrays_amd/view.py); the test suite binds
+prefix 'orc_' on the CPU oracle with this same class, so the parity tests drive both sides through
+the same calls with the same bytes.
+"""
+import ctypes as C
+import numpy as np
+
+from . import abi
+from .materials import pack_materials
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p) if a is not None else None
+
+
+class Backend:
+    """One rendering context ( == one V3d_View on one GPU )."""
+
+    def __init__(self, lib, prefix, create_args=()):
+        self._lib, self._p = lib, prefix
+        f = self._fn("create")
+        f.restype = C.c_void_p
+        self._ctx = C.c_void_p(f(*create_args))
+        if not self._ctx.value:
+            raise BackendError(f"{prefix}create failed")
+        self.width = self.height = 0
+        self._fn("last_error").restype = C.c_char_p
+
+    def _fn(self, name):
+        return getattr(self._lib, self._p + name)
+
+    def _call(self, name, *args):
+        f = self._fn(name)
+        f.restype = C.c_int
+        rc = f(self._ctx, *args)
+        if rc != 0:
+            msg = self._fn("last_error")(self._ctx)
+            raise BackendError(f"{self._p}{name} -> {rc}: {msg.decode() if msg else ''}")
+        return rc
+
+    def close(self):
+        if self._ctx and self._ctx.value:
+            f = self._fn("destroy")
+            f.restype = None
+            f(self._ctx)
+            self._ctx = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scene ---------------------------------------------------------------------------
+    def set_geometry(self, pos, nrm, tri, uv=None, tri_object=None, obj_xform=None):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+        tri = np.ascontiguousarray(tri, np.int32).reshape(-1, 4)
+        uv = None if uv is None else np.ascontiguousarray(uv, np.float32)
+        to = None if tri_object is None else np.ascontiguousarray(tri_object, np.int32)
+        xf = None if obj_xform is None else np.ascontiguousarray(obj_xform, np.float32).reshape(-1, 12)
+        self._call("set_geometry", _fp(pos), _fp(nrm), _fp(uv), C.c_uint32(len(pos)),
+                   tri.ctypes.data_as(_i32p), C.c_uint32(len(tri)),
+                   to.ctypes.data_as(_i32p) if to is not None else None,
+                   _fp(xf), C.c_uint32(0 if xf is None else len(xf)))
+
+    def set_materials(self, bsdfs):
+        arr = pack_materials(bsdfs)
+        self._call("set_materials", arr, C.c_uint32(len(bsdfs)))
+
+    def set_lights(self, lights):
+        arr = (abi.crh_light * max(len(lights), 1))()
+        for i, l in enumerate(lights):
+            arr[i].vec[:] = [float(x) for x in l.vec]
+            arr[i].is_point = 1.0 if l.is_point else 0.0
+            arr[i].emission[:] = [float(np.float32(c) * np.float32(l.intensity)) for c in l.color]
+            arr[i].smoothness = float(l.smoothness)
+        self._call("set_lights", arr, C.c_uint32(len(lights)))
+
+    def set_envmap(self, env):
+        if env is None:
+            self._call("set_envmap", None, C.c_uint32(0), C.c_uint32(0))
+        else:
+            env = np.ascontiguousarray(env, np.float32)
+            h, w, _ = env.shape
+            self._call("set_envmap", _fp(env), C.c_uint32(w), C.c_uint32(h))
+
+    def set_camera(self, cam):
+        c = abi.crh_camera()
+        c.eye[:] = [float(x) for x in cam.eye]
+        c.dir[:] = [float(x) for x in cam.dir]
+        c.up[:] = [float(x) for x in cam.up]
+        c.fovy_deg, c.aspect = float(cam.fovy_deg), float(cam.aspect)
+        c.is_ortho, c.ortho_scale = int(cam.is_ortho), float(cam.ortho_scale)
+        c.aperture_radius, c.focal_dist = float(cam.aperture_radius), float(cam.focal_dist)
+        self._call("set_camera", C.byref(c))
+
+    def set_params(self, p):
+        q = abi.crh_params()
+        q.width, q.height, q.max_depth = int(p.width), int(p.height), int(p.max_depth)
+        q.radiance_clamp, q.two_sided, q.coherent_rng = float(p.radiance_clamp), int(p.two_sided), int(p.coherent_rng)
+        q.seed, q.tile_size, q.tonemap_mode = int(p.seed), int(p.tile_size), int(p.tonemap_mode)
+        q.exposure, q.white_point = float(p.exposure), float(p.white_point)
+        q.background[:] = [float(x) for x in p.background]
+        q.env_as_background, q.scene_epsilon = int(p.env_as_background), float(p.scene_epsilon)
+        q.russian_roulette = int(p.russian_roulette)
+        self._call("set_params", C.byref(q))
+        self.width, self.height, self.tile_size = int(p.width), int(p.height), int(p.tile_size)
+
+    def load_scene(self, scene):
+        self.set_geometry(scene.pos, scene.nrm, scene.tri, scene.uv)
+        self.set_materials(scene.materials)
+        self.set_lights(scene.lights)
+        self.set_envmap(scene.env)
+        self.set_camera(scene.camera)
+        self.set_params(scene.params)
+        self.build()
+        return self
+
+    # -- rendering -----------------------------------------------------------------------
+    def build(self):
+        self._call("build")
+
+    def reset(self):
+        self._call("reset")
+
+    def render(self, n_iterations=1):
+        self._call("render", C.c_uint32(n_iterations))
+
+    def render_tiles(self, tile_ids, first_sample, n_samples):
+        t = np.ascontiguousarray(tile_ids, np.uint32)
+        self._call("render_tiles", t.ctypes.data_as(_u32p), C.c_uint32(len(t)),
+                   C.c_uint32(first_sample), C.c_uint32(n_samples))
+
+    def n_tiles(self):
+        ts = self.tile_size or 32
+        return ((self.width + ts - 1) // ts) * ((self.height + ts - 1) // ts)
+
+    def read_hdr(self):
+        out = np.empty((self.height, self.width, 3), np.float32)
+        self._call("read_hdr", _fp(out))
+        return out
+
+    def read_ldr(self):
+        out = np.empty((self.height, self.width, 3), np.uint8)
+        self._call("read_ldr", out.ctypes.data_as(_u8p))
+        return out
+
+    def stats(self):
+        s = abi.crh_stats()
+        self._call("get_stats", C.byref(s))
+        return s.as_dict()
+
+    # -- kernel-level --------------------------------------------------------------------
+    def trace_nearest(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.empty((len(rays), 4), np.float32)
+        self._call("trace_nearest", _fp(rays), C.c_uint32(len(rays)), _fp(out))
+        return out
+
+    def trace_any(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.empty(len(rays), np.uint32)
+        self._call("trace_any", _fp(rays), C.c_uint32(len(rays)), out.ctypes.data_as(_u32p))
+        return out
+
+    def get_bvh(self):
+        nn, nt = C.c_uint32(0), C.c_uint32(0)
+        self._call("get_bvh", None, C.byref(nn), None, C.byref(nt))
+        nodes = np.empty((nn.value, 32), np.float32)
+        tris = np.empty((nt.value, 12), np.float32)
+        self._call("get_bvh", _fp(nodes), C.byref(nn), _fp(tris), C.byref(nt))
+        return nodes, tris

@@ -1,0 +1,226 @@
+// bvh_builder.cpp -- parallel binned-SAH builder + 4-wide collapse (host, C++17).
+//
+// Build rules (DESIGN.md "BVH"): triangle box centre = (min+max)*0.5; at each node all three axes are
+// binned in one pass over SoA primitive arrays (32 bins, bin = int(((c - cmin) / extent) * 32), clamped);
+// the cheapest split by  area(L)*n(L) + area(R)*n(R)  wins, ties to the lower axis, then the lower bin;
+// the partition is stable; leaves hold <= 4 triangles; when the remaining depth budget is only enough
+// for balanced splitting, split at the object median of the widest centroid axis (total order by
+// (centre, index)).  The binary tree is then collapsed by replacing children with grandchildren and
+// numbered in DFS pre-order.  Large subtrees are built by separate threads; the result does not depend
+// on the thread count because every subtree owns a disjoint index range and numbering happens afterwards.
+#include "bvh_builder.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <future>
+#include <thread>
+
+namespace crh {
+namespace {
+
+inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+struct Box {
+  float mn[3], mx[3];
+  void clear() { for (int a = 0; a < 3; ++a) { mn[a] = 3.0e38f; mx[a] = -3.0e38f; } }
+  void grow(const Box& o) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], o.mn[a]); mx[a] = std::max(mx[a], o.mx[a]); } }
+  float half_area() const {
+    float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return fma_(dx, dy, fma_(dy, dz, dz * dx));
+  }
+};
+
+struct BNode { Box box; uint32_t lo, hi; int32_t left, right; };
+
+struct Builder {
+  // SoA primitive data
+  std::vector<float> pmn[3], pmx[3], cen[3];
+  std::vector<uint32_t> idx, tmp;
+  std::vector<BNode> nodes;
+  std::atomic<uint32_t> next{0};
+  std::atomic<int> spare_threads{0};
+
+  uint32_t alloc() { return next.fetch_add(1, std::memory_order_relaxed); }
+
+  Box prim_box(uint32_t p) const {
+    Box b; for (int a = 0; a < 3; ++a) { b.mn[a] = pmn[a][p]; b.mx[a] = pmx[a][p]; } return b;
+  }
+
+  static int ceil_log2(uint32_t v) { int l = 0; uint32_t p = 1; while (p < v) { p <<= 1; ++l; } return l; }
+
+  // returns the split position, reorders idx[lo,hi)
+  uint32_t split(uint32_t lo, uint32_t hi, int depth, const float cmn[3], const float cmx[3]) {
+    const uint32_t n = hi - lo;
+    const int need = ceil_log2((n + kLeafSize - 1) / kLeafSize);
+    const bool force_median = depth + need >= kMaxDepth;
+    if (!force_median) {
+      float ext[3], inv_ok[3];
+      for (int a = 0; a < 3; ++a) { ext[a] = cmx[a] - cmn[a]; inv_ok[a] = ext[a] > 0.f ? 1.f : 0.f; }
+      uint32_t cnt[3][kBins]; Box bb[3][kBins];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < kBins; ++b) { cnt[a][b] = 0; bb[a][b].clear(); }
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t p = idx[i];
+        const Box pb = prim_box(p);
+        for (int a = 0; a < 3; ++a) {
+          if (inv_ok[a] == 0.f) continue;
+          int b = (int)(((cen[a][p] - cmn[a]) / ext[a]) * (float)kBins);
+          if (b > kBins - 1) b = kBins - 1;
+          cnt[a][b]++; bb[a][b].grow(pb);
+        }
+      }
+      float best = 3.0e38f; int baxis = -1, bsplit = -1;
+      for (int a = 0; a < 3; ++a) {
+        if (inv_ok[a] == 0.f) continue;
+        float rarea[kBins]; uint32_t rcnt[kBins];
+        Box acc; acc.clear(); uint32_t c = 0;
+        for (int b = kBins - 1; b >= 1; --b) {
+          if (cnt[a][b]) acc.grow(bb[a][b]);
+          c += cnt[a][b]; rcnt[b] = c; rarea[b] = c ? acc.half_area() : 0.f;
+        }
+        acc.clear(); c = 0;
+        for (int s = 0; s < kBins - 1; ++s) {
+          if (cnt[a][s]) acc.grow(bb[a][s]);
+          c += cnt[a][s];
+          if (c == 0 || rcnt[s + 1] == 0) continue;
+          const float cost = fma_(acc.half_area(), (float)c, rarea[s + 1] * (float)rcnt[s + 1]);
+          if (cost < best) { best = cost; baxis = a; bsplit = s; }
+        }
+      }
+      if (baxis >= 0) {
+        const std::vector<float>& cc = cen[baxis];
+        const float c0 = cmn[baxis], e = ext[baxis];
+        uint32_t nl = 0, nr = 0;
+        uint32_t* right = tmp.data() + lo;            // this subtree's private scratch range
+        for (uint32_t i = lo; i < hi; ++i) {
+          const uint32_t p = idx[i];
+          int b = (int)(((cc[p] - c0) / e) * (float)kBins);
+          if (b > kBins - 1) b = kBins - 1;
+          if (b <= bsplit) idx[lo + nl++] = p; else right[nr++] = p;
+        }
+        std::memcpy(&idx[lo + nl], right, sizeof(uint32_t) * nr);
+        return lo + nl;
+      }
+    }
+    // object median on the widest centroid axis
+    int ax = 0; float em = cmx[0] - cmn[0];
+    if (cmx[1] - cmn[1] > em) { em = cmx[1] - cmn[1]; ax = 1; }
+    if (cmx[2] - cmn[2] > em) { em = cmx[2] - cmn[2]; ax = 2; }
+    if (em > 0.f) {
+      const std::vector<float>& cc = cen[ax];
+      std::sort(idx.begin() + lo, idx.begin() + hi, [&](uint32_t x, uint32_t y) {
+        const float kx = cc[x], ky = cc[y];
+        return kx < ky || (kx == ky && x < y);
+      });
+    }
+    return lo + n / 2;
+  }
+
+  void build(uint32_t me, uint32_t lo, uint32_t hi, int depth) {
+    for (;;) {
+      BNode& nd = nodes[me];
+      nd.lo = lo; nd.hi = hi; nd.left = nd.right = -1;
+      Box box; box.clear();
+      float cmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t p = idx[i];
+        for (int a = 0; a < 3; ++a) {
+          box.mn[a] = std::min(box.mn[a], pmn[a][p]); box.mx[a] = std::max(box.mx[a], pmx[a][p]);
+          cmn[a] = std::min(cmn[a], cen[a][p]); cmx[a] = std::max(cmx[a], cen[a][p]);
+        }
+      }
+      nd.box = box;
+      if (hi - lo <= kLeafSize) return;
+      const uint32_t mid = split(lo, hi, depth, cmn, cmx);
+      const uint32_t l = alloc(), r = alloc();
+      nodes[me].left = (int32_t)l; nodes[me].right = (int32_t)r;
+      // hand the left half to another thread when it is big enough and one is free
+      if (mid - lo > 32768u && spare_threads.fetch_sub(1) > 0) {
+        auto fut = std::async(std::launch::async, [this, l, lo, mid, depth] { build(l, lo, mid, depth + 1); spare_threads.fetch_add(1); });
+        build(r, mid, hi, depth + 1);
+        fut.get();
+        return;
+      }
+      else if (mid - lo > 32768u) spare_threads.fetch_add(1);
+      build(l, lo, mid, depth + 1);
+      me = r; lo = mid; ++depth;   // tail-iterate on the right half
+    }
+  }
+};
+
+struct Collapser {
+  const std::vector<BNode>& bn;
+  std::vector<QNode>& qn;
+  static uint32_t leaf_ref(const BNode& b) { return kLeafBit | ((b.hi - b.lo - 1u) << 28) | b.lo; }
+  static float bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+  uint32_t run(uint32_t bi) {
+    const uint32_t me = (uint32_t)qn.size();
+    qn.emplace_back();
+    uint32_t kids[4]; int nk = 0;
+    const BNode& b = bn[bi];
+    if (b.left < 0) kids[nk++] = bi;
+    else {
+      for (uint32_t ch : {(uint32_t)b.left, (uint32_t)b.right}) {
+        const BNode& c = bn[ch];
+        if (c.left < 0) kids[nk++] = ch;
+        else { kids[nk++] = (uint32_t)c.left; kids[nk++] = (uint32_t)c.right; }
+      }
+    }
+    QNode q; std::memset(&q, 0, sizeof q);
+    uint32_t refs[4] = {kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef};
+    for (int k = 0; k < 4; ++k) {
+      if (k < nk) {
+        const Box& cb = bn[kids[k]].box;
+        q.f[0 + k] = cb.mn[0]; q.f[4 + k] = cb.mn[1]; q.f[8 + k] = cb.mn[2];
+        q.f[12 + k] = cb.mx[0]; q.f[16 + k] = cb.mx[1]; q.f[20 + k] = cb.mx[2];
+      } else {
+        q.f[0 + k] = q.f[4 + k] = q.f[8 + k] = 3.0e38f;
+        q.f[12 + k] = q.f[16 + k] = q.f[20 + k] = -3.0e38f;
+      }
+    }
+    for (int k = 0; k < nk; ++k) {
+      const BNode& c = bn[kids[k]];
+      if (c.left < 0) refs[k] = c.hi > c.lo ? leaf_ref(c) : kEmptyRef;
+      else            refs[k] = run(kids[k]);
+    }
+    for (int k = 0; k < 4; ++k) q.f[24 + k] = bits(refs[k]);
+    q.f[28] = bits((uint32_t)nk);
+    qn[me] = q;
+    return me;
+  }
+};
+
+}  // namespace
+
+void build_qbvh(const float* pos, const int32_t* tri, uint32_t n, QBvh& out, int threads) {
+  Builder B;
+  const uint32_t cap = n ? n : 1;
+  for (int a = 0; a < 3; ++a) { B.pmn[a].resize(cap); B.pmx[a].resize(cap); B.cen[a].resize(cap); }
+  B.idx.resize(cap); B.tmp.resize(cap);
+  Box scene; scene.clear();
+  for (uint32_t t = 0; t < n; ++t) {
+    for (int a = 0; a < 3; ++a) {
+      const float v0 = pos[3 * tri[4 * t + 0] + a], v1 = pos[3 * tri[4 * t + 1] + a], v2 = pos[3 * tri[4 * t + 2] + a];
+      const float lo = std::min(v0, std::min(v1, v2)), hi = std::max(v0, std::max(v1, v2));
+      B.pmn[a][t] = lo; B.pmx[a][t] = hi; B.cen[a][t] = (lo + hi) * 0.5f;
+      scene.mn[a] = std::min(scene.mn[a], lo); scene.mx[a] = std::max(scene.mx[a], hi);
+    }
+    B.idx[t] = t;
+  }
+  B.nodes.resize(2 * (size_t)cap + 1);
+  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  if (threads < 1) threads = 1;
+  B.spare_threads.store(threads - 1);
+  const uint32_t root = B.alloc();
+  B.build(root, 0, n, 0);
+
+  out.nodes.clear();
+  out.nodes.reserve(n / 2 + 16);
+  Collapser C{B.nodes, out.nodes};
+  C.run(root);
+  out.prim_order.assign(B.idx.begin(), B.idx.begin() + n);
+  for (int a = 0; a < 3; ++a) { out.bbmin[a] = n ? scene.mn[a] : 0.f; out.bbmax[a] = n ? scene.mx[a] : 0.f; }
+}
+
+}  // namespace crh

@@ -1,0 +1,29 @@
+// bvh_builder.h -- host-side construction of the 4-wide BVH the gfx950 traversal kernels walk.
+// Takes the place of OCCT's BVH_BinnedBuilder + BVH_Tree::CollapseToQuadTree, which CADRays reaches
+// through AIS_InteractiveContext::Display -> OpenGl_View::updateRaytraceGeometry (SURVEY.md a3/a4;
+// the only reference-side evidence is the TBB build option, reference CMakeLists.txt:79).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace crh {
+
+// spec constants (DESIGN.md "BVH"): must match what the traversal kernels assume
+constexpr int      kBins      = 32;
+constexpr uint32_t kLeafSize  = 4;
+constexpr int      kMaxDepth  = 40;
+constexpr uint32_t kEmptyRef  = 0xFFFFFFFFu;
+constexpr uint32_t kLeafBit   = 0x80000000u;
+
+struct QNode { float f[32]; };   // 128 B: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] rsv[4]
+
+struct QBvh {
+  std::vector<QNode>    nodes;       // DFS pre-order
+  std::vector<uint32_t> prim_order;  // leaf order -> input triangle index
+  float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
+};
+
+// pos: 3*nV floats (world space); tri: 4*nT ints {i0,i1,i2,material}.  threads <= 0: hardware concurrency.
+void build_qbvh(const float* pos, const int32_t* tri, uint32_t n_tris, QBvh& out, int threads = 0);
+
+}  // namespace crh

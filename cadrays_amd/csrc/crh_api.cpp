@@ -1,0 +1,574 @@
+// crh_api.cpp -- the C ABI of libcadrays_hip.so (include/cadrays_hip.h): context, HBM residency of the
+// scene, and the per-iteration wavefront schedule.  This is the code that sits behind CADRays'
+// `myInternal->View->Redraw()` (reference src/Launcher/AppViewer.cxx:1047).
+//
+// There is NO CPU fallback: every entry point that renders or traces launches the gfx950 kernels and
+// reports CRH_E_DEVICE when the HIP runtime refuses.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cadrays_hip.h"
+#include "bvh_builder.h"
+#include "kernels.h"
+
+using namespace crh;
+
+struct crh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int grid = 2048;
+  std::string err;
+  // ---- host copies of the inputs
+  std::vector<float> pos, nrm, uv;
+  std::vector<int32_t> tri;
+  std::vector<crh_bsdf> mats;
+  std::vector<crh_light> lights;
+  std::vector<float> env; uint32_t envW = 0, envH = 0;
+  crh_camera cam{};
+  crh_params par{};
+  // ---- built scene
+  QBvh bvh;
+  std::vector<float> h_tris;      // 12 floats per triangle, leaf order
+  bool built = false;
+  // ---- device
+  float4 *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_env = nullptr;
+  float4* d_accum = nullptr; uint32_t accumW = 0, accumH = 0;
+  DPaths paths{}; DQueues queues{}; uint32_t path_cap = 0;
+  uint32_t* d_tile_ids = nullptr; uint32_t tile_cap = 0;
+  uint32_t* d_seeds = nullptr; uint32_t seed_cap = 0;
+  DCounters* d_counters = nullptr;
+  void* d_scratch = nullptr; size_t scratch_bytes = 0;
+  bool counters_on = false, timing_on = false;
+  uint32_t frames_done = 0;       // whole-frame iterations since reset (crh_render continues from here)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> render_ev, trace_ev;
+  std::vector<hipEvent_t> ev_pool;
+  double seconds_acc = 0.0, trace_ms_acc = 0.0, all_ms_acc = 0.0; uint64_t trace_launches = 0;
+  uint32_t max_paths = 8u << 20;
+};
+
+namespace {
+
+#define CRH_HIP(call)                                                                             \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess) {                                            \
+      char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      c->err = b_; return CRH_E_DEVICE; } } while (0)
+
+int fail(crh_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
+
+template <class T> int dev_upload(crh_ctx* c, T*& dptr, const void* src, size_t bytes)
+{
+  if (dptr) { CRH_HIP(hipFree(dptr)); dptr = nullptr; }
+  if (!bytes) return CRH_OK;
+  CRH_HIP(hipMalloc((void**)&dptr, bytes));
+  CRH_HIP(hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+  return CRH_OK;
+}
+
+hipEvent_t get_event(crh_ctx* c)
+{
+  if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr; hipEventCreate(&e); return e;
+}
+
+// Fold finished event pairs into the accumulated times (stream must be idle).
+void drain_events(crh_ctx* c)
+{
+  for (auto& p : c->render_ev) { float ms = 0.f; if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { c->seconds_acc += 1e-3 * ms; c->all_ms_acc += ms; } c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second); }
+  c->render_ev.clear();
+  for (auto& p : c->trace_ev) { float ms = 0.f; if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { c->trace_ms_acc += ms; c->trace_launches++; } c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second); }
+  c->trace_ev.clear();
+}
+
+uint32_t frame_seed(uint32_t seed, uint32_t n)   // Bullard generator, SURVEY.md a14
+{
+  uint32_t hi = seed, lo = seed ^ 0x49616E42u, r = 0;
+  for (uint32_t i = 0; i <= n; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; r = hi; }
+  return r >> 2;
+}
+
+int ensure_paths(crh_ctx* c, uint32_t need)
+{
+  if (need <= c->path_cap) return CRH_OK;
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  void** ptrs[] = {(void**)&c->paths.ray_o, (void**)&c->paths.ray_d, (void**)&c->paths.hit, (void**)&c->paths.thr, (void**)&c->paths.rad,
+                   (void**)&c->paths.st, (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c,
+                   (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh};
+  const size_t sz[] = {16, 16, 16, 16, 16, 8, 16, 16, 16, 4, 4, 4};
+  for (int i = 0; i < 12; ++i) {
+    if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
+    CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
+  }
+  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, 4 * sizeof(uint32_t))); CRH_HIP(hipMemset(c->queues.counts, 0, 4 * sizeof(uint32_t))); }
+  c->path_cap = need;
+  return CRH_OK;
+}
+
+int ensure_scratch(crh_ctx* c, size_t bytes)
+{
+  if (bytes <= c->scratch_bytes) return CRH_OK;
+  if (c->d_scratch) { CRH_HIP(hipFree(c->d_scratch)); c->d_scratch = nullptr; }
+  CRH_HIP(hipMalloc(&c->d_scratch, bytes));
+  c->scratch_bytes = bytes;
+  return CRH_OK;
+}
+
+void fill_scene(const crh_ctx* c, DScene& S)
+{
+  std::memset(&S, 0, sizeof S);
+  S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = c->d_env;
+  S.n_mats = (uint32_t)c->mats.size(); S.n_lights = (uint32_t)c->lights.size(); S.env_w = c->envW; S.env_h = c->envH;
+  for (int k = 0; k < 3; ++k) S.bg[k] = c->par.background[k];
+  S.env_as_bg = c->par.env_as_background;
+  S.eye = crh_mk3(c->cam.eye[0], c->cam.eye[1], c->cam.eye[2]);
+  S.fwd = crh_norm3(crh_mk3(c->cam.dir[0], c->cam.dir[1], c->cam.dir[2]));
+  S.right = crh_norm3(crh_cross3(S.fwd, crh_mk3(c->cam.up[0], c->cam.up[1], c->cam.up[2])));
+  S.up = crh_cross3(S.right, S.fwd);
+  float s, cs; crh_sincos((c->cam.fovy_deg * 0.5f) * (CRH_PI / 180.0f), &s, &cs);
+  S.tan_half = s / cs;
+  S.aspect = c->cam.aspect > 0.f ? c->cam.aspect : (float)c->par.width / (float)c->par.height;
+  S.ortho_scale = c->cam.ortho_scale; S.aperture = c->cam.aperture_radius; S.focal = c->cam.focal_dist; S.is_ortho = c->cam.is_ortho;
+  S.width = c->par.width; S.height = c->par.height; S.max_depth = c->par.max_depth; S.tile_size = c->par.tile_size;
+  S.clampv = c->par.radiance_clamp;
+  const crh_v3 dg = crh_mk3(c->bvh.bbmax[0] - c->bvh.bbmin[0], c->bvh.bbmax[1] - c->bvh.bbmin[1], c->bvh.bbmax[2] - c->bvh.bbmin[2]);
+  S.eps = c->par.scene_epsilon > 0.f ? c->par.scene_epsilon : crh_max(1.0e-6f, 1.0e-5f * crh_len3(dg));
+  S.two_sided = c->par.two_sided; S.coherent = c->par.coherent_rng; S.rr = c->par.russian_roulette;
+}
+
+int upload_lights(crh_ctx* c)
+{
+  std::vector<float> l(8 * std::max<size_t>(c->lights.size(), 1), 0.f);
+  for (size_t i = 0; i < c->lights.size(); ++i) {
+    const crh_light& s = c->lights[i]; float* o = &l[8 * i];
+    if (s.is_point != 0.f) { o[0] = s.vec[0]; o[1] = s.vec[1]; o[2] = s.vec[2]; o[3] = 1.f; o[7] = s.smoothness; }
+    else {
+      const crh_v3 d = crh_norm3(crh_mk3(-s.vec[0], -s.vec[1], -s.vec[2]));
+      float sn, cn; crh_sincos(s.smoothness, &sn, &cn);
+      o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = 0.f; o[7] = s.smoothness > 0.f ? cn : 1.0f;
+    }
+    o[4] = s.emission[0]; o[5] = s.emission[1]; o[6] = s.emission[2];
+  }
+  return dev_upload(c, c->d_lights, l.data(), l.size() * sizeof(float));
+}
+
+int alloc_accum(crh_ctx* c)
+{
+  if (c->d_accum && c->accumW == c->par.width && c->accumH == c->par.height) return CRH_OK;
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_accum) { CRH_HIP(hipFree(c->d_accum)); c->d_accum = nullptr; }
+  CRH_HIP(hipMalloc((void**)&c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height));
+  c->accumW = c->par.width; c->accumH = c->par.height;
+  return CRH_OK;
+}
+
+int do_reset(crh_ctx* c)
+{
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  int rc = alloc_accum(c); if (rc) return rc;
+  CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, c->stream));
+  CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  drain_events(c);
+  c->seconds_acc = c->trace_ms_acc = c->all_ms_acc = 0.0; c->trace_launches = 0; c->frames_done = 0;
+  return CRH_OK;
+}
+
+// One batch: `ns` samples of `nt` tiles whose ids sit at d_tiles; seeds at d_seeds.
+int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns)
+{
+  Launch L{c->stream, c->grid, c->counters_on};
+  launch_raygen(L, S, c->paths, c->queues, 0, d_tiles, nt, d_seeds, ns);
+  int qin = 0;
+  for (uint32_t b = 0; b < S.max_depth; ++b) {
+    if (c->timing_on) {
+      hipEvent_t e0 = get_event(c), e1 = get_event(c);
+      hipEventRecord(e0, c->stream);
+      launch_trace_nearest(L, S, c->paths, c->queues, qin, c->d_counters);
+      hipEventRecord(e1, c->stream);
+      c->trace_ev.emplace_back(e0, e1);
+    } else launch_trace_nearest(L, S, c->paths, c->queues, qin, c->d_counters);
+    launch_shade(L, S, c->paths, c->queues, qin, b, c->d_counters);
+    if (S.n_lights > 0) launch_trace_any(L, S, c->paths, c->queues, c->d_counters);
+    qin = 1 - qin;
+  }
+  launch_accumulate(L, S, c->paths, c->d_accum, d_tiles, nt, ns, c->d_counters);
+  CRH_HIP(hipGetLastError());
+  return CRH_OK;
+}
+
+int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, uint32_t ns)
+{
+  if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
+  if (ns == 0 || nt == 0) return CRH_OK;
+  CRH_HIP(hipSetDevice(c->device));
+  const uint32_t ts = c->par.tile_size, tpp = ts * ts;
+  const uint32_t tx = (c->par.width + ts - 1) / ts, ty = (c->par.height + ts - 1) / ts;
+  for (uint32_t i = 0; i < nt; ++i) if (tiles[i] >= tx * ty) return fail(c, CRH_E_INVALID, "tile id out of range");
+  // tile ids + frame seeds to the device (stream-ordered behind any kernels still reading the old ones)
+  if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; }
+  if (ns > c->seed_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * ns)); c->seed_cap = ns; }
+  CRH_HIP(hipMemcpyAsync(c->d_tile_ids, tiles, sizeof(uint32_t) * nt, hipMemcpyHostToDevice, c->stream));
+  std::vector<uint32_t> seeds(ns);
+  {
+    uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;   // sequential form of frame_seed()
+    for (uint32_t i = 0; i < first + ns; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; if (i >= first) seeds[i - first] = hi >> 2; }
+  }
+  CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));   // host staging buffers may go out of scope
+
+  const uint32_t cap_tiles = std::max<uint32_t>(1u, c->max_paths / tpp);
+  const uint32_t group = std::min(nt, cap_tiles);
+  const uint32_t spb = std::max<uint32_t>(1u, std::min(ns, c->max_paths / (group * tpp)));
+  int rc = ensure_paths(c, group * tpp * spb); if (rc) return rc;
+  DScene S; fill_scene(c, S);
+  hipEvent_t e0 = get_event(c), e1 = get_event(c);
+  hipEventRecord(e0, c->stream);
+  for (uint32_t t0 = 0; t0 < nt; t0 += group) {
+    const uint32_t g = std::min(group, nt - t0);
+    for (uint32_t s0 = 0; s0 < ns; s0 += spb) {
+      rc = run_batch(c, S, c->d_tile_ids + t0, g, c->d_seeds + s0, std::min(spb, ns - s0));
+      if (rc) return rc;
+    }
+  }
+  hipEventRecord(e1, c->stream);
+  c->render_ev.emplace_back(e0, e1);
+  if (c->render_ev.size() + c->trace_ev.size() > 4096) { CRH_HIP(hipStreamSynchronize(c->stream)); drain_events(c); }
+  return CRH_OK;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+crh_ctx* crh_create(int device_ordinal)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) {
+    fprintf(stderr, "crh_create: no HIP device %d (device count %d) -- this backend has no CPU fallback\n", device_ordinal, n);
+    return nullptr;
+  }
+  crh_ctx* c = new crh_ctx();
+  c->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&c->d_counters, sizeof(DCounters)) != hipSuccess || hipMemset(c->d_counters, 0, sizeof(DCounters)) != hipSuccess) {
+    fprintf(stderr, "crh_create: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
+    delete c; return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->grid = prop.multiProcessorCount * 8;
+  if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)v; }
+  if (const char* e = getenv("CRH_GRID")) { int v = atoi(e); if (v > 0) c->grid = v; }
+  // reference defaults: GI on, depth as vrenderparams default, two-sided (SettingsWidget.cxx:65-90)
+  c->par.width = 64; c->par.height = 64; c->par.max_depth = 5; c->par.two_sided = 1; c->par.seed = 1; c->par.tile_size = 32;
+  c->par.white_point = 1.0f; c->par.russian_roulette = 1; c->par.env_as_background = 1;
+  c->cam.dir[1] = 1.0f; c->cam.up[2] = 1.0f; c->cam.fovy_deg = 45.0f;
+  return c;
+}
+
+void crh_destroy(crh_ctx* c)
+{
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  drain_events(c);
+  for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o, c->paths.ray_d,
+                  c->paths.hit, c->paths.thr, c->paths.rad, c->paths.st, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
+                  c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_scratch};
+  for (void* p : ptrs) if (p) hipFree(p);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* crh_last_error(crh_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float* uv, uint32_t nV, const int32_t* tri, uint32_t nT,
+                     const int32_t* tri_obj, const float* xf, uint32_t nO)
+{
+  if (!c) return CRH_E_INVALID;
+  if ((nV && (!pos || !nrm)) || (nT && !tri)) return fail(c, CRH_E_INVALID, "null geometry array");
+  if (nT >= (1u << 28)) return fail(c, CRH_E_INVALID, "too many triangles (limit 2^28)");
+  for (uint32_t t = 0; t < nT; ++t)
+    for (int k = 0; k < 3; ++k)
+      if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) { char b[96]; snprintf(b, sizeof b, "triangle %u index out of range", t); return fail(c, CRH_E_INVALID, b); }
+  c->pos.assign(pos, pos + 3 * (size_t)nV); c->nrm.assign(nrm, nrm + 3 * (size_t)nV);
+  if (uv) c->uv.assign(uv, uv + 2 * (size_t)nV); else c->uv.clear();
+  c->tri.assign(tri, tri + 4 * (size_t)nT);
+  if (tri_obj && xf) {
+    // flatten per-object 3x4 transforms into world space (two-level BVH: SURVEY.md section 8(f) rank 4)
+    std::vector<uint8_t> done(nV ? nV : 1, 0);
+    for (uint32_t t = 0; t < nT; ++t) {
+      const int32_t ob = tri_obj[t];
+      if (ob < 0 || (uint32_t)ob >= nO) return fail(c, CRH_E_INVALID, "triangle object id out of range");
+      const float* m = &xf[12 * ob];
+      const crh_v3 r0 = crh_mk3(m[0], m[1], m[2]), r1 = crh_mk3(m[4], m[5], m[6]), r2 = crh_mk3(m[8], m[9], m[10]);
+      for (int k = 0; k < 3; ++k) {
+        const int32_t vi = tri[4 * t + k]; if (done[vi]) continue; done[vi] = 1;
+        const crh_v3 p = crh_mk3(pos[3 * vi], pos[3 * vi + 1], pos[3 * vi + 2]), n = crh_mk3(nrm[3 * vi], nrm[3 * vi + 1], nrm[3 * vi + 2]);
+        c->pos[3 * vi + 0] = crh_dot3(r0, p) + m[3]; c->pos[3 * vi + 1] = crh_dot3(r1, p) + m[7]; c->pos[3 * vi + 2] = crh_dot3(r2, p) + m[11];
+        const crh_v3 nn = crh_norm3(crh_mk3(crh_dot3(r0, n), crh_dot3(r1, n), crh_dot3(r2, n)));
+        c->nrm[3 * vi + 0] = nn.x; c->nrm[3 * vi + 1] = nn.y; c->nrm[3 * vi + 2] = nn.z;
+      }
+    }
+  }
+  c->built = false;
+  return CRH_OK;
+}
+
+int crh_set_materials(crh_ctx* c, const crh_bsdf* m, uint32_t n)
+{
+  if (!c || (n && !m)) return fail(c, CRH_E_INVALID, "null materials");
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  c->mats.assign(m, m + n);
+  return dev_upload(c, c->d_mats, c->mats.data(), sizeof(crh_bsdf) * n);
+}
+
+int crh_set_lights(crh_ctx* c, const crh_light* l, uint32_t n)
+{
+  if (!c || (n && !l)) return fail(c, CRH_E_INVALID, "null lights");
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  c->lights.assign(l, l + n);
+  return upload_lights(c);
+}
+
+int crh_set_envmap(crh_ctx* c, const float* rgb, uint32_t w, uint32_t h)
+{
+  if (!c) return CRH_E_INVALID;
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  c->envW = c->envH = 0;
+  if (c->d_env) { CRH_HIP(hipFree(c->d_env)); c->d_env = nullptr; }
+  if (rgb && w && h) {
+    std::vector<float> t(4 * (size_t)w * h);
+    for (size_t i = 0; i < (size_t)w * h; ++i) { t[4 * i] = rgb[3 * i]; t[4 * i + 1] = rgb[3 * i + 1]; t[4 * i + 2] = rgb[3 * i + 2]; t[4 * i + 3] = 0.f; }
+    int rc = dev_upload(c, c->d_env, t.data(), t.size() * sizeof(float)); if (rc) return rc;
+    c->envW = w; c->envH = h;
+  }
+  return CRH_OK;
+}
+
+int crh_set_camera(crh_ctx* c, const crh_camera* cam) { if (!c || !cam) return fail(c, CRH_E_INVALID, "null camera"); c->cam = *cam; return CRH_OK; }
+
+int crh_set_params(crh_ctx* c, const crh_params* p)
+{
+  if (!c || !p) return fail(c, CRH_E_INVALID, "null params");
+  if (!p->width || !p->height || p->max_depth < 1 || p->max_depth > 32) return fail(c, CRH_E_INVALID, "width/height must be > 0 and max_depth in 1..32");
+  if (p->tile_size < 8 || (p->tile_size & 7u) || p->tile_size > 1024) return fail(c, CRH_E_INVALID, "tile_size must be a multiple of 8 in 8..1024");
+  c->par = *p;
+  return do_reset(c);
+}
+
+int crh_build(crh_ctx* c)
+{
+  if (!c) return CRH_E_INVALID;
+  const uint32_t nT = (uint32_t)(c->tri.size() / 4);
+  if (nT && c->mats.empty()) return fail(c, CRH_E_INVALID, "no materials");
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  int threads = 0; if (const char* e = getenv("CRH_BUILD_THREADS")) threads = atoi(e);
+  build_qbvh(c->pos.data(), c->tri.data(), nT, c->bvh, threads);
+  // leaf-ordered triangle and shading records
+  c->h_tris.assign(12 * (size_t)std::max(nT, 1u), 0.f);
+  std::vector<float> sh(12 * (size_t)std::max(nT, 1u), 0.f);
+  for (uint32_t i = 0; i < nT; ++i) {
+    const uint32_t t = c->bvh.prim_order[i];
+    for (int k = 0; k < 3; ++k) {
+      const int32_t vi = c->tri[4 * t + k];
+      for (int a = 0; a < 3; ++a) { c->h_tris[12 * (size_t)i + 4 * k + a] = c->pos[3 * vi + a]; sh[12 * (size_t)i + 4 * k + a] = c->nrm[3 * vi + a]; }
+    }
+    std::memcpy(&c->h_tris[12 * (size_t)i + 3], &t, 4);
+    const int32_t mat = c->tri[4 * t + 3];
+    std::memcpy(&sh[12 * (size_t)i + 3], &mat, 4);
+  }
+  int rc;
+  if ((rc = dev_upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode)))) return rc;
+  if ((rc = dev_upload(c, c->d_tris, c->h_tris.data(), c->h_tris.size() * sizeof(float)))) return rc;
+  if ((rc = dev_upload(c, c->d_shade, sh.data(), sh.size() * sizeof(float)))) return rc;
+  c->built = true;
+  return do_reset(c);
+}
+
+int crh_reset(crh_ctx* c) { if (!c) return CRH_E_INVALID; return do_reset(c); }
+
+int crh_render(crh_ctx* c, uint32_t n)
+{
+  if (!c) return CRH_E_INVALID;
+  if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
+  const uint32_t ts = c->par.tile_size;
+  const uint32_t nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
+  std::vector<uint32_t> all(nt);
+  for (uint32_t i = 0; i < nt; ++i) all[i] = i;
+  int rc = render_impl(c, all.data(), nt, c->frames_done, n);
+  if (rc == CRH_OK) c->frames_done += n;
+  return rc;
+}
+
+int crh_render_tiles(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, uint32_t ns)
+{
+  if (!c || (nt && !tiles)) return fail(c, CRH_E_INVALID, "null tile list");
+  return render_impl(c, tiles, nt, first, ns);
+}
+
+int crh_sync(crh_ctx* c) { if (!c) return CRH_E_INVALID; CRH_HIP(hipSetDevice(c->device)); CRH_HIP(hipStreamSynchronize(c->stream)); return CRH_OK; }
+
+int crh_read_hdr(crh_ctx* c, float* out)
+{
+  if (!c || !out || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null output");
+  CRH_HIP(hipSetDevice(c->device));
+  const uint32_t n = c->par.width * c->par.height;
+  int rc = ensure_scratch(c, sizeof(float) * 3 * (size_t)n); if (rc) return rc;
+  Launch L{c->stream, c->grid, false};
+  launch_hdr(L, c->d_accum, (float*)c->d_scratch, n);
+  CRH_HIP(hipMemcpyAsync(out, c->d_scratch, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  return CRH_OK;
+}
+
+int crh_read_ldr(crh_ctx* c, uint8_t* out)
+{
+  if (!c || !out || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null output");
+  CRH_HIP(hipSetDevice(c->device));
+  const uint32_t n = c->par.width * c->par.height;
+  int rc = ensure_scratch(c, 3 * (size_t)n); if (rc) return rc;
+  Launch L{c->stream, c->grid, false};
+  launch_tonemap(L, c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point);
+  CRH_HIP(hipMemcpyAsync(out, c->d_scratch, 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  return CRH_OK;
+}
+
+int crh_accum_device_ptr(crh_ctx* c, void** p, uint64_t* nbytes)
+{
+  if (!c || !p || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator");
+  *p = c->d_accum; if (nbytes) *nbytes = sizeof(float4) * (uint64_t)c->par.width * c->par.height;
+  return CRH_OK;
+}
+
+int crh_enable_counters(crh_ctx* c, int on) { if (!c) return CRH_E_INVALID; c->counters_on = on != 0; return CRH_OK; }
+
+int crh_get_stats(crh_ctx* c, crh_stats* out)
+{
+  if (!c || !out) return fail(c, CRH_E_INVALID, "null stats");
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  drain_events(c);
+  DCounters h;
+  CRH_HIP(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+  out->rays_nearest = h.rays_nearest; out->rays_any = h.rays_any; out->nodes_nearest = h.nodes_nearest; out->tris_nearest = h.tris_nearest;
+  out->nodes_any = h.nodes_any; out->tris_any = h.tris_any; out->shaded_hits = h.shaded_hits; out->samples = h.samples;
+  out->seconds = c->seconds_acc;
+  return CRH_OK;
+}
+
+static int trace_api(crh_ctx* c, const float* rays, uint32_t n, int any_hit, float* out_hit, uint32_t* out_vis)
+{
+  if (!c || (n && (!rays || (!out_hit && !out_vis)))) return fail(c, CRH_E_INVALID, "null ray buffers");
+  if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
+  if (!n) return CRH_OK;
+  CRH_HIP(hipSetDevice(c->device));
+  const size_t in_b = 32 * (size_t)n, out_b = (any_hit ? 4 : 16) * (size_t)n;
+  int rc = ensure_scratch(c, in_b + out_b); if (rc) return rc;
+  char* base = (char*)c->d_scratch;
+  CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
+  DScene S; fill_scene(c, S);
+  Launch L{c->stream, c->grid, c->counters_on};
+  launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_counters);
+  CRH_HIP(hipGetLastError());
+  CRH_HIP(hipMemcpyAsync(any_hit ? (void*)out_vis : (void*)out_hit, base + in_b, out_b, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  return CRH_OK;
+}
+int crh_trace_nearest(crh_ctx* c, const float* rays, uint32_t n, float* out_hit) { return trace_api(c, rays, n, 0, out_hit, nullptr); }
+int crh_trace_any(crh_ctx* c, const float* rays, uint32_t n, uint32_t* out_vis) { return trace_api(c, rays, n, 1, nullptr, out_vis); }
+
+int crh_get_bvh(crh_ctx* c, float* nodes, uint32_t* nn, float* tris, uint32_t* nt)
+{
+  if (!c) return CRH_E_INVALID;
+  if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
+  const uint32_t nT = (uint32_t)(c->tri.size() / 4);
+  if (nn) *nn = (uint32_t)c->bvh.nodes.size();
+  if (nt) *nt = nT;
+  if (nodes) std::memcpy(nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode));
+  if (tris && nT) std::memcpy(tris, c->h_tris.data(), 48 * (size_t)nT);
+  return CRH_OK;
+}
+
+int crh_build_bvh_host(const float* pos, uint32_t nV, const int32_t* tri, uint32_t nT, int threads, float* nodes, uint32_t* n_nodes,
+                       uint32_t* prim_order)
+{
+  if ((nT && (!pos || !tri)) || !n_nodes) return CRH_E_INVALID;
+  for (uint32_t t = 0; t < nT; ++t) for (int k = 0; k < 3; ++k) if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) return CRH_E_INVALID;
+  QBvh b; build_qbvh(pos, tri, nT, b, threads);
+  *n_nodes = (uint32_t)b.nodes.size();
+  if (nodes) std::memcpy(nodes, b.nodes.data(), b.nodes.size() * sizeof(QNode));
+  if (prim_order && nT) std::memcpy(prim_order, b.prim_order.data(), sizeof(uint32_t) * nT);
+  return CRH_OK;
+}
+
+int crh_bench_trace(crh_ctx* c, const float* rays, uint32_t n, int any_hit, uint32_t repeat, float* avg_ms)
+{
+  if (!c || !rays || !avg_ms || !n || !repeat) return fail(c, CRH_E_INVALID, "bad bench arguments");
+  if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
+  CRH_HIP(hipSetDevice(c->device));
+  const size_t in_b = 32 * (size_t)n, out_b = 16 * (size_t)n;
+  int rc = ensure_scratch(c, in_b + out_b); if (rc) return rc;
+  char* base = (char*)c->d_scratch;
+  CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
+  DScene S; fill_scene(c, S);
+  Launch L{c->stream, c->grid, false};
+  launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_counters);
+  hipEvent_t e0 = get_event(c), e1 = get_event(c);
+  CRH_HIP(hipEventRecord(e0, c->stream));
+  for (uint32_t r = 0; r < repeat; ++r)
+    launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_counters);
+  CRH_HIP(hipEventRecord(e1, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  float ms = 0.f; CRH_HIP(hipEventElapsedTime(&ms, e0, e1));
+  c->ev_pool.push_back(e0); c->ev_pool.push_back(e1);
+  *avg_ms = ms / (float)repeat;
+  return CRH_OK;
+}
+
+int crh_debug_math(crh_ctx* c, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n)
+{
+  if (!c || !a || !b || !out || !out2 || !n) return fail(c, CRH_E_INVALID, "bad debug_math arguments");
+  CRH_HIP(hipSetDevice(c->device));
+  const size_t bytes = sizeof(float) * (size_t)n;
+  int rc = ensure_scratch(c, 4 * bytes); if (rc) return rc;
+  float* d = (float*)c->d_scratch;
+  CRH_HIP(hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipMemcpyAsync(d + n, b, bytes, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipMemsetAsync(d + 2 * (size_t)n, 0, 2 * bytes, c->stream));
+  Launch L{c->stream, c->grid, false};
+  launch_debug_math(L, fn, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n);
+  CRH_HIP(hipGetLastError());
+  CRH_HIP(hipMemcpyAsync(out, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipMemcpyAsync(out2, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  return CRH_OK;
+}
+
+int crh_enable_kernel_timing(crh_ctx* c, int on) { if (!c) return CRH_E_INVALID; c->timing_on = on != 0; return CRH_OK; }
+
+int crh_get_kernel_timing(crh_ctx* c, double* trace_ms_total, uint64_t* trace_launches, double* all_ms_total)
+{
+  if (!c) return CRH_E_INVALID;
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  drain_events(c);
+  if (trace_ms_total) *trace_ms_total = c->trace_ms_acc;
+  if (trace_launches) *trace_launches = c->trace_launches;
+  if (all_ms_total) *all_ms_total = c->all_ms_acc;
+  return CRH_OK;
+}
+
+}  // extern "C"

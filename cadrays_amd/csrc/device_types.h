@@ -1,0 +1,65 @@
+// device_types.h -- HBM-resident scene and path state shared by the host API and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/crh_math.h"
+
+namespace crh {
+
+// ---- spec constants -----------------------------------------------------------------
+constexpr float    kDirEps        = 1.0e-15f;
+constexpr float    kBsdfEps       = 1.0e-5f;
+constexpr float    kMinThroughput = 1.0e-3f;
+constexpr float    kMinContrib    = 1.0e-2f;
+constexpr uint32_t kQEmpty        = 0xFFFFFFFFu;
+constexpr uint32_t kQLeafBit      = 0x80000000u;
+
+constexpr int kBlock      = 256;   // threads per workgroup (4 waves)
+constexpr int kLdsStack   = 16;    // traversal stack entries per lane kept in LDS
+constexpr int kOvfStack   = 48;    // spill entries per lane (scratch); 16 + 48 = 64 >= 3 * quad depth bound
+
+// Scene as the kernels see it.  All arrays are float4-granular so every fetch is one dwordx4.
+struct DScene {
+  const float4* nodes;    // 8 x float4 per node (128 B, one L2 line): minx miny minz maxx maxy maxz ref rsv
+  const float4* tris;     // 3 x float4 per triangle in leaf order: v0|prim, v1, v2
+  const float4* shade;    // 3 x float4 per triangle in leaf order: n0|material, n1, n2
+  const float4* mats;     // 8 x float4 per material (crh_bsdf)
+  const float4* lights;   // 2 x float4 per light: {vec.xyz (unit to-light dir | position), is_point}, {emission.rgb, cosmax | radius}
+  const float4* env;      // W*H float4 texels, row 0 = zenith; nullptr -> constant background
+  uint32_t n_mats, n_lights, env_w, env_h;
+  float bg[3]; int env_as_bg;
+  // camera frame
+  crh_v3 eye, fwd, right, up;
+  float tan_half, aspect, ortho_scale, aperture, focal;
+  int is_ortho;
+  // params
+  uint32_t width, height, max_depth, tile_size;
+  float clampv, eps;
+  int two_sided, coherent, rr;
+};
+
+// Wavefront path state, structure-of-arrays over path slots.
+struct DPaths {
+  float4* ray_o;   // origin.xyz, tmax
+  float4* ray_d;   // direction.xyz, -
+  float4* hit;     // t, u, v, leaf-order triangle index (int bits; -1 = miss)
+  float4* thr;     // throughput.rgb, implicit (BSDF) pdf of the ray that is in flight
+  float4* rad;     // radiance.rgb accumulated along the path
+  uint2*  st;      // rng state, flags (bit 0: inside a medium)
+  float4* sh_o;    // shadow ray origin.xyz, tmax
+  float4* sh_d;    // shadow ray direction.xyz
+  float4* sh_c;    // throughput * contribution to add when unoccluded
+};
+
+struct DCounters {          // device-side mirror of crh_stats
+  unsigned long long rays_nearest, rays_any, nodes_nearest, tris_nearest, nodes_any, tris_any, shaded_hits, samples;
+};
+
+struct DQueues {
+  uint32_t* q[2];           // active path ids, ping-pong
+  uint32_t* q_sh;           // path ids with a pending shadow ray
+  uint32_t* counts;         // [0],[1]: active counts (ping-pong), [2]: shadow count
+};
+
+}  // namespace crh

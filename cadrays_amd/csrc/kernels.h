@@ -1,0 +1,33 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (implemented in kernels.hip).
+#pragma once
+#include "device_types.h"
+
+namespace crh {
+
+struct Launch {
+  hipStream_t stream;
+  int grid;          // workgroups for the grid-stride kernels
+  bool counters;     // collect node / triangle counters (slower)
+};
+
+// camera rays for n_samples x n_tiles x tile^2 path slots; fills queue `qsel` and its count
+void launch_raygen(const Launch&, const DScene&, const DPaths&, const DQueues&, int qsel,
+                   const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_frame_seeds, uint32_t n_samples);
+// nearest-hit traversal of queue `qin`; also zeroes the other queue's count and the shadow count
+void launch_trace_nearest(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, DCounters*);
+// emission, NEE, BSDF sampling, Russian roulette; survivors -> queue 1-qin, shadow rays -> q_sh
+void launch_shade(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, uint32_t bounce, DCounters*);
+// any-hit traversal of the shadow queue; unoccluded contributions are added to the path radiance
+void launch_trace_any(const Launch&, const DScene&, const DPaths&, const DQueues&, DCounters*);
+// clamp + running mean of the finished paths into the float4 accumulator, sample by sample
+void launch_accumulate(const Launch&, const DScene&, const DPaths&, float4* accum,
+                       const uint32_t* d_tile_ids, uint32_t n_tiles, uint32_t n_samples, DCounters*);
+void launch_tonemap(const Launch&, const float4* accum, uint8_t* out_rgb, uint32_t n_pixels,
+                    int mode, float exposure, float white_point);
+void launch_hdr(const Launch&, const float4* accum, float* out_rgb, uint32_t n_pixels);
+// API-level ray tracing on a plain ray buffer (8 floats per ray)
+void launch_trace_rays(const Launch&, const DScene&, const float4* rays, uint32_t n, int any_hit,
+                       float4* out_hit, uint32_t* out_vis, DCounters*);
+void launch_debug_math(const Launch&, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n);
+
+}  // namespace crh

@@ -1,0 +1,789 @@
+// kernels.hip -- hand-written gfx950 kernels of the progressive path tracer (wavefront formulation).
+//
+// One launch per stage and bounce, all on one HIP stream, no host round trip inside an iteration:
+//   k_raygen -> [ k_trace_nearest -> k_shade -> k_trace_any ] x depth -> k_accumulate
+// Stage boundaries exchange path ids through compacted queues built with wave64 ballot + prefix
+// popcount and ONE atomic per wavefront.  Traversal keeps a per-lane stack in LDS (lane-interleaved,
+// conflict free), BVH nodes are 128-B float4 records (one L2 line per visit), triangles 48-B records
+// in leaf order.  No MFMA: there is no dense contraction on this path.
+//
+// Arithmetic follows DESIGN.md "Algorithm spec" operation by operation (fma only where written;
+// built with -ffp-contract=off) so that results are bit-identical to the CPU oracle.
+#include "kernels.h"
+
+namespace crh {
+namespace {
+
+typedef crh_v3 v3;
+
+__device__ __forceinline__ v3 xyz(float4 a) { return crh_mk3(a.x, a.y, a.z); }
+__device__ __forceinline__ float4 mk4(v3 a, float w) { return make_float4(a.x, a.y, a.z, w); }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;   // total in lane 0
+}
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Append `value` of every lane with `pred` to a global queue: ballot, prefix popcount, one atomic per wave.
+__device__ __forceinline__ void wave_enqueue(bool pred, uint32_t value, uint32_t* __restrict__ q, uint32_t* __restrict__ count)
+{
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0ull) return;
+  const uint32_t lane = lane_id();
+  const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (pred) q[base + prefix] = value;
+}
+
+// ================================================================== traversal
+__device__ __forceinline__ float inv_dir(float d)
+{ return 1.0f / (crh_abs(d) < kDirEps ? (d < 0.f ? -kDirEps : kDirEps) : d); }
+
+__device__ __forceinline__ uint32_t pick(uint4 r, uint32_t s)
+{ return s == 0u ? r.x : (s == 1u ? r.y : (s == 2u ? r.z : r.w)); }
+
+#define CRH_CE(a, b) { const uint32_t lo_ = min(a, b); const uint32_t hi_ = max(a, b); a = lo_; b = hi_; }
+
+// Ordered stack traversal.  lds: this lane's column of the workgroup's stack (stride kBlock dwords).
+// hit = {t, u, v, leaf-order triangle index as int bits (-1: none)}.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                         v3 o, v3 d, float tmax, uint32_t* lds, float4& hit,
+                                         uint32_t& n_nodes, uint32_t& n_tris)
+{
+  uint32_t ovf[kOvfStack];
+  int sp = 0;
+  const float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
+  const float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
+  float best = tmax;
+  bool found = false;
+  hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
+  uint32_t cur = 0u;
+  for (;;) {
+    if (cur & kQLeafBit) {
+      const uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const float4* tp = tris + 3u * (off + k);
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        if (COUNT) ++n_tris;
+        const v3 v0 = xyz(a), v1 = xyz(b), v2 = xyz(c);
+        const v3 e0 = crh_sub3(v1, v0), e1 = crh_sub3(v0, v2);
+        const v3 n = crh_cross3(e1, e0);
+        const v3 to = crh_sub3(v0, o);
+        const float inv = 1.0f / crh_dot3(n, d);
+        const v3 vc = crh_cross3(d, to);
+        const float tt = crh_dot3(n, to) * inv;
+        const float uu = crh_dot3(vc, e1) * inv;
+        const float vv = crh_dot3(vc, e0) * inv;
+        if (tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f && tt < best) {
+          best = tt; found = true;
+          hit = make_float4(tt, uu, vv, __int_as_float((int)(off + k)));
+          if (ANY) return true;
+        }
+      }
+    } else {
+      const float4* np = nodes + 8u * cur;
+      const float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
+      const float4 rf = np[6];
+      const uint4 refs = make_uint4(__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w));
+      if (COUNT) ++n_nodes;
+      uint32_t key[4];
+#define CRH_CHILD(K, MNX, MNY, MNZ, MXX, MXY, MXZ, REF)                                                    \
+      {                                                                                                     \
+        const float a0 = CRH_FMA(MNX, ix, nox), a1 = CRH_FMA(MXX, ix, nox);                               \
+        const float b0 = CRH_FMA(MNY, iy, noy), b1 = CRH_FMA(MXY, iy, noy);                               \
+        const float c0 = CRH_FMA(MNZ, iz, noz), c1 = CRH_FMA(MXZ, iz, noz);                               \
+        const float tmin = fmaxf(fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), 0.f);          \
+        const float tmx  = fminf(fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)), best);         \
+        const int bits = max(__float_as_int(tmin), 0);                                                     \
+        key[K] = (REF != kQEmpty && tmin <= tmx) ? (((uint32_t)bits & ~3u) | (uint32_t)K) : 0xFFFFFFFFu;   \
+      }
+      CRH_CHILD(0, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, refs.x)
+      CRH_CHILD(1, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, refs.y)
+      CRH_CHILD(2, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, refs.z)
+      CRH_CHILD(3, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, refs.w)
+#undef CRH_CHILD
+      CRH_CE(key[0], key[1]) CRH_CE(key[2], key[3]) CRH_CE(key[0], key[2]) CRH_CE(key[1], key[3]) CRH_CE(key[1], key[2])
+      // far .. near onto the stack, nearest continues in registers
+#define CRH_PUSH(V)                                                          \
+      { const uint32_t v_ = (V);                                             \
+        if (sp < kLdsStack) lds[sp * kBlock] = v_; else ovf[sp - kLdsStack] = v_; \
+        ++sp; }
+      if (key[3] != 0xFFFFFFFFu) CRH_PUSH(pick(refs, key[3] & 3u))
+      if (key[2] != 0xFFFFFFFFu) CRH_PUSH(pick(refs, key[2] & 3u))
+      if (key[1] != 0xFFFFFFFFu) CRH_PUSH(pick(refs, key[1] & 3u))
+#undef CRH_PUSH
+      if (key[0] != 0xFFFFFFFFu) { cur = pick(refs, key[0] & 3u); continue; }
+    }
+    if (sp == 0) break;
+    --sp;
+    cur = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
+  }
+  return found;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_nearest(DScene S, DPaths P, const uint32_t* __restrict__ q,
+                                                           const uint32_t* __restrict__ count,
+                                                           uint32_t* zero_a, uint32_t* zero_b, DCounters* C)
+{
+  __shared__ uint32_t stk[kLdsStack * kBlock];
+  const uint32_t n = *count;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *zero_a = 0u; *zero_b = 0u;
+    atomicAdd(&C->rays_nearest, (unsigned long long)n);
+  }
+  uint32_t nn = 0, nt = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t pid = q[i];
+    const float4 o4 = P.ray_o[pid], d4 = P.ray_d[pid];
+    float4 h;
+    traverse<false, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
+    P.hit[pid] = h;
+  }
+  if (COUNT) {
+    nn = wave_sum(nn); nt = wave_sum(nt);
+    if (lane_id() == 0) { atomicAdd(&C->nodes_nearest, (unsigned long long)nn); atomicAdd(&C->tris_nearest, (unsigned long long)nt); }
+  }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_any(DScene S, DPaths P, const uint32_t* __restrict__ q,
+                                                       const uint32_t* __restrict__ count, DCounters* C)
+{
+  __shared__ uint32_t stk[kLdsStack * kBlock];
+  const uint32_t n = *count;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
+  uint32_t nn = 0, nt = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t pid = q[i];
+    const float4 o4 = P.sh_o[pid], d4 = P.sh_d[pid];
+    float4 h;
+    const bool occluded = traverse<true, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
+    if (!occluded) {
+      const float4 c = P.sh_c[pid];
+      float4 r = P.rad[pid];
+      r.x += c.x; r.y += c.y; r.z += c.z;
+      P.rad[pid] = r;
+    }
+  }
+  if (COUNT) {
+    nn = wave_sum(nn); nt = wave_sum(nt);
+    if (lane_id() == 0) { atomicAdd(&C->nodes_any, (unsigned long long)nn); atomicAdd(&C->tris_any, (unsigned long long)nt); }
+  }
+}
+
+// API-level tracing of a caller ray buffer {o.xyz, tmax, d.xyz, -}
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace_rays(DScene S, const float4* __restrict__ rays, uint32_t n,
+                                                        float4* __restrict__ out_hit, uint32_t* __restrict__ out_vis, DCounters* C)
+{
+  __shared__ uint32_t stk[kLdsStack * kBlock];
+  uint32_t nn = 0, nt = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 o4 = rays[2u * i], d4 = rays[2u * i + 1u];
+    float4 h;
+    const bool f = traverse<ANY, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
+    if (ANY) out_vis[i] = f ? 0u : 1u;
+    else {
+      const int k = __float_as_int(h.w);
+      if (k >= 0) h.w = S.tris[3u * (uint32_t)k].w;   // leaf order -> caller's triangle index
+      out_hit[i] = h;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &C->rays_any : &C->rays_nearest, (unsigned long long)n);
+  if (COUNT) {
+    nn = wave_sum(nn); nt = wave_sum(nt);
+    if (lane_id() == 0) {
+      atomicAdd(ANY ? &C->nodes_any : &C->nodes_nearest, (unsigned long long)nn);
+      atomicAdd(ANY ? &C->tris_any : &C->tris_nearest, (unsigned long long)nt);
+    }
+  }
+}
+
+// ================================================================== BSDF
+struct Bsdf {
+  v3 Kc, Kd, Ks, Kt, Le, Fc;
+  float Rc, Rs;
+  float4 fc, fb, ab;
+};
+
+__device__ v3 fresnel_media(float cosI, float4 f)
+{
+  if (f.x > -0.5f) {
+    const float m = 1.0f - crh_abs(cosI); const float m2 = m * m; const float m5 = (m2 * m2) * m;
+    return crh_mk3(CRH_FMA(1.0f - f.x, m5, f.x), CRH_FMA(1.0f - f.y, m5, f.y), CRH_FMA(1.0f - f.z, m5, f.z));
+  }
+  if (f.x > -1.5f) return crh_mk3(f.z, f.z, f.z);
+  if (f.x > -2.5f) {
+    const float ci = crh_abs(cosI), n = f.y, k = f.z;
+    const float tmp = (2.0f * n) * ci;
+    const float t1 = CRH_FMA(n, n, k * k);
+    const float ci2 = ci * ci;
+    const float sperp = ((t1 - tmp) + ci2) / ((t1 + tmp) + ci2);
+    const float t2 = t1 * ci2;
+    const float sparl = ((t2 - tmp) + 1.0f) / ((t2 + tmp) + 1.0f);
+    const float r = (sperp + sparl) * 0.5f;
+    return crh_mk3(r, r, r);
+  }
+  const float n = f.y;
+  const float etaI = cosI > 0.f ? 1.0f : n, etaT = cosI > 0.f ? n : 1.0f;
+  float r = 1.0f;
+  const float ratio = etaI / etaT;
+  const float sinT2 = (ratio * ratio) * CRH_FMA(-cosI, cosI, 1.0f);
+  if (sinT2 < 1.0f) {
+    const float ci = crh_abs(cosI), ct = crh_sqrt(1.0f - sinT2);
+    const float p0 = etaT * ci, p1 = etaI * ct, q0 = etaI * ci, q1 = etaT * ct;
+    const float parl = (p0 - p1) / (p0 + p1);
+    const float perp = (q0 - q1) / (q0 + q1);
+    const float pp = parl * parl, qq = perp * perp;
+    r = (pp + qq) * 0.5f;
+  }
+  return crh_mk3(r, r, r);
+}
+
+__device__ float smith_g1(v3 w, v3 m, float rough)
+{
+  float r = 0.f;
+  if (crh_dot3(w, m) * w.z > 0.f) {
+    const float tanT = crh_sqrt(crh_max(CRH_FMA(-w.z, w.z, 1.0f), 0.f)) / w.z;
+    if (tanT == 0.f) r = 1.0f;
+    else {
+      const float a = 1.0f / (rough * tanT);
+      r = CRH_FMA(2.181f, a, 3.535f) / CRH_FMA(2.577f, a, 1.0f / a + 2.276f);
+    }
+  }
+  return crh_min(r, 1.0f);
+}
+
+__device__ __forceinline__ float blinn_power(float rough) { return crh_max(2.0f / (rough * rough) - 2.0f, 0.f); }
+
+__device__ v3 eval_blinn(v3 wi, v3 wo, float4 fr, float rough)
+{
+  if (wi.z <= 0.f || wo.z <= 0.f) return crh_mk3(0.f, 0.f, 0.f);
+  const v3 h = crh_norm3(crh_add3(wi, wo));
+  const float e = blinn_power(rough);
+  const float D = ((e + 2.0f) * CRH_INV_TWOPI) * crh_pow(h.z, e);
+  const float G = smith_g1(wo, h, rough) * smith_g1(wi, h, rough);
+  const v3 F = fresnel_media(crh_dot3(wo, h), fr);
+  const float s = (D * G) / (4.0f * wo.z);
+  return crh_scale3(F, s);
+}
+
+__device__ v3 eval_layered(const Bsdf& b, v3 wi, v3 wo, int two_sided)
+{
+  if (two_sided) { const float sg = crh_sign(wo.z); wi.z *= sg; wo.z *= sg; }
+  const float lam = (wi.z <= 0.f || wo.z <= 0.f) ? 0.f : wi.z * CRH_INV_PI;
+  v3 r = crh_scale3(b.Kd, lam);
+  if (b.Rs > kBsdfEps) r = crh_add3(r, crh_mul3(b.Ks, eval_blinn(wi, wo, b.fb, b.Rs)));
+  r = crh_mul3(r, crh_mk3(1.0f - b.Fc.x, 1.0f - b.Fc.y, 1.0f - b.Fc.z));
+  if (b.Rc > kBsdfEps) r = crh_add3(r, crh_mul3(b.Kc, eval_blinn(wi, wo, b.fc, b.Rc)));
+  return r;
+}
+
+struct Lobes { float pc, pd, ps, pt, total; v3 Tc; };
+__device__ __forceinline__ Lobes lobe_probs(const Bsdf& b, v3 W)
+{
+  Lobes L;
+  L.Tc = crh_mk3(1.0f - b.Fc.x, 1.0f - b.Fc.y, 1.0f - b.Fc.z);
+  L.pc = crh_dot3(crh_mul3(b.Kc, b.Fc), W);
+  L.pd = crh_dot3(crh_mul3(b.Kd, L.Tc), W);
+  L.ps = crh_dot3(crh_mul3(b.Ks, L.Tc), W);
+  L.pt = crh_dot3(crh_mul3(b.Kt, L.Tc), W);
+  L.total = ((L.pc + L.pd) + L.ps) + L.pt;
+  return L;
+}
+
+__device__ float blinn_pdf(float hz, float dih, float rough)
+{
+  const float e = blinn_power(rough);
+  return (((e + 2.0f) * CRH_INV_TWOPI) * crh_pow(crh_abs(hz), e + 1.0f)) / (4.0f * crh_abs(dih));
+}
+
+__device__ float pdf_layered(const Bsdf& b, v3 wo, v3 wi, v3 W, int two_sided)
+{
+  const Lobes L = lobe_probs(b, W);
+  if (!(L.total > kBsdfEps)) return 0.f;
+  if (two_sided) { const float sg = crh_sign(wo.z); wi.z *= sg; wo.z *= sg; }
+  float pdf = 0.f;
+  if (wi.z > 0.f && wo.z > 0.f) {
+    const v3 h = crh_norm3(crh_add3(wi, wo));
+    const float dih = crh_dot3(wi, h);
+    pdf = L.pd * (wi.z * CRH_INV_PI);
+    if (b.Rc > kBsdfEps) pdf = CRH_FMA(L.pc, blinn_pdf(h.z, dih, b.Rc), pdf);
+    if (b.Rs > kBsdfEps) pdf = CRH_FMA(L.ps, blinn_pdf(h.z, dih, b.Rs), pdf);
+  }
+  return pdf / L.total;
+}
+
+__device__ v3 sample_blinn(v3 wo, v3& wi, float4 fr, float rough, uint32_t& rng, int two_sided, bool& ok)
+{
+  const float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+  const float e = blinn_power(rough);
+  const float cm = crh_pow(k1, 1.0f / (e + 2.0f));
+  float s, c; crh_sincos2pi(k2, &s, &c);
+  const float sm = crh_sqrt(crh_max(CRH_FMA(-cm, cm, 1.0f), 0.f));
+  const v3 m = crh_mk3(c * sm, s * sm, cm);
+  bool flip = false;
+  if (two_sided && wo.z < 0.f) { flip = true; wo.z = -wo.z; }
+  const float cd = crh_dot3(wo, m);
+  const float cd2 = 2.0f * cd;
+  wi = crh_mk3(CRH_FMA(cd2, m.x, -wo.x), CRH_FMA(cd2, m.y, -wo.y), CRH_FMA(cd2, m.z, -wo.z));
+  if (wi.z <= 0.f || wo.z <= 0.f || !(cd > 0.f)) { ok = false; return crh_mk3(0.f, 0.f, 0.f); }
+  const float G = smith_g1(wo, m, rough) * smith_g1(wi, m, rough);
+  const v3 F = fresnel_media(cd, fr);
+  const float w = (G * cd) / (wo.z * m.z);
+  if (flip) wi.z = -wi.z;
+  ok = true;
+  return crh_scale3(F, w);
+}
+
+// returns alive; W multiplied by the lobe weight; inside toggled on transmission
+__device__ bool sample_layered(const Bsdf& b, v3 wo, v3& wi, v3& W, bool& inside, bool& delta, uint32_t& rng, int two_sided)
+{
+  const Lobes L = lobe_probs(b, W);
+  const float ksi = L.total * crh_rng_next(&rng);
+  delta = false;
+  if (!(L.total > kBsdfEps)) { W = crh_mk3(0.f, 0.f, 0.f); return false; }
+  const v3 mirror = crh_mk3(-wo.x, -wo.y, wo.z);
+  bool ok = true; v3 k;
+  if (ksi < L.pc) {
+    k = crh_scale3(b.Kc, L.total / L.pc);
+    if (b.Rc > kBsdfEps) k = crh_mul3(k, sample_blinn(wo, wi, b.fc, b.Rc, rng, two_sided, ok));
+    else { k = crh_mul3(k, b.Fc); wi = mirror; delta = true; }
+  } else if (ksi < L.pc + L.pd) {
+    k = crh_scale3(crh_mul3(b.Kd, L.Tc), L.total / L.pd);
+    const float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+    float s, c; crh_sincos2pi(k1, &s, &c);
+    const float r = crh_sqrt(k2);
+    wi = crh_mk3(c * r, s * r, crh_sqrt(1.0f - k2));
+    if (two_sided) { if (wo.z < 0.f) wi.z = -wi.z; }
+    else if (!(wo.z > 0.f)) ok = false;
+  } else if (ksi < (L.pc + L.pd) + L.ps) {
+    k = crh_scale3(crh_mul3(b.Ks, L.Tc), L.total / L.ps);
+    if (b.Rs > kBsdfEps) k = crh_mul3(k, sample_blinn(wo, wi, b.fb, b.Rs, rng, two_sided, ok));
+    else { k = crh_mul3(k, fresnel_media(wo.z, b.fb)); wi = mirror; delta = true; }
+  } else {
+    k = crh_scale3(crh_mul3(b.Kt, L.Tc), L.total / L.pt);
+    const float ior = b.fc.y;
+    const float eta = wo.z > 0.f ? 1.0f / ior : ior;
+    const float sinT2 = (eta * eta) * CRH_FMA(-wo.z, wo.z, 1.0f);
+    if (!(sinT2 < 1.0f) || !(L.pt > 0.f)) ok = false;
+    else {
+      float ct = crh_sqrt(1.0f - sinT2); if (wo.z > 0.f) ct = -ct;
+      wi = crh_norm3(crh_mk3(-(eta * wo.x), -(eta * wo.y), ct));
+      inside = !inside; delta = true;
+    }
+  }
+  if (!ok) { W = crh_mk3(0.f, 0.f, 0.f); return false; }
+  W = crh_mul3(W, k);
+  return true;
+}
+
+// ================================================================== frames, lights, environment
+struct Frame { v3 t, b, n; };
+__device__ __forceinline__ Frame make_frame(v3 n)
+{
+  Frame f; f.n = n;
+  const v3 t = (crh_abs(n.x) > crh_abs(n.z)) ? crh_mk3(-n.y, n.x, 0.f) : crh_mk3(0.f, -n.z, n.y);
+  f.t = crh_norm3(t); f.b = crh_cross3(n, f.t);
+  return f;
+}
+__device__ __forceinline__ v3 to_local(const Frame& f, v3 v) { return crh_mk3(crh_dot3(v, f.t), crh_dot3(v, f.b), crh_dot3(v, f.n)); }
+__device__ __forceinline__ v3 from_local(const Frame& f, v3 l)
+{
+  return crh_mk3(CRH_FMA(f.n.x, l.z, CRH_FMA(f.b.x, l.y, f.t.x * l.x)),
+                 CRH_FMA(f.n.y, l.z, CRH_FMA(f.b.y, l.y, f.t.y * l.x)),
+                 CRH_FMA(f.n.z, l.z, CRH_FMA(f.b.z, l.y, f.t.z * l.x)));
+}
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return CRH_FMA(t, b - a, a); }
+
+__device__ v3 env_lookup(const DScene& S, v3 d)
+{
+  if (!S.env) return crh_mk3(S.bg[0], S.bg[1], S.bg[2]);
+  const float u = (crh_atan2(d.y, d.x) + CRH_PI) * CRH_INV_TWOPI;
+  const float v = crh_acos(d.z) * CRH_INV_PI;
+  const float x = CRH_FMA(u, (float)S.env_w, -0.5f), y = CRH_FMA(v, (float)S.env_h, -0.5f);
+  float xf = (float)(int)x; if (xf > x) xf -= 1.0f;
+  float yf = (float)(int)y; if (yf > y) yf -= 1.0f;
+  const float fx = x - xf, fy = y - yf;
+  const int W = (int)S.env_w, H = (int)S.env_h;
+  int x0 = (int)xf % W; if (x0 < 0) x0 += W;
+  int x1 = x0 + 1; if (x1 >= W) x1 = 0;
+  int y0 = (int)yf; int y1 = y0 + 1;
+  if (y0 < 0) y0 = 0; if (y0 > H - 1) y0 = H - 1; if (y1 < 0) y1 = 0; if (y1 > H - 1) y1 = H - 1;
+  const float4 p00 = S.env[y0 * W + x0], p10 = S.env[y0 * W + x1], p01 = S.env[y1 * W + x0], p11 = S.env[y1 * W + x1];
+  return crh_mk3(lerpf(lerpf(p00.x, p10.x, fx), lerpf(p01.x, p11.x, fx), fy),
+                 lerpf(lerpf(p00.y, p10.y, fx), lerpf(p01.y, p11.y, fx), fy),
+                 lerpf(lerpf(p00.z, p10.z, fx), lerpf(p01.z, p11.z, fx), fy));
+}
+
+__device__ __forceinline__ float cone_pdf(float cosmax) { return 1.0f / (CRH_TWO_PI * (1.0f - cosmax)); }
+__device__ __forceinline__ float sphere_cosmax(float radius, float dist)
+{ const float q = radius / dist; return 1.0f / crh_sqrt(CRH_FMA(q, q, 1.0f)); }
+
+__device__ v3 intersect_light(const DScene& S, v3 o, v3 d, uint32_t bounce, float hit_t, float& exp_pdf)
+{
+  v3 rad = crh_mk3(0.f, 0.f, 0.f); float pdf = 0.f; float hd = hit_t;
+  const float sel = S.n_lights ? 1.0f / (float)S.n_lights : 0.f;
+  for (uint32_t i = 0; i < S.n_lights; ++i) {
+    const float4 l0 = S.lights[2u * i], l1 = S.lights[2u * i + 1u];
+    if (l0.w != 0.f) {
+      const v3 tl = crh_sub3(xyz(l0), o);
+      const float dist = crh_len3(tl);
+      if (dist < hd) {
+        const float cm = sphere_cosmax(l1.w, dist);
+        if (cm < 1.0f && crh_dot3(d, tl) * (1.0f / dist) >= cm) { hd = dist; rad = xyz(l1); pdf = sel * cone_pdf(cm); }
+      }
+    } else if (hd == CRH_MAXFLOAT) {
+      const float cm = l1.w;
+      if (cm < 1.0f && crh_dot3(d, xyz(l0)) >= cm) { rad = crh_add3(rad, xyz(l1)); pdf += sel * cone_pdf(cm); }
+    }
+  }
+  if (pdf == 0.f && hd == CRH_MAXFLOAT) {
+    if (bounce == 0u && !S.env_as_bg) rad = crh_mk3(S.bg[0], S.bg[1], S.bg[2]);
+    else rad = env_lookup(S, d);
+  }
+  exp_pdf = pdf;
+  return rad;
+}
+
+__device__ __forceinline__ v3 offset_origin(v3 p, v3 dir, v3 ng, float eps)
+{
+  const v3 o = crh_madd3(p, dir, eps);
+  const float s = crh_dot3(ng, dir) >= 0.f ? eps : -eps;
+  return crh_madd3(o, ng, s);
+}
+
+// ================================================================== path slot <-> pixel
+// Slot layout inside one sample: tile-major, and inside a tile 8x8-pixel blocks so that one wavefront
+// owns one 8x8 block (coherent primary rays, coalesced accumulator rows of 8 float4 = 128 B).
+__device__ __forceinline__ bool slot_pixel(const DScene& S, const uint32_t* __restrict__ tile_ids, uint32_t local,
+                                           uint32_t& px, uint32_t& py)
+{
+  const uint32_t ts = S.tile_size, tpp = ts * ts;
+  const uint32_t ti = local / tpp, off = local - ti * tpp;
+  const uint32_t tile = tile_ids ? tile_ids[ti] : ti;
+  const uint32_t tx = (S.width + ts - 1u) / ts, ty = (S.height + ts - 1u) / ts;
+  const uint32_t blk = off >> 6, l = off & 63u, bpr = ts >> 3;
+  px = (tile % tx) * ts + (blk % bpr) * 8u + (l & 7u);
+  py = (tile / tx) * ts + (blk / bpr) * 8u + (l >> 3);
+  return tile < tx * ty && px < S.width && py < S.height;
+}
+
+__global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t* __restrict__ q, uint32_t* __restrict__ count,
+                                                    const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
+                                                    const uint32_t* __restrict__ seeds, uint32_t n_samples)
+{
+  const uint32_t per_sample = n_tiles * S.tile_size * S.tile_size;
+  const uint32_t total = per_sample * n_samples;
+  for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
+    const uint32_t pid = base + threadIdx.x;
+    bool valid = pid < total;
+    uint32_t px = 0, py = 0, s = 0;
+    if (valid) { s = pid / per_sample; valid = slot_pixel(S, tile_ids, pid - s * per_sample, px, py); }
+    if (valid) {
+      const uint32_t pix = S.coherent ? ((py / 16u) * ((S.width + 15u) / 16u) + (px / 16u)) : (py * S.width + px);
+      uint32_t rng = crh_rng_seed(pix, seeds[s]);
+      const float jx = crh_rng_next(&rng), jy = crh_rng_next(&rng);
+      const float nx = CRH_FMA(((float)px + jx) / (float)S.width, 2.0f, -1.0f);
+      const float ny = CRH_FMA(((float)py + jy) / (float)S.height, -2.0f, 1.0f);
+      v3 o, d;
+      if (S.is_ortho) {
+        const float sx = (nx * S.ortho_scale) * S.aspect, sy = ny * S.ortho_scale;
+        o = crh_madd3(crh_madd3(S.eye, S.right, sx), S.up, sy);
+        d = S.fwd;
+      } else {
+        const float sx = (nx * S.tan_half) * S.aspect, sy = ny * S.tan_half;
+        o = S.eye;
+        d = crh_norm3(crh_madd3(crh_madd3(S.fwd, S.right, sx), S.up, sy));
+      }
+      if (S.aperture > 0.f) {
+        const float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+        const float ft = S.focal / crh_dot3(d, S.fwd);
+        const v3 focus = crh_madd3(o, d, ft);
+        const float r = S.aperture * crh_sqrt(k1); float sn, cs; crh_sincos2pi(k2, &sn, &cs);
+        o = crh_madd3(crh_madd3(o, S.right, r * cs), S.up, r * sn);
+        d = crh_norm3(crh_sub3(focus, o));
+      }
+      P.ray_o[pid] = mk4(o, CRH_MAXFLOAT);
+      P.ray_d[pid] = mk4(d, 0.f);
+      P.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT);
+      P.rad[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      P.st[pid] = make_uint2(rng, 0u);
+    }
+    wave_enqueue(valid, pid, q, count);
+  }
+}
+
+// ================================================================== shade
+constexpr int kLdsMats = 64;   // materials staged in LDS (8 KB); larger tables are read from HBM/L2
+
+__global__ __launch_bounds__(kBlock) void k_shade(DScene S, DPaths P, uint32_t bounce,
+                                                   const uint32_t* __restrict__ q_in, const uint32_t* __restrict__ count_in,
+                                                   uint32_t* __restrict__ q_out, uint32_t* __restrict__ count_out,
+                                                   uint32_t* __restrict__ q_sh, uint32_t* __restrict__ count_sh, DCounters* C)
+{
+  __shared__ float4 s_mats[kLdsMats * 8];
+  const bool mats_in_lds = S.n_mats <= (uint32_t)kLdsMats;
+  if (mats_in_lds) {
+    for (uint32_t i = threadIdx.x; i < S.n_mats * 8u; i += kBlock) s_mats[i] = S.mats[i];
+    __syncthreads();
+  }
+  const uint32_t n = *count_in;
+  const bool last = bounce + 1u >= S.max_depth;
+  uint32_t n_shaded = 0;
+  for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    const uint32_t i = base + threadIdx.x;
+    bool cont = false, shadow = false;
+    uint32_t pid = 0;
+    if (i < n) {
+      pid = q_in[i];
+      const float4 o4 = P.ray_o[pid], d4 = P.ray_d[pid], h = P.hit[pid], t4 = P.thr[pid];
+      float4 r4 = P.rad[pid];
+      uint2 st = P.st[pid];
+      const v3 o = xyz(o4), d = xyz(d4);
+      v3 W = xyz(t4); float imp_pdf = t4.w;
+      v3 rad = xyz(r4);
+      const int hk = __float_as_int(h.w);
+      const bool found = hk >= 0;
+      float exp_pdf;
+      const v3 le = intersect_light(S, o, d, bounce, found ? h.x : CRH_MAXFLOAT, exp_pdf);
+      if (le.x > 0.f || le.y > 0.f || le.z > 0.f || !found) {
+        const float mis = (bounce == 0u || imp_pdf == CRH_MAXFLOAT) ? 1.0f : (imp_pdf * imp_pdf) / CRH_FMA(exp_pdf, exp_pdf, imp_pdf * imp_pdf);
+        rad = crh_add3(rad, crh_scale3(crh_mul3(W, le), mis));
+        P.rad[pid] = mk4(rad, 0.f);
+      } else {
+        ++n_shaded;
+        const float4* tp = S.tris + 3u * (uint32_t)hk;
+        const float4* sp = S.shade + 3u * (uint32_t)hk;
+        const float4 a = tp[0], b4 = tp[1], c4 = tp[2], s0 = sp[0], s1 = sp[1], s2 = sp[2];
+        const v3 p0 = xyz(a), p1 = xyz(b4), p2 = xyz(c4);
+        const v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
+        const float w0 = (1.0f - h.y) - h.z;
+        v3 ns = crh_norm3(crh_mk3(CRH_FMA(s2.x, h.z, CRH_FMA(s1.x, h.y, s0.x * w0)),
+                                  CRH_FMA(s2.y, h.z, CRH_FMA(s1.y, h.y, s0.y * w0)),
+                                  CRH_FMA(s2.z, h.z, CRH_FMA(s1.z, h.y, s0.z * w0))));
+        if (!(crh_dot3(ns, ns) > 0.f)) ns = ng;
+        const v3 p = crh_madd3(o, d, h.x);
+        int mat = __float_as_int(s0.w); if (mat < 0 || (uint32_t)mat >= S.n_mats) mat = 0;
+        const float4* mp = mats_in_lds ? (s_mats + 8 * mat) : (S.mats + 8 * mat);
+        Bsdf bs;
+        { const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3], m4 = mp[4];
+          bs.Kc = xyz(m0); bs.Rc = m0.w; bs.Kd = xyz(m1); bs.Ks = xyz(m2); bs.Rs = m2.w; bs.Kt = xyz(m3); bs.Le = xyz(m4);
+          bs.ab = mp[5]; bs.fc = mp[6]; bs.fb = mp[7]; }
+        const Frame fr = make_frame(ns);
+        const v3 wo = to_local(fr, crh_mk3(-d.x, -d.y, -d.z));
+        bs.Fc = fresnel_media(wo.z, bs.fc);
+        bool inside = (st.y & 1u) != 0u;
+        if (inside) {
+          const float k = -(h.x * bs.ab.w);
+          W = crh_mul3(W, crh_mk3(crh_exp(k * (1.0f - bs.ab.x)), crh_exp(k * (1.0f - bs.ab.y)), crh_exp(k * (1.0f - bs.ab.z))));
+        }
+        rad = crh_add3(rad, crh_mul3(W, bs.Le));
+        uint32_t rng = st.x;
+        // ---- next event estimation
+        {
+          const v3 z3 = crh_mk3(0.f, 0.f, 0.f);
+          const v3 nd = crh_add3(bs.Kd, crh_add3(bs.Rc > kBsdfEps ? bs.Kc : z3, bs.Rs > kBsdfEps ? bs.Ks : z3));
+          if (S.n_lights > 0u && crh_dot3(nd, W) > kBsdfEps) {
+            const float fl = crh_rng_next(&rng) * (float)S.n_lights;
+            uint32_t li = (uint32_t)fl; if (li > S.n_lights - 1u) li = S.n_lights - 1u;
+            const float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+            const float4 l0 = S.lights[2u * li], l1 = S.lights[2u * li + 1u];
+            v3 axis; float dist, cm;
+            if (l0.w != 0.f) { const v3 tl = crh_sub3(xyz(l0), p); dist = crh_len3(tl); axis = crh_scale3(tl, 1.0f / dist); cm = sphere_cosmax(l1.w, dist); }
+            else { axis = xyz(l0); dist = CRH_MAXFLOAT; cm = l1.w; }
+            const Frame lf = make_frame(axis);
+            const float ct = CRH_FMA(-k2, 1.0f - cm, 1.0f);
+            float sn, cs; crh_sincos2pi(k1, &sn, &cs);
+            const float sq = crh_sqrt(crh_max(CRH_FMA(-ct, ct, 1.0f), 0.f));
+            const v3 ld = crh_norm3(from_local(lf, crh_mk3(cs * sq, sn * sq, ct)));
+            const float e_pdf = (cm < 1.0f) ? (1.0f / (float)S.n_lights) * cone_pdf(cm) : CRH_MAXFLOAT;
+            const v3 wi = to_local(fr, ld);
+            const float i_pdf = pdf_layered(bs, wo, wi, W, S.two_sided);
+            const float mis = (e_pdf == CRH_MAXFLOAT) ? 1.0f : e_pdf / CRH_FMA(e_pdf, e_pdf, i_pdf * i_pdf);
+            const v3 contrib = crh_scale3(crh_mul3(xyz(l1), eval_layered(bs, wi, wo, S.two_sided)), mis);
+            const v3 wc = crh_mul3(W, contrib);
+            if (contrib.x > kMinContrib || contrib.y > kMinContrib || contrib.z > kMinContrib) {
+              shadow = true;
+              P.sh_o[pid] = mk4(offset_origin(p, ld, ng, S.eps), dist);
+              P.sh_d[pid] = mk4(ld, 0.f);
+              P.sh_c[pid] = mk4(wc, 0.f);
+            }
+          }
+        }
+        P.rad[pid] = mk4(rad, 0.f);
+        // ---- BSDF sampling + Russian roulette (the last bounce has no successor ray)
+        if (!last) {
+          v3 wi; bool delta; const v3 Wsel = W;
+          const bool alive = sample_layered(bs, wo, wi, W, inside, delta, rng, S.two_sided);
+          if (alive) imp_pdf = delta ? CRH_MAXFLOAT : pdf_layered(bs, wo, wi, Wsel, S.two_sided);
+          float survive = (W.x > kMinThroughput || W.y > kMinThroughput || W.z > kMinThroughput) ? 1.0f : 0.f;
+          if (S.rr && bounce >= 3u)
+            survive = crh_min(CRH_FMA(0.0722f, W.z, CRH_FMA(0.7152f, W.y, 0.2126f * W.x)), 0.95f) * survive;
+          const float kr = crh_rng_next(&rng);
+          if (alive && kr < survive) {
+            if (S.rr && bounce >= 3u) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
+            const v3 nd2 = crh_norm3(from_local(fr, wi));
+            P.ray_o[pid] = mk4(offset_origin(p, nd2, ng, S.eps), CRH_MAXFLOAT);
+            P.ray_d[pid] = mk4(nd2, 0.f);
+            P.thr[pid] = mk4(W, imp_pdf);
+            P.st[pid] = make_uint2(rng, inside ? 1u : 0u);
+            cont = true;
+          }
+        }
+      }
+    }
+    wave_enqueue(shadow, pid, q_sh, count_sh);
+    wave_enqueue(cont, pid, q_out, count_out);
+  }
+  n_shaded = wave_sum(n_shaded);
+  if (lane_id() == 0 && n_shaded) atomicAdd(&C->shaded_hits, (unsigned long long)n_shaded);
+}
+
+// ================================================================== accumulate / display
+__global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float4* __restrict__ accum,
+                                                        const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
+                                                        uint32_t n_samples, DCounters* C)
+{
+  const uint32_t per_sample = n_tiles * S.tile_size * S.tile_size;
+  uint32_t done = 0;
+  for (uint32_t local = blockIdx.x * kBlock + threadIdx.x; local < per_sample; local += gridDim.x * kBlock) {
+    uint32_t px, py;
+    if (!slot_pixel(S, tile_ids, local, px, py)) continue;
+    float4 a = accum[(size_t)py * S.width + px];
+    for (uint32_t s = 0; s < n_samples; ++s) {
+      const float4 r = P.rad[s * per_sample + local];
+      const float w = 1.0f / (a.w + 1.0f);
+      float v[3] = {r.x, r.y, r.z};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (!(v[k] == v[k])) v[k] = 0.f;
+        if (S.clampv > 0.f && v[k] > S.clampv) v[k] = S.clampv;
+      }
+      a.x = CRH_FMA(v[0] - a.x, w, a.x);
+      a.y = CRH_FMA(v[1] - a.y, w, a.y);
+      a.z = CRH_FMA(v[2] - a.z, w, a.z);
+      a.w = a.w + 1.0f;
+      ++done;
+    }
+    accum[(size_t)py * S.width + px] = a;
+  }
+  done = wave_sum(done);
+  if (lane_id() == 0 && done) atomicAdd(&C->samples, (unsigned long long)done);
+}
+
+__device__ __forceinline__ float hable(float x)
+{
+  const float A = 0.22f, B = 0.30f, Cc = 0.10f, D = 0.20f, E = 0.01f, F = 0.30f;
+  return (CRH_FMA(x, CRH_FMA(A, x, Cc * B), D * E) / CRH_FMA(x, CRH_FMA(A, x, B), D * F)) - E / F;
+}
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float4* __restrict__ accum, uint8_t* __restrict__ out, uint32_t n,
+                                                     int mode, float exposure, float white_point)
+{
+  const float gain = crh_exp(exposure * 0.69314718056f);
+  const float wp = hable(white_point > 0.f ? white_point : 1.0f);
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 a = accum[i];
+    float v[3] = {a.x, a.y, a.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float x = v[k];
+      if (!(x == x) || x < 0.f) x = 0.f;
+      x = x * gain;
+      if (mode == 1) x = hable(x) / wp;
+      x = crh_pow(crh_clamp(x, 0.f, 1.0f), 1.0f / 2.2f);
+      out[3u * i + k] = (uint8_t)(int)CRH_FMA(x, 255.0f, 0.5f);
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_hdr(const float4* __restrict__ accum, float* __restrict__ out, uint32_t n)
+{
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 a = accum[i];
+    out[3u * i] = a.x; out[3u * i + 1u] = a.y; out[3u * i + 2u] = a.z;
+  }
+}
+
+__global__ void k_debug_math(int fn, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                             float* __restrict__ out2, uint32_t n)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    switch (fn) {
+      case 0: crh_sincos2pi(a[i], &out[i], &out2[i]); break;
+      case 1: out[i] = crh_exp(a[i]); break;
+      case 2: out[i] = crh_log(a[i]); break;
+      case 3: out[i] = crh_pow(a[i], b[i]); break;
+      case 4: out[i] = crh_acos(a[i]); break;
+      case 5: out[i] = crh_atan2(a[i], b[i]); break;
+      case 6: crh_sincos(a[i], &out[i], &out2[i]); break;
+      case 7: out[i] = crh_sqrt(a[i]); break;
+      case 8: out[i] = a[i] / b[i]; break;
+      case 9: { uint32_t s = crh_rng_seed(__float_as_uint(a[i]), __float_as_uint(b[i])); out[i] = crh_rng_next(&s); out2[i] = crh_rng_next(&s); } break;
+      case 10: { const v3 x = crh_norm3(crh_mk3(a[i], b[i], a[i] * b[i])); out[i] = x.x; out2[i] = crh_dot3(x, crh_mk3(b[i], a[i], 1.0f)); } break;
+      default: out[i] = 0.f;
+    }
+  }
+}
+
+}  // namespace
+
+// ================================================================== launch wrappers
+void launch_raygen(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qsel,
+                   const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds, uint32_t n_samples)
+{
+  hipMemsetAsync(Q.counts + qsel, 0, sizeof(uint32_t), L.stream);
+  hipLaunchKernelGGL(k_raygen, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, d_tile_ids, n_tiles, d_seeds, n_samples);
+}
+void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, DCounters* C)
+{
+  if (L.counters)
+    hipLaunchKernelGGL(k_trace_nearest<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], Q.counts + qin, Q.counts + (1 - qin), Q.counts + 2, C);
+  else
+    hipLaunchKernelGGL(k_trace_nearest<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], Q.counts + qin, Q.counts + (1 - qin), Q.counts + 2, C);
+}
+void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, uint32_t bounce, DCounters* C)
+{
+  hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, bounce, Q.q[qin], Q.counts + qin,
+                     Q.q[1 - qin], Q.counts + (1 - qin), Q.q_sh, Q.counts + 2, C);
+}
+void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, DCounters* C)
+{
+  if (L.counters) hipLaunchKernelGGL(k_trace_any<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, C);
+  else            hipLaunchKernelGGL(k_trace_any<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, C);
+}
+void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, const uint32_t* d_tile_ids,
+                       uint32_t n_tiles, uint32_t n_samples, DCounters* C)
+{
+  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, d_tile_ids, n_tiles, n_samples, C);
+}
+void launch_tonemap(const Launch& L, const float4* accum, uint8_t* out, uint32_t n, int mode, float exposure, float wp)
+{
+  hipLaunchKernelGGL(k_tonemap, dim3(L.grid), dim3(kBlock), 0, L.stream, accum, out, n, mode, exposure, wp);
+}
+void launch_hdr(const Launch& L, const float4* accum, float* out, uint32_t n)
+{
+  hipLaunchKernelGGL(k_hdr, dim3(L.grid), dim3(kBlock), 0, L.stream, accum, out, n);
+}
+void launch_trace_rays(const Launch& L, const DScene& S, const float4* rays, uint32_t n, int any_hit, float4* out_hit,
+                       uint32_t* out_vis, DCounters* C)
+{
+  if (any_hit) {
+    if (L.counters) hipLaunchKernelGGL((k_trace_rays<true, true>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, out_hit, out_vis, C);
+    else            hipLaunchKernelGGL((k_trace_rays<true, false>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, out_hit, out_vis, C);
+  } else {
+    if (L.counters) hipLaunchKernelGGL((k_trace_rays<false, true>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, out_hit, out_vis, C);
+    else            hipLaunchKernelGGL((k_trace_rays<false, false>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, out_hit, out_vis, C);
+  }
+}
+void launch_debug_math(const Launch& L, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n)
+{
+  hipLaunchKernelGGL(k_debug_math, dim3(L.grid), dim3(kBlock), 0, L.stream, fn, a, b, out, out2, n);
+}
+
+}  // namespace crh

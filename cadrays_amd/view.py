@@ -1,0 +1,101 @@
+"""Host-side mirror of the rendering boundary CADRays drives (reference file:line in brackets).
+
+    view = View(device=0)                       # new OpenGl_GraphicDriver + V3d_Viewer + CreateView   [AppViewer.cxx:601-638]
+    view.load_scene(scene)                      # AIS Display + SetBSDF + lights + env + camera          [AisMesh.cxx:357-423, MaterialEditor.cxx:331-337]
+    view.ChangeRenderingParams(max_depth=5)     # Graphic3d_RenderingParams field writes                 [SettingsWidget.cxx:263-477]
+    view.Redraw()                               # +1 sample per pixel                                    [AppViewer.cxx:1047]
+    img = view.BufferDump(BT_RGB_RayTraceHdrLeft)   # linear HDR read-back                               [AppGui.cxx:345-349]
+
+Everything below the method names is libcadrays_hip.so (hand-written gfx950 kernels) through ctypes.
+"""
+import ctypes as C
+import dataclasses
+
+import numpy as np
+
+from ._lib import load_library
+from .binding import Backend
+
+BT_RGB = "Graphic3d_BT_RGB"                             # AppViewer.cxx:1259-1261
+BT_RGB_RayTraceHdrLeft = "Graphic3d_BT_RGB_RayTraceHdrLeft"   # AppGui.cxx:349
+
+
+class View(Backend):
+    def __init__(self, device=0):
+        super().__init__(load_library(), "crh_", (C.c_int(int(device)),))
+        self.device = int(device)
+        self._params = None
+
+    # ---- V3d_View vocabulary ----------------------------------------------------------------
+    def Redraw(self):
+        """One progressive iteration: +1 spp over the whole target (AppViewer.cxx:1047)."""
+        self.render(1)
+
+    def BufferDump(self, buffer_type=BT_RGB):
+        if buffer_type == BT_RGB_RayTraceHdrLeft:
+            return self.read_hdr()
+        if buffer_type == BT_RGB:
+            return self.read_ldr()
+        raise ValueError(buffer_type)
+
+    def set_params(self, p):
+        self._params = dataclasses.replace(p)
+        super().set_params(p)
+
+    def ChangeRenderingParams(self, **fields):
+        """Write Graphic3d_RenderingParams fields; like OCCT, any change restarts accumulation."""
+        if self._params is None:
+            raise RuntimeError("set_params / load_scene first")
+        self.set_params(dataclasses.replace(self._params, **fields))
+
+    # ---- device-side extras -----------------------------------------------------------------
+    def sync(self):
+        self._call("sync")
+
+    def enable_counters(self, on=True):
+        self._call("enable_counters", C.c_int(int(on)))
+
+    def enable_kernel_timing(self, on=True):
+        self._call("enable_kernel_timing", C.c_int(int(on)))
+
+    def kernel_timing(self):
+        ms, n, allms = C.c_double(0), C.c_uint64(0), C.c_double(0)
+        self._call("get_kernel_timing", C.byref(ms), C.byref(n), C.byref(allms))
+        return {"trace_nearest_ms_total": ms.value, "trace_nearest_launches": n.value, "render_ms_total": allms.value}
+
+    def accum_device_ptr(self):
+        p, n = C.c_void_p(0), C.c_uint64(0)
+        self._call("accum_device_ptr", C.byref(p), C.byref(n))
+        return p.value, n.value
+
+    def bench_trace(self, rays, any_hit=False, repeat=10):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        ms = C.c_float(0)
+        self._call("bench_trace", rays.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(len(rays)), C.c_int(int(any_hit)),
+                   C.c_uint32(repeat), C.byref(ms))
+        return ms.value
+
+    def debug_math(self, fn, a, b=None):
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), np.float32)
+        out, out2 = np.empty_like(a), np.empty_like(a)
+        fp = C.POINTER(C.c_float)
+        self._call("debug_math", C.c_int(fn), a.ctypes.data_as(fp), b.ctypes.data_as(fp), out.ctypes.data_as(fp),
+                   out2.ctypes.data_as(fp), C.c_uint32(a.size))
+        return out, out2
+
+
+def build_bvh_host(pos, tri, threads=0):
+    """Run the product's BVH builder on the host only (no GPU): returns (nodes[n,32] f32, prim_order[nT] u32)."""
+    lib = load_library()
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    tri = np.ascontiguousarray(tri, np.int32).reshape(-1, 4)
+    nn = C.c_uint32(0)
+    fp, ip, up = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    args = (pos.ctypes.data_as(fp), C.c_uint32(len(pos)), tri.ctypes.data_as(ip), C.c_uint32(len(tri)), C.c_int(threads))
+    nodes = np.empty((max(len(tri), 4), 32), np.float32)   # nodes <= max(1, ~nT/2)
+    order = np.empty(len(tri), np.uint32)
+    rc = lib.crh_build_bvh_host(*args, nodes.ctypes.data_as(fp), C.byref(nn), order.ctypes.data_as(up))
+    if rc != 0:
+        raise RuntimeError(f"crh_build_bvh_host -> {rc}")
+    return nodes[:nn.value].copy(), order

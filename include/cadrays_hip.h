@@ -1,0 +1,202 @@
+/* cadrays_hip.h -- C ABI of libcadrays_hip.so, the MI355X path-tracing backend that
+ * stands where CADRays calls OCCT's ray-tracing core.
+ *
+ * Every entry point cites the reference call (file:line under /root/reference) it
+ * replaces; see INTEGRATION.md for the shim a CADRays maintainer would add.
+ *
+ * Conventions: plain C, opaque handle, int status (0 = ok, negative = CRH_E_*),
+ * caller owns all input buffers (copied during the call), the module owns device
+ * memory, one host thread per context, one context per GPU.  No torch types.
+ */
+#ifndef CADRAYS_HIP_H
+#define CADRAYS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define CRH_API __attribute__((visibility("default")))
+#else
+#define CRH_API
+#endif
+
+#define CRH_OK            0
+#define CRH_E_INVALID    -1   /* bad argument / bad state               */
+#define CRH_E_DEVICE     -2   /* HIP runtime error (see crh_last_error) */
+#define CRH_E_NOMEM      -3
+#define CRH_E_NOTBUILT   -4   /* render/trace before crh_build          */
+
+typedef struct crh_ctx crh_ctx;
+
+/* The double-layer material, field-for-field Graphic3d_BSDF as the reference fills
+ * and serialises it (MaterialEditor.cxx:281-338, ImportExport.cxx:164-231):
+ *   Kc.rgb coat weight, Kc.w coat roughness        (MaterialEditor.cxx:890-896)
+ *   Kd.rgb diffuse weight                          (:680)
+ *   Ks.rgb glossy weight,  Ks.w base roughness     (:707-713)
+ *   Kt.rgb transmission weight                     (:811)
+ *   Le.rgb emission                                (:1068-1089)
+ *   Absorption.rgb colour, .w coefficient          (:817-823)
+ *   FresnelCoat / FresnelBase: serialised Graphic3d_Fresnel (MaterialEditor.cxx:209-255):
+ *       Schlick    : x,y,z = F0 rgb (x >= 0)
+ *       Constant   : x = -1, z = value
+ *       Conductor  : x = -2, y = n, z = k
+ *       Dielectric : x = -3, y = n
+ */
+typedef struct crh_bsdf {
+  float Kc[4];
+  float Kd[4];
+  float Ks[4];
+  float Kt[4];
+  float Le[4];
+  float Absorption[4];
+  float FresnelCoat[4];
+  float FresnelBase[4];
+} crh_bsdf;                       /* 128 B */
+
+#define CRH_FRESNEL_CONSTANT   -1.0f
+#define CRH_FRESNEL_CONDUCTOR  -2.0f
+#define CRH_FRESNEL_DIELECTRIC -3.0f
+
+/* V3d directional / positional light as the light editor sets it
+ * (LightSourcesEditor.cxx:242-310): colour*intensity -> emission;
+ * directional: vec = direction the light travels, smoothness = cone half-angle [rad];
+ * positional : vec = position, smoothness = sphere radius. */
+typedef struct crh_light {
+  float vec[3];
+  float is_point;                 /* 0 = directional, 1 = positional */
+  float emission[3];
+  float smoothness;
+} crh_light;                      /* 32 B */
+
+/* Graphic3d_Camera subset the reference drives (AppViewer.cxx:993-1042,
+ * SettingsWidget.cxx:179-229). */
+typedef struct crh_camera {
+  float eye[3];
+  float dir[3];
+  float up[3];
+  float fovy_deg;                 /* perspective: vertical field of view      */
+  float aspect;                   /* width / height; <= 0 -> taken from params */
+  int32_t is_ortho;
+  float ortho_scale;              /* orthographic: half height of the view    */
+  float aperture_radius;          /* CameraApertureRadius  (0 = pinhole)      */
+  float focal_dist;               /* CameraFocalPlaneDist                     */
+} crh_camera;
+
+/* Graphic3d_RenderingParams subset (SettingsWidget.cxx:65-90, 263-477). */
+typedef struct crh_params {
+  uint32_t width, height;         /* render target (SettingsWidget.cxx:93-123)        */
+  uint32_t max_depth;             /* RaytracingDepth 1..32 (:310-315)                  */
+  float    radiance_clamp;        /* RadianceClampingValue (:318-325); <=0 = no clamp  */
+  int32_t  two_sided;             /* TwoSidedBsdfModels (:328-333)                     */
+  int32_t  coherent_rng;          /* CoherentPathTracingMode (:419-424)                */
+  uint32_t seed;                  /* Bullard generator seed; OCCT restarts with 1      */
+  uint32_t tile_size;             /* RT tile edge in pixels (sharding unit), e.g. 32   */
+  int32_t  tonemap_mode;          /* 0 = disabled, 1 = filmic (:343-404)               */
+  float    exposure;              /* stops                                              */
+  float    white_point;
+  float    background[3];         /* linear radiance used when no env map is set       */
+  int32_t  env_as_background;     /* UseEnvironmentMapBackground (LightSourcesEditor.cxx:359-364) */
+  float    scene_epsilon;         /* <= 0: auto = max(1e-6, 1e-5 * scene diagonal)      */
+  int32_t  russian_roulette;      /* 1 = on (default in GI mode)                        */
+} crh_params;
+
+typedef struct crh_stats {
+  uint64_t rays_nearest;          /* nearest-hit rays traced            */
+  uint64_t rays_any;              /* any-hit (shadow) rays traced       */
+  uint64_t nodes_nearest;         /* QBVH inner-node visits by nearest-hit rays  (N_inner = nearest + any) */
+  uint64_t tris_nearest;          /* ray/triangle tests by nearest-hit rays      (N_tri   = nearest + any) */
+  uint64_t nodes_any;             /* ... by any-hit rays                */
+  uint64_t tris_any;
+  uint64_t shaded_hits;           /* H                                  */
+  uint64_t samples;               /* pixel-samples accumulated (S)      */
+  double   seconds;               /* device time inside crh_render*     */
+} crh_stats;
+
+/* create/destroy == new OpenGl_GraphicDriver + V3d_Viewer + CreateView + FBOCreate
+ * (AppViewer.cxx:601-638) / release (AppViewer.cxx:1268). */
+CRH_API crh_ctx*    crh_create(int device_ordinal);
+CRH_API void        crh_destroy(crh_ctx* ctx);
+CRH_API const char* crh_last_error(crh_ctx* ctx);
+
+/* geometry == what AIS Display/SetLocation feeds OpenGl_SceneGeometry: indexed
+ * triangle arrays with normals (+uv) and a material id per triangle
+ * (AisMesh.cxx:357-423), per-object 3x4 row-major transforms (DataNode.cxx:239-242). */
+CRH_API int crh_set_geometry(crh_ctx* ctx,
+                     const float* pos, const float* nrm, const float* uv, uint32_t n_vertices,
+                     const int32_t* tri /* 4*nT: i0,i1,i2,material */, uint32_t n_triangles,
+                     const int32_t* tri_object /* nT or NULL */,
+                     const float* obj_xform /* 12*nO or NULL */, uint32_t n_objects);
+/* == Graphic3d_MaterialAspect::SetBSDF + SynchronizeAspects (MaterialEditor.cxx:331-337, Utils.cxx:57-93) */
+CRH_API int crh_set_materials(crh_ctx* ctx, const crh_bsdf* m, uint32_t n);
+/* == V3d_Viewer::SetLightOn/UpdateLights (LightSourcesEditor.cxx:47-87, 401-413) */
+CRH_API int crh_set_lights(crh_ctx* ctx, const crh_light* l, uint32_t n);
+/* == V3d_View::SetTextureEnv (LightSourcesEditor.cxx:339-354); rgb = W*H*3 linear float
+ * lat-long, NULL = constant crh_params.background */
+CRH_API int crh_set_envmap(crh_ctx* ctx, const float* rgb, uint32_t w, uint32_t h);
+/* == Graphic3d_Camera setters (AppViewer.cxx:993-1042) */
+CRH_API int crh_set_camera(crh_ctx* ctx, const crh_camera* cam);
+/* == ChangeRenderingParams() field writes (SettingsWidget.cxx:263-477) */
+CRH_API int crh_set_params(crh_ctx* ctx, const crh_params* p);
+/* == OCCT updateRaytraceGeometry + uploadRaytraceData on a changed scene: BVH build,
+ * QBVH collapse, upload.  Invalidates the accumulator. */
+CRH_API int crh_build(crh_ctx* ctx);
+/* == accumulation restart (camera/scene/param change, AppViewer.cxx:979-984) */
+CRH_API int crh_reset(crh_ctx* ctx);
+/* == n x V3d_View::Redraw() (AppViewer.cxx:1047): +n samples per pixel over the whole target */
+CRH_API int crh_render(crh_ctx* ctx, uint32_t n_iterations);
+/* The RT tile entry point (adaptive tiles, SettingsWidget.cxx:451-476): render samples
+ * [first_sample, first_sample + n_samples) of the listed tiles only.  Tiles are
+ * tile_size x tile_size, numbered row-major over ceil(W/ts) x ceil(H/ts). */
+CRH_API int crh_render_tiles(crh_ctx* ctx, const uint32_t* tile_ids, uint32_t n_tiles,
+                     uint32_t first_sample, uint32_t n_samples);
+/* wait for all queued device work of this context */
+CRH_API int crh_sync(crh_ctx* ctx);
+/* == BufferDump(Graphic3d_BT_RGB_RayTraceHdrLeft -> ImgRGBF) (AppGui.cxx:345-349):
+ * W*H*3 linear float, row 0 = top */
+CRH_API int crh_read_hdr(crh_ctx* ctx, float* rgb_out);
+/* == BufferDump(Graphic3d_BT_RGB) (AppViewer.cxx:1259-1261): W*H*3 uint8 after exposure,
+ * tone map, gamma 2.2 */
+CRH_API int crh_read_ldr(crh_ctx* ctx, uint8_t* rgb_out);
+/* Device address of the float4 accumulator (W*H*4 floats: rgb running mean, a = number of
+ * samples accumulated in that pixel) so a host process can hand it to RCCL without a copy.
+ * Replaces the zero-copy GL texture id the GUI displays (AppViewer.cxx:1099). */
+CRH_API int crh_accum_device_ptr(crh_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
+/* counters since the last crh_reset; collecting node/triangle counters needs
+ * crh_enable_counters(ctx, 1) (slower kernels) */
+CRH_API int crh_enable_counters(crh_ctx* ctx, int on);
+CRH_API int crh_get_stats(crh_ctx* ctx, crh_stats* out);
+
+/* --- kernel-level entry points (parity tests and micro-benchmarks) ------------------ */
+/* Trace n rays {ox,oy,oz,tmax, dx,dy,dz,tmin-unused} (8 floats each) against the built scene.
+ * nearest: out_hit = n x {t, u, v, prim-id-as-int-bits}; prim = -1 on miss, t = tmax.
+ * any    : out_vis = n x uint32 (1 = unoccluded up to tmax). */
+CRH_API int crh_trace_nearest(crh_ctx* ctx, const float* rays, uint32_t n, float* out_hit);
+CRH_API int crh_trace_any(crh_ctx* ctx, const float* rays, uint32_t n, uint32_t* out_vis);
+/* Copy out the built QBVH: nodes (32 floats = 128 B each) and the leaf-ordered triangle
+ * records (12 floats = 48 B each).  Pass NULL buffers to query the counts. */
+CRH_API int crh_get_bvh(crh_ctx* ctx, float* nodes, uint32_t* n_nodes, float* tris, uint32_t* n_tris);
+/* Host-only: run the BVH builder (no device needed) and copy out nodes / leaf-ordered triangles.
+ * Call with NULL outputs to get the counts.  == BVH_BinnedBuilder + CollapseToQuadTree. */
+CRH_API int crh_build_bvh_host(const float* pos, uint32_t n_vertices, const int32_t* tri, uint32_t n_triangles, int threads,
+                       float* nodes, uint32_t* n_nodes, uint32_t* prim_order);
+/* Device-resident micro-benchmark: trace the same device ray buffer `repeat` times, return
+ * average kernel milliseconds measured with HIP events on the context's stream. */
+CRH_API int crh_bench_trace(crh_ctx* ctx, const float* rays, uint32_t n, int any_hit, uint32_t repeat,
+                    float* avg_ms);
+/* Average duration (ms) of the dominant kernel (nearest-hit traversal) launches since the last
+ * crh_reset, measured with HIP events on the launch stream when timing is enabled. */
+/* Test hook: evaluate an elementary function of include/crh_math.h on the device, n elements
+ * (fn: 0 sincos2pi, 1 exp, 2 log, 3 pow(a,b), 4 acos, 5 atan2(a,b), 6 sincos, 7 sqrt, 8 a/b, 9 rng stream
+ * of seed (a-bits, b-bits)).  The parity tests require bit equality with the CPU build. */
+CRH_API int crh_debug_math(crh_ctx* ctx, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n);
+CRH_API int crh_enable_kernel_timing(crh_ctx* ctx, int on);
+CRH_API int crh_get_kernel_timing(crh_ctx* ctx, double* trace_ms_total, uint64_t* trace_launches,
+                          double* all_ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CADRAYS_HIP_H */

@@ -1,0 +1,1020 @@
+/* crh_oracle.c -- CPU restatement of the path-tracing hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * library; the product (cadrays_amd/, libcadrays_hip.so) never links or calls it.
+ *
+ * PARITY UNPINNED against the reference renderer: the algorithm CADRays runs on this path
+ * lives in Open CASCADE Technology's TKOpenGl (OpenGl_View_Raytrace.cxx, src/Shaders/
+ * {RaytraceBase,PathtraceBase,Display}.fs, BVH_* package), an external, un-vendored,
+ * version-unpinned dependency ("Current OCCT development snapshot", reference README.md:51;
+ * found via CMakeLists.txt:64-71) that is absent from /root/reference and from this image.
+ * The reference holds no golden image, known-answer vector or expected number for the path
+ * (testing/CADRays_Testing.py compares against a user-supplied template folder).  What this
+ * file follows is therefore (1) the reference's *input contract* -- cited per function -- and
+ * (2) the published structure of OCCT's GLSL path tracer restated as this project's frozen
+ * spec (DESIGN.md "Algorithm spec").  It is pinned by analytic known-answer tests
+ * (tests/test_oracle_kat.py) and by self-generated golden vectors (tests/golden/).
+ *
+ * Plain C, scalar, AoS, recursive -- written independently of the HIP product; they share only
+ * include/crh_math.h (the definition of the elementary arithmetic) and include/cadrays_hip.h
+ * (the input structs of the boundary).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/crh_math.h"
+#include "../include/cadrays_hip.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ spec constants */
+#define BVH_NBINS      32          /* OCCT BVH_Constants_NbBinsOptimal [OCCT-ext]           */
+#define BVH_LEAF       4           /* max triangles per leaf                                 */
+#define BVH_MAXDEPTH   40          /* binary depth bound (root = 0); median splits keep it  */
+#define QBVH_EMPTY     0xFFFFFFFFu
+#define QBVH_LEAFBIT   0x80000000u
+#define STACK_MAX      64          /* >= 3 * ceil((BVH_MAXDEPTH+1)/2)                       */
+#define DIR_EPS        1.0e-15f
+#define BSDF_EPS       1.0e-5f     /* roughness / weight threshold ("FLT_EPSILON" in GLSL)  */
+#define MIN_THROUGHPUT 1.0e-3f
+#define MIN_CONTRIB    1.0e-2f
+#define LUMA_R 0.2126f
+#define LUMA_G 0.7152f
+#define LUMA_B 0.0722f
+
+typedef crh_v3 v3;
+
+typedef struct { float f[32]; } qnode;     /* 128 B: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] rsv[4] */
+typedef struct { float f[12]; } qtri;      /* 48 B: v0.xyz,prim | v1.xyz,0 | v2.xyz,0 */
+
+typedef struct { uint64_t nodes, tris, nodes_any, tris_any; } trav_counters;
+
+typedef struct orc_ctx {
+  /* inputs */
+  uint32_t nV, nT, nM, nL;
+  float* pos; float* nrm; float* uv; int32_t* tri;
+  crh_bsdf* mats; crh_light* lights;
+  float* env; uint32_t envW, envH;
+  crh_camera cam; crh_params par;
+  /* derived */
+  qnode* nodes; uint32_t nNodes; qtri* qtris; uint32_t nQT;
+  float bbmin[3], bbmax[3]; float eps;
+  int built;
+  /* camera frame */
+  v3 c_eye, c_fwd, c_right, c_up; float c_tanh, c_aspect;
+  /* lights prepared: vec = to-light dir (directional, normalized) or position; param = cosmax or radius */
+  v3* l_vec; float* l_par;
+  /* accumulator */
+  float* accum;     /* W*H*4 */
+  crh_stats st;
+  char err[256];
+} orc_ctx;
+
+/* ------------------------------------------------------------------ Bullard frame seeds */
+/* SURVEY.md a14 / Appendix A [OCCT-ext]: host generator reseeded when accumulation restarts;
+ * frame n uses next() >> 2. */
+static uint32_t frame_seed(uint32_t seed, uint32_t n)
+{
+  uint32_t hi = seed, lo = seed ^ 0x49616E42u, r = 0;
+  for (uint32_t i = 0; i <= n; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; r = hi; }
+  return r >> 2;
+}
+
+/* ================================================================== BVH build */
+typedef struct { float mn[3], mx[3]; } aabb;
+typedef struct { aabb box; int32_t left, right; uint32_t lo, hi; } bnode;   /* left < 0 => leaf [lo,hi) */
+
+typedef struct {
+  const aabb* pb; const float* cen; /* 3*n */
+  uint32_t* idx; uint32_t* tmp;
+  bnode* bn; uint32_t nbn, cap;
+} builder;
+
+static void aabb_empty(aabb* b) { for (int a = 0; a < 3; ++a) { b->mn[a] = 3.0e38f; b->mx[a] = -3.0e38f; } }
+static void aabb_grow(aabb* b, const aabb* o)
+{ for (int a = 0; a < 3; ++a) { if (o->mn[a] < b->mn[a]) b->mn[a] = o->mn[a]; if (o->mx[a] > b->mx[a]) b->mx[a] = o->mx[a]; } }
+static float aabb_harea(const aabb* b)
+{
+  float dx = b->mx[0] - b->mn[0], dy = b->mx[1] - b->mn[1], dz = b->mx[2] - b->mn[2];
+  return CRH_FMA(dx, dy, CRH_FMA(dy, dz, dz * dx));
+}
+static int ceil_log2_u32(uint32_t v) { int l = 0; uint32_t p = 1; while (p < v) { p <<= 1; ++l; } return l; }
+
+/* sort helper for median splits: total order (key, prim index) */
+typedef struct { float k; uint32_t i; } keyidx;
+static int keyidx_cmp(const void* a, const void* b)
+{
+  const keyidx* x = (const keyidx*)a; const keyidx* y = (const keyidx*)b;
+  if (x->k < y->k) return -1; if (x->k > y->k) return 1;
+  return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0);
+}
+
+static uint32_t bn_new(builder* B)
+{
+  if (B->nbn == B->cap) { B->cap *= 2; B->bn = (bnode*)realloc(B->bn, sizeof(bnode) * B->cap); }
+  return B->nbn++;
+}
+
+static uint32_t build_rec(builder* B, uint32_t lo, uint32_t hi, int depth)
+{
+  uint32_t me = bn_new(B);
+  aabb box; aabb_empty(&box);
+  for (uint32_t i = lo; i < hi; ++i) aabb_grow(&box, &B->pb[B->idx[i]]);
+  uint32_t n = hi - lo;
+  B->bn[me].box = box; B->bn[me].lo = lo; B->bn[me].hi = hi; B->bn[me].left = B->bn[me].right = -1;
+  if (n <= BVH_LEAF) return me;
+
+  /* centroid bounds */
+  float cmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (uint32_t i = lo; i < hi; ++i) {
+    const float* c = &B->cen[3 * B->idx[i]];
+    for (int a = 0; a < 3; ++a) { if (c[a] < cmn[a]) cmn[a] = c[a]; if (c[a] > cmx[a]) cmx[a] = c[a]; }
+  }
+  uint32_t mid = 0; int done = 0;
+  /* depth budget: once balanced median splits are needed to finish within BVH_MAXDEPTH, use them */
+  int need = ceil_log2_u32((n + BVH_LEAF - 1) / BVH_LEAF);
+  int force_median = (depth + need >= BVH_MAXDEPTH);
+
+  if (!force_median) {
+    float best = 3.0e38f; int baxis = -1, bsplit = -1;
+    for (int a = 0; a < 3; ++a) {
+      float ext = cmx[a] - cmn[a];
+      if (!(ext > 0.f)) continue;
+      uint32_t cnt[BVH_NBINS]; aabb bb[BVH_NBINS];
+      for (int b = 0; b < BVH_NBINS; ++b) { cnt[b] = 0; aabb_empty(&bb[b]); }
+      for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t p = B->idx[i];
+        int b = (int)(((B->cen[3 * p + a] - cmn[a]) / ext) * (float)BVH_NBINS);
+        if (b > BVH_NBINS - 1) b = BVH_NBINS - 1;
+        cnt[b]++; aabb_grow(&bb[b], &B->pb[p]);
+      }
+      /* right-to-left suffix */
+      float rarea[BVH_NBINS]; uint32_t rcnt[BVH_NBINS];
+      aabb acc; aabb_empty(&acc); uint32_t c = 0;
+      for (int b = BVH_NBINS - 1; b >= 1; --b) { if (cnt[b]) aabb_grow(&acc, &bb[b]); c += cnt[b]; rcnt[b] = c; rarea[b] = c ? aabb_harea(&acc) : 0.f; }
+      aabb_empty(&acc); c = 0;
+      for (int s = 0; s < BVH_NBINS - 1; ++s) {   /* split after bin s: left = bins [0..s] */
+        if (cnt[s]) aabb_grow(&acc, &bb[s]); c += cnt[s];
+        if (c == 0 || rcnt[s + 1] == 0) continue;
+        float cost = CRH_FMA(aabb_harea(&acc), (float)c, rarea[s + 1] * (float)rcnt[s + 1]);
+        if (cost < best) { best = cost; baxis = a; bsplit = s; }
+      }
+    }
+    if (baxis >= 0) {
+      /* stable partition by bin(prim) <= bsplit */
+      float ext = cmx[baxis] - cmn[baxis];
+      uint32_t nl = 0, nr = 0;
+      for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t p = B->idx[i];
+        int b = (int)(((B->cen[3 * p + baxis] - cmn[baxis]) / ext) * (float)BVH_NBINS);
+        if (b > BVH_NBINS - 1) b = BVH_NBINS - 1;
+        if (b <= bsplit) B->idx[lo + nl++] = p; else B->tmp[nr++] = p;
+      }
+      memcpy(&B->idx[lo + nl], B->tmp, sizeof(uint32_t) * nr);
+      mid = lo + nl; done = 1;
+    }
+  }
+  if (!done) {
+    /* median split along the widest centroid axis (ties: lowest axis); zero extent -> index order */
+    int ax = 0; float e0 = cmx[0] - cmn[0], e1 = cmx[1] - cmn[1], e2 = cmx[2] - cmn[2];
+    float em = e0; if (e1 > em) { em = e1; ax = 1; } if (e2 > em) { em = e2; ax = 2; }
+    if (em > 0.f) {
+      keyidx* ks = (keyidx*)malloc(sizeof(keyidx) * n);
+      for (uint32_t i = 0; i < n; ++i) { ks[i].i = B->idx[lo + i]; ks[i].k = B->cen[3 * ks[i].i + ax]; }
+      qsort(ks, n, sizeof(keyidx), keyidx_cmp);
+      for (uint32_t i = 0; i < n; ++i) B->idx[lo + i] = ks[i].i;
+      free(ks);
+    }
+    mid = lo + n / 2;
+  }
+  uint32_t l = build_rec(B, lo, mid, depth + 1);
+  uint32_t r = build_rec(B, mid, hi, depth + 1);
+  B->bn[me].left = (int32_t)l; B->bn[me].right = (int32_t)r;
+  return me;
+}
+
+/* collapse binary -> 4-wide (OCCT BVH_Tree::CollapseToQuadTree idea: children := grandchildren),
+ * nodes numbered in DFS pre-order, children visited in slot order. */
+typedef struct { const bnode* bn; qnode* qn; uint32_t nq, capq; } collapser;
+
+static uint32_t leaf_ref(const bnode* b)
+{ return QBVH_LEAFBIT | ((b->hi - b->lo - 1u) << 28) | b->lo; }
+
+static uint32_t collapse_rec(collapser* C, uint32_t bi)
+{
+  if (C->nq == C->capq) { C->capq *= 2; C->qn = (qnode*)realloc(C->qn, sizeof(qnode) * C->capq); }
+  uint32_t me = C->nq++;
+  uint32_t kids[4]; int nk = 0;
+  const bnode* b = &C->bn[bi];
+  if (b->left < 0) { kids[nk++] = bi; }
+  else {
+    uint32_t two[2] = {(uint32_t)b->left, (uint32_t)b->right};
+    for (int k = 0; k < 2; ++k) {
+      const bnode* c = &C->bn[two[k]];
+      if (c->left < 0) kids[nk++] = two[k];
+      else { kids[nk++] = (uint32_t)c->left; kids[nk++] = (uint32_t)c->right; }
+    }
+  }
+  qnode q; memset(&q, 0, sizeof q);
+  uint32_t refs[4] = {QBVH_EMPTY, QBVH_EMPTY, QBVH_EMPTY, QBVH_EMPTY};
+  for (int k = 0; k < 4; ++k) {
+    if (k < nk) {
+      const bnode* c = &C->bn[kids[k]];
+      q.f[0 + k] = c->box.mn[0]; q.f[4 + k] = c->box.mn[1]; q.f[8 + k] = c->box.mn[2];
+      q.f[12 + k] = c->box.mx[0]; q.f[16 + k] = c->box.mx[1]; q.f[20 + k] = c->box.mx[2];
+    } else {
+      q.f[0 + k] = q.f[4 + k] = q.f[8 + k] = 3.0e38f;
+      q.f[12 + k] = q.f[16 + k] = q.f[20 + k] = -3.0e38f;
+    }
+  }
+  for (int k = 0; k < nk; ++k) {
+    const bnode* c = &C->bn[kids[k]];
+    if (c->left < 0) refs[k] = (c->hi > c->lo) ? leaf_ref(c) : QBVH_EMPTY;
+    else             refs[k] = collapse_rec(C, kids[k]);
+  }
+  for (int k = 0; k < 4; ++k) q.f[24 + k] = crh_u2f(refs[k]);
+  q.f[28] = crh_u2f((uint32_t)nk);
+  C->qn[me] = q;
+  return me;
+}
+
+static int do_build(orc_ctx* c)
+{
+  uint32_t n = c->nT;
+  free(c->nodes); free(c->qtris); c->nodes = NULL; c->qtris = NULL;
+  aabb* pb = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
+  float* cen = (float*)malloc(sizeof(float) * 3 * (n ? n : 1));
+  aabb sb; aabb_empty(&sb);
+  for (uint32_t t = 0; t < n; ++t) {
+    aabb b; aabb_empty(&b);
+    for (int k = 0; k < 3; ++k) {
+      const float* p = &c->pos[3 * c->tri[4 * t + k]];
+      for (int a = 0; a < 3; ++a) { if (p[a] < b.mn[a]) b.mn[a] = p[a]; if (p[a] > b.mx[a]) b.mx[a] = p[a]; }
+    }
+    pb[t] = b; aabb_grow(&sb, &b);
+    for (int a = 0; a < 3; ++a) cen[3 * t + a] = (b.mn[a] + b.mx[a]) * 0.5f;
+  }
+  builder B; B.pb = pb; B.cen = cen;
+  B.idx = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  B.tmp = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  for (uint32_t t = 0; t < n; ++t) B.idx[t] = t;
+  B.cap = 1024; B.nbn = 0; B.bn = (bnode*)malloc(sizeof(bnode) * B.cap);
+  build_rec(&B, 0, n, 0);
+  collapser C; C.bn = B.bn; C.capq = 1024; C.nq = 0; C.qn = (qnode*)malloc(sizeof(qnode) * C.capq);
+  collapse_rec(&C, 0);
+  c->nodes = C.qn; c->nNodes = C.nq;
+  c->qtris = (qtri*)malloc(sizeof(qtri) * (n ? n : 1)); c->nQT = n;
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t t = B.idx[i]; qtri* q = &c->qtris[i];
+    for (int k = 0; k < 3; ++k) {
+      const float* p = &c->pos[3 * c->tri[4 * t + k]];
+      q->f[4 * k + 0] = p[0]; q->f[4 * k + 1] = p[1]; q->f[4 * k + 2] = p[2]; q->f[4 * k + 3] = 0.f;
+    }
+    q->f[3] = crh_u2f(t);
+  }
+  if (n) { for (int a = 0; a < 3; ++a) { c->bbmin[a] = sb.mn[a]; c->bbmax[a] = sb.mx[a]; } }
+  else   { for (int a = 0; a < 3; ++a) { c->bbmin[a] = 0.f; c->bbmax[a] = 0.f; } }
+  free(pb); free(cen); free(B.idx); free(B.tmp); free(B.bn);
+  return 0;
+}
+
+/* ================================================================== traversal */
+typedef struct { float t, u, v; int32_t prim; } hit_t;
+
+static inline float inv_dir(float d) { return 1.0f / (crh_abs(d) < DIR_EPS ? (d < 0.f ? -DIR_EPS : DIR_EPS) : d); }
+
+/* Ray/triangle: n = (v0-v2) x (v1-v0); t = n.(v0-o) / n.d; u,v from (d x (v0-o)). */
+static inline int tri_test(const qtri* q, v3 o, v3 d, float tmax, float* t, float* u, float* v)
+{
+  v3 v0 = crh_mk3(q->f[0], q->f[1], q->f[2]), v1 = crh_mk3(q->f[4], q->f[5], q->f[6]), v2 = crh_mk3(q->f[8], q->f[9], q->f[10]);
+  v3 e0 = crh_sub3(v1, v0), e1 = crh_sub3(v0, v2);
+  v3 n = crh_cross3(e1, e0);
+  v3 to = crh_sub3(v0, o);
+  float inv = 1.0f / crh_dot3(n, d);
+  v3 vc = crh_cross3(d, to);
+  float tt = crh_dot3(n, to) * inv;
+  float uu = crh_dot3(vc, e1) * inv;
+  float vv = crh_dot3(vc, e0) * inv;
+  if (tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f && tt < tmax) { *t = tt; *u = uu; *v = vv; return 1; }
+  return 0;
+}
+
+/* Ordered stack traversal of the 4-wide BVH.  any_hit: stop at the first accepted triangle. */
+static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t* h, trav_counters* cn)
+{
+  uint32_t stack[STACK_MAX]; int sp = 0;
+  float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
+  float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
+  float best = tmax; int found = 0;
+  h->t = tmax; h->u = 0.f; h->v = 0.f; h->prim = -1;
+  uint32_t cur = 0;
+  for (;;) {
+    if (cur & QBVH_LEAFBIT) {
+      uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        float t, u, v; if (any_hit) cn->tris_any++; else cn->tris++;
+        if (tri_test(&c->qtris[off + k], o, d, best, &t, &u, &v)) {
+          best = t; found = 1; h->t = t; h->u = u; h->v = v; h->prim = (int32_t)crh_f2u(c->qtris[off + k].f[3]);
+          if (any_hit) return 1;
+        }
+      }
+    } else {
+      const qnode* q = &c->nodes[cur]; if (any_hit) cn->nodes_any++; else cn->nodes++;
+      uint32_t key[4]; uint32_t rf[4]; int nh = 0;
+      for (int k = 0; k < 4; ++k) {
+        uint32_t r = crh_f2u(q->f[24 + k]);
+        if (r == QBVH_EMPTY) continue;
+        float a0 = CRH_FMA(q->f[0 + k], ix, nox),  a1 = CRH_FMA(q->f[12 + k], ix, nox);
+        float b0 = CRH_FMA(q->f[4 + k], iy, noy),  b1 = CRH_FMA(q->f[16 + k], iy, noy);
+        float c0 = CRH_FMA(q->f[8 + k], iz, noz),  c1 = CRH_FMA(q->f[20 + k], iz, noz);
+        float tmin = crh_max(crh_max(crh_max(crh_min(a0, a1), crh_min(b0, b1)), crh_min(c0, c1)), 0.f);
+        float tmx  = crh_min(crh_min(crh_min(crh_max(a0, a1), crh_max(b0, b1)), crh_max(c0, c1)), best);
+        if (tmin <= tmx) {
+          /* order key: entry distance with the slot index in the two low mantissa bits -> unique keys,
+           * ascending unsigned order == near-to-far, ties by slot */
+          int32_t bits = (int32_t)crh_f2u(tmin); if (bits < 0) bits = 0;
+          uint32_t ky = ((uint32_t)bits & ~3u) | (uint32_t)k;
+          int j = nh++;
+          while (j > 0 && key[j - 1] > ky) { key[j] = key[j - 1]; rf[j] = rf[j - 1]; --j; }
+          key[j] = ky; rf[j] = r;
+        }
+      }
+      if (nh > 0) {
+        for (int j = nh - 1; j >= 1; --j) stack[sp++] = rf[j];   /* far .. near */
+        cur = rf[0];
+        continue;
+      }
+    }
+    if (sp == 0) break;
+    cur = stack[--sp];
+  }
+  return found;
+}
+
+/* ================================================================== BSDF */
+typedef struct { v3 Kc; float Rc; v3 Kd; v3 Ks; float Rs; v3 Kt; v3 Le; v3 Fc; float fc[4]; float fb[4]; float ab[4]; } bsdf_t;
+
+static v3 fresnel_media(float cosI, const float f[4])
+{
+  if (f[0] > -0.5f) {                                 /* Schlick: F0 + (1-F0)(1-|cos|)^5 */
+    float m = 1.0f - crh_abs(cosI); float m2 = m * m; float m5 = (m2 * m2) * m;
+    return crh_mk3(CRH_FMA(1.0f - f[0], m5, f[0]), CRH_FMA(1.0f - f[1], m5, f[1]), CRH_FMA(1.0f - f[2], m5, f[2]));
+  }
+  if (f[0] > -1.5f) return crh_mk3(f[2], f[2], f[2]); /* constant */
+  if (f[0] > -2.5f) {                                 /* conductor (n = y, k = z), unpolarised approx. */
+    float ci = crh_abs(cosI), n = f[1], k = f[2];
+    float tmp = (2.0f * n) * ci;
+    float t1 = CRH_FMA(n, n, k * k);
+    float ci2 = ci * ci;
+    float sperp = ((t1 - tmp) + ci2) / ((t1 + tmp) + ci2);
+    float t2 = t1 * ci2;
+    float sparl = ((t2 - tmp) + 1.0f) / ((t2 + tmp) + 1.0f);
+    float r = (sperp + sparl) * 0.5f;
+    return crh_mk3(r, r, r);
+  }
+  {                                                   /* dielectric (n = y), signed cosine */
+    float n = f[1];
+    float etaI = cosI > 0.f ? 1.0f : n, etaT = cosI > 0.f ? n : 1.0f;
+    float r = 1.0f;
+    float ratio = etaI / etaT;
+    float sinT2 = (ratio * ratio) * CRH_FMA(-cosI, cosI, 1.0f);
+    if (sinT2 < 1.0f) {
+      float ci = crh_abs(cosI), ct = crh_sqrt(1.0f - sinT2);
+      float parl = (etaT * ci - etaI * ct) / (etaT * ci + etaI * ct);
+      float perp = (etaI * ci - etaT * ct) / (etaI * ci + etaT * ct);
+      r = (parl * parl + perp * perp) * 0.5f;
+    }
+    return crh_mk3(r, r, r);
+  }
+}
+
+static float smith_g1(v3 w, v3 m, float rough)
+{
+  float r = 0.f;
+  if (crh_dot3(w, m) * w.z > 0.f) {
+    float tanT = crh_sqrt(crh_max(CRH_FMA(-w.z, w.z, 1.0f), 0.f)) / w.z;
+    if (tanT == 0.f) r = 1.0f;
+    else {
+      float a = 1.0f / (rough * tanT);
+      r = CRH_FMA(2.181f, a, 3.535f) / CRH_FMA(2.577f, a, 1.0f / a + 2.276f);
+    }
+  }
+  return crh_min(r, 1.0f);
+}
+
+static float blinn_power(float rough) { return crh_max(2.0f / (rough * rough) - 2.0f, 0.f); }
+
+/* f * cos(theta_i) of the Blinn microfacet lobe, local frame, wi.z, wo.z > 0 required */
+static v3 eval_blinn(v3 wi, v3 wo, const float fr[4], float rough)
+{
+  if (wi.z <= 0.f || wo.z <= 0.f) return crh_mk3(0.f, 0.f, 0.f);
+  v3 h = crh_norm3(crh_add3(wi, wo));
+  float e = blinn_power(rough);
+  float D = ((e + 2.0f) * CRH_INV_TWOPI) * crh_pow(h.z, e);
+  float G = smith_g1(wo, h, rough) * smith_g1(wi, h, rough);
+  v3 F = fresnel_media(crh_dot3(wo, h), fr);
+  float s = (D * G) / (4.0f * wo.z);
+  return crh_scale3(F, s);
+}
+
+static v3 eval_layered(const bsdf_t* b, v3 wi, v3 wo, int two_sided)
+{
+  if (two_sided) { wi.z *= crh_sign(wo.z); wo.z *= crh_sign(wo.z); }   /* same hemisphere test in the +z frame */
+  float lam = (wi.z <= 0.f || wo.z <= 0.f) ? 0.f : wi.z * CRH_INV_PI;
+  v3 r = crh_scale3(b->Kd, lam);
+  if (b->Rs > BSDF_EPS) r = crh_add3(r, crh_mul3(b->Ks, eval_blinn(wi, wo, b->fb, b->Rs)));
+  r = crh_mul3(r, crh_mk3(1.0f - b->Fc.x, 1.0f - b->Fc.y, 1.0f - b->Fc.z));
+  if (b->Rc > BSDF_EPS) r = crh_add3(r, crh_mul3(b->Kc, eval_blinn(wi, wo, b->fc, b->Rc)));
+  return r;
+}
+
+typedef struct { float pc, pd, ps, pt, total; v3 Tc; } lobes_t;
+static void lobe_probs(const bsdf_t* b, v3 W, lobes_t* L)
+{
+  L->Tc = crh_mk3(1.0f - b->Fc.x, 1.0f - b->Fc.y, 1.0f - b->Fc.z);
+  L->pc = crh_dot3(crh_mul3(b->Kc, b->Fc), W);
+  L->pd = crh_dot3(crh_mul3(b->Kd, L->Tc), W);
+  L->ps = crh_dot3(crh_mul3(b->Ks, L->Tc), W);
+  L->pt = crh_dot3(crh_mul3(b->Kt, L->Tc), W);
+  L->total = ((L->pc + L->pd) + L->ps) + L->pt;
+}
+
+static float blinn_pdf(float hz, float dotih, float rough)
+{
+  float e = blinn_power(rough);
+  return (((e + 2.0f) * CRH_INV_TWOPI) * crh_pow(crh_abs(hz), e + 1.0f)) / (4.0f * crh_abs(dotih));
+}
+
+/* mixture pdf of the non-delta lobes for direction wi (solid angle) */
+static float pdf_layered(const bsdf_t* b, v3 wo, v3 wi, v3 W, int two_sided)
+{
+  lobes_t L; lobe_probs(b, W, &L);
+  if (!(L.total > BSDF_EPS)) return 0.f;
+  if (two_sided) { wi.z *= crh_sign(wo.z); wo.z *= crh_sign(wo.z); }
+  float pdf = 0.f;
+  if (wi.z > 0.f && wo.z > 0.f) {
+    v3 h = crh_norm3(crh_add3(wi, wo));
+    float dih = crh_dot3(wi, h);
+    pdf = L.pd * (wi.z * CRH_INV_PI);
+    if (b->Rc > BSDF_EPS) pdf = CRH_FMA(L.pc, blinn_pdf(h.z, dih, b->Rc), pdf);
+    if (b->Rs > BSDF_EPS) pdf = CRH_FMA(L.ps, blinn_pdf(h.z, dih, b->Rs), pdf);
+  }
+  return pdf / L.total;
+}
+
+/* Blinn half-vector sampling; returns f*cos/pdf (without K), sets *ok = 0 for a failed sample */
+static v3 sample_blinn(v3 wo, v3* wi, const float fr[4], float rough, uint32_t* rng, int two_sided, int* ok)
+{
+  float k1 = crh_rng_next(rng), k2 = crh_rng_next(rng);
+  float e = blinn_power(rough);
+  float cm = crh_pow(k1, 1.0f / (e + 2.0f));
+  float s, c; crh_sincos2pi(k2, &s, &c);
+  float sm = crh_sqrt(crh_max(CRH_FMA(-cm, cm, 1.0f), 0.f));
+  v3 m = crh_mk3(c * sm, s * sm, cm);
+  int flip = 0;
+  if (two_sided && wo.z < 0.f) { flip = 1; wo.z = -wo.z; }
+  float cd = crh_dot3(wo, m);
+  *wi = crh_mk3(CRH_FMA(2.0f * cd, m.x, -wo.x), CRH_FMA(2.0f * cd, m.y, -wo.y), CRH_FMA(2.0f * cd, m.z, -wo.z));
+  if (wi->z <= 0.f || wo.z <= 0.f || !(cd > 0.f)) { *ok = 0; return crh_mk3(0.f, 0.f, 0.f); }
+  float G = smith_g1(wo, m, rough) * smith_g1(*wi, m, rough);
+  v3 F = fresnel_media(cd, fr);
+  float w = (G * cd) / (wo.z * m.z);
+  if (flip) wi->z = -wi->z;
+  *ok = 1;
+  return crh_scale3(F, w);
+}
+
+/* Sample the layered BSDF.  In: wo, throughput *W (updated), *inside (toggled on transmission).
+ * Out: wi (local), *delta = 1 when a delta lobe was chosen.  Returns 0 when the path dies. */
+static int sample_layered(const bsdf_t* b, v3 wo, v3* wi, v3* W, int* inside, int* delta, uint32_t* rng, int two_sided)
+{
+  lobes_t L; lobe_probs(b, *W, &L);
+  float ksi = L.total * crh_rng_next(rng);
+  *delta = 0;
+  if (!(L.total > BSDF_EPS)) { *W = crh_mk3(0.f, 0.f, 0.f); return 0; }
+  v3 mirror = crh_mk3(-wo.x, -wo.y, wo.z);
+  int ok = 1; v3 k;
+  if (ksi < L.pc) {                                           /* coat reflection */
+    k = crh_scale3(b->Kc, L.total / L.pc);
+    if (b->Rc > BSDF_EPS) k = crh_mul3(k, sample_blinn(wo, wi, b->fc, b->Rc, rng, two_sided, &ok));
+    else { k = crh_mul3(k, b->Fc); *wi = mirror; *delta = 1; }
+  } else if (ksi < L.pc + L.pd) {                             /* diffuse base */
+    k = crh_scale3(crh_mul3(b->Kd, L.Tc), L.total / L.pd);
+    float k1 = crh_rng_next(rng), k2 = crh_rng_next(rng);
+    float s, c; crh_sincos2pi(k1, &s, &c);
+    float r = crh_sqrt(k2);
+    *wi = crh_mk3(c * r, s * r, crh_sqrt(1.0f - k2));
+    if (two_sided) { if (wo.z < 0.f) wi->z = -wi->z; }
+    else if (!(wo.z > 0.f)) ok = 0;
+  } else if (ksi < (L.pc + L.pd) + L.ps) {                    /* glossy base */
+    k = crh_scale3(crh_mul3(b->Ks, L.Tc), L.total / L.ps);
+    if (b->Rs > BSDF_EPS) k = crh_mul3(k, sample_blinn(wo, wi, b->fb, b->Rs, rng, two_sided, &ok));
+    else { k = crh_mul3(k, fresnel_media(wo.z, b->fb)); *wi = mirror; *delta = 1; }
+  } else {                                                    /* specular transmission */
+    k = crh_scale3(crh_mul3(b->Kt, L.Tc), L.total / L.pt);
+    float ior = b->fc[1];
+    float eta = wo.z > 0.f ? 1.0f / ior : ior;
+    float sinT2 = (eta * eta) * CRH_FMA(-wo.z, wo.z, 1.0f);
+    if (!(sinT2 < 1.0f) || !(L.pt > 0.f)) ok = 0;
+    else {
+      float ct = crh_sqrt(1.0f - sinT2); if (wo.z > 0.f) ct = -ct;
+      *wi = crh_norm3(crh_mk3(-(eta * wo.x), -(eta * wo.y), ct));
+      *inside = !*inside; *delta = 1;
+    }
+  }
+  if (!ok) { *W = crh_mk3(0.f, 0.f, 0.f); return 0; }
+  *W = crh_mul3(*W, k);
+  return 1;
+}
+
+static void load_bsdf(const orc_ctx* c, int32_t mat, bsdf_t* b)
+{
+  const crh_bsdf* m = &c->mats[(mat >= 0 && (uint32_t)mat < c->nM) ? mat : 0];
+  b->Kc = crh_mk3(m->Kc[0], m->Kc[1], m->Kc[2]); b->Rc = m->Kc[3];
+  b->Kd = crh_mk3(m->Kd[0], m->Kd[1], m->Kd[2]);
+  b->Ks = crh_mk3(m->Ks[0], m->Ks[1], m->Ks[2]); b->Rs = m->Ks[3];
+  b->Kt = crh_mk3(m->Kt[0], m->Kt[1], m->Kt[2]);
+  b->Le = crh_mk3(m->Le[0], m->Le[1], m->Le[2]);
+  memcpy(b->fc, m->FresnelCoat, 16); memcpy(b->fb, m->FresnelBase, 16); memcpy(b->ab, m->Absorption, 16);
+}
+
+/* ================================================================== lights / env (a11, a12) */
+typedef struct { v3 t, b, n; } frame_t;
+static frame_t make_frame(v3 n)
+{
+  frame_t f; f.n = n;
+  v3 t = (crh_abs(n.x) > crh_abs(n.z)) ? crh_mk3(-n.y, n.x, 0.f) : crh_mk3(0.f, -n.z, n.y);
+  f.t = crh_norm3(t); f.b = crh_cross3(n, f.t);
+  return f;
+}
+static v3 to_local(const frame_t* f, v3 v) { return crh_mk3(crh_dot3(v, f->t), crh_dot3(v, f->b), crh_dot3(v, f->n)); }
+static v3 from_local(const frame_t* f, v3 l)
+{
+  return crh_mk3(CRH_FMA(f->n.x, l.z, CRH_FMA(f->b.x, l.y, f->t.x * l.x)),
+                 CRH_FMA(f->n.y, l.z, CRH_FMA(f->b.y, l.y, f->t.y * l.x)),
+                 CRH_FMA(f->n.z, l.z, CRH_FMA(f->b.z, l.y, f->t.z * l.x)));
+}
+
+static float lerpf(float a, float b, float t) { return CRH_FMA(t, b - a, a); }
+
+static v3 env_lookup(const orc_ctx* c, v3 d)
+{
+  if (!c->env) return crh_mk3(c->par.background[0], c->par.background[1], c->par.background[2]);
+  float u = (crh_atan2(d.y, d.x) + CRH_PI) * CRH_INV_TWOPI;
+  float v = crh_acos(d.z) * CRH_INV_PI;
+  float x = CRH_FMA(u, (float)c->envW, -0.5f), y = CRH_FMA(v, (float)c->envH, -0.5f);
+  float xf = (float)(int)x; if (xf > x) xf -= 1.0f;
+  float yf = (float)(int)y; if (yf > y) yf -= 1.0f;
+  float fx = x - xf, fy = y - yf;
+  int W = (int)c->envW, H = (int)c->envH;
+  int x0 = (int)xf % W; if (x0 < 0) x0 += W; int x1 = x0 + 1; if (x1 >= W) x1 = 0;
+  int y0 = (int)yf; int y1 = y0 + 1;
+  if (y0 < 0) y0 = 0; if (y0 > H - 1) y0 = H - 1; if (y1 < 0) y1 = 0; if (y1 > H - 1) y1 = H - 1;
+  const float* p00 = &c->env[3 * (y0 * W + x0)]; const float* p10 = &c->env[3 * (y0 * W + x1)];
+  const float* p01 = &c->env[3 * (y1 * W + x0)]; const float* p11 = &c->env[3 * (y1 * W + x1)];
+  return crh_mk3(lerpf(lerpf(p00[0], p10[0], fx), lerpf(p01[0], p11[0], fx), fy),
+                 lerpf(lerpf(p00[1], p10[1], fx), lerpf(p01[1], p11[1], fx), fy),
+                 lerpf(lerpf(p00[2], p10[2], fx), lerpf(p01[2], p11[2], fx), fy));
+}
+
+static float cone_pdf(float cosmax) { return 1.0f / (CRH_TWO_PI * (1.0f - cosmax)); }
+static float sphere_cosmax(float radius, float dist) { return 1.0f / crh_sqrt(CRH_FMA(radius / dist, radius / dist, 1.0f)); }
+
+/* Radiance arriving along a BSDF-sampled (or camera) ray from the analytic lights in front of the
+ * surface hit, or from the environment on a miss; *exp_pdf = pdf NEE would have had. */
+static v3 intersect_light(const orc_ctx* c, v3 o, v3 d, int bounce, float hit_t_, float* exp_pdf)
+{
+  v3 rad = crh_mk3(0.f, 0.f, 0.f); float pdf = 0.f; float hd = hit_t_;
+  float sel = c->nL ? 1.0f / (float)c->nL : 0.f;
+  for (uint32_t i = 0; i < c->nL; ++i) {
+    const crh_light* l = &c->lights[i];
+    if (l->is_point != 0.f) {
+      v3 tl = crh_sub3(c->l_vec[i], o);
+      float dist = crh_len3(tl);
+      if (dist < hd) {
+        float cm = sphere_cosmax(c->l_par[i], dist);
+        if (cm < 1.0f && crh_dot3(d, tl) * (1.0f / dist) >= cm) {
+          hd = dist; rad = crh_mk3(l->emission[0], l->emission[1], l->emission[2]); pdf = sel * cone_pdf(cm);
+        }
+      }
+    } else if (hd == CRH_MAXFLOAT) {
+      float cm = c->l_par[i];
+      if (cm < 1.0f && crh_dot3(d, c->l_vec[i]) >= cm) {
+        rad = crh_add3(rad, crh_mk3(l->emission[0], l->emission[1], l->emission[2]));
+        pdf += sel * cone_pdf(cm);
+      }
+    }
+  }
+  if (pdf == 0.f && hd == CRH_MAXFLOAT) {
+    if (bounce == 0 && !c->par.env_as_background)
+      rad = crh_mk3(c->par.background[0], c->par.background[1], c->par.background[2]);
+    else rad = env_lookup(c, d);
+  }
+  *exp_pdf = pdf;
+  return rad;
+}
+
+/* ================================================================== path integrator (a13) */
+static void gen_camera_ray(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t* rng, v3* o, v3* d)
+{
+  float jx = crh_rng_next(rng), jy = crh_rng_next(rng);
+  float W = (float)c->par.width, H = (float)c->par.height;
+  float nx = CRH_FMA(((float)px + jx) / W, 2.0f, -1.0f);
+  float ny = CRH_FMA(((float)py + jy) / H, -2.0f, 1.0f);
+  if (c->cam.is_ortho) {
+    float sx = (nx * c->cam.ortho_scale) * c->c_aspect, sy = ny * c->cam.ortho_scale;
+    *o = crh_madd3(crh_madd3(c->c_eye, c->c_right, sx), c->c_up, sy);
+    *d = c->c_fwd;
+  } else {
+    float sx = (nx * c->c_tanh) * c->c_aspect, sy = ny * c->c_tanh;
+    *o = c->c_eye;
+    *d = crh_norm3(crh_madd3(crh_madd3(c->c_fwd, c->c_right, sx), c->c_up, sy));
+  }
+  if (c->cam.aperture_radius > 0.f) {
+    float k1 = crh_rng_next(rng), k2 = crh_rng_next(rng);
+    float ft = c->cam.focal_dist / crh_dot3(*d, c->c_fwd);
+    v3 focus = crh_madd3(*o, *d, ft);
+    float r = c->cam.aperture_radius * crh_sqrt(k1); float s, cc; crh_sincos2pi(k2, &s, &cc);
+    *o = crh_madd3(crh_madd3(*o, c->c_right, r * cc), c->c_up, r * s);
+    *d = crh_norm3(crh_sub3(focus, *o));
+  }
+}
+
+static v3 offset_origin(v3 p, v3 dir, v3 ng, float eps)
+{
+  v3 o = crh_madd3(p, dir, eps);
+  float s = crh_dot3(ng, dir) >= 0.f ? eps : -eps;
+  return crh_madd3(o, ng, s);
+}
+
+static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed, crh_stats* st, trav_counters* cn)
+{
+  uint32_t pix = c->par.coherent_rng ? ((py / 16u) * ((c->par.width + 15u) / 16u) + (px / 16u)) : (py * c->par.width + px);
+  uint32_t rng = crh_rng_seed(pix, fseed);
+  v3 o, d; gen_camera_ray(c, px, py, &rng, &o, &d);
+  v3 rad = crh_mk3(0.f, 0.f, 0.f), W = crh_mk3(1.0f, 1.0f, 1.0f);
+  int inside = 0; float imp_pdf = CRH_MAXFLOAT;
+  int two = c->par.two_sided;
+  for (uint32_t bounce = 0; bounce < c->par.max_depth; ++bounce) {
+    hit_t h; st->rays_nearest++;
+    int found = traverse(c, o, d, CRH_MAXFLOAT, 0, &h, cn);
+    float exp_pdf;
+    v3 le = intersect_light(c, o, d, (int)bounce, found ? h.t : CRH_MAXFLOAT, &exp_pdf);
+    if (le.x > 0.f || le.y > 0.f || le.z > 0.f || !found) {
+      float mis = (bounce == 0 || imp_pdf == CRH_MAXFLOAT) ? 1.0f : (imp_pdf * imp_pdf) / CRH_FMA(exp_pdf, exp_pdf, imp_pdf * imp_pdf);
+      rad = crh_add3(rad, crh_scale3(crh_mul3(W, le), mis));
+      break;
+    }
+    st->shaded_hits++;
+    const int32_t* ti = &c->tri[4 * h.prim];
+    v3 p0 = crh_mk3(c->pos[3 * ti[0]], c->pos[3 * ti[0] + 1], c->pos[3 * ti[0] + 2]);
+    v3 p1 = crh_mk3(c->pos[3 * ti[1]], c->pos[3 * ti[1] + 1], c->pos[3 * ti[1] + 2]);
+    v3 p2 = crh_mk3(c->pos[3 * ti[2]], c->pos[3 * ti[2] + 1], c->pos[3 * ti[2] + 2]);
+    v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
+    float w0 = (1.0f - h.u) - h.v;
+    const float* n0 = &c->nrm[3 * ti[0]]; const float* n1 = &c->nrm[3 * ti[1]]; const float* n2 = &c->nrm[3 * ti[2]];
+    v3 ns = crh_norm3(crh_mk3(CRH_FMA(n2[0], h.v, CRH_FMA(n1[0], h.u, n0[0] * w0)),
+                               CRH_FMA(n2[1], h.v, CRH_FMA(n1[1], h.u, n0[1] * w0)),
+                               CRH_FMA(n2[2], h.v, CRH_FMA(n1[2], h.u, n0[2] * w0))));
+    if (!(crh_dot3(ns, ns) > 0.f)) ns = ng;
+    v3 p = crh_madd3(o, d, h.t);
+    bsdf_t b; load_bsdf(c, ti[3], &b);
+    frame_t fr = make_frame(ns);
+    v3 wo = to_local(&fr, crh_mk3(-d.x, -d.y, -d.z));
+    b.Fc = fresnel_media(wo.z, b.fc);
+    if (inside) {                                           /* Beer-Lambert along the segment just travelled */
+      float k = -(h.t * b.ab[3]);
+      W = crh_mul3(W, crh_mk3(crh_exp(k * (1.0f - b.ab[0])), crh_exp(k * (1.0f - b.ab[1])), crh_exp(k * (1.0f - b.ab[2]))));
+    }
+    rad = crh_add3(rad, crh_mul3(W, b.Le));
+    /* next event estimation */
+    {
+      v3 nd = crh_add3(b.Kd, crh_add3(b.Rc > BSDF_EPS ? b.Kc : crh_mk3(0.f, 0.f, 0.f), b.Rs > BSDF_EPS ? b.Ks : crh_mk3(0.f, 0.f, 0.f)));
+      if (c->nL > 0 && crh_dot3(nd, W) > BSDF_EPS) {
+        float fl = crh_rng_next(&rng) * (float)c->nL;
+        uint32_t li = (uint32_t)fl; if (li > c->nL - 1u) li = c->nL - 1u;
+        float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+        const crh_light* l = &c->lights[li];
+        v3 axis; float dist, cm;
+        if (l->is_point != 0.f) { v3 tl = crh_sub3(c->l_vec[li], p); dist = crh_len3(tl); axis = crh_scale3(tl, 1.0f / dist); cm = sphere_cosmax(c->l_par[li], dist); }
+        else { axis = c->l_vec[li]; dist = CRH_MAXFLOAT; cm = c->l_par[li]; }
+        frame_t lf = make_frame(axis);
+        float ct = CRH_FMA(-k2, 1.0f - cm, 1.0f);
+        float s, cc; crh_sincos2pi(k1, &s, &cc);
+        float sn = crh_sqrt(crh_max(CRH_FMA(-ct, ct, 1.0f), 0.f));
+        v3 ld = crh_norm3(from_local(&lf, crh_mk3(cc * sn, s * sn, ct)));
+        float e_pdf = (cm < 1.0f) ? (1.0f / (float)c->nL) * cone_pdf(cm) : CRH_MAXFLOAT;
+        v3 wi = to_local(&fr, ld);
+        float i_pdf = pdf_layered(&b, wo, wi, W, two);
+        float mis = (e_pdf == CRH_MAXFLOAT) ? 1.0f : e_pdf / CRH_FMA(e_pdf, e_pdf, i_pdf * i_pdf);
+        v3 contrib = crh_scale3(crh_mul3(crh_mk3(l->emission[0], l->emission[1], l->emission[2]), eval_layered(&b, wi, wo, two)), mis);
+        v3 wc = crh_mul3(W, contrib);
+        if (contrib.x > MIN_CONTRIB || contrib.y > MIN_CONTRIB || contrib.z > MIN_CONTRIB) {
+          hit_t sh; st->rays_any++;
+          v3 so = offset_origin(p, ld, ng, c->eps);
+          if (!traverse(c, so, ld, dist, 1, &sh, cn)) rad = crh_add3(rad, wc);
+        }
+      }
+    }
+    /* BSDF sampling */
+    v3 wi; int delta; v3 Wsel = W;      /* lobe-selection weights = throughput before the bounce */
+    int alive = sample_layered(&b, wo, &wi, &W, &inside, &delta, &rng, two);
+    if (alive) imp_pdf = delta ? CRH_MAXFLOAT : pdf_layered(&b, wo, wi, Wsel, two);
+    float survive = (W.x > MIN_THROUGHPUT || W.y > MIN_THROUGHPUT || W.z > MIN_THROUGHPUT) ? 1.0f : 0.f;
+    if (c->par.russian_roulette && bounce >= 3)
+      survive = crh_min(CRH_FMA(LUMA_B, W.z, CRH_FMA(LUMA_G, W.y, LUMA_R * W.x)), 0.95f) * survive;
+    float kr = crh_rng_next(&rng);
+    if (!alive || !(kr < survive)) break;
+    if (c->par.russian_roulette && bounce >= 3) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
+    v3 nd2 = crh_norm3(from_local(&fr, wi));
+    o = offset_origin(p, nd2, ng, c->eps);
+    d = nd2;
+  }
+  return rad;
+}
+
+/* ================================================================== accumulate / render (a15) */
+static void prepare(orc_ctx* c)
+{
+  c->c_eye = crh_mk3(c->cam.eye[0], c->cam.eye[1], c->cam.eye[2]);
+  c->c_fwd = crh_norm3(crh_mk3(c->cam.dir[0], c->cam.dir[1], c->cam.dir[2]));
+  c->c_right = crh_norm3(crh_cross3(c->c_fwd, crh_mk3(c->cam.up[0], c->cam.up[1], c->cam.up[2])));
+  c->c_up = crh_cross3(c->c_right, c->c_fwd);
+  float s, cs; crh_sincos((c->cam.fovy_deg * 0.5f) * (CRH_PI / 180.0f), &s, &cs);
+  c->c_tanh = s / cs;
+  c->c_aspect = c->cam.aspect > 0.f ? c->cam.aspect : (float)c->par.width / (float)c->par.height;
+  free(c->l_vec); free(c->l_par);
+  c->l_vec = (v3*)malloc(sizeof(v3) * (c->nL ? c->nL : 1)); c->l_par = (float*)malloc(sizeof(float) * (c->nL ? c->nL : 1));
+  for (uint32_t i = 0; i < c->nL; ++i) {
+    const crh_light* l = &c->lights[i];
+    if (l->is_point != 0.f) { c->l_vec[i] = crh_mk3(l->vec[0], l->vec[1], l->vec[2]); c->l_par[i] = l->smoothness; }
+    else {
+      c->l_vec[i] = crh_norm3(crh_mk3(-l->vec[0], -l->vec[1], -l->vec[2]));
+      float sn, cn; crh_sincos(l->smoothness, &sn, &cn); c->l_par[i] = l->smoothness > 0.f ? cn : 1.0f;
+    }
+  }
+  v3 dg = crh_mk3(c->bbmax[0] - c->bbmin[0], c->bbmax[1] - c->bbmin[1], c->bbmax[2] - c->bbmin[2]);
+  c->eps = c->par.scene_epsilon > 0.f ? c->par.scene_epsilon : crh_max(1.0e-6f, 1.0e-5f * crh_len3(dg));
+}
+
+static void accumulate_px(const orc_ctx* c, float* a, v3 s)
+{
+  float clampv = c->par.radiance_clamp;
+  float r[3] = {s.x, s.y, s.z};
+  float n = a[3];
+  float w = 1.0f / (n + 1.0f);
+  for (int k = 0; k < 3; ++k) {
+    float v = r[k];
+    if (!(v == v)) v = 0.f;                 /* NaN -> 0 */
+    if (clampv > 0.f && v > clampv) v = clampv;
+    a[k] = CRH_FMA(v - a[k], w, a[k]);
+  }
+  a[3] = n + 1.0f;
+}
+
+static int render_tiles(orc_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, uint32_t ns)
+{
+  if (!c->built) return CRH_E_NOTBUILT;
+  uint32_t ts = c->par.tile_size ? c->par.tile_size : 32u;
+  uint32_t tx = (c->par.width + ts - 1) / ts, ty = (c->par.height + ts - 1) / ts;
+  uint32_t* seeds = (uint32_t*)malloc(sizeof(uint32_t) * (ns ? ns : 1));
+  for (uint32_t s = 0; s < ns; ++s) seeds[s] = frame_seed(c->par.seed, first + s);
+  struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  uint64_t rn = 0, ra = 0, nn = 0, tt = 0, na = 0, ta = 0, hh = 0, sm = 0;
+  uint32_t total = tiles ? nt : tx * ty;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : rn, ra, nn, tt, na, ta, hh, sm)
+  for (uint32_t ti = 0; ti < total; ++ti) {
+    uint32_t t = tiles ? tiles[ti] : ti;
+    if (t >= tx * ty) continue;
+    uint32_t x0 = (t % tx) * ts, y0 = (t / tx) * ts;
+    crh_stats st; memset(&st, 0, sizeof st); trav_counters cn = {0, 0, 0, 0};
+    for (uint32_t s = 0; s < ns; ++s)
+      for (uint32_t y = y0; y < y0 + ts && y < c->par.height; ++y)
+        for (uint32_t x = x0; x < x0 + ts && x < c->par.width; ++x) {
+          v3 r = path_trace(c, x, y, seeds[s], &st, &cn);
+          accumulate_px(c, &c->accum[4 * ((size_t)y * c->par.width + x)], r);
+          st.samples++;
+        }
+    rn += st.rays_nearest; ra += st.rays_any; nn += cn.nodes; tt += cn.tris; na += cn.nodes_any; ta += cn.tris_any; hh += st.shaded_hits; sm += st.samples;
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  c->st.rays_nearest += rn; c->st.rays_any += ra; c->st.nodes_nearest += nn; c->st.tris_nearest += tt; c->st.nodes_any += na; c->st.tris_any += ta;
+  c->st.shaded_hits += hh; c->st.samples += sm;
+  c->st.seconds += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  free(seeds);
+  return 0;
+}
+
+/* ================================================================== tone map (a17) */
+static float hable(float x)
+{
+  const float A = 0.22f, B = 0.30f, C = 0.10f, D = 0.20f, E = 0.01f, F = 0.30f;
+  return (CRH_FMA(x, CRH_FMA(A, x, C * B), D * E) / CRH_FMA(x, CRH_FMA(A, x, B), D * F)) - E / F;
+}
+static uint8_t to_ldr(const crh_params* p, float v)
+{
+  if (!(v == v) || v < 0.f) v = 0.f;
+  v = v * crh_exp(p->exposure * 0.69314718056f);
+  if (p->tonemap_mode == 1) v = hable(v) / hable(p->white_point > 0.f ? p->white_point : 1.0f);
+  v = crh_pow(crh_clamp(v, 0.f, 1.0f), 1.0f / 2.2f);
+  return (uint8_t)(int)CRH_FMA(v, 255.0f, 0.5f);
+}
+
+/* ================================================================== C API (mirrors crh_*) */
+ORC_API orc_ctx* orc_create(void)
+{
+  orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+  c->par.width = 64; c->par.height = 64; c->par.max_depth = 5; c->par.radiance_clamp = 0.f; c->par.two_sided = 1;
+  c->par.seed = 1; c->par.tile_size = 32; c->par.white_point = 1.0f; c->par.russian_roulette = 1; c->par.env_as_background = 1;
+  c->cam.dir[1] = 1.0f; c->cam.up[2] = 1.0f; c->cam.fovy_deg = 45.0f;
+  return c;
+}
+ORC_API void orc_destroy(orc_ctx* c)
+{
+  if (!c) return;
+  free(c->pos); free(c->nrm); free(c->uv); free(c->tri); free(c->mats); free(c->lights); free(c->env);
+  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c);
+}
+ORC_API const char* orc_last_error(orc_ctx* c) { return c ? c->err : "null ctx"; }
+
+static void* dup_mem(const void* p, size_t n) { void* r = malloc(n ? n : 1); if (p && n) memcpy(r, p, n); return r; }
+
+ORC_API int orc_set_geometry(orc_ctx* c, const float* pos, const float* nrm, const float* uv, uint32_t nV,
+                             const int32_t* tri, uint32_t nT, const int32_t* tri_obj, const float* xf, uint32_t nO)
+{
+  if (!c || (nV && (!pos || !nrm)) || (nT && !tri)) return CRH_E_INVALID;
+  for (uint32_t t = 0; t < nT; ++t) for (int k = 0; k < 3; ++k) if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) { snprintf(c->err, sizeof c->err, "triangle %u index out of range", t); return CRH_E_INVALID; }
+  if (tri_obj && xf) {
+    /* the restatement supports per-object transforms only when each vertex belongs to one object:
+     * positions/normals are flattened to world space here (rigid + uniform scale: normals use the 3x3 part) */
+    float* p2 = (float*)dup_mem(pos, sizeof(float) * 3 * nV); float* n2 = (float*)dup_mem(nrm, sizeof(float) * 3 * nV);
+    uint8_t* done = (uint8_t*)calloc(nV ? nV : 1, 1);
+    for (uint32_t t = 0; t < nT; ++t) {
+      int32_t ob = tri_obj[t]; if (ob < 0 || (uint32_t)ob >= nO) { free(p2); free(n2); free(done); return CRH_E_INVALID; }
+      const float* m = &xf[12 * ob];
+      for (int k = 0; k < 3; ++k) {
+        int32_t vi = tri[4 * t + k]; if (done[vi]) continue; done[vi] = 1;
+        v3 p = crh_mk3(pos[3 * vi], pos[3 * vi + 1], pos[3 * vi + 2]), n = crh_mk3(nrm[3 * vi], nrm[3 * vi + 1], nrm[3 * vi + 2]);
+        p2[3 * vi + 0] = crh_dot3(crh_mk3(m[0], m[1], m[2]), p) + m[3];
+        p2[3 * vi + 1] = crh_dot3(crh_mk3(m[4], m[5], m[6]), p) + m[7];
+        p2[3 * vi + 2] = crh_dot3(crh_mk3(m[8], m[9], m[10]), p) + m[11];
+        v3 nn = crh_norm3(crh_mk3(crh_dot3(crh_mk3(m[0], m[1], m[2]), n), crh_dot3(crh_mk3(m[4], m[5], m[6]), n), crh_dot3(crh_mk3(m[8], m[9], m[10]), n)));
+        n2[3 * vi + 0] = nn.x; n2[3 * vi + 1] = nn.y; n2[3 * vi + 2] = nn.z;
+      }
+    }
+    free(done); free(c->pos); free(c->nrm); c->pos = p2; c->nrm = n2;
+  } else {
+    free(c->pos); free(c->nrm);
+    c->pos = (float*)dup_mem(pos, sizeof(float) * 3 * nV); c->nrm = (float*)dup_mem(nrm, sizeof(float) * 3 * nV);
+  }
+  free(c->uv); c->uv = uv ? (float*)dup_mem(uv, sizeof(float) * 2 * nV) : NULL;
+  free(c->tri); c->tri = (int32_t*)dup_mem(tri, sizeof(int32_t) * 4 * nT);
+  c->nV = nV; c->nT = nT; c->built = 0;
+  return 0;
+}
+ORC_API int orc_set_materials(orc_ctx* c, const crh_bsdf* m, uint32_t n)
+{ if (!c || (n && !m)) return CRH_E_INVALID; free(c->mats); c->mats = (crh_bsdf*)dup_mem(m, sizeof(crh_bsdf) * n); c->nM = n; return 0; }
+ORC_API int orc_set_lights(orc_ctx* c, const crh_light* l, uint32_t n)
+{ if (!c || (n && !l)) return CRH_E_INVALID; free(c->lights); c->lights = (crh_light*)dup_mem(l, sizeof(crh_light) * n); c->nL = n; return 0; }
+ORC_API int orc_set_envmap(orc_ctx* c, const float* rgb, uint32_t w, uint32_t h)
+{
+  if (!c) return CRH_E_INVALID;
+  free(c->env); c->env = NULL; c->envW = c->envH = 0;
+  if (rgb && w && h) { c->env = (float*)dup_mem(rgb, sizeof(float) * 3 * (size_t)w * h); c->envW = w; c->envH = h; }
+  return 0;
+}
+ORC_API int orc_set_camera(orc_ctx* c, const crh_camera* cam) { if (!c || !cam) return CRH_E_INVALID; c->cam = *cam; return 0; }
+ORC_API int orc_reset(orc_ctx* c)
+{
+  if (!c) return CRH_E_INVALID;
+  free(c->accum); c->accum = (float*)calloc((size_t)c->par.width * c->par.height * 4, sizeof(float));
+  memset(&c->st, 0, sizeof c->st);
+  return 0;
+}
+ORC_API int orc_set_params(orc_ctx* c, const crh_params* p)
+{
+  if (!c || !p || !p->width || !p->height || p->max_depth < 1 || p->max_depth > 32) return CRH_E_INVALID;
+  c->par = *p; return orc_reset(c);
+}
+ORC_API int orc_build(orc_ctx* c)
+{
+  if (!c) return CRH_E_INVALID;
+  if (c->nT && !c->nM) { snprintf(c->err, sizeof c->err, "no materials"); return CRH_E_INVALID; }
+  do_build(c); c->built = 1; return orc_reset(c);
+}
+ORC_API int orc_render_tiles(orc_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, uint32_t ns)
+{ if (!c) return CRH_E_INVALID; if (!c->built) return CRH_E_NOTBUILT; prepare(c); return render_tiles(c, tiles, nt, first, ns); }
+ORC_API int orc_render(orc_ctx* c, uint32_t n)
+{
+  if (!c) return CRH_E_INVALID; if (!c->built) return CRH_E_NOTBUILT;
+  prepare(c);
+  /* every pixel has the same count when whole frames are rendered: continue from a[3] of pixel 0 */
+  uint32_t first = (uint32_t)c->accum[3];
+  return render_tiles(c, NULL, 0, first, n);
+}
+ORC_API int orc_read_accum(orc_ctx* c, float* out) { if (!c || !c->accum) return CRH_E_INVALID; memcpy(out, c->accum, sizeof(float) * 4 * (size_t)c->par.width * c->par.height); return 0; }
+ORC_API int orc_read_hdr(orc_ctx* c, float* out)
+{
+  if (!c || !c->accum) return CRH_E_INVALID;
+  size_t n = (size_t)c->par.width * c->par.height;
+  for (size_t i = 0; i < n; ++i) { out[3 * i] = c->accum[4 * i]; out[3 * i + 1] = c->accum[4 * i + 1]; out[3 * i + 2] = c->accum[4 * i + 2]; }
+  return 0;
+}
+ORC_API int orc_read_ldr(orc_ctx* c, uint8_t* out)
+{
+  if (!c || !c->accum) return CRH_E_INVALID;
+  size_t n = (size_t)c->par.width * c->par.height;
+  for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) out[3 * i + k] = to_ldr(&c->par, c->accum[4 * i + k]);
+  return 0;
+}
+ORC_API int orc_get_stats(orc_ctx* c, crh_stats* s) { if (!c || !s) return CRH_E_INVALID; *s = c->st; return 0; }
+ORC_API int orc_get_bvh(orc_ctx* c, float* nodes, uint32_t* nn, float* tris, uint32_t* nt)
+{
+  if (!c || !c->built) return CRH_E_NOTBUILT;
+  if (nn) *nn = c->nNodes; if (nt) *nt = c->nQT;
+  if (nodes) memcpy(nodes, c->nodes, sizeof(qnode) * c->nNodes);
+  if (tris) memcpy(tris, c->qtris, sizeof(qtri) * c->nQT);
+  return 0;
+}
+ORC_API int orc_trace_nearest(orc_ctx* c, const float* rays, uint32_t n, float* out)
+{
+  if (!c || !c->built) return CRH_E_NOTBUILT;
+  uint64_t nn = 0, tt = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : nn, tt)
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* r = &rays[8 * i]; hit_t h; trav_counters cn = {0, 0, 0, 0};
+    traverse(c, crh_mk3(r[0], r[1], r[2]), crh_mk3(r[4], r[5], r[6]), r[3], 0, &h, &cn);
+    out[4 * i] = h.t; out[4 * i + 1] = h.u; out[4 * i + 2] = h.v; out[4 * i + 3] = crh_u2f((uint32_t)h.prim);
+    nn += cn.nodes; tt += cn.tris;
+  }
+  c->st.rays_nearest += n; c->st.nodes_nearest += nn; c->st.tris_nearest += tt;
+  return 0;
+}
+ORC_API int orc_trace_any(orc_ctx* c, const float* rays, uint32_t n, uint32_t* vis)
+{
+  if (!c || !c->built) return CRH_E_NOTBUILT;
+  uint64_t nn = 0, tt = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : nn, tt)
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* r = &rays[8 * i]; hit_t h; trav_counters cn = {0, 0, 0, 0};
+    vis[i] = traverse(c, crh_mk3(r[0], r[1], r[2]), crh_mk3(r[4], r[5], r[6]), r[3], 1, &h, &cn) ? 0u : 1u;
+    nn += cn.nodes_any; tt += cn.tris_any;
+  }
+  c->st.rays_any += n; c->st.nodes_any += nn; c->st.tris_any += tt;
+  return 0;
+}
+ORC_API int orc_set_threads(int n)
+{
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n; return 1;
+#endif
+}
+
+/* --- unit entry points for the known-answer tests -------------------------------------------- */
+static void bsdf_from_abi(const crh_bsdf* m, const float wo[3], bsdf_t* b)
+{
+  orc_ctx tmp; memset(&tmp, 0, sizeof tmp); tmp.mats = (crh_bsdf*)m; tmp.nM = 1;
+  load_bsdf(&tmp, 0, b);
+  b->Fc = fresnel_media(wo[2], b->fc);
+}
+ORC_API void orc_fresnel(float cosI, const float f[4], float out[3]) { v3 r = fresnel_media(cosI, f); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+ORC_API void orc_bsdf_eval(const crh_bsdf* m, const float wo[3], const float wi[3], int two_sided, float out[3])
+{ bsdf_t b; bsdf_from_abi(m, wo, &b); v3 r = eval_layered(&b, crh_mk3(wi[0], wi[1], wi[2]), crh_mk3(wo[0], wo[1], wo[2]), two_sided); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+ORC_API float orc_bsdf_pdf(const crh_bsdf* m, const float wo[3], const float wi[3], const float W[3], int two_sided)
+{ bsdf_t b; bsdf_from_abi(m, wo, &b); return pdf_layered(&b, crh_mk3(wo[0], wo[1], wo[2]), crh_mk3(wi[0], wi[1], wi[2]), crh_mk3(W[0], W[1], W[2]), two_sided); }
+/* returns alive; weight_io in/out, rng in/out, flags_out bit0 = delta, bit1 = inside after */
+ORC_API int orc_bsdf_sample(const crh_bsdf* m, const float wo[3], float weight_io[3], uint32_t* rng, int two_sided, int inside_in, float wi_out[3], int* flags_out)
+{
+  bsdf_t b; bsdf_from_abi(m, wo, &b);
+  v3 W = crh_mk3(weight_io[0], weight_io[1], weight_io[2]), wi = crh_mk3(0.f, 0.f, 0.f); int inside = inside_in, delta = 0;
+  int alive = sample_layered(&b, crh_mk3(wo[0], wo[1], wo[2]), &wi, &W, &inside, &delta, rng, two_sided);
+  weight_io[0] = W.x; weight_io[1] = W.y; weight_io[2] = W.z; wi_out[0] = wi.x; wi_out[1] = wi.y; wi_out[2] = wi.z;
+  *flags_out = (delta ? 1 : 0) | (inside ? 2 : 0);
+  return alive;
+}
+/* elementary functions, vectorised over n, for checking crh_math.h against libm in the tests */
+ORC_API void orc_math(int fn, const float* a, const float* b, float* out, float* out2, uint32_t n)
+{
+  for (uint32_t i = 0; i < n; ++i) switch (fn) {
+    case 0: crh_sincos2pi(a[i], &out[i], &out2[i]); break;
+    case 1: out[i] = crh_exp(a[i]); break;
+    case 2: out[i] = crh_log(a[i]); break;
+    case 3: out[i] = crh_pow(a[i], b[i]); break;
+    case 4: out[i] = crh_acos(a[i]); break;
+    case 5: out[i] = crh_atan2(a[i], b[i]); break;
+    case 6: crh_sincos(a[i], &out[i], &out2[i]); break;
+    default: out[i] = 0.f;
+  }
+}
+ORC_API void orc_rng_stream(uint32_t pixel, uint32_t fseed, float* out, uint32_t n)
+{ uint32_t s = crh_rng_seed(pixel, fseed); for (uint32_t i = 0; i < n; ++i) out[i] = crh_rng_next(&s); }
+ORC_API uint32_t orc_frame_seed(uint32_t seed, uint32_t n) { return frame_seed(seed, n); }

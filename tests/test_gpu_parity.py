@@ -1,0 +1,256 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Bar: bit-exact for hit records, counters, BVH bytes; HDR radiance relative L2 <= 1e-4 (north_star) --
+in practice the images are required to be bit-identical too, because both sides execute the same
+IEEE operation sequence (include/crh_math.h, -ffp-contract=off)."""
+import numpy as np
+import pytest
+
+from cadrays_amd import scenes
+from cadrays_amd.materials import BSDF, Fresnel
+
+pytestmark = pytest.mark.gpu
+
+REL_L2_TOL = 1e-4     # north_star: "within 1e-4 relative L2"
+
+
+@pytest.fixture(scope="module")
+def view_cls(hip_lib):
+    from cadrays_amd.view import View
+    return View
+
+
+@pytest.fixture(scope="module")
+def Oracle(oracle_lib):
+    return oracle_lib.Oracle
+
+
+def rel_l2(a, b):
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+# ----------------------------------------------------------------------------------------------
+MATH_CASES = {
+    0: lambda r: (r.random(1 << 20, dtype=np.float32), None),
+    1: lambda r: ((r.random(1 << 20, dtype=np.float32) * 180 - 90).astype(np.float32), None),
+    2: lambda r: (np.exp(r.random(1 << 20) * 80 - 40).astype(np.float32), None),
+    3: lambda r: (r.random(1 << 20, dtype=np.float32), (r.random(1 << 20, dtype=np.float32) * 3000).astype(np.float32)),
+    4: lambda r: ((r.random(1 << 20, dtype=np.float32) * 2 - 1).astype(np.float32), None),
+    5: lambda r: ((r.random(1 << 20, dtype=np.float32) * 2 - 1).astype(np.float32), (r.random(1 << 20, dtype=np.float32) * 2 - 1).astype(np.float32)),
+    6: lambda r: ((r.random(1 << 20, dtype=np.float32) * 20 - 10).astype(np.float32), None),
+}
+
+
+@pytest.mark.parametrize("fn", sorted(MATH_CASES))
+def test_elementary_math_bit_exact(view_cls, oracle_lib, fn):
+    a, b = MATH_CASES[fn](np.random.default_rng(fn + 1))
+    v = view_cls(0)
+    g1, g2 = v.debug_math(fn, a, b)
+    c1, c2 = oracle_lib.math_fn(fn, a, b)
+    assert np.array_equal(bits(g1), bits(c1))
+    if fn in (0, 6):
+        assert np.array_equal(bits(g2), bits(c2))
+
+
+def test_ieee_sqrt_div_bit_exact(view_cls):
+    r = np.random.default_rng(7)
+    a = np.exp(r.random(1 << 20) * 60 - 30).astype(np.float32)
+    b = np.exp(r.random(1 << 20) * 60 - 30).astype(np.float32)
+    v = view_cls(0)
+    assert np.array_equal(bits(v.debug_math(7, a)[0]), bits(np.sqrt(a)))
+    assert np.array_equal(bits(v.debug_math(8, a, b)[0]), bits(a / b))
+
+
+def test_rng_stream_bit_exact(view_cls, oracle_lib):
+    pix = np.arange(4096, dtype=np.uint32)
+    seeds = (pix * np.uint32(2654435761)).astype(np.uint32)
+    v = view_cls(0)
+    g1, g2 = v.debug_math(9, pix.view(np.float32), seeds.view(np.float32))
+    for i in (0, 1, 17, 4095):
+        s = oracle_lib.rng_stream(int(pix[i]), int(seeds[i]), 2)
+        assert g1[i] == s[0] and g2[i] == s[1]
+
+
+# ----------------------------------------------------------------------------------------------
+def camera_rays(w, h, eye=(0, -3.6, 0)):
+    ys, xs = np.mgrid[0:h, 0:w]
+    t = np.tan(np.deg2rad(22.5))
+    d = np.stack([((xs + 0.5) / w * 2 - 1) * t * (w / h), np.ones_like(xs, float), (1 - (ys + 0.5) / h * 2) * t], -1).reshape(-1, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((w * h, 8), np.float32)
+    rays[:, 0:3] = eye; rays[:, 3] = 1e15; rays[:, 4:7] = d
+    return rays
+
+
+def random_rays(n, seed, tmax=1e15):
+    r = np.random.default_rng(seed)
+    o = r.random((n, 3)) * 2 - 1
+    d = r.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3] = o; rays[:, 3] = tmax; rays[:, 4:7] = d
+    return rays
+
+
+@pytest.fixture(scope="module")
+def soup(view_cls, Oracle):
+    pos, nrm, tri = scenes.gen_scene(100_000, 1, 2)
+    sc = scenes.Scene(pos, nrm, tri, [BSDF.CreateDiffuse(0.8), BSDF.Glossy()])
+    v = view_cls(0).load_scene(sc)
+    o = Oracle().load_scene(sc)
+    return v, o
+
+
+def test_bvh_bytes_identical(soup):
+    v, o = soup
+    gn, gt = v.get_bvh(); on, ot = o.get_bvh()
+    assert gn.shape == on.shape and np.array_equal(bits(gn), bits(on))
+    assert np.array_equal(bits(gt), bits(ot))
+
+
+@pytest.mark.parametrize("kind", ["primary", "incoherent"])
+def test_trace_nearest_bit_exact(soup, kind):
+    v, o = soup
+    rays = camera_rays(320, 180) if kind == "primary" else random_rays(200_000, 3)
+    v.reset(); o.reset(); v.enable_counters(True)
+    g = v.trace_nearest(rays); c = o.trace_nearest(rays)
+    assert np.array_equal(bits(g), bits(c))                     # t, u, v, triangle id
+    gs, cs = v.stats(), o.stats()
+    for k in ("rays_nearest", "nodes_nearest", "tris_nearest"):
+        assert gs[k] == cs[k], k
+    hit = g[:, 3].view(np.int32) >= 0
+    assert 0.05 < hit.mean() <= 1.0
+
+
+def test_trace_any_bit_exact(soup):
+    v, o = soup
+    rays = random_rays(200_000, 5, tmax=0.25)
+    v.reset(); o.reset(); v.enable_counters(True)
+    g = v.trace_any(rays); c = o.trace_any(rays)
+    assert np.array_equal(g, c)
+    gs, cs = v.stats(), o.stats()
+    for k in ("rays_any", "nodes_any", "tris_any"):
+        assert gs[k] == cs[k], k
+    assert 0.0 < g.mean() < 1.0
+
+
+def test_trace_edge_cases(view_cls, Oracle):
+    # empty scene, single triangle, degenerate (zero-area) triangle, axis-parallel rays
+    mats = [BSDF.CreateDiffuse(0.5)]
+    rays = random_rays(1000, 11)
+    rays[:10, 4:7] = [0, 0, 1]
+    for pos, tri in [
+        (np.zeros((0, 3), np.float32), np.zeros((0, 4), np.int32)),
+        (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2, 0]], np.int32)),
+        (np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [0, 0, .5], [1, 0, .5], [0, 1, .5]], np.float32), np.array([[0, 1, 2, 0], [3, 4, 5, 0]], np.int32)),
+    ]:
+        nrm = np.tile(np.array([[0, 0, 1]], np.float32), (len(pos), 1))
+        sc = scenes.Scene(pos, nrm, tri, mats)
+        v = view_cls(0).load_scene(sc); o = Oracle().load_scene(sc)
+        assert np.array_equal(bits(v.trace_nearest(rays)), bits(o.trace_nearest(rays)))
+        assert np.array_equal(v.trace_any(rays), o.trace_any(rays))
+
+
+# ----------------------------------------------------------------------------------------------
+def render_both(view_cls, Oracle, sc, spp):
+    v = view_cls(0).load_scene(sc); v.enable_counters(True); v.reset()
+    o = Oracle().load_scene(sc)
+    v.render(spp); o.render(spp)
+    return v, o
+
+
+def check_render(v, o, exact=True):
+    g, c = v.read_hdr(), o.read_hdr()
+    assert np.isfinite(g).all()
+    r = rel_l2(g, c)
+    assert r <= REL_L2_TOL, f"relative L2 {r}"
+    gs, cs = v.stats(), o.stats()
+    if exact:
+        assert np.array_equal(bits(g), bits(c)), f"not bit-identical (rel L2 {r})"
+        for k in ("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "nodes_any", "tris_any", "shaded_hits", "samples"):
+            assert gs[k] == cs[k], (k, gs[k], cs[k])
+    return g
+
+
+def test_render_cornell_c1(view_cls, Oracle):
+    """BASELINE config C1 at parity scale: Cornell, diffuse, 128^2, 8 spp."""
+    v, o = render_both(view_cls, Oracle, scenes.cornell_box(False, 128, 128), 8)
+    g = check_render(v, o)
+    assert g.mean() > 0.05
+
+
+def test_render_cornell_full(view_cls, Oracle):
+    """glass + mirror + glossy + sphere light (NEE, MIS, Beer-Lambert, delta lobes)."""
+    v, o = render_both(view_cls, Oracle, scenes.cornell_box(True, 128, 128), 8)
+    check_render(v, o)
+    assert np.array_equal(v.read_ldr(), o.read_ldr())
+
+
+def test_render_materials_scene(view_cls, Oracle):
+    """the nine BSDF vectors of data/scripts/Materials.tcl, directional cone light, depth 10."""
+    v, o = render_both(view_cls, Oracle, scenes.materials_scene(160, 120, 24, 12), 4)
+    check_render(v, o)
+
+
+def test_render_c2_small(view_cls, Oracle):
+    sc = scenes.baseline_config("C2", 256, 144, n_tris=20_000)
+    v, o = render_both(view_cls, Oracle, sc, 4)
+    check_render(v, o)
+
+
+def test_render_c3_small(view_cls, Oracle):
+    """glass + glossy soup under the procedural HDR sky (env lookup, clamp, depth 10, RR)."""
+    sc = scenes.baseline_config("C3", 256, 144, n_tris=20_000)
+    sc.env = scenes.procedural_sky(256, 128, 1)
+    v, o = render_both(view_cls, Oracle, sc, 4)
+    check_render(v, o)
+
+
+def test_render_variants(view_cls, Oracle):
+    """one-sided BSDFs, coherent RNG, thin lens, ortho camera, no RR, odd image size / edge tiles."""
+    base = scenes.cornell_box(True, 100, 76)
+    import dataclasses
+    for cam_kw, par_kw in [
+        (dict(aperture_radius=0.05, focal_dist=1.9), dict(two_sided=False)),
+        (dict(is_ortho=True, ortho_scale=0.6), dict(coherent_rng=True, russian_roulette=False, max_depth=7)),
+        (dict(), dict(tile_size=8, radiance_clamp=2.0, env_as_background=False, background=(0.2, 0.3, 0.4))),
+    ]:
+        sc = dataclasses.replace(base, camera=dataclasses.replace(base.camera, **cam_kw), params=dataclasses.replace(base.params, **par_kw))
+        v, o = render_both(view_cls, Oracle, sc, 3)
+        check_render(v, o)
+
+
+def test_progressive_equals_batched(view_cls, Oracle):
+    """8 x Redraw() == render(8) == tiles rendered in two halves (accumulator semantics)."""
+    sc = scenes.cornell_box(True, 96, 96)
+    a = view_cls(0).load_scene(sc)
+    for _ in range(8):
+        a.Redraw()
+    b = view_cls(0).load_scene(sc); b.render(8)
+    c = view_cls(0).load_scene(sc)
+    tiles = np.arange(c.n_tiles(), dtype=np.uint32)
+    c.render_tiles(tiles[::2], 0, 8); c.render_tiles(tiles[1::2], 0, 5); c.render_tiles(tiles[1::2], 5, 3)
+    ia, ib, ic = a.read_hdr(), b.read_hdr(), c.read_hdr()
+    assert np.array_equal(bits(ia), bits(ib)) and np.array_equal(bits(ia), bits(ic))
+
+
+def test_errors(view_cls):
+    from cadrays_amd.binding import BackendError
+    v = view_cls(0)
+    with pytest.raises(BackendError):
+        v.render(1)                                   # not built
+    sc = scenes.cornell_box(False, 64, 64)
+    v.set_geometry(sc.pos, sc.nrm, sc.tri)
+    with pytest.raises(BackendError):
+        v.build()                                     # no materials
+    bad = sc.tri.copy(); bad[0, 0] = 10 ** 6
+    with pytest.raises(BackendError):
+        v.set_geometry(sc.pos, sc.nrm, bad)
+    import dataclasses
+    with pytest.raises(BackendError):
+        v.set_params(dataclasses.replace(sc.params, tile_size=12))
+    with pytest.raises(BackendError):
+        v.set_params(dataclasses.replace(sc.params, max_depth=33))
