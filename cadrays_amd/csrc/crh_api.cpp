@@ -104,7 +104,7 @@ int ensure_paths(crh_ctx* c, uint32_t need)
     if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
     CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
   }
-  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, 4 * sizeof(uint32_t))); CRH_HIP(hipMemset(c->queues.counts, 0, 4 * sizeof(uint32_t))); }
+  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, 8 * sizeof(uint32_t))); CRH_HIP(hipMemset(c->queues.counts, 0, 8 * sizeof(uint32_t))); }
   c->path_cap = need;
   return CRH_OK;
 }

@@ -59,7 +59,7 @@ struct DCounters {          // device-side mirror of crh_stats
 struct DQueues {
   uint32_t* q[2];           // active path ids, ping-pong
   uint32_t* q_sh;           // path ids with a pending shadow ray
-  uint32_t* counts;         // [0],[1]: active counts (ping-pong), [2]: shadow count
+  uint32_t* counts;         // [0],[1]: active counts (ping-pong), [2]: shadow count, [4..6]: work cursors (nearest, shade, any)
 };
 
 }  // namespace crh

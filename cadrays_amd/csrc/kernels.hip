@@ -39,6 +39,37 @@ __device__ __forceinline__ void wave_enqueue(bool pred, uint32_t value, uint32_t
   if (pred) q[base + prefix] = value;
 }
 
+// Persistent-wave work distribution: each wavefront pulls the next 64 queue entries from a global cursor
+// (one returning atomic per wave per chunk), so the grid only needs to fill the machine once and no
+// workgroup is left running a statically assigned share after the others have drained.
+__device__ __forceinline__ uint32_t wave_next_chunk(uint32_t* __restrict__ cursor)
+{
+  uint32_t base = 0;
+  if (lane_id() == 0) base = atomicAdd(cursor, 64u);
+  return __shfl(base, 0);
+}
+
+// Workgroup-aggregated append: ballots and prefix popcounts inside each wave, wave totals combined in LDS,
+// ONE global atomic per workgroup per call (4x fewer than per-wave; a single counter word sustains only
+// ~88 atomics/us on MI355X).  Must be called by all kBlock threads.  `sh` = 8 dwords of LDS scratch.
+__device__ __forceinline__ void block_enqueue(bool pred, uint32_t value, uint32_t* __restrict__ q, uint32_t* __restrict__ count, uint32_t* sh)
+{
+  const unsigned long long mask = __ballot(pred);
+  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+  const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  if (lane == 0) sh[wv] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t c0 = sh[0], c1 = sh[1], c2 = sh[2], c3 = sh[3];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    const uint32_t base = tot ? atomicAdd(count, tot) : 0u;
+    sh[4] = base; sh[5] = base + c0; sh[6] = base + c0 + c1; sh[7] = base + c0 + c1 + c2;
+  }
+  __syncthreads();
+  if (pred) q[sh[4 + wv] + prefix] = value;
+  __syncthreads();
+}
+
 // ================================================================== traversal
 __device__ __forceinline__ float inv_dir(float d)
 { return 1.0f / (crh_abs(d) < kDirEps ? (d < 0.f ? -kDirEps : kDirEps) : d); }
@@ -128,22 +159,28 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_nearest(DScene S, DPaths P, const uint32_t* __restrict__ q,
-                                                           const uint32_t* __restrict__ count,
+                                                           const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors,
                                                            uint32_t* zero_a, uint32_t* zero_b, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   const uint32_t n = *count;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *zero_a = 0u; *zero_b = 0u;
+    cursors[1] = 0u; cursors[2] = 0u;            // shade / any-hit cursors for the launches that follow
     atomicAdd(&C->rays_nearest, (unsigned long long)n);
   }
   uint32_t nn = 0, nt = 0;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint32_t pid = q[i];
-    const float4 o4 = P.ray_o[pid], d4 = P.ray_d[pid];
-    float4 h;
-    traverse<false, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
-    P.hit[pid] = h;
+  for (;;) {
+    const uint32_t base = wave_next_chunk(cursors + 0);
+    if (base >= n) break;
+    const uint32_t i = base + lane_id();
+    if (i < n) {
+      const uint32_t pid = q[i];
+      const float4 o4 = P.ray_o[pid], d4 = P.ray_d[pid];
+      float4 h;
+      traverse<false, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
+      P.hit[pid] = h;
+    }
   }
   if (COUNT) {
     nn = wave_sum(nn); nt = wave_sum(nt);
@@ -153,22 +190,27 @@ __global__ __launch_bounds__(kBlock) void k_trace_nearest(DScene S, DPaths P, co
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_trace_any(DScene S, DPaths P, const uint32_t* __restrict__ q,
-                                                       const uint32_t* __restrict__ count, DCounters* C)
+                                                       const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   const uint32_t n = *count;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
   uint32_t nn = 0, nt = 0;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint32_t pid = q[i];
-    const float4 o4 = P.sh_o[pid], d4 = P.sh_d[pid];
-    float4 h;
-    const bool occluded = traverse<true, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
-    if (!occluded) {
-      const float4 c = P.sh_c[pid];
-      float4 r = P.rad[pid];
-      r.x += c.x; r.y += c.y; r.z += c.z;
-      P.rad[pid] = r;
+  for (;;) {
+    const uint32_t base = wave_next_chunk(cursors + 2);
+    if (base >= n) break;
+    const uint32_t i = base + lane_id();
+    if (i < n) {
+      const uint32_t pid = q[i];
+      const float4 o4 = P.sh_o[pid], d4 = P.sh_d[pid];
+      float4 h;
+      const bool occluded = traverse<true, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
+      if (!occluded) {
+        const float4 c = P.sh_c[pid];
+        float4 r = P.rad[pid];
+        r.x += c.x; r.y += c.y; r.z += c.z;
+        P.rad[pid] = r;
+      }
     }
   }
   if (COUNT) {
@@ -476,9 +518,12 @@ __device__ __forceinline__ bool slot_pixel(const DScene& S, const uint32_t* __re
 }
 
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t* __restrict__ q, uint32_t* __restrict__ count,
+                                                    uint32_t* __restrict__ cursors,
                                                     const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
                                                     const uint32_t* __restrict__ seeds, uint32_t n_samples)
 {
+  __shared__ uint32_t s_enq[8];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { cursors[0] = 0u; cursors[1] = 0u; cursors[2] = 0u; }
   const uint32_t per_sample = n_tiles * S.tile_size * S.tile_size;
   const uint32_t total = per_sample * n_samples;
   for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
@@ -516,7 +561,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
       P.rad[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
       P.st[pid] = make_uint2(rng, 0u);
     }
-    wave_enqueue(valid, pid, q, count);
+    block_enqueue(valid, pid, q, count, s_enq);
   }
 }
 
@@ -526,9 +571,13 @@ constexpr int kLdsMats = 64;   // materials staged in LDS (8 KB); larger tables 
 __global__ __launch_bounds__(kBlock) void k_shade(DScene S, DPaths P, uint32_t bounce,
                                                    const uint32_t* __restrict__ q_in, const uint32_t* __restrict__ count_in,
                                                    uint32_t* __restrict__ q_out, uint32_t* __restrict__ count_out,
-                                                   uint32_t* __restrict__ q_sh, uint32_t* __restrict__ count_sh, DCounters* C)
+                                                   uint32_t* __restrict__ q_sh, uint32_t* __restrict__ count_sh,
+                                                   uint32_t* __restrict__ cursors, DCounters* C)
 {
   __shared__ float4 s_mats[kLdsMats * 8];
+  __shared__ uint32_t s_enq[8];
+  __shared__ uint32_t s_base;
+  if (blockIdx.x == 0 && threadIdx.x == 0) cursors[0] = 0u;     // nearest-hit cursor of the next bounce
   const bool mats_in_lds = S.n_mats <= (uint32_t)kLdsMats;
   if (mats_in_lds) {
     for (uint32_t i = threadIdx.x; i < S.n_mats * 8u; i += kBlock) s_mats[i] = S.mats[i];
@@ -537,7 +586,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, DPaths P, uint32_t b
   const uint32_t n = *count_in;
   const bool last = bounce + 1u >= S.max_depth;
   uint32_t n_shaded = 0;
-  for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = atomicAdd(cursors + 1, (uint32_t)kBlock);
+    __syncthreads();
+    const uint32_t base = s_base;
+    if (base >= n) break;
     const uint32_t i = base + threadIdx.x;
     bool cont = false, shadow = false;
     uint32_t pid = 0;
@@ -639,8 +693,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, DPaths P, uint32_t b
         }
       }
     }
-    wave_enqueue(shadow, pid, q_sh, count_sh);
-    wave_enqueue(cont, pid, q_out, count_out);
+    if (S.n_lights > 0u) block_enqueue(shadow, pid, q_sh, count_sh, s_enq);
+    block_enqueue(cont, pid, q_out, count_out, s_enq);
   }
   n_shaded = wave_sum(n_shaded);
   if (lane_id() == 0 && n_shaded) atomicAdd(&C->shaded_hits, (unsigned long long)n_shaded);
@@ -738,24 +792,24 @@ void launch_raygen(const Launch& L, const DScene& S, const DPaths& P, const DQue
                    const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds, uint32_t n_samples)
 {
   hipMemsetAsync(Q.counts + qsel, 0, sizeof(uint32_t), L.stream);
-  hipLaunchKernelGGL(k_raygen, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, d_tile_ids, n_tiles, d_seeds, n_samples);
+  hipLaunchKernelGGL(k_raygen, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples);
 }
 void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, DCounters* C)
 {
   if (L.counters)
-    hipLaunchKernelGGL(k_trace_nearest<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], Q.counts + qin, Q.counts + (1 - qin), Q.counts + 2, C);
+    hipLaunchKernelGGL(k_trace_nearest<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, C);
   else
-    hipLaunchKernelGGL(k_trace_nearest<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], Q.counts + qin, Q.counts + (1 - qin), Q.counts + 2, C);
+    hipLaunchKernelGGL(k_trace_nearest<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, C);
 }
 void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, uint32_t bounce, DCounters* C)
 {
   hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, bounce, Q.q[qin], Q.counts + qin,
-                     Q.q[1 - qin], Q.counts + (1 - qin), Q.q_sh, Q.counts + 2, C);
+                     Q.q[1 - qin], Q.counts + (1 - qin), Q.q_sh, Q.counts + 2, Q.counts + 4, C);
 }
 void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, DCounters* C)
 {
-  if (L.counters) hipLaunchKernelGGL(k_trace_any<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, C);
-  else            hipLaunchKernelGGL(k_trace_any<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, C);
+  if (L.counters) hipLaunchKernelGGL(k_trace_any<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C);
+  else            hipLaunchKernelGGL(k_trace_any<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C);
 }
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, const uint32_t* d_tile_ids,
                        uint32_t n_tiles, uint32_t n_samples, DCounters* C)
