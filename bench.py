@@ -31,10 +31,10 @@ HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3"])
-    ap.add_argument("--spp", type=int, default=4, help="samples per pixel per step (per GPU share)")
+    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step (per GPU share)")
     ap.add_argument("--tris", type=int, default=0, help="override triangle count (debug)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)

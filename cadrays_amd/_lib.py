@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcadrays_hip.so")
+LIB_PATH = os.environ.get("CRH_LIB_PATH") or os.path.join(_HERE, "libcadrays_hip.so")   # CRH_LIB_PATH: A/B builds of the same ABI
 _LIB = None
 
 

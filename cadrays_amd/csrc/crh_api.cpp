@@ -49,7 +49,7 @@ struct crh_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> render_ev, trace_ev;
   std::vector<hipEvent_t> ev_pool;
   double seconds_acc = 0.0, trace_ms_acc = 0.0, all_ms_acc = 0.0; uint64_t trace_launches = 0;
-  uint32_t max_paths = 8u << 20;
+  uint32_t max_paths = 32u << 20;   // path slots per batch (148 B each); more in flight keeps late, sparse bounces busy
 };
 
 namespace {

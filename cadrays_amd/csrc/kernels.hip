@@ -71,6 +71,14 @@ __device__ __forceinline__ void block_enqueue(bool pred, uint32_t value, uint32_
 }
 
 // ================================================================== traversal
+#ifndef CRH_TRACE_MINWAVES
+#define CRH_TRACE_MINWAVES 0
+#endif
+#if CRH_TRACE_MINWAVES > 0
+#define CRH_TRACE_BOUNDS __launch_bounds__(kBlock, CRH_TRACE_MINWAVES)
+#else
+#define CRH_TRACE_BOUNDS __launch_bounds__(kBlock)
+#endif
 __device__ __forceinline__ float inv_dir(float d)
 { return 1.0f / (crh_abs(d) < kDirEps ? (d < 0.f ? -kDirEps : kDirEps) : d); }
 
@@ -158,7 +166,7 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_nearest(DScene S, DPaths P, const uint32_t* __restrict__ q,
+__global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint32_t* __restrict__ q,
                                                            const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors,
                                                            uint32_t* zero_a, uint32_t* zero_b, DCounters* C)
 {
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_nearest(DScene S, DPaths P, co
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_any(DScene S, DPaths P, const uint32_t* __restrict__ q,
+__global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t* __restrict__ q,
                                                        const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];

@@ -1,0 +1,155 @@
+"""CPU suite: the C-ABI library loads and exports every declared symbol (no compute without a GPU),
+the product's host-side BVH builder equals the oracle's bytes, the elementary math is accurate, the host
+mirror of the reference's material interface behaves like MaterialEditor::setBSDF."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cadrays_amd import abi, scenes
+from cadrays_amd.materials import BSDF, Fresnel, phong_to_roughness
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "cadrays_hip.h")).read()
+    declared = set(re.findall(r"CRH_API\s+[\w\s\*]+?\b(crh_\w+)\s*\(", hdr))
+    assert declared == set(abi.EXPORTS), declared ^ set(abi.EXPORTS)
+    for name in declared:
+        assert hasattr(hip_lib, name), name
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof/offsetof as gcc sees include/cadrays_hip.h == the ctypes mirror."""
+    import subprocess
+    names = ["crh_bsdf", "crh_light", "crh_camera", "crh_params", "crh_stats"]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "cadrays_hip.h"\nint main(){' + "".join(
+        f'printf("%zu ", sizeof({n}));' for n in names) + 'printf("%zu %zu %zu", offsetof(crh_params, background), offsetof(crh_camera, is_ortho), offsetof(crh_stats, seconds)); return 0;}'
+    (tmp_path / "t.c").write_text(src)
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(tmp_path / "t.c"), "-o", str(tmp_path / "t")])
+    got = [int(x) for x in subprocess.check_output([str(tmp_path / "t")]).split()]
+    want = [C.sizeof(getattr(abi, n)) for n in names] + [abi.crh_params.background.offset, abi.crh_camera.is_ortho.offset, abi.crh_stats.seconds.offset]
+    assert got == want, (got, want)
+    assert C.sizeof(abi.crh_bsdf) == 128 and C.sizeof(abi.crh_light) == 32
+
+
+def test_no_gpu_means_loud_failure_not_fallback(hip_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    hip_lib.crh_create.restype = C.c_void_p
+    assert hip_lib.crh_create(0) is None
+    from cadrays_amd.binding import BackendError
+    from cadrays_amd.view import View
+    with pytest.raises(BackendError):
+        View(0)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cadrays_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower() or f in ("binding.py", "kernels.hip", "sharding.py", "abi.py", "bvh_builder.cpp"), f
+                assert "pyoracle" not in txt and "crh_oracle" not in txt and "libcrh_oracle" not in txt, f
+
+
+@pytest.mark.parametrize("n,threads", [(0, 1), (1, 1), (4, 1), (5, 2), (257, 3), (20000, 8), (150000, 8)])
+def test_host_bvh_builder_equals_oracle_bytes(hip_lib, oracle_lib, n, threads):
+    from cadrays_amd.view import build_bvh_host
+    pos, nrm, tri = scenes.gen_scene(max(n, 1), 3, 2)
+    pos, nrm, tri = pos[:3 * n], nrm[:3 * n], tri[:n]
+    nodes, order = build_bvh_host(pos, tri, threads)
+    o = oracle_lib.Oracle()
+    o.set_geometry(pos, nrm, tri); o.set_materials([BSDF.CreateDiffuse(0.5)] * 2); o.build()
+    on, ot = o.get_bvh()
+    assert nodes.shape == on.shape and np.array_equal(nodes.view(np.uint32), on.view(np.uint32))
+    assert np.array_equal(ot[:, 3].view(np.uint32)[:n], order)
+    # structural invariants: every triangle referenced exactly once, leaves <= 4, children inside parents
+    refs = nodes[:, 24:28].view(np.uint32)
+    leaf = (refs & 0x80000000) != 0
+    leaf &= refs != 0xFFFFFFFF
+    cnt = ((refs >> 28) & 7) + 1
+    assert cnt[leaf].sum() == n and (cnt[leaf] <= 4).all()
+    inner = (~leaf) & (refs != 0xFFFFFFFF)
+    assert sorted(refs[inner].tolist()) == list(range(1, len(nodes)))
+
+
+def test_host_bvh_degenerate_inputs(hip_lib, oracle_lib):
+    """identical triangles (zero centroid extent -> median by index) and a thin line of triangles."""
+    from cadrays_amd.view import build_bvh_host
+    one = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    for pos in (np.tile(one, (300, 1)), np.concatenate([one + np.array([i * 1e-3, 0, 0], np.float32) for i in range(300)])):
+        tri = np.zeros((300, 4), np.int32); tri[:, :3] = np.arange(900).reshape(300, 3)
+        nrm = np.tile(np.array([[0, 0, 1]], np.float32), (900, 1))
+        nodes, order = build_bvh_host(pos, tri, 2)
+        o = oracle_lib.Oracle(); o.set_geometry(pos, nrm, tri); o.set_materials([BSDF.CreateDiffuse(0.5)]); o.build()
+        on, ot = o.get_bvh()
+        assert np.array_equal(nodes.view(np.uint32), on.view(np.uint32))
+        assert sorted(order.tolist()) == list(range(300))
+
+
+# ---------------------------------------------------------------------------------------------- math accuracy
+def test_elementary_math_accuracy(oracle_lib):
+    r = np.random.default_rng(0)
+    x = r.random(200000, dtype=np.float32)
+    s, c = oracle_lib.math_fn(0, x)
+    assert np.abs(s - np.sin(2 * np.pi * x.astype(np.float64))).max() < 4e-7
+    assert np.abs(c - np.cos(2 * np.pi * x.astype(np.float64))).max() < 4e-7
+    e = (x * 170 - 85).astype(np.float32)
+    assert (np.abs(oracle_lib.math_fn(1, e)[0] / np.exp(e.astype(np.float64)) - 1)).max() < 3e-7
+    l = np.exp(x * 60 - 30).astype(np.float32)
+    assert np.abs(oracle_lib.math_fn(2, l)[0] - np.log(l.astype(np.float64))).max() < 3e-6
+    y = (r.random(200000, dtype=np.float32) * 50).astype(np.float32)
+    p = oracle_lib.math_fn(3, x, y)[0]
+    ref = np.power(x.astype(np.float64), y.astype(np.float64))
+    assert np.abs(p - ref).max() < 2e-5 and (np.abs(p / np.maximum(ref, 1e-30) - 1)[ref > 1e-20]).max() < 1e-4
+    a = (x * 2 - 1).astype(np.float32)
+    assert np.abs(oracle_lib.math_fn(4, a)[0] - np.arccos(a.astype(np.float64))).max() < 1e-6
+    b = (r.random(200000, dtype=np.float32) * 2 - 1).astype(np.float32)
+    assert np.abs(oracle_lib.math_fn(5, a, b)[0] - np.arctan2(a.astype(np.float64), b.astype(np.float64))).max() < 1e-6
+    assert oracle_lib.math_fn(3, np.array([0.0, 0.5], np.float32), np.array([2.0, 0.0], np.float32))[0].tolist() == [0.0, 1.0]
+    u = oracle_lib.rng_stream(7, 9, 100000)
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01
+
+
+# ---------------------------------------------------------------------------------------------- material contract
+def test_setbsdf_normalisation_like_material_editor():
+    b = BSDF(); b.Kd = np.array([1.0, 0.8, 0.2], np.float32); b.Ks = np.array([0.3, 0.3, 0.3, 0.1], np.float32)
+    b.Sanitize()                               # MaterialEditor.cxx:311-329: divide by max_c(Kd+Ks+Kt) = 1.3
+    np.testing.assert_allclose(b.Kd, np.array([1.0, 0.8, 0.2]) / 1.3, rtol=1e-6)
+    np.testing.assert_allclose(b.Ks[:3], 0.3 / 1.3, rtol=1e-6)
+    assert float(np.max(b.Kd + b.Ks[:3] + b.Kt)) <= 1.0 + 1e-6 and b.Ks[3] == np.float32(0.1)
+    b2 = BSDF(); b2.Kd = np.array([1.5, -1, 0.5], np.float32); b2.Le = np.array([-1, 2, 0], np.float32); b2.Absorption = np.array([2, 0.5, -1, -3], np.float32)
+    b2.Sanitize()
+    assert b2.Kd.tolist() == [1.0, 0.0, 0.5] and b2.Le.tolist() == [0, 2, 0] and b2.Absorption.tolist() == [1, 0.5, 0, 0]
+
+
+def test_fresnel_serialisation_layout():
+    assert Fresnel.CreateSchlick((0.58, 0.42, 0.2)).Serialize()[:3] == pytest.approx((0.58, 0.42, 0.2))
+    assert Fresnel.CreateConstant(0.4).Serialize() == (-1.0, 0.0, pytest.approx(0.4), 0.0)
+    assert Fresnel.CreateConductor(0.8, 5.8).Serialize()[:3] == (-2.0, pytest.approx(0.8), pytest.approx(5.8))
+    assert Fresnel.CreateDielectric(0.5).Serialize()[:2] == (-3.0, 1.0)          # clamped to [1, 1e3]
+    assert Fresnel.CreateConductor(0.0, 1e9).Serialize()[1:3] == (pytest.approx(1e-2), pytest.approx(1e3))
+
+
+def test_material_type_predicate_and_presets():
+    assert BSDF.Matte().MaterialType() == 0 and BSDF.Metal().MaterialType() == 1 and BSDF.Glossy().MaterialType() == 2
+    assert BSDF.Glass().MaterialType() == 3 and BSDF.Paint().MaterialType() == 4
+    g = BSDF.Glass(ior=1.62)
+    assert g.Kc.tolist() == [1, 1, 1, 0] and g.FresnelCoat.Serialize()[1] == pytest.approx(1.62)
+    assert phong_to_roughness(0) == pytest.approx(1.0) and phong_to_roughness(98) == pytest.approx(np.sqrt(0.02))
+    m = BSDF.Paint().to_abi()
+    assert list(m.FresnelCoat)[:2] == [-3.0, 1.5] and list(m.Kd)[:3] == [0.5, 0.5, 0.5]
+
+
+def test_scene_generators_are_deterministic():
+    a = scenes.gen_scene(1000, 1, 2); b = scenes.gen_scene(1000, 1, 2); c = scenes.gen_scene(1000, 2, 2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and not np.array_equal(a[0], c[0])
+    assert np.abs(a[0]).max() <= 1.0 + 1.5 * 1000 ** (-1 / 3) * 1.01 and set(a[2][:, 3]) == {0, 1}
+    assert len(scenes.cornell_box(False).tri) == 34            # BASELINE C1: "~36 tris"
+    sky = scenes.procedural_sky(512, 256, 1)     # the 1-degree sun disc needs texels finer than ~1 degree
+    assert sky.shape == (256, 512, 3) and sky.max() >= 4e4 and sky.min() > 0

@@ -1,0 +1,62 @@
+"""N > 1 path on CPU: two gloo ranks shard the tiles (cadrays_amd.sharding), each renders its shard with
+the CPU oracle standing in for the GPU backend, the float4 framebuffers are reduced to rank 0, and the
+result must be bit-identical to a single-process render (tile sharding keeps the
+1-GPU RNG, so there is no sum-order issue)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, spp, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from cadrays_amd import scenes, sharding
+    from oracle.pyoracle import Oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Oracle.set_threads(2)
+        o = Oracle().load_scene(scenes.cornell_box(True, 96, 72))
+        # two passes like bench.py's steps: samples [0, spp) then [spp, 2*spp)
+        for step in range(2):
+            tiles = sharding.render_shard(o, rank, world, step * spp, spp)
+        assert len(tiles) > 0 and (tiles % world == rank).all()
+        acc = torch.from_numpy(o.read_accum().copy())
+        sharding.reduce_framebuffer(acc, 0)
+        if rank == 0:
+            np.save(out_path, acc.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_sharded_render_equals_single_process(tmp_path, oracle_lib, world):
+    import torch.multiprocessing as mp
+    from cadrays_amd import scenes
+    spp = 2
+    out = str(tmp_path / "acc.npy")
+    mp.spawn(_worker, args=(world, _free_port(), spp, out), nprocs=world, join=True)
+    got = np.load(out)
+    o = oracle_lib.Oracle().load_scene(scenes.cornell_box(True, 96, 72))
+    o.render(2 * spp)
+    ref = o.read_accum()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert (got[..., 3] == 2 * spp).all()
+
+
+def test_tile_assignment_partitions_all_tiles():
+    from cadrays_amd import sharding
+    for n, w in [(2040, 8), (2040, 3), (7, 8), (1, 1)]:
+        parts = [sharding.tiles_for_rank(n, r, w) for r in range(w)]
+        assert sorted(np.concatenate(parts).tolist()) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
