@@ -116,8 +116,15 @@ def main():
         per_launch = alg_bytes / launches
         avg_ms = kt["trace_nearest_ms_total"] / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = args.pmc_traffic
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if traffic is None and args.config == "C3" and not (args.tris or args.width or args.height) and os.path.exists(pmc_file):
+            # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
+            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+            if traffic is not None and args.spp != 16:
+                traffic = traffic * args.spp / 16.0
         roof = {"bound": "hbm", "kernel": "k_trace_nearest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": args.pmc_traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": round(per_launch), "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
                 "kernel_time_share": round(kt["trace_nearest_ms_total"] / max(kt["render_ms_total"], 1e-9), 3),
                 "nodes_per_ray": round(cs["nodes_nearest"] / max(cs["rays_nearest"], 1), 2),

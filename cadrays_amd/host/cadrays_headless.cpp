@@ -1,0 +1,98 @@
+// cadrays_headless.cpp -- headless C++ host driver over the C ABI of libcadrays_hip.so.
+//
+// Restates, without window / ImGui / Tcl, the part of the reference application that drives the hot
+// path in test mode:
+//   CADRays <script.tcl> <nFrames>                         reference src/Launcher/main.cxx:164-189
+//   loop: View->Redraw() once per frame, count frames      src/Launcher/AppViewer.cxx:1045-1071
+//   BufferDump(Graphic3d_BT_RGB) after the last frame      src/Launcher/AppViewer.cxx:1255-1264
+//   write Output_<name>_<n>.png and Output_<name>_<n>.txt (average frame rate)   main.cxx:193-228
+// Here: cadrays_headless <scene.crhscene> <nFrames> [device] writes Output_<name>_<n>.ppm (LDR),
+// Output_<name>_<n>.pfm (linear HDR, the parity buffer of AppGui.cxx:345-349) and Output_<name>_<n>.txt.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cadrays_hip.h"
+
+namespace {
+
+template <class T> bool read_vec(FILE* f, std::vector<T>& v, size_t n)
+{
+  v.resize(n);
+  return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+
+int die(crh_ctx* c, const char* what, int rc)
+{
+  fprintf(stderr, "cadrays_headless: %s failed (%d): %s\n", what, rc, c ? crh_last_error(c) : "");
+  if (c) crh_destroy(c);
+  return 1;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+  if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene> <nFrames> [device]\n", argv[0]); return 2; }
+  const std::string path = argv[1];
+  const int n_frames = atoi(argv[2]);
+  const int device = argc > 3 ? atoi(argv[3]) : 0;
+  if (n_frames <= 0) { fprintf(stderr, "nFrames must be > 0\n"); return 2; }
+
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { perror(path.c_str()); return 1; }
+  char magic[4]; uint32_t hdr[7];
+  if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "CRHS", 4) != 0 || fread(hdr, 4, 7, f) != 7 || hdr[0] != 1) { fprintf(stderr, "not a .crhscene v1 file\n"); return 1; }
+  const uint32_t nV = hdr[1], nT = hdr[2], nM = hdr[3], nL = hdr[4], eW = hdr[5], eH = hdr[6];
+  crh_camera cam; crh_params par;
+  std::vector<float> pos, nrm, env; std::vector<int32_t> tri; std::vector<crh_bsdf> mats; std::vector<crh_light> lights;
+  bool ok = fread(&cam, sizeof cam, 1, f) == 1 && fread(&par, sizeof par, 1, f) == 1 && read_vec(f, pos, 3 * (size_t)nV) && read_vec(f, nrm, 3 * (size_t)nV) &&
+            read_vec(f, tri, 4 * (size_t)nT) && read_vec(f, mats, nM) && read_vec(f, lights, nL) && read_vec(f, env, 3 * (size_t)eW * eH);
+  fclose(f);
+  if (!ok) { fprintf(stderr, "truncated scene file\n"); return 1; }
+
+  crh_ctx* c = crh_create(device);                       // == driver + viewer + view + FBO (AppViewer.cxx:601-638)
+  if (!c) return die(nullptr, "crh_create", CRH_E_DEVICE);
+  int rc;
+  if ((rc = crh_set_geometry(c, pos.data(), nrm.data(), nullptr, nV, tri.data(), nT, nullptr, nullptr, 0))) return die(c, "crh_set_geometry", rc);
+  if ((rc = crh_set_materials(c, mats.data(), nM))) return die(c, "crh_set_materials", rc);
+  if ((rc = crh_set_lights(c, lights.data(), nL))) return die(c, "crh_set_lights", rc);
+  if ((rc = crh_set_envmap(c, env.empty() ? nullptr : env.data(), eW, eH))) return die(c, "crh_set_envmap", rc);
+  if ((rc = crh_set_camera(c, &cam))) return die(c, "crh_set_camera", rc);
+  if ((rc = crh_set_params(c, &par))) return die(c, "crh_set_params", rc);
+  if ((rc = crh_build(c))) return die(c, "crh_build", rc);
+
+  // the render loop of AppViewer::Run in test mode: one Redraw per frame until MaxFramesCount
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int frame = 0; frame < n_frames; ++frame)
+    if ((rc = crh_render(c, 1))) return die(c, "crh_render", rc);
+  if ((rc = crh_sync(c))) return die(c, "crh_sync", rc);
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const double fps = n_frames / secs;
+
+  std::vector<uint8_t> ldr(3 * (size_t)par.width * par.height);
+  std::vector<float> hdr_img(3 * (size_t)par.width * par.height);
+  if ((rc = crh_read_ldr(c, ldr.data()))) return die(c, "crh_read_ldr", rc);   // BufferDump(Graphic3d_BT_RGB)
+  if ((rc = crh_read_hdr(c, hdr_img.data()))) return die(c, "crh_read_hdr", rc);   // Graphic3d_BT_RGB_RayTraceHdrLeft
+  crh_stats st; crh_get_stats(c, &st);
+
+  std::string stem = path; const size_t sl = stem.find_last_of('/'); std::string dir = sl == std::string::npos ? "." : stem.substr(0, sl);
+  std::string name = sl == std::string::npos ? stem : stem.substr(sl + 1); const size_t dot = name.find_last_of('.'); if (dot != std::string::npos) name = name.substr(0, dot);
+  const std::string base = dir + "/Output_" + name + "_" + std::to_string(n_frames);
+  if (FILE* o = fopen((base + ".ppm").c_str(), "wb")) { fprintf(o, "P6\n%u %u\n255\n", par.width, par.height); fwrite(ldr.data(), 1, ldr.size(), o); fclose(o); }
+  if (FILE* o = fopen((base + ".pfm").c_str(), "wb")) {
+    fprintf(o, "PF\n%u %u\n-1.0\n", par.width, par.height);
+    for (uint32_t y = par.height; y-- > 0;) fwrite(&hdr_img[3 * (size_t)y * par.width], sizeof(float), 3 * (size_t)par.width, o);   // PFM is bottom-up
+    fclose(o);
+  }
+  if (FILE* o = fopen((base + ".txt").c_str(), "w")) { fprintf(o, "%g", fps); fclose(o); }
+  printf("{\"scene\": \"%s\", \"frames\": %d, \"fps\": %.4f, \"seconds\": %.6f, \"rays_nearest\": %llu, \"rays_any\": %llu, \"samples\": %llu, \"mrays_per_s\": %.3f}\n",
+         name.c_str(), n_frames, fps, secs, (unsigned long long)st.rays_nearest, (unsigned long long)st.rays_any, (unsigned long long)st.samples,
+         (double)(st.rays_nearest + st.rays_any) / secs / 1e6);
+  crh_destroy(c);
+  return 0;
+}

@@ -254,3 +254,25 @@ def test_errors(view_cls):
         v.set_params(dataclasses.replace(sc.params, tile_size=12))
     with pytest.raises(BackendError):
         v.set_params(dataclasses.replace(sc.params, max_depth=33))
+
+
+def test_headless_cpp_driver_matches_oracle(tmp_path, Oracle):
+    """the C++ host driver (script + frame count -> Output_*.ppm/.pfm/.txt, like main.cxx:164-228)."""
+    import json, os, subprocess
+    from cadrays_amd.scene_io import save_scene
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cadrays_amd", "host", "cadrays_headless")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    sc = scenes.cornell_box(True, 96, 64)
+    path = save_scene(sc, str(tmp_path / "cornell.crhscene"))
+    out = subprocess.check_output([exe, path, "5"], text=True)
+    info = json.loads(out.strip().splitlines()[-1])
+    assert info["frames"] == 5 and info["samples"] == 96 * 64 * 5 and info["fps"] > 0
+    with open(tmp_path / "Output_cornell_5.pfm", "rb") as f:
+        assert f.readline() == b"PF\n"; w, h = map(int, f.readline().split()); f.readline()
+        img = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]
+    o = Oracle().load_scene(sc); o.render(5)
+    assert np.array_equal(bits(img), bits(o.read_hdr()))
+    ppm = open(tmp_path / "Output_cornell_5.ppm", "rb").read()
+    assert ppm.startswith(b"P6\n96 64\n255\n") and np.array_equal(np.frombuffer(ppm[len(b"P6\n96 64\n255\n"):], np.uint8).reshape(64, 96, 3), o.read_ldr())
+    assert float(open(tmp_path / "Output_cornell_5.txt").read()) > 0
