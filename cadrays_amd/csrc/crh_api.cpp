@@ -43,6 +43,7 @@ struct crh_ctx {
   uint32_t* d_tile_ids = nullptr; uint32_t tile_cap = 0;
   uint32_t* d_seeds = nullptr; uint32_t seed_cap = 0;
   DCounters* d_counters = nullptr;
+  uint32_t* d_api_cursor = nullptr;   // work cursor of the API-level trace kernels
   void* d_scratch = nullptr; size_t scratch_bytes = 0;
   bool counters_on = false, timing_on = false;
   uint32_t frames_done = 0;       // whole-frame iterations since reset (crh_render continues from here)
@@ -257,7 +258,7 @@ crh_ctx* crh_create(int device_ordinal)
   crh_ctx* c = new crh_ctx();
   c->device = device_ordinal;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&c->d_counters, sizeof(DCounters)) != hipSuccess || hipMemset(c->d_counters, 0, sizeof(DCounters)) != hipSuccess) {
+      hipMalloc((void**)&c->d_counters, sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemset(c->d_counters, 0, sizeof(DCounters)) != hipSuccess) {
     fprintf(stderr, "crh_create: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
     delete c; return nullptr;
   }
@@ -281,7 +282,7 @@ void crh_destroy(crh_ctx* c)
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o, c->paths.ray_d,
                   c->paths.hit, c->paths.thr, c->paths.rad, c->paths.st, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
-                  c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_scratch};
+                  c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch};
   for (void* p : ptrs) if (p) hipFree(p);
   hipStreamDestroy(c->stream);
   delete c;
@@ -481,7 +482,7 @@ static int trace_api(crh_ctx* c, const float* rays, uint32_t n, int any_hit, flo
   CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
   DScene S; fill_scene(c, S);
   Launch L{c->stream, c->grid, c->counters_on};
-  launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_counters);
+  launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
   CRH_HIP(hipGetLastError());
   CRH_HIP(hipMemcpyAsync(any_hit ? (void*)out_vis : (void*)out_hit, base + in_b, out_b, hipMemcpyDeviceToHost, c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
@@ -525,11 +526,11 @@ int crh_bench_trace(crh_ctx* c, const float* rays, uint32_t n, int any_hit, uint
   CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
   DScene S; fill_scene(c, S);
   Launch L{c->stream, c->grid, false};
-  launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_counters);
+  launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
   hipEvent_t e0 = get_event(c), e1 = get_event(c);
   CRH_HIP(hipEventRecord(e0, c->stream));
   for (uint32_t r = 0; r < repeat; ++r)
-    launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_counters);
+    launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
   CRH_HIP(hipEventRecord(e1, c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
   float ms = 0.f; CRH_HIP(hipEventElapsedTime(&ms, e0, e1));

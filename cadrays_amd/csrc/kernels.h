@@ -27,7 +27,7 @@ void launch_tonemap(const Launch&, const float4* accum, uint8_t* out_rgb, uint32
 void launch_hdr(const Launch&, const float4* accum, float* out_rgb, uint32_t n_pixels);
 // API-level ray tracing on a plain ray buffer (8 floats per ray)
 void launch_trace_rays(const Launch&, const DScene&, const float4* rays, uint32_t n, int any_hit,
-                       float4* out_hit, uint32_t* out_vis, DCounters*);
+                       float4* out_hit, uint32_t* out_vis, uint32_t* d_cursor, DCounters*);
 void launch_debug_math(const Launch&, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n);
 
 }  // namespace crh

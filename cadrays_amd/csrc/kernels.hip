@@ -79,6 +79,15 @@ __device__ __forceinline__ void block_enqueue(bool pred, uint32_t value, uint32_
 #else
 #define CRH_TRACE_BOUNDS __launch_bounds__(kBlock)
 #endif
+#ifndef CRH_INNER_STEPS
+#define CRH_INNER_STEPS 4      // 0: descend until every lane holds a leaf; k > 0: at most k inner steps per round
+#endif
+#ifndef CRH_REFILL_IDLE
+#define CRH_REFILL_IDLE 24     // refill a wavefront once this many of its 64 lanes have no ray
+#endif
+constexpr uint32_t kPoolChunk = 512;   // rays a wavefront takes from the global cursor per atomic
+constexpr uint32_t kDone = 0xFFFFFFFFu;
+
 __device__ __forceinline__ float inv_dir(float d)
 { return 1.0f / (crh_abs(d) < kDirEps ? (d < 0.f ? -kDirEps : kDirEps) : d); }
 
@@ -87,44 +96,76 @@ __device__ __forceinline__ uint32_t pick(uint4 r, uint32_t s)
 
 #define CRH_CE(a, b) { const uint32_t lo_ = min(a, b); const uint32_t hi_ = max(a, b); a = lo_; b = hi_; }
 
-// Ordered stack traversal.  lds: this lane's column of the workgroup's stack (stride kBlock dwords).
-// hit = {t, u, v, leaf-order triangle index as int bits (-1: none)}.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                         v3 o, v3 d, float tmax, uint32_t* lds, float4& hit,
-                                         uint32_t& n_nodes, uint32_t& n_tris)
+// Persistent-wave traversal engine shared by every tracing kernel.
+//
+// A wavefront owns 64 ray slots.  It takes rays from a wave-local pool (kPoolChunk queue entries claimed with
+// one atomic on the global cursor) and REFILLS idle lanes as soon as CRH_REFILL_IDLE of them have finished,
+// instead of waiting for the slowest ray of a 64-ray packet.  Inside, the classic "while-while" shape keeps
+// lanes convergent: (A) every lane descends inner nodes until it holds a leaf (or runs dry), (B) all lanes
+// holding a leaf test its triangles together.  The per-ray sequence of node visits and triangle tests -- and
+// therefore every result bit and counter -- is exactly the ordered stack traversal of DESIGN.md section 3.
+//
+// load(idx, o, d, tmax, tag) fetches queue entry idx; store(tag, hit, found) commits a finished ray.
+// lds: this lane's column of the workgroup's stack (stride kBlock dwords), 16 entries; deeper entries
+// spill to scratch (never touched on ordinary scenes).
+template <bool ANY, bool COUNT, class Load, class Store>
+__device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                             uint32_t* __restrict__ cursor, uint32_t n, uint32_t* lds,
+                                             Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris)
 {
   uint32_t ovf[kOvfStack];
+  const uint32_t lane = lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  // per-lane ray state
+  bool have = false;
+  uint32_t cur = kDone, tag = 0;
   int sp = 0;
-  const float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
-  const float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
-  float best = tmax;
+  v3 o = crh_mk3(0.f, 0.f, 0.f), d = o;
+  float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, best = 0.f;
+  float4 hit = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   bool found = false;
-  hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
-  uint32_t cur = 0u;
+  // wave-uniform pool state
+  uint32_t pool_next = 0, pool_end = 0;
+  bool exhausted = false;
+
   for (;;) {
-    if (cur & kQLeafBit) {
-      const uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t k = 0; k < cnt; ++k) {
-        const float4* tp = tris + 3u * (off + k);
-        const float4 a = tp[0], b = tp[1], c = tp[2];
-        if (COUNT) ++n_tris;
-        const v3 v0 = xyz(a), v1 = xyz(b), v2 = xyz(c);
-        const v3 e0 = crh_sub3(v1, v0), e1 = crh_sub3(v0, v2);
-        const v3 n = crh_cross3(e1, e0);
-        const v3 to = crh_sub3(v0, o);
-        const float inv = 1.0f / crh_dot3(n, d);
-        const v3 vc = crh_cross3(d, to);
-        const float tt = crh_dot3(n, to) * inv;
-        const float uu = crh_dot3(vc, e1) * inv;
-        const float vv = crh_dot3(vc, e0) * inv;
-        if (tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f && tt < best) {
-          best = tt; found = true;
-          hit = make_float4(tt, uu, vv, __int_as_float((int)(off + k)));
-          if (ANY) return true;
+    // ------------------------------------------------------------------ refill idle lanes
+    unsigned long long idle = __ballot(!have);
+    if (!exhausted && (uint32_t)__popcll(idle) >= (uint32_t)CRH_REFILL_IDLE) {
+      for (int round = 0; round < 2 && idle != 0ull; ++round) {
+        if (pool_next == pool_end) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(cursor, kPoolChunk);
+          base = __shfl(base, 0);
+          if (base >= n) { exhausted = true; break; }
+          pool_next = base; pool_end = min(base + kPoolChunk, n);
         }
+        const uint32_t avail = pool_end - pool_next;
+        const uint32_t want = (uint32_t)__popcll(idle);
+        const uint32_t take = min(avail, want);
+        const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+        const bool mine = !have && ((idle >> lane) & 1ull) && rank < take;
+        if (mine) {
+          float tmax;
+          load(pool_next + rank, o, d, tmax, tag);
+          ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
+          nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
+          best = tmax; found = false; sp = 0; cur = 0u; have = true;
+          hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
+        }
+        pool_next += take;
+        idle &= ~__ballot(mine);
       }
-    } else {
+    }
+    if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
+
+    // ------------------------------------------------------------------ (A) inner nodes until a leaf is in hand
+#if CRH_INNER_STEPS > 0
+#pragma unroll 1
+    for (int step_ = 0; step_ < CRH_INNER_STEPS && have && !(cur & kQLeafBit); ++step_) {
+#else
+    while (have && !(cur & kQLeafBit)) {
+#endif
       const float4* np = nodes + 8u * cur;
       const float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
       const float4 rf = np[6];
@@ -156,19 +197,46 @@ __device__ __forceinline__ bool traverse(const float4* __restrict__ nodes, const
       if (key[2] != 0xFFFFFFFFu) CRH_PUSH(pick(refs, key[2] & 3u))
       if (key[1] != 0xFFFFFFFFu) CRH_PUSH(pick(refs, key[1] & 3u))
 #undef CRH_PUSH
-      if (key[0] != 0xFFFFFFFFu) { cur = pick(refs, key[0] & 3u); continue; }
+      if (key[0] != 0xFFFFFFFFu) cur = pick(refs, key[0] & 3u);
+      else if (sp == 0) cur = kDone;
+      else { --sp; cur = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack]; }
     }
-    if (sp == 0) break;
-    --sp;
-    cur = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
+
+    // ------------------------------------------------------------------ (B) the leaf in hand
+    if (have && (cur & kQLeafBit) && cur != kDone) {
+      const uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const float4* tp = tris + 3u * (off + k);
+        const float4 a = tp[0], b = tp[1], c = tp[2];
+        if (COUNT) ++n_tris;
+        const v3 v0 = xyz(a), v1 = xyz(b), v2 = xyz(c);
+        const v3 e0 = crh_sub3(v1, v0), e1 = crh_sub3(v0, v2);
+        const v3 nrm = crh_cross3(e1, e0);
+        const v3 to = crh_sub3(v0, o);
+        const float inv = 1.0f / crh_dot3(nrm, d);
+        const v3 vc = crh_cross3(d, to);
+        const float tt = crh_dot3(nrm, to) * inv;
+        const float uu = crh_dot3(vc, e1) * inv;
+        const float vv = crh_dot3(vc, e0) * inv;
+        if (tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f && tt < best) {
+          best = tt; found = true;
+          hit = make_float4(tt, uu, vv, __int_as_float((int)(off + k)));
+          if (ANY) break;
+        }
+      }
+      if ((ANY && found) || sp == 0) cur = kDone;
+      else { --sp; cur = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack]; }
+    }
+
+    // ------------------------------------------------------------------ (C) retire finished rays
+    if (have && cur == kDone) { store(tag, hit, found); have = false; }
   }
-  return found;
 }
 
 template <bool COUNT>
 __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint32_t* __restrict__ q,
-                                                           const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors,
-                                                           uint32_t* zero_a, uint32_t* zero_b, DCounters* C)
+                                                  const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors,
+                                                  uint32_t* zero_a, uint32_t* zero_b, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   const uint32_t n = *count;
@@ -178,18 +246,13 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint3
     atomicAdd(&C->rays_nearest, (unsigned long long)n);
   }
   uint32_t nn = 0, nt = 0;
-  for (;;) {
-    const uint32_t base = wave_next_chunk(cursors + 0);
-    if (base >= n) break;
-    const uint32_t i = base + lane_id();
-    if (i < n) {
-      const uint32_t pid = q[i];
-      const float4 o4 = P.ray_o[pid], d4 = P.ray_d[pid];
-      float4 h;
-      traverse<false, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
-      P.hit[pid] = h;
-    }
-  }
+  trace_engine<false, COUNT>(S.nodes, S.tris, cursors + 0, n, &stk[threadIdx.x],
+    [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
+      tag = q[idx];
+      const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
+      o = xyz(o4); d = xyz(d4); tmax = o4.w;
+    },
+    [&](uint32_t tag, float4 h, bool) { P.hit[tag] = h; }, nn, nt);
   if (COUNT) {
     nn = wave_sum(nn); nt = wave_sum(nt);
     if (lane_id() == 0) { atomicAdd(&C->nodes_nearest, (unsigned long long)nn); atomicAdd(&C->tris_nearest, (unsigned long long)nt); }
@@ -198,53 +261,53 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint3
 
 template <bool COUNT>
 __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t* __restrict__ q,
-                                                       const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors, DCounters* C)
+                                              const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   const uint32_t n = *count;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
   uint32_t nn = 0, nt = 0;
-  for (;;) {
-    const uint32_t base = wave_next_chunk(cursors + 2);
-    if (base >= n) break;
-    const uint32_t i = base + lane_id();
-    if (i < n) {
-      const uint32_t pid = q[i];
-      const float4 o4 = P.sh_o[pid], d4 = P.sh_d[pid];
-      float4 h;
-      const bool occluded = traverse<true, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
+  trace_engine<true, COUNT>(S.nodes, S.tris, cursors + 2, n, &stk[threadIdx.x],
+    [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
+      tag = q[idx];
+      const float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
+      o = xyz(o4); d = xyz(d4); tmax = o4.w;
+    },
+    [&](uint32_t tag, float4, bool occluded) {
       if (!occluded) {
-        const float4 c = P.sh_c[pid];
-        float4 r = P.rad[pid];
+        const float4 c = P.sh_c[tag];
+        float4 r = P.rad[tag];
         r.x += c.x; r.y += c.y; r.z += c.z;
-        P.rad[pid] = r;
+        P.rad[tag] = r;
       }
-    }
-  }
+    }, nn, nt);
   if (COUNT) {
     nn = wave_sum(nn); nt = wave_sum(nt);
     if (lane_id() == 0) { atomicAdd(&C->nodes_any, (unsigned long long)nn); atomicAdd(&C->tris_any, (unsigned long long)nt); }
   }
 }
 
-// API-level tracing of a caller ray buffer {o.xyz, tmax, d.xyz, -}
+// API-level tracing of a caller ray buffer {o.xyz, tmax, d.xyz, -}; `cursor` must be zero at launch
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace_rays(DScene S, const float4* __restrict__ rays, uint32_t n,
-                                                        float4* __restrict__ out_hit, uint32_t* __restrict__ out_vis, DCounters* C)
+__global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict__ rays, uint32_t n, uint32_t* __restrict__ cursor,
+                                               float4* __restrict__ out_hit, uint32_t* __restrict__ out_vis, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   uint32_t nn = 0, nt = 0;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float4 o4 = rays[2u * i], d4 = rays[2u * i + 1u];
-    float4 h;
-    const bool f = traverse<ANY, COUNT>(S.nodes, S.tris, xyz(o4), xyz(d4), o4.w, &stk[threadIdx.x], h, nn, nt);
-    if (ANY) out_vis[i] = f ? 0u : 1u;
-    else {
-      const int k = __float_as_int(h.w);
-      if (k >= 0) h.w = S.tris[3u * (uint32_t)k].w;   // leaf order -> caller's triangle index
-      out_hit[i] = h;
-    }
-  }
+  trace_engine<ANY, COUNT>(S.nodes, S.tris, cursor, n, &stk[threadIdx.x],
+    [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
+      tag = idx;
+      const float4 o4 = rays[2u * idx], d4 = rays[2u * idx + 1u];
+      o = xyz(o4); d = xyz(d4); tmax = o4.w;
+    },
+    [&](uint32_t tag, float4 h, bool f) {
+      if (ANY) out_vis[tag] = f ? 0u : 1u;
+      else {
+        const int k = __float_as_int(h.w);
+        if (k >= 0) h.w = S.tris[3u * (uint32_t)k].w;   // leaf order -> caller's triangle index
+        out_hit[tag] = h;
+      }
+    }, nn, nt);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY ? &C->rays_any : &C->rays_nearest, (unsigned long long)n);
   if (COUNT) {
     nn = wave_sum(nn); nt = wave_sum(nt);
@@ -833,14 +896,15 @@ void launch_hdr(const Launch& L, const float4* accum, float* out, uint32_t n)
   hipLaunchKernelGGL(k_hdr, dim3(L.grid), dim3(kBlock), 0, L.stream, accum, out, n);
 }
 void launch_trace_rays(const Launch& L, const DScene& S, const float4* rays, uint32_t n, int any_hit, float4* out_hit,
-                       uint32_t* out_vis, DCounters* C)
+                       uint32_t* out_vis, uint32_t* cursor, DCounters* C)
 {
+  hipMemsetAsync(cursor, 0, sizeof(uint32_t), L.stream);
   if (any_hit) {
-    if (L.counters) hipLaunchKernelGGL((k_trace_rays<true, true>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, out_hit, out_vis, C);
-    else            hipLaunchKernelGGL((k_trace_rays<true, false>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, out_hit, out_vis, C);
+    if (L.counters) hipLaunchKernelGGL((k_trace_rays<true, true>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C);
+    else            hipLaunchKernelGGL((k_trace_rays<true, false>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C);
   } else {
-    if (L.counters) hipLaunchKernelGGL((k_trace_rays<false, true>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, out_hit, out_vis, C);
-    else            hipLaunchKernelGGL((k_trace_rays<false, false>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, out_hit, out_vis, C);
+    if (L.counters) hipLaunchKernelGGL((k_trace_rays<false, true>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C);
+    else            hipLaunchKernelGGL((k_trace_rays<false, false>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C);
   }
 }
 void launch_debug_math(const Launch& L, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n)
