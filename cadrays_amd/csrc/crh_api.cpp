@@ -22,7 +22,9 @@ using namespace crh;
 struct crh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  int grid = 2048;
+  int grid = 2048;        // streaming / shading kernels: 8 workgroups per CU
+  int grid_trace = 1024;  // traversal kernels: 4 workgroups (= 4 waves/SIMD) per CU -- measured optimum: more rays in
+                          // flight only enlarge the working set the 4 MB-per-XCD L2s have to hold
   std::string err;
   // ---- host copies of the inputs
   std::vector<float> pos, nrm, uv;
@@ -184,18 +186,19 @@ int do_reset(crh_ctx* c)
 int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns)
 {
   Launch L{c->stream, c->grid, c->counters_on};
+  Launch LT{c->stream, c->grid_trace, c->counters_on};
   launch_raygen(L, S, c->paths, c->queues, 0, d_tiles, nt, d_seeds, ns);
   int qin = 0;
   for (uint32_t b = 0; b < S.max_depth; ++b) {
     if (c->timing_on) {
       hipEvent_t e0 = get_event(c), e1 = get_event(c);
       hipEventRecord(e0, c->stream);
-      launch_trace_nearest(L, S, c->paths, c->queues, qin, c->d_counters);
+      launch_trace_nearest(LT, S, c->paths, c->queues, qin, c->d_counters);
       hipEventRecord(e1, c->stream);
       c->trace_ev.emplace_back(e0, e1);
-    } else launch_trace_nearest(L, S, c->paths, c->queues, qin, c->d_counters);
+    } else launch_trace_nearest(LT, S, c->paths, c->queues, qin, c->d_counters);
     launch_shade(L, S, c->paths, c->queues, qin, b, c->d_counters);
-    if (S.n_lights > 0) launch_trace_any(L, S, c->paths, c->queues, c->d_counters);
+    if (S.n_lights > 0) launch_trace_any(LT, S, c->paths, c->queues, c->d_counters);
     qin = 1 - qin;
   }
   launch_accumulate(L, S, c->paths, c->d_accum, d_tiles, nt, ns, c->d_counters);
@@ -263,9 +266,10 @@ crh_ctx* crh_create(int device_ordinal)
     delete c; return nullptr;
   }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->grid = prop.multiProcessorCount * 8;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->grid = prop.multiProcessorCount * 8; c->grid_trace = prop.multiProcessorCount * 4; }
   if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)v; }
   if (const char* e = getenv("CRH_GRID")) { int v = atoi(e); if (v > 0) c->grid = v; }
+  if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }
   // reference defaults: GI on, depth as vrenderparams default, two-sided (SettingsWidget.cxx:65-90)
   c->par.width = 64; c->par.height = 64; c->par.max_depth = 5; c->par.two_sided = 1; c->par.seed = 1; c->par.tile_size = 32;
   c->par.white_point = 1.0f; c->par.russian_roulette = 1; c->par.env_as_background = 1;
@@ -481,7 +485,7 @@ static int trace_api(crh_ctx* c, const float* rays, uint32_t n, int any_hit, flo
   char* base = (char*)c->d_scratch;
   CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
   DScene S; fill_scene(c, S);
-  Launch L{c->stream, c->grid, c->counters_on};
+  Launch L{c->stream, c->grid_trace, c->counters_on};
   launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
   CRH_HIP(hipGetLastError());
   CRH_HIP(hipMemcpyAsync(any_hit ? (void*)out_vis : (void*)out_hit, base + in_b, out_b, hipMemcpyDeviceToHost, c->stream));
@@ -525,7 +529,7 @@ int crh_bench_trace(crh_ctx* c, const float* rays, uint32_t n, int any_hit, uint
   char* base = (char*)c->d_scratch;
   CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
   DScene S; fill_scene(c, S);
-  Launch L{c->stream, c->grid, false};
+  Launch L{c->stream, c->grid_trace, false};
   launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
   hipEvent_t e0 = get_event(c), e1 = get_event(c);
   CRH_HIP(hipEventRecord(e0, c->stream));

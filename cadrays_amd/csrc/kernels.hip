@@ -91,8 +91,14 @@ constexpr uint32_t kDone = 0xFFFFFFFFu;
 __device__ __forceinline__ float inv_dir(float d)
 { return 1.0f / (crh_abs(d) < kDirEps ? (d < 0.f ? -kDirEps : kDirEps) : d); }
 
+// select r[s & 3] without branches: two selects on bit 0, one on bit 1
 __device__ __forceinline__ uint32_t pick(uint4 r, uint32_t s)
-{ return s == 0u ? r.x : (s == 1u ? r.y : (s == 2u ? r.z : r.w)); }
+{
+  const bool b0 = (s & 1u) != 0u, b1 = (s & 2u) != 0u;
+  const uint32_t lo = b0 ? r.y : r.x;
+  const uint32_t hi = b0 ? r.w : r.z;
+  return b1 ? hi : lo;
+}
 
 #define CRH_CE(a, b) { const uint32_t lo_ = min(a, b); const uint32_t hi_ = max(a, b); a = lo_; b = hi_; }
 
@@ -188,18 +194,34 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       CRH_CHILD(3, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, refs.w)
 #undef CRH_CHILD
       CRH_CE(key[0], key[1]) CRH_CE(key[2], key[3]) CRH_CE(key[0], key[2]) CRH_CE(key[1], key[3]) CRH_CE(key[1], key[2])
-      // far .. near onto the stack, nearest continues in registers
+      // The sorted keys put the nh hit children first (miss keys have bit 31 set).  Far .. near go onto the
+      // stack, the nearest continues in registers.  Common case (room for three entries in the LDS part of
+      // the stack): three UNCONDITIONAL stores -- hit children land at sp + (nh-1-j), the others in the dead
+      // slots above the new top -- so the step has no per-child branches.
+      const uint32_t r0 = pick(refs, key[0]), r1 = pick(refs, key[1]), r2 = pick(refs, key[2]), r3 = pick(refs, key[3]);
+      const int nh = 4 + ((((int)key[0] >> 31) + ((int)key[1] >> 31)) + (((int)key[2] >> 31) + ((int)key[3] >> 31)));
+      if (__builtin_expect(sp <= kLdsStack - 3, 1)) {
+        uint32_t* top = lds + sp * kBlock;
+        const int p1 = max(nh, 2) - 2, p2 = (nh == 3) ? 0 : 1, p3 = (nh == 4) ? 0 : 2;
+        top[p3 * kBlock] = r3; top[p2 * kBlock] = r2; top[p1 * kBlock] = r1;
+        sp += max(nh, 1) - 1;
+      } else {
 #define CRH_PUSH(V)                                                          \
-      { const uint32_t v_ = (V);                                             \
-        if (sp < kLdsStack) lds[sp * kBlock] = v_; else ovf[sp - kLdsStack] = v_; \
-        ++sp; }
-      if (key[3] != 0xFFFFFFFFu) CRH_PUSH(pick(refs, key[3] & 3u))
-      if (key[2] != 0xFFFFFFFFu) CRH_PUSH(pick(refs, key[2] & 3u))
-      if (key[1] != 0xFFFFFFFFu) CRH_PUSH(pick(refs, key[1] & 3u))
+        { const uint32_t v_ = (V);                                           \
+          if (sp < kLdsStack) lds[sp * kBlock] = v_; else ovf[sp - kLdsStack] = v_; \
+          ++sp; }
+        if (nh == 4) CRH_PUSH(r3)
+        if (nh >= 3) CRH_PUSH(r2)
+        if (nh >= 2) CRH_PUSH(r1)
 #undef CRH_PUSH
-      if (key[0] != 0xFFFFFFFFu) cur = pick(refs, key[0] & 3u);
+      }
+      if (nh >= 1) cur = r0;
       else if (sp == 0) cur = kDone;
-      else { --sp; cur = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack]; }
+      else {
+        --sp;
+        if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
+        else { cur = ovf[sp - kLdsStack]; asm volatile("" : "+v"(cur)); }
+      }
     }
 
     // ------------------------------------------------------------------ (B) the leaf in hand
@@ -225,7 +247,11 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         }
       }
       if ((ANY && found) || sp == 0) cur = kDone;
-      else { --sp; cur = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack]; }
+      else {
+        --sp;
+        if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
+        else { cur = ovf[sp - kLdsStack]; asm volatile("" : "+v"(cur)); }
+      }
     }
 
     // ------------------------------------------------------------------ (C) retire finished rays
