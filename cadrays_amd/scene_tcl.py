@@ -1,0 +1,656 @@
+"""Reader / writer of the CADRays scene wire format.
+
+What CADRays writes on export (reference src/ImportExport/ImportExport.cxx:350-607): `model.tcl` -- a flat list
+of DRAW/ViewerTest commands -- plus `meshes/<name>.ply` (binary PLY through assimp 'plyb', AisMesh.cxx:490) and
+`textures/`.  The same command vocabulary drives the demo scripts data/scripts/*.tcl.  This module evaluates
+the subset of Tcl those files use (set / $var / [expr] / for / if / incr / eval / lrepeat) and implements the
+commands that feed the path tracer:
+
+  rtmeshread   (ImportExport.cxx:88-92, ImportExportPlugin.cxx:132-354)      vdisplay, vclear
+  vbsdf        (ImportExport.cxx:166-231; data/scripts/Materials.tcl:42-52)    vsetmaterial (stock names)
+  vlocation    (ImportExport.cxx:276-305; CornellBox.tcl:23-27,55)             box / psphere / explode / ttranslate
+  vlight, rtlight (ImportExport.cxx:534-604; CornellBox.tcl:11-14)             vtextureenv (ImportExport.cxx:509)
+  vcamera, vviewparams, vfront, vfit (ImportExport.cxx:442-498)                vrenderparams (CornellBox.tcl:76)
+
+`restore <file.brep>` (CAD B-Rep shapes) needs OCCT's tessellator and is reported as unsupported.
+Stock `vsetmaterial` BSDFs live inside OCCT [OCCT-ext]; the table below holds stand-ins that the scripts
+override field by field.
+"""
+import math
+import os
+import re
+import struct
+
+import numpy as np
+
+from .materials import BSDF, Fresnel
+from .scenes import Camera, Light, Params, Scene, _Mesh
+
+
+class TclError(RuntimeError):
+    pass
+
+
+_NUM = re.compile(r"[-+]?(\d+\.?\d*|\.\d+)([eE][-+]?\d+)?")
+
+
+# ------------------------------------------------------------------------------------------ mini Tcl
+def _split_commands(script):
+    """split on newlines / ';' outside braces, brackets and quotes; drop comments"""
+    cmds, cur, depth_b, depth_k, in_q, i = [], [], 0, 0, False, 0
+    while i < len(script):
+        c = script[i]
+        if c == "\\" and i + 1 < len(script):
+            if script[i + 1] == "\n":
+                cur.append(" "); i += 2; continue
+            cur.append(script[i:i + 2]); i += 2; continue
+        if c == "#" and not in_q and depth_b == 0 and depth_k == 0 and not "".join(cur).strip():
+            while i < len(script) and script[i] != "\n":
+                i += 1
+            continue
+        if c == '"' and depth_b == 0:
+            in_q = not in_q
+        elif not in_q:
+            if c == "{": depth_b += 1
+            elif c == "}": depth_b -= 1
+            elif c == "[" and depth_b == 0: depth_k += 1
+            elif c == "]" and depth_b == 0: depth_k -= 1
+        if (c == "\n" or c == ";") and depth_b == 0 and depth_k == 0 and not in_q:
+            s = "".join(cur).strip()
+            if s:
+                cmds.append(s)
+            cur = []
+        else:
+            cur.append(c)
+        i += 1
+    s = "".join(cur).strip()
+    if s:
+        cmds.append(s)
+    return cmds
+
+
+class MiniTcl:
+    def __init__(self, commands, variables=None):
+        self.cmds = commands
+        self.vars = dict(variables or {})
+
+    # ---- substitution
+    def _subst(self, word):
+        out, i = [], 0
+        while i < len(word):
+            c = word[i]
+            if c == "\\" and i + 1 < len(word):
+                out.append(word[i + 1]); i += 2
+            elif c == "$":
+                m = re.match(r"\$(::)?(\w+)(\(([^)]*)\))?|\$\{([^}]*)\}", word[i:])
+                if not m:
+                    out.append(c); i += 1; continue
+                name = m.group(5) or m.group(2)
+                if m.group(4) is not None:
+                    name = f"{name}({self._subst(m.group(4))})"
+                if name not in self.vars:
+                    raise TclError(f'can\'t read "{name}": no such variable')
+                out.append(str(self.vars[name])); i += m.end()
+            elif c == "[":
+                depth, j = 1, i + 1
+                while j < len(word) and depth:
+                    depth += word[j] == "["; depth -= word[j] == "]"; j += 1
+                out.append(str(self.eval(word[i + 1:j - 1]))); i = j
+            else:
+                out.append(c); i += 1
+        return "".join(out)
+
+    def _words(self, cmd):
+        words, i, n = [], 0, len(cmd)
+        while i < n:
+            while i < n and cmd[i] in " \t":
+                i += 1
+            if i >= n:
+                break
+            if cmd[i] == "{":
+                depth, j = 1, i + 1
+                while j < n and depth:
+                    depth += cmd[j] == "{"; depth -= cmd[j] == "}"; j += 1
+                words.append(cmd[i + 1:j - 1]); i = j
+            elif cmd[i] == '"':
+                j = i + 1
+                while j < n and cmd[j] != '"':
+                    j += 2 if cmd[j] == "\\" else 1
+                words.append(self._subst(cmd[i + 1:j])); i = j + 1
+            else:
+                j, depth = i, 0
+                while j < n and (depth or cmd[j] not in " \t"):
+                    depth += cmd[j] == "["; depth -= cmd[j] == "]"; j += 1
+                words.append(self._subst(cmd[i:j])); i = j
+        return words
+
+    # ---- expr: numbers, variables, + - * / % comparisons, && || !, parentheses, a few functions
+    def expr(self, text):
+        text = self._subst(text)
+        text = text.replace("&&", " and ").replace("||", " or ")
+        text = re.sub(r"!(?!=)", " not ", text)
+        if not re.fullmatch(r"[\w\s\.\+\-\*/%\(\)<>=!,]*", text):
+            raise TclError(f"unsupported expression: {text}")
+        env = {"__builtins__": {}, "sqrt": math.sqrt, "sin": math.sin, "cos": math.cos, "abs": abs, "int": int, "double": float,
+               "round": round, "pow": pow, "min": min, "max": max}
+        text = re.sub(r"(?<![\w.])(\d+)\s*/\s*(\d+)(?![\w.])", r"(\1//\2)", text)      # Tcl integer division
+        v = eval(text, env)  # noqa: S307 -- character set restricted above
+        if isinstance(v, bool):
+            return int(v)
+        return v
+
+    def eval(self, script):
+        result = ""
+        for cmd in _split_commands(script):
+            w = self._words(cmd)
+            if not w:
+                continue
+            result = self.call(w)
+        return result
+
+    def call(self, w):
+        name, a = w[0], w[1:]
+        if name == "set":
+            if len(a) == 1:
+                return self.vars[a[0]]
+            self.vars[a[0]] = a[1]; return a[1]
+        if name == "variable":
+            self.vars[a[0]] = a[1] if len(a) > 1 else ""; return ""
+        if name == "expr":
+            return self.expr(" ".join(a))
+        if name == "incr":
+            self.vars[a[0]] = int(self.vars.get(a[0], 0)) + (int(a[1]) if len(a) > 1 else 1); return self.vars[a[0]]
+        if name == "for":
+            self.eval(a[0])
+            guard = 0
+            while self.expr(a[1]):
+                self.eval(a[3]); self.eval(a[2])
+                guard += 1
+                if guard > 10_000_000:
+                    raise TclError("for loop does not terminate")
+            return ""
+        if name == "if":
+            i = 0
+            while i < len(a):
+                if self.expr(a[i]):
+                    body = a[i + 1] if a[i + 1] != "then" else a[i + 2]
+                    return self.eval(body)
+                i += 2 if a[i + 1] != "then" else 3
+                if i < len(a) and a[i] == "else":
+                    return self.eval(a[i + 1])
+                if i < len(a) and a[i] == "elseif":
+                    i += 1; continue
+                break
+            return ""
+        if name == "eval":
+            return self.eval(" ".join(a))
+        if name == "lrepeat":
+            return " ".join([" ".join(a[1:])] * int(a[0]))
+        if name == "list":
+            return " ".join(a)
+        if name == "puts":
+            return ""
+        if name == "file":
+            return self.vars.get("Root", ".")       # [file dirname [file normalize [info script]]]
+        if name == "info":
+            return self.vars.get("__script__", "")
+        if name in ("pload", "source", "vinit", "catch"):
+            return ""
+        if name in self.cmds:
+            return self.cmds[name](a) or ""
+        raise TclError(f'invalid command name "{name}"')
+
+
+# ------------------------------------------------------------------------------------------ binary PLY
+_PLY_T = {"char": "b", "uchar": "B", "short": "h", "ushort": "H", "int": "i", "uint": "I", "float": "f", "double": "d",
+          "int8": "b", "uint8": "B", "int16": "h", "uint16": "H", "int32": "i", "uint32": "I", "float32": "f", "float64": "d"}
+
+
+def read_ply(path):
+    """vertices (x y z [nx ny nz] [s t | u v]) + triangle/polygon faces; binary little endian or ascii."""
+    with open(path, "rb") as f:
+        data = f.read()
+    end = data.index(b"end_header") + len(b"end_header")
+    header = data[:end].decode("ascii", "replace").split("\n")
+    body = data[end:].lstrip(b"\r")[1:] if data[end:end + 2] == b"\r\n" else data[end + 1:]
+    fmt, elems = None, []
+    for line in header:
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "format":
+            fmt = t[1]
+        elif t[0] == "element":
+            elems.append([t[1], int(t[2]), []])
+        elif t[0] == "property" and elems:
+            elems[-1][2].append(t[1:])
+    if fmt not in ("binary_little_endian", "ascii"):
+        raise ValueError(f"unsupported PLY format {fmt}")
+    pos = nrm = uv = None
+    faces = []
+    off = 0
+    tokens = body.split() if fmt == "ascii" else None
+    ti = 0
+    for name, count, props in elems:
+        if all(p[0] != "list" for p in props):
+            names = [p[1] for p in props]
+            if fmt == "ascii":
+                arr = np.array(tokens[ti:ti + count * len(props)], dtype=np.float64).reshape(count, len(props)); ti += count * len(props)
+                cols = {n: arr[:, i] for i, n in enumerate(names)}
+            else:
+                dt = np.dtype([(p[1], "<" + _PLY_T[p[0]]) for p in props])
+                arr = np.frombuffer(body, dt, count, off); off += dt.itemsize * count
+                cols = {n: arr[n] for n in names}
+            if name == "vertex":
+                pos = np.stack([cols["x"], cols["y"], cols["z"]], 1).astype(np.float32)
+                if "nx" in cols:
+                    nrm = np.stack([cols["nx"], cols["ny"], cols["nz"]], 1).astype(np.float32)
+                for a, b in (("s", "t"), ("u", "v"), ("texture_u", "texture_v")):
+                    if a in cols:
+                        uv = np.stack([cols[a], cols[b]], 1).astype(np.float32)
+        else:
+            for _ in range(count):
+                for p in props:
+                    if p[0] == "list":
+                        if fmt == "ascii":
+                            n = int(tokens[ti]); idx = [int(x) for x in tokens[ti + 1:ti + 1 + n]]; ti += 1 + n
+                        else:
+                            (n,) = struct.unpack_from("<" + _PLY_T[p[1]], body, off); off += struct.calcsize(_PLY_T[p[1]])
+                            idx = struct.unpack_from("<%d%s" % (n, _PLY_T[p[2]]), body, off); off += n * struct.calcsize(_PLY_T[p[2]])
+                        if name == "face":
+                            for k in range(1, n - 1):
+                                faces.append((idx[0], idx[k], idx[k + 1]))
+                    else:
+                        if fmt == "ascii":
+                            ti += 1
+                        else:
+                            off += struct.calcsize(_PLY_T[p[0]])
+    faces = np.array(faces, np.int32).reshape(-1, 3)
+    if nrm is None:
+        nrm = np.zeros_like(pos)
+        fn = np.cross(pos[faces[:, 1]] - pos[faces[:, 0]], pos[faces[:, 2]] - pos[faces[:, 0]])
+        for k in range(3):
+            np.add.at(nrm, faces[:, k], fn)
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+    return pos, nrm.astype(np.float32), faces, uv
+
+
+def write_ply(path, pos, nrm, faces):
+    """binary little-endian PLY with normals, the layout assimp's 'plyb' exporter writes (AisMesh.cxx:490)."""
+    with open(path, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\ncomment cadrays-hip\nelement vertex %d\nproperty float x\nproperty float y\n"
+                 "property float z\nproperty float nx\nproperty float ny\nproperty float nz\nelement face %d\n"
+                 "property list uchar int vertex_index\nend_header\n" % (len(pos), len(faces))).encode())
+        f.write(np.concatenate([pos, nrm], 1).astype("<f4").tobytes())
+        rec = np.zeros(len(faces), np.dtype([("n", "u1"), ("i", "<i4", 3)]))
+        rec["n"] = 3; rec["i"] = faces
+        f.write(rec.tobytes())
+
+
+# ------------------------------------------------------------------------------------------ scene builder
+def _quat_matrix(x, y, z, w):
+    n = math.sqrt(x * x + y * y + z * z + w * w) or 1.0
+    x, y, z, w = x / n, y / n, z / n, w / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _axis_angle_matrix(axis, deg):
+    a = np.asarray(axis, float); a /= np.linalg.norm(a) or 1.0
+    c, s = math.cos(math.radians(deg)), math.sin(math.radians(deg))
+    x, y, z = a
+    return np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                     [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                     [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
+
+
+# stand-ins for OCCT's stock materials [OCCT-ext]; scripts override them through vbsdf
+def _stock(name):
+    n = name.lower()
+    if n in ("glass", "diamond", "transparent", "water"):
+        return BSDF.CreateGlass(1.0, (1, 1, 1), 0.0, {"diamond": 2.42, "water": 1.33}.get(n, 1.5))
+    if n in ("brass", "bronze", "copper", "gold", "silver", "steel", "aluminium", "aluminum", "chrome", "pewter", "metalized"):
+        return BSDF.Metal(1.0, 0.1, 0.8)
+    if n in ("plastic", "shiny_plastic", "satin", "jade", "obsidian", "neon_gnc", "neon_phc"):
+        return BSDF.Glossy(0.5, 0.5, 0.1, 0.8)
+    return BSDF.CreateDiffuse(0.8)          # plaster, stone, default ...
+
+
+class _Obj:
+    def __init__(self, pos, nrm, faces):
+        self.pos, self.nrm, self.faces = np.asarray(pos, np.float64), np.asarray(nrm, np.float64), np.asarray(faces, np.int32)
+        self.R, self.s, self.t = np.eye(3), 1.0, np.zeros(3)
+        self.bsdf = BSDF.CreateDiffuse(0.8)
+        self.displayed = False
+
+    def world(self):
+        return (self.pos * self.s) @ self.R.T + self.t, self.nrm @ self.R.T
+
+
+class SceneBuilder:
+    """state that the v* / rt* commands mutate; snapshot() turns it into a cadrays_amd.scenes.Scene"""
+
+    def __init__(self, root=".", sphere_res=(48, 24)):
+        self.root, self.sphere_res = root, sphere_res
+        self.objs, self.lights, self.light_colors = {}, [], {}
+        self.cam = dict(eye=None, at=None, up=(0, 0, 1), proj=None, fovy=45.0, ortho=False, distance=None, size=None)
+        self.depth, self.env_path, self.unsupported = 5, None, []
+        self.commands = {k[4:]: getattr(self, k) for k in dir(self) if k.startswith("cmd_")}
+
+    # ---- geometry sources
+    def cmd_rtmeshread(self, a):
+        path, name = a[0], a[1]
+        pos, nrm, faces, _ = read_ply(path)
+        self.objs[name] = _Obj(pos, nrm, faces)
+        self.objs[name].displayed = True                     # rtmeshread displays what it loads (ImportExportPlugin.cxx:132-354)
+
+    def cmd_restore(self, a):
+        self.unsupported.append("restore " + " ".join(a))    # B-Rep: needs OCCT's mesher
+
+    def cmd_box(self, a):
+        name, v = a[0], [float(x) for x in a[1:]]
+        org, size = ((0, 0, 0), v[:3]) if len(v) == 3 else (v[:3], v[3:6])
+        m = _Mesh(); m.box(size, 0, org)
+        pos, nrm, tri = m.arrays()
+        o = _Obj(pos, nrm, tri[:, :3]); o.box = (org, size)
+        self.objs[name] = o
+
+    def cmd_psphere(self, a):
+        m = _Mesh(); m.sphere((0, 0, 0), float(a[1]), 0, *self.sphere_res)
+        pos, nrm, tri = m.arrays()
+        self.objs[a[0]] = _Obj(pos, nrm, tri[:, :3])
+
+    def cmd_compound(self, a):
+        *parts, name = a
+        o = _Obj(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3), np.int32)); o.parts = parts
+        self.objs[name] = o
+
+    def cmd_explode(self, a):
+        src = self.objs[a[0]]
+        if hasattr(src, "parts"):                           # compound -> name_1 .. name_n copies of its parts
+            for i, p in enumerate(src.parts, 1):
+                q = self.objs[p]
+                c = _Obj(q.pos.copy(), q.nrm.copy(), q.faces.copy()); c.R, c.s, c.t = q.R.copy(), q.s, q.t.copy()
+                self.objs[f"{a[0]}_{i}"] = c
+            return
+        if len(a) > 1 and a[1].upper().startswith("F") and hasattr(src, "box"):
+            # OCCT box face order: 1 x-min, 2 x-max, 3 y-min, 4 y-max, 5 z-min, 6 z-max (CornellBox.tcl:19-27)
+            (ox, oy, oz), (sx, sy, sz) = src.box
+            q = {1: ([(ox, oy, oz), (ox, oy, oz + sz), (ox, oy + sy, oz + sz), (ox, oy + sy, oz)], (-1, 0, 0)),
+                 2: ([(ox + sx, oy, oz), (ox + sx, oy + sy, oz), (ox + sx, oy + sy, oz + sz), (ox + sx, oy, oz + sz)], (1, 0, 0)),
+                 3: ([(ox, oy, oz), (ox + sx, oy, oz), (ox + sx, oy, oz + sz), (ox, oy, oz + sz)], (0, -1, 0)),
+                 4: ([(ox, oy + sy, oz), (ox, oy + sy, oz + sz), (ox + sx, oy + sy, oz + sz), (ox + sx, oy + sy, oz)], (0, 1, 0)),
+                 5: ([(ox, oy, oz), (ox, oy + sy, oz), (ox + sx, oy + sy, oz), (ox + sx, oy, oz)], (0, 0, -1)),
+                 6: ([(ox, oy, oz + sz), (ox + sx, oy, oz + sz), (ox + sx, oy + sy, oz + sz), (ox, oy + sy, oz + sz)], (0, 0, 1))}
+            for i, (pts, n) in q.items():
+                self.objs[f"{a[0]}_{i}"] = _Obj(pts, [n] * 4, [[0, 1, 2], [0, 2, 3]])
+            return
+        self.unsupported.append("explode " + " ".join(a))
+
+    def cmd_ttranslate(self, a):
+        self.objs[a[0]].pos = self.objs[a[0]].pos + np.array([float(x) for x in a[1:4]])
+
+    # ---- display state
+    def _names(self, a):
+        return [x for x in a if not x.startswith("-") and x in self.objs]
+
+    def cmd_vdisplay(self, a):
+        for n in self._names(a):
+            self.objs[n].displayed = True
+
+    def cmd_verase(self, a):
+        for n in self._names(a):
+            self.objs[n].displayed = False
+
+    def cmd_vclear(self, a):
+        for o in self.objs.values():
+            o.displayed = False
+
+    def cmd_vsetmaterial(self, a):
+        args = [x for x in a if not x.startswith("-")]
+        self.objs[args[0]].bsdf = _stock(args[1])
+
+    def cmd_vlocation(self, a):
+        args = [x for x in a if x != "-noupdate"]
+        o, i = self.objs[args[0]], 1
+        while i < len(args):
+            k = args[i].lower()
+            if k in ("-location", "-setlocation"):
+                o.t = np.array([float(x) for x in args[i + 1:i + 4]]); i += 4
+            elif k in ("-rotation", "-setrotation"):
+                o.R = _quat_matrix(*[float(x) for x in args[i + 1:i + 5]]); i += 5
+            elif k in ("-scale", "-setscale"):
+                o.s = float(args[i + 1]); i += 2
+            elif k == "-rotate":                               # local transformation := old * rotation(point, direction, degrees)
+                p = np.array([float(x) for x in args[i + 1:i + 4]])
+                R = _axis_angle_matrix([float(x) for x in args[i + 4:i + 7]], float(args[i + 7]))
+                o.t = o.t + o.s * (o.R @ (p - R @ p)); o.R = o.R @ R; i += 8
+            elif k == "-reset":
+                o.R, o.s, o.t = np.eye(3), 1.0, np.zeros(3); i += 1
+            else:
+                raise TclError(f"vlocation: unknown option {args[i]}")
+
+    def cmd_vbsdf(self, a):
+        args = [x for x in a if x != "-noupdate"]
+        b, i = self.objs[args[0]].bsdf, 1
+
+        def take(n):
+            nonlocal i
+            vals = []
+            while len(vals) < n and i + 1 < len(args) and _NUM.fullmatch(args[i + 1]):
+                vals.append(float(args[i + 1])); i += 1
+            if len(vals) == 1 and n == 3:
+                vals = vals * 3
+            if len(vals) != n:
+                raise TclError(f"vbsdf: {args[i - len(vals)]} expects {n} value(s)")
+            return vals
+
+        def fresnel():
+            nonlocal i
+            kind = args[i + 1].lower(); i += 1
+            if kind == "constant": return Fresnel.CreateConstant(*take(1))
+            if kind == "schlick": return Fresnel.CreateSchlick(take(3))
+            if kind == "conductor": return Fresnel.CreateConductor(*take(2))
+            if kind == "dielectric": return Fresnel.CreateDielectric(*take(1))
+            raise TclError(f"vbsdf: unknown Fresnel model {kind}")
+
+        while i < len(args):
+            k = args[i].lower()
+            if k == "-kc": b.Kc[:3] = take(3)
+            elif k == "-kd": b.Kd = np.array(take(3), np.float32)
+            elif k == "-ks": b.Ks[:3] = take(3)
+            elif k == "-kt": b.Kt = np.array(take(3), np.float32)
+            elif k == "-le": b.Le = np.array(take(3), np.float32)
+            elif k == "-baseroughness": b.Ks[3] = take(1)[0]
+            elif k == "-coatroughness": b.Kc[3] = take(1)[0]
+            elif k in ("-absorpcolor", "-absorptioncolor"): b.Absorption[:3] = take(3)
+            elif k in ("-absorpcoeff", "-absorptioncoeff"): b.Absorption[3] = take(1)[0]
+            elif k == "-basefresnel": b.FresnelBase = fresnel()
+            elif k == "-coatfresnel": b.FresnelCoat = fresnel()
+            elif k in ("-n", "-normalize"): b.Normalize()
+            else:
+                raise TclError(f"vbsdf: unknown option {args[i]}")
+            i += 1
+
+    # ---- lights
+    def cmd_vlight(self, a):
+        if not a:
+            return
+        op = a[0].lower()
+        if op == "clear":
+            self.lights, self.light_colors = [], {}; return
+        if op in ("del", "delete"):
+            idx = int(a[1])
+            if 0 <= idx < len(self.lights):
+                self.lights[idx] = None
+            return
+        if op == "add":
+            kind = a[1].lower()
+            l = dict(kind=kind, vec=(0.0, 0.0, -1.0) if kind == "directional" else (0.0, 0.0, 0.0), sm=0.0, int=1.0, head=0, color=(1.0, 1.0, 1.0))
+            self.lights.append(l); rest = a[2:]
+        elif op == "change":
+            l = self.lights[int(a[1])]; rest = a[2:]
+        else:
+            raise TclError(f"vlight: unknown operation {a[0]}")
+        i = 0
+        while i < len(rest):
+            k = rest[i].lower().lstrip("-")
+            if k in ("direction", "dir", "pos", "position"):
+                l["vec"] = tuple(float(x) for x in rest[i + 1:i + 4]); i += 4
+            elif k in ("sm", "smoothness"):
+                l["sm"] = float(rest[i + 1]); i += 2
+            elif k in ("int", "intensity"):
+                l["int"] = float(rest[i + 1]); i += 2
+            elif k in ("head", "headlight"):
+                l["head"] = int(rest[i + 1]); i += 2
+            elif k in ("color", "colour"):
+                i += 2
+            else:
+                raise TclError(f"vlight: unknown parameter {rest[i]}")
+
+    def cmd_rtlight(self, a):                                   # rtlight <id> -color r g b  (ImportExportPlugin.cxx:813-841)
+        idx = int(a[0])
+        if "-color" in a:
+            j = a.index("-color")
+            if 0 <= idx < len(self.lights) and self.lights[idx]:
+                self.lights[idx]["color"] = tuple(float(x) for x in a[j + 1:j + 4])
+
+    # ---- camera / params / env
+    def cmd_vcamera(self, a):
+        i = 0
+        while i < len(a):
+            k = a[i].lower()
+            if k in ("-persp", "-perspective"): self.cam["ortho"] = False; i += 1
+            elif k in ("-ortho", "-orthographic"): self.cam["ortho"] = True; i += 1
+            elif k == "-fovy": self.cam["fovy"] = float(a[i + 1]); i += 2
+            elif k == "-distance": self.cam["distance"] = float(a[i + 1]); i += 2
+            else: i += 1
+
+    def cmd_vviewparams(self, a):
+        i = 0
+        while i < len(a):
+            k = a[i].lower()
+            if k in ("-proj", "-up", "-at", "-eye"):
+                self.cam[k[1:]] = tuple(float(x) for x in a[i + 1:i + 4]); i += 4
+            elif k in ("-size", "-scale"):
+                self.cam[k[1:]] = float(a[i + 1]); i += 2
+            else:
+                i += 1
+
+    def cmd_vfront(self, a):
+        self.cam["proj"], self.cam["up"], self.cam["eye"] = (0.0, -1.0, 0.0), (0.0, 0.0, 1.0), None
+
+    def cmd_vfit(self, a):
+        self.cam["eye"] = None; self.cam["at"] = None       # resolved against the displayed geometry in snapshot()
+
+    def cmd_vrenderparams(self, a):
+        for i, k in enumerate(a):
+            if k.lower() == "-raydepth":
+                self.depth = int(a[i + 1])
+
+    def cmd_vtextureenv(self, a):
+        self.env_path = a[1] if len(a) > 1 and a[0].lower() == "on" else None
+
+    def _noop(self, a):
+        return ""
+
+    cmd_vsetdispmode = cmd_vaspects = cmd_vvbo = cmd_rtmodel = cmd_rtgroup = cmd_vfps = cmd_vdump = cmd_vtop = cmd_vaxo = _noop
+    cmd_vzbufftrihedron = cmd_vsetcolor = cmd_vselect = cmd_vupdate = cmd_vrepaint = cmd_rtdisplay = cmd_rttexture = _noop
+
+    # ---- result
+    def snapshot(self, width=512, height=512, name="tcl_scene"):
+        pos, nrm, tri, mats, nv = [], [], [], [], 0
+        for o in self.objs.values():
+            if not o.displayed or len(o.faces) == 0:
+                continue
+            p, n = o.world()
+            t = np.empty((len(o.faces), 4), np.int32); t[:, :3] = o.faces + nv; t[:, 3] = len(mats)
+            pos.append(p); nrm.append(n); tri.append(t); mats.append(o.bsdf); nv += len(p)
+        if not pos:
+            raise TclError("no displayed geometry")
+        pos = np.concatenate(pos).astype(np.float32); nrm = np.concatenate(nrm).astype(np.float32); tri = np.concatenate(tri)
+        c = self.cam
+        proj = np.array(c["proj"] if c["proj"] is not None else (0.0, -1.0, 0.0), float)
+        if c["eye"] is not None and c["at"] is not None:
+            eye, at = np.array(c["eye"], float), np.array(c["at"], float)
+        else:                                                  # vfit: frame the bounding sphere
+            lo, hi = pos.min(0), pos.max(0)
+            at = (lo + hi) / 2
+            r = np.linalg.norm(hi - lo) / 2
+            half = math.radians(c["fovy"]) / 2
+            half = min(half, math.atan(math.tan(half) * width / height))
+            eye = at + proj / np.linalg.norm(proj) * (r / math.sin(half))
+        cam = Camera(eye=tuple(eye), dir=tuple(at - eye), up=tuple(c["up"]), fovy_deg=c["fovy"], is_ortho=c["ortho"],
+                     ortho_scale=(c["size"] or 2.0) / 2)
+        lights = []
+        for l in self.lights:
+            if not l or l["kind"] not in ("directional", "positional"):
+                continue                                       # ambient / spot are ignored by the path tracer (LightSourcesEditor.cxx:157-178)
+            mk = Light.directional if l["kind"] == "directional" else Light.positional
+            lights.append(mk(l["vec"], smoothness=l["sm"], intensity=l["int"], color=l["color"]))
+        env = None
+        if self.env_path and os.path.exists(self.env_path):
+            from PIL import Image
+            im = np.asarray(Image.open(self.env_path).convert("RGB"), np.float32) / 255.0
+            env = np.ascontiguousarray(im * im)                # OCCT linearises LDR env texels by squaring [OCCT-ext]
+        return Scene(pos, nrm, tri, mats, lights=lights, env=env, camera=cam,
+                     params=Params(width=width, height=height, max_depth=self.depth), name=name)
+
+
+def read_scene(path, width=512, height=512, sphere_res=(48, 24)):
+    """Evaluate a CADRays model.tcl / demo script and return (Scene, builder)."""
+    root = os.path.dirname(os.path.abspath(path))
+    b = SceneBuilder(root, sphere_res)
+    interp = MiniTcl(b.commands, {"Root": root, "__script__": os.path.abspath(path), "env(APP_DATA)": root + "/"})
+    interp.eval(open(path).read())
+    return b.snapshot(width, height, os.path.splitext(os.path.basename(path))[0]), b
+
+
+def write_scene(scene, directory, object_names=None):
+    """Write `scene` the way ImportExport::Export does (ImportExport.cxx:350-607): model.tcl + meshes/<name>.ply,
+    one mesh per material."""
+    os.makedirs(os.path.join(directory, "meshes"), exist_ok=True)
+    lines = ["variable Root [file dirname [file normalize [info script]]]", "", "# Restore exported meshes"]
+    names = []
+    for m in range(len(scene.materials)):
+        sel = scene.tri[scene.tri[:, 3] == m]
+        if not len(sel):
+            continue
+        used, inv = np.unique(sel[:, :3], return_inverse=True)
+        name = (object_names or {}).get(m, f"Mesh{m}")
+        write_ply(os.path.join(directory, "meshes", name + ".ply"), scene.pos[used], scene.nrm[used], inv.reshape(-1, 3).astype(np.int32))
+        lines.append(f"rtmeshread $Root/meshes/{name}.ply {name} -group ")
+        names.append((name, scene.materials[m]))
+    g = lambda v: repr(float(np.float32(v)))
+    for name, b in names:
+        lines += ["", f"# Setup object '{name}'", f"vdisplay {name} -noupdate"]
+        for key, val in (("Kc", b.Kc[:3]), ("Kd", b.Kd), ("Ks", b.Ks[:3]), ("Kt", b.Kt)):
+            lines.append(f"vbsdf {name} -{key} {g(val[0])} {g(val[1])} {g(val[2])} -noupdate")
+        lines += [f"vbsdf {name} -baseRoughness {g(b.Ks[3])} -noupdate", f"vbsdf {name} -coatRoughness {g(b.Kc[3])} -noupdate",
+                  f"vbsdf {name} -Le {g(b.Le[0])} {g(b.Le[1])} {g(b.Le[2])} -noupdate",
+                  f"vbsdf {name} -absorpColor {g(b.Absorption[0])} {g(b.Absorption[1])} {g(b.Absorption[2])} -noupdate",
+                  f"vbsdf {name} -absorpCoeff {g(b.Absorption[3])} -noupdate"]
+        for layer, fr in (("coat", b.FresnelCoat), ("base", b.FresnelBase)):
+            kind = {"schlick": "Schlick", "constant": "Constant", "conductor": "Conductor", "dielectric": "Dielectric"}[fr.kind]
+            lines.append(f"vbsdf {name} -{layer}Fresnel {kind} " + " ".join(g(x) for x in fr.data) + " -noupdate")
+    c = scene.camera
+    eye, d = np.array(c.eye, float), np.array(c.dir, float)
+    at = eye + d
+    lines += ["", "# Restore scene hierarchy", "rtmodel -sync default", "", "# Restore view parameters",
+              "vcamera -orthographic " if c.is_ortho else f"vcamera -perspective -fovy {c.fovy_deg!r}",
+              f"vcamera -distance {float(np.linalg.norm(d))!r}",
+              "vviewparams -proj " + " ".join(repr(float(x)) for x in -d / np.linalg.norm(d)),
+              "vviewparams -up " + " ".join(repr(float(x)) for x in c.up),
+              "vviewparams -at " + " ".join(repr(float(x)) for x in at),
+              "vviewparams -eye " + " ".join(repr(float(x)) for x in eye),
+              f"vviewparams -size {2 * c.ortho_scale!r}", "", "# Restore light source parameters", "vlight clear"]
+    for i, l in enumerate(scene.lights):
+        kind = "positional position" if l.is_point else "directional direction"
+        lines.append(f"vlight add {kind} " + " ".join(repr(float(x)) for x in l.vec) + f" smoothness {l.smoothness!r} intensity {l.intensity!r}")
+        lines.append(f"rtlight {i} -color " + " ".join(repr(float(x)) for x in l.color))
+    lines.append(f"vrenderparams -ray -gi -rayDepth {scene.params.max_depth}")
+    path = os.path.join(directory, "model.tcl")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return path

@@ -1,0 +1,141 @@
+"""Scene wire format: the restricted Tcl evaluator, the reader of CADRays'
+exported model.tcl + binary PLY, the writer that emits the exporter's layout, and -- when the reference tree is
+mounted -- the reference's own demo scripts parsed into the same BSDF vectors the hand-restated fixtures hold."""
+import os
+
+import numpy as np
+import pytest
+
+from cadrays_amd import scenes
+from cadrays_amd.scene_tcl import MiniTcl, TclError, read_ply, read_scene, write_ply, write_scene
+
+REF = "/root/reference/data/scripts"
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
+
+
+def abi_key(m):
+    return tuple(np.round(np.frombuffer(bytes(m.to_abi()), np.float32), 6))
+
+
+def test_mini_tcl_constructs():
+    log = []
+    t = MiniTcl({"emit": lambda a: log.append(" ".join(a))})
+    t.eval('''
+      # comment line
+      set n 3
+      for {set i 0} {$i < $n} {incr i} {
+        for {set j 1} {$j <= 2} {incr j} {
+          if {($i + $j) % 2 == 0} { emit even_[expr 12 * $i + $j] } else { emit odd_[expr $i * 10 - 90] }
+        }
+      }
+      eval emit [lrepeat 3 x] tail
+      emit "quoted $n" {braced $n}
+    ''')
+    assert log == ["odd_-90", "even_2", "even_13", "odd_-80", "odd_-70", "even_26", "x x x tail", "quoted 3 braced $n"]
+    assert t.expr("7 / 2") == 3 and t.expr("7.0 / 2") == 3.5 and t.expr("(1 + 2) * 3 == 9") == 1
+    with pytest.raises(TclError):
+        t.eval("nosuchcommand 1 2")
+    with pytest.raises(TclError):
+        t.eval("emit $undefined")
+
+
+def test_ply_round_trip(tmp_path):
+    pos, nrm, tri = scenes.gen_scene(50, 3, 1)
+    p = str(tmp_path / "m.ply")
+    write_ply(p, pos, nrm, tri[:, :3])
+    rp, rn, rf, uv = read_ply(p)
+    assert np.array_equal(rp, pos) and np.array_equal(rn, nrm) and np.array_equal(rf, tri[:, :3]) and uv is None
+    # ascii variant with a quad face and no normals
+    (tmp_path / "a.ply").write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                                    "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    ap, an, af, _ = read_ply(str(tmp_path / "a.ply"))
+    assert af.tolist() == [[0, 1, 2], [0, 2, 3]] and np.allclose(an, [0, 0, 1])
+
+
+def test_export_format_round_trip(tmp_path):
+    """write_scene emits what ImportExport::Export emits (model.tcl + meshes/*.ply); read_scene restores it."""
+    sc = scenes.cornell_box(True, 64, 64)
+    path = write_scene(sc, str(tmp_path))
+    text = open(path).read()
+    assert text.startswith("variable Root [file dirname [file normalize [info script]]]")
+    assert "rtmeshread $Root/meshes/Mesh0.ply Mesh0 -group" in text and "vlight add positional position" in text
+    back, b = read_scene(path, 64, 64)
+    assert not b.unsupported and len(back.tri) == len(sc.tri) and len(back.materials) == len(sc.materials)
+    assert [abi_key(m) for m in back.materials] == [abi_key(m) for m in sc.materials]
+    # same triangle soup (the exporter groups triangles per object, so compare as sets of vertex triples)
+    canon = lambda s: sorted(map(tuple, np.round(s.pos[s.tri[:, :3]].reshape(len(s.tri), 9), 6).tolist()))
+    assert canon(back) == canon(sc)
+    l0, l1 = sc.lights[0], back.lights[0]
+    assert l1.is_point and np.allclose(l1.vec, l0.vec) and l1.smoothness == l0.smoothness and l1.intensity == l0.intensity
+    assert np.allclose(back.camera.eye, sc.camera.eye) and np.allclose(np.array(back.camera.dir) / np.linalg.norm(back.camera.dir), [0, 1, 0])
+    assert back.camera.fovy_deg == sc.camera.fovy_deg and back.params.max_depth == sc.params.max_depth
+
+
+def test_vbsdf_vlocation_vlight_semantics(tmp_path):
+    script = tmp_path / "s.tcl"
+    script.write_text('''
+      box b 0 0 0 1 2 3
+      vdisplay b
+      vsetmaterial b plastic
+      vbsdf b -kd 1.0 0.8 0.2 -ks 0.3 -n
+      vbsdf b -baseFresnel Schlick 0.58 0.42 0.2 -coatFresnel Dielectric 1.62 -Kc 1 1 1 -coatRoughness 0.05
+      vlocation b -setLocation 1 0 0
+      vlocation b -rotate 0 0 0 0 0 1 90
+      vlight clear
+      vlight add directional direction -0.25 -1 -1 sm 0.3 int 10
+      vlight add ambient
+      vlight add positional head 0 pos 0.5 0.5 0.85
+      vlight change 2 sm 0.06
+      vlight change 2 int 25.0
+      rtlight 0 -color 1 0.5 0.25
+      vcamera -persp -fovy 30
+      vviewparams -eye 0 -5 1 -at 0 0 1 -up 0 0 1
+      vrenderparams -ray -gi -rayDepth 7
+    ''')
+    sc, b = read_scene(str(script), 32, 32)
+    m = sc.materials[0]
+    np.testing.assert_allclose(m.Kd, np.array([1, 0.8, 0.2]) / 1.3, rtol=1e-6)          # -n == Normalize (MaterialEditor.cxx:311-329)
+    np.testing.assert_allclose(m.Ks[:3], 0.3 / 1.3, rtol=1e-6)
+    assert m.FresnelCoat.Serialize()[:2] == (-3.0, pytest.approx(1.62)) and m.Kc.tolist() == pytest.approx([1, 1, 1, 0.05])
+    # local transformation = translation(1,0,0) * rotation(+90 deg about z): the 1x2x3 box turns in place, then moves
+    assert np.allclose(sc.pos.min(0), [-1, 0, 0], atol=1e-6) and np.allclose(sc.pos.max(0), [1, 1, 3], atol=1e-6)
+    assert len(sc.lights) == 2                                     # ambient is ignored by the path tracer
+    assert sc.lights[0].color == (1.0, 0.5, 0.25) and sc.lights[0].smoothness == 0.3 and not sc.lights[0].is_point
+    assert sc.lights[1].is_point and sc.lights[1].smoothness == 0.06 and sc.lights[1].intensity == 25.0
+    assert sc.camera.fovy_deg == 30 and sc.params.max_depth == 7 and np.allclose(sc.camera.dir, [0, 5, 0])
+
+
+@needs_ref
+def test_reference_materials_script_matches_fixture():
+    """data/scripts/Materials.tcl evaluated by the reader == cadrays_amd.scenes.materials_scene()."""
+    sc, b = read_scene(os.path.join(REF, "Materials.tcl"), 256, 192)
+    fx = scenes.materials_scene(256, 192)
+    assert not b.unsupported and len(sc.tri) == len(fx.tri)
+    assert {abi_key(m) for m in sc.materials} == {abi_key(m) for m in fx.materials}
+    assert np.allclose(sc.camera.eye, fx.camera.eye) and sc.camera.fovy_deg == fx.camera.fovy_deg
+    assert np.allclose(sc.lights[0].vec, fx.lights[0].vec) and sc.lights[0].intensity == 12 and sc.lights[0].smoothness == 0.3
+    assert np.allclose(np.sort(sc.pos, 0), np.sort(fx.pos, 0), atol=1e-4)
+
+
+@needs_ref
+def test_reference_cornell_script():
+    sc, b = read_scene(os.path.join(REF, "CornellBox.tcl"), 128, 128)
+    assert not b.unsupported and sc.params.max_depth == 5
+    l = sc.lights[0]
+    assert l.is_point and l.vec == (0.5, 0.5, 0.85) and l.smoothness == 0.06 and l.intensity == 25.0
+    kd = {tuple(float(x) for x in np.round(m.Kd.astype(np.float64), 4)) for m in sc.materials}
+    assert (1.0, 0.3, 0.3) in kd and (0.3, 0.5, 1.0) in kd and (1.0, 1.0, 1.0) in kd
+    # walls of the unit cube minus the front face: x in [0,1], y in [0,1], z in [0,1]
+    assert np.allclose(sc.pos.min(0), 0, atol=1e-6) and np.allclose(sc.pos.max(0), 1, atol=1e-6)
+    glass = [m for m in sc.materials if m.Kt.sum() > 0]
+    assert len(glass) == 2 and {tuple(float(x) for x in np.round(g.Absorption.astype(np.float64), 3)) for g in glass} == {(0.8, 0.8, 1.0, 6.0), (0.8, 1.0, 0.8, 6.0)}
+
+
+@pytest.mark.gpu
+def test_parsed_scene_renders_bit_exact_on_gpu(tmp_path, hip_lib, oracle_lib):
+    from cadrays_amd.view import View
+    sc0 = scenes.materials_scene(96, 72, 16, 8)
+    back, _ = read_scene(write_scene(sc0, str(tmp_path)), 96, 72)
+    v = View(0).load_scene(back); v.render(3)
+    o = oracle_lib.Oracle().load_scene(back); o.render(3)
+    assert np.array_equal(v.read_hdr().view(np.uint32), o.read_hdr().view(np.uint32))
