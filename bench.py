@@ -75,8 +75,8 @@ def main():
     def step(i):
         v.render_tiles(tiles, i * spp_step, spp_step)
         if dist is not None:
-            v.sync()
-            sharding.reduce_framebuffer(fb.tensor, 0)
+            v.sync()                                          # the accumulator is written on the context's own stream
+            sharding.reduce_framebuffer(fb.tensor, 0)         # RCCL reduce of a staging copy; returns synchronised
 
     for i in range(args.warmup):
         step(i)

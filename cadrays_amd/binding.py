@@ -143,6 +143,17 @@ class Backend:
         self._call("render_tiles", t.ctypes.data_as(_u32p), C.c_uint32(len(t)),
                    C.c_uint32(first_sample), C.c_uint32(n_samples))
 
+    def set_adaptive(self, on=True, tiles_per_iteration=128):
+        """AdaptiveScreenSampling / NbRayTracingTiles (SettingsWidget.cxx:427-477); restarts accumulation."""
+        self._call("set_adaptive", C.c_int(int(on)), C.c_uint32(int(tiles_per_iteration)))
+
+    def tile_stats(self):
+        n = C.c_uint32(0)
+        self._call("get_tile_stats", None, None, C.byref(n))
+        err, cnt = np.empty(n.value, np.float32), np.empty(n.value, np.uint32)
+        self._call("get_tile_stats", _fp(err), cnt.ctypes.data_as(_u32p), C.byref(n))
+        return err, cnt
+
     def n_tiles(self):
         ts = self.tile_size or 32
         return ((self.width + ts - 1) // ts) * ((self.height + ts - 1) // ts)

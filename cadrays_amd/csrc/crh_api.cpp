@@ -41,6 +41,9 @@ struct crh_ctx {
   // ---- device
   float4 *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_env = nullptr;
   float4* d_accum = nullptr; uint32_t accumW = 0, accumH = 0;
+  float* d_m2 = nullptr;            // running mean of squared luminance (adaptive sampling only)
+  float* d_tile_err = nullptr; uint32_t* d_tile_cnt = nullptr; uint32_t tile_stat_cap = 0;
+  bool adaptive = false; uint32_t adaptive_tiles = 128; uint32_t adaptive_picks = 0;   // NbRayTracingTiles, Halton index
   DPaths paths{}; DQueues queues{}; uint32_t path_cap = 0;
   uint32_t* d_tile_ids = nullptr; uint32_t tile_cap = 0;
   uint32_t* d_seeds = nullptr; uint32_t seed_cap = 0;
@@ -165,6 +168,8 @@ int alloc_accum(crh_ctx* c)
   CRH_HIP(hipStreamSynchronize(c->stream));
   if (c->d_accum) { CRH_HIP(hipFree(c->d_accum)); c->d_accum = nullptr; }
   CRH_HIP(hipMalloc((void**)&c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height));
+  if (c->d_m2) { CRH_HIP(hipFree(c->d_m2)); c->d_m2 = nullptr; }
+  CRH_HIP(hipMalloc((void**)&c->d_m2, sizeof(float) * (size_t)c->par.width * c->par.height));
   c->accumW = c->par.width; c->accumH = c->par.height;
   return CRH_OK;
 }
@@ -175,6 +180,8 @@ int do_reset(crh_ctx* c)
   CRH_HIP(hipStreamSynchronize(c->stream));
   int rc = alloc_accum(c); if (rc) return rc;
   CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, c->stream));
+  CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, c->stream));
+  c->adaptive_picks = 0;
   CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
   drain_events(c);
@@ -183,11 +190,11 @@ int do_reset(crh_ctx* c)
 }
 
 // One batch: `ns` samples of `nt` tiles whose ids sit at d_tiles; seeds at d_seeds.
-int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns)
+int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile = 0)
 {
   Launch L{c->stream, c->grid, c->counters_on};
   Launch LT{c->stream, c->grid_trace, c->counters_on};
-  launch_raygen(L, S, c->paths, c->queues, 0, d_tiles, nt, d_seeds, ns);
+  launch_raygen(L, S, c->paths, c->queues, 0, d_tiles, nt, d_seeds, ns, seed_per_tile);
   int qin = 0;
   for (uint32_t b = 0; b < S.max_depth; ++b) {
     if (c->timing_on) {
@@ -201,7 +208,7 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
     if (S.n_lights > 0) launch_trace_any(LT, S, c->paths, c->queues, c->d_counters);
     qin = 1 - qin;
   }
-  launch_accumulate(L, S, c->paths, c->d_accum, d_tiles, nt, ns, c->d_counters);
+  launch_accumulate(L, S, c->paths, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, ns, c->d_counters);
   CRH_HIP(hipGetLastError());
   return CRH_OK;
 }
@@ -246,6 +253,71 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   return CRH_OK;
 }
 
+// ---- adaptive screen sampling (reference: AdaptiveScreenSampling / NbRayTracingTiles, SettingsWidget.cxx:427-477) ----------
+int tile_stats(crh_ctx* c, std::vector<float>& err, std::vector<uint32_t>& cnt)
+{
+  const uint32_t ts = c->par.tile_size;
+  const uint32_t nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
+  if (nt > c->tile_stat_cap) {
+    CRH_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_tile_err) CRH_HIP(hipFree(c->d_tile_err));
+    if (c->d_tile_cnt) CRH_HIP(hipFree(c->d_tile_cnt));
+    CRH_HIP(hipMalloc((void**)&c->d_tile_err, sizeof(float) * nt)); CRH_HIP(hipMalloc((void**)&c->d_tile_cnt, sizeof(uint32_t) * nt));
+    c->tile_stat_cap = nt;
+  }
+  DScene S; fill_scene(c, S);
+  Launch L{c->stream, c->grid, false};
+  launch_tile_error(L, S, c->d_accum, c->d_m2, c->d_tile_err, c->d_tile_cnt, nt);
+  err.resize(nt); cnt.resize(nt);
+  CRH_HIP(hipMemcpyAsync(err.data(), c->d_tile_err, sizeof(float) * nt, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipMemcpyAsync(cnt.data(), c->d_tile_cnt, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  return CRH_OK;
+}
+
+// One adaptive iteration: pick `adaptive_tiles` tiles with probability proportional to their error estimate (inverse CDF
+// driven by the base-2 radical inverse of a running pick counter), render +1 sample on the distinct tiles picked.
+int adaptive_iteration(crh_ctx* c)
+{
+  std::vector<float> err; std::vector<uint32_t> cnt;
+  int rc = tile_stats(c, err, cnt); if (rc) return rc;
+  const uint32_t nt = (uint32_t)err.size();
+  std::vector<float> cdf(nt);
+  float acc = 0.f;
+  for (uint32_t i = 0; i < nt; ++i) { acc += err[i] > 0.f ? err[i] : 0.f; cdf[i] = acc; }
+  std::vector<uint8_t> picked(nt, 0);
+  for (uint32_t k = 0; k < c->adaptive_tiles; ++k) {
+    uint32_t v = c->adaptive_picks++;
+    v = (v << 16) | (v >> 16); v = ((v & 0x00ff00ffu) << 8) | ((v & 0xff00ff00u) >> 8); v = ((v & 0x0f0f0f0fu) << 4) | ((v & 0xf0f0f0f0u) >> 4);
+    v = ((v & 0x33333333u) << 2) | ((v & 0xccccccccu) >> 2); v = ((v & 0x55555555u) << 1) | ((v & 0xaaaaaaaau) >> 1);
+    const float u = (float)(v >> 8) * 5.9604644775390625e-8f;
+    uint32_t t;
+    if (!(acc > 0.f)) t = (uint32_t)(u * (float)nt);                       // no estimate yet: uniform
+    else { const float x = u * acc; t = (uint32_t)(std::upper_bound(cdf.begin(), cdf.end(), x) - cdf.begin()); }
+    if (t >= nt) t = nt - 1;
+    picked[t] = 1;
+  }
+  std::vector<uint32_t> tiles, seeds; uint32_t maxc = 0;
+  for (uint32_t i = 0; i < nt; ++i) if (picked[i]) { tiles.push_back(i); maxc = std::max(maxc, cnt[i]); }
+  std::vector<uint32_t> table(maxc + 1);
+  { uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u; for (uint32_t i = 0; i <= maxc; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; table[i] = hi >> 2; } }
+  for (uint32_t t : tiles) seeds.push_back(table[cnt[t]]);
+  const uint32_t n = (uint32_t)tiles.size(), tpp = c->par.tile_size * c->par.tile_size;
+  if (n > c->tile_cap) { if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * n)); c->tile_cap = n; }
+  if (n > c->seed_cap) { if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * n)); c->seed_cap = n; }
+  CRH_HIP(hipMemcpyAsync(c->d_tile_ids, tiles.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  rc = ensure_paths(c, n * tpp); if (rc) return rc;
+  DScene S; fill_scene(c, S);
+  hipEvent_t e0 = get_event(c), e1 = get_event(c);
+  hipEventRecord(e0, c->stream);
+  rc = run_batch(c, S, c->d_tile_ids, n, c->d_seeds, 1, 1); if (rc) return rc;
+  hipEventRecord(e1, c->stream);
+  c->render_ev.emplace_back(e0, e1);
+  return CRH_OK;
+}
+
 }  // namespace
 
 // =============================================================================================== C ABI
@@ -286,7 +358,8 @@ void crh_destroy(crh_ctx* c)
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o, c->paths.ray_d,
                   c->paths.hit, c->paths.thr, c->paths.rad, c->paths.st, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
-                  c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch};
+                  c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
+                  c->d_m2, c->d_tile_err, c->d_tile_cnt};
   for (void* p : ptrs) if (p) hipFree(p);
   hipStreamDestroy(c->stream);
   delete c;
@@ -408,6 +481,12 @@ int crh_render(crh_ctx* c, uint32_t n)
 {
   if (!c) return CRH_E_INVALID;
   if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
+  if (c->adaptive) {
+    CRH_HIP(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < n; ++i) { int rc = adaptive_iteration(c); if (rc) return rc; }
+    c->frames_done += n;
+    return CRH_OK;
+  }
   const uint32_t ts = c->par.tile_size;
   const uint32_t nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
   std::vector<uint32_t> all(nt);
@@ -421,6 +500,25 @@ int crh_render_tiles(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t fi
 {
   if (!c || (nt && !tiles)) return fail(c, CRH_E_INVALID, "null tile list");
   return render_impl(c, tiles, nt, first, ns);
+}
+
+int crh_set_adaptive(crh_ctx* c, int on, uint32_t tiles_per_iteration)
+{
+  if (!c || (on && tiles_per_iteration == 0)) return fail(c, CRH_E_INVALID, "tiles_per_iteration must be > 0");
+  c->adaptive = on != 0; if (on) c->adaptive_tiles = tiles_per_iteration;
+  return do_reset(c);                                   // like every rendering-parameter change, restarts accumulation
+}
+
+int crh_get_tile_stats(crh_ctx* c, float* err, uint32_t* counts, uint32_t* n_tiles)
+{
+  if (!c || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator");
+  CRH_HIP(hipSetDevice(c->device));
+  std::vector<float> e; std::vector<uint32_t> n;
+  int rc = tile_stats(c, e, n); if (rc) return rc;
+  if (n_tiles) *n_tiles = (uint32_t)e.size();
+  if (err) std::memcpy(err, e.data(), sizeof(float) * e.size());
+  if (counts) std::memcpy(counts, n.data(), sizeof(uint32_t) * n.size());
+  return CRH_OK;
 }
 
 int crh_sync(crh_ctx* c) { if (!c) return CRH_E_INVALID; CRH_HIP(hipSetDevice(c->device)); CRH_HIP(hipStreamSynchronize(c->stream)); return CRH_OK; }

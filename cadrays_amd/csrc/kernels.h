@@ -12,7 +12,8 @@ struct Launch {
 
 // camera rays for n_samples x n_tiles x tile^2 path slots; fills queue `qsel` and its count
 void launch_raygen(const Launch&, const DScene&, const DPaths&, const DQueues&, int qsel,
-                   const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_frame_seeds, uint32_t n_samples);
+                   const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_frame_seeds, uint32_t n_samples,
+                   int seed_per_tile = 0);
 // nearest-hit traversal of queue `qin`; also zeroes the other queue's count and the shadow count
 void launch_trace_nearest(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, DCounters*);
 // emission, NEE, BSDF sampling, Russian roulette; survivors -> queue 1-qin, shadow rays -> q_sh
@@ -20,8 +21,11 @@ void launch_shade(const Launch&, const DScene&, const DPaths&, const DQueues&, i
 // any-hit traversal of the shadow queue; unoccluded contributions are added to the path radiance
 void launch_trace_any(const Launch&, const DScene&, const DPaths&, const DQueues&, DCounters*);
 // clamp + running mean of the finished paths into the float4 accumulator, sample by sample
-void launch_accumulate(const Launch&, const DScene&, const DPaths&, float4* accum,
+void launch_accumulate(const Launch&, const DScene&, const DPaths&, float4* accum, float* m2 /* or nullptr */,
                        const uint32_t* d_tile_ids, uint32_t n_tiles, uint32_t n_samples, DCounters*);
+// adaptive tile sampler: per-tile mean standard error and minimum per-pixel sample count (one workgroup per tile)
+void launch_tile_error(const Launch&, const DScene&, const float4* accum, const float* m2, float* tile_err,
+                       uint32_t* tile_min_count, uint32_t n_tiles_total);
 void launch_tonemap(const Launch&, const float4* accum, uint8_t* out_rgb, uint32_t n_pixels,
                     int mode, float exposure, float white_point);
 void launch_hdr(const Launch&, const float4* accum, float* out_rgb, uint32_t n_pixels);

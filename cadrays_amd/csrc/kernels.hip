@@ -617,7 +617,7 @@ __device__ __forceinline__ bool slot_pixel(const DScene& S, const uint32_t* __re
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t* __restrict__ q, uint32_t* __restrict__ count,
                                                     uint32_t* __restrict__ cursors,
                                                     const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
-                                                    const uint32_t* __restrict__ seeds, uint32_t n_samples)
+                                                    const uint32_t* __restrict__ seeds, uint32_t n_samples, int seed_per_tile)
 {
   __shared__ uint32_t s_enq[8];
   if (blockIdx.x == 0 && threadIdx.x == 0) { cursors[0] = 0u; cursors[1] = 0u; cursors[2] = 0u; }
@@ -630,7 +630,9 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
     if (valid) { s = pid / per_sample; valid = slot_pixel(S, tile_ids, pid - s * per_sample, px, py); }
     if (valid) {
       const uint32_t pix = S.coherent ? ((py / 16u) * ((S.width + 15u) / 16u) + (px / 16u)) : (py * S.width + px);
-      uint32_t rng = crh_rng_seed(pix, seeds[s]);
+      // whole-frame passes share one frame seed per sample; adaptive passes give every tile its own sample index
+      const uint32_t fseed = seed_per_tile ? seeds[(pid - s * per_sample) / (S.tile_size * S.tile_size)] : seeds[s];
+      uint32_t rng = crh_rng_seed(pix, fseed);
       const float jx = crh_rng_next(&rng), jy = crh_rng_next(&rng);
       const float nx = CRH_FMA(((float)px + jx) / (float)S.width, 2.0f, -1.0f);
       const float ny = CRH_FMA(((float)py + jy) / (float)S.height, -2.0f, 1.0f);
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, DPaths P, uint32_t b
 }
 
 // ================================================================== accumulate / display
-__global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float4* __restrict__ accum,
+__global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float4* __restrict__ accum, float* __restrict__ m2,
                                                         const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
                                                         uint32_t n_samples, DCounters* C)
 {
@@ -807,7 +809,9 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float
   for (uint32_t local = blockIdx.x * kBlock + threadIdx.x; local < per_sample; local += gridDim.x * kBlock) {
     uint32_t px, py;
     if (!slot_pixel(S, tile_ids, local, px, py)) continue;
-    float4 a = accum[(size_t)py * S.width + px];
+    const size_t pi = (size_t)py * S.width + px;
+    float4 a = accum[pi];
+    float q = m2 ? m2[pi] : 0.f;
     for (uint32_t s = 0; s < n_samples; ++s) {
       const float4 r = P.rad[s * per_sample + local];
       const float w = 1.0f / (a.w + 1.0f);
@@ -821,12 +825,57 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float
       a.y = CRH_FMA(v[1] - a.y, w, a.y);
       a.z = CRH_FMA(v[2] - a.z, w, a.z);
       a.w = a.w + 1.0f;
+      if (m2) {      // running mean of the squared luminance (adaptive sampling's variance estimate)
+        const float l = CRH_FMA(0.0722f, v[2], CRH_FMA(0.7152f, v[1], 0.2126f * v[0]));
+        q = CRH_FMA(l * l - q, w, q);
+      }
       ++done;
     }
-    accum[(size_t)py * S.width + px] = a;
+    accum[pi] = a;
+    if (m2) m2[pi] = q;
   }
   done = wave_sum(done);
   if (lane_id() == 0 && done) atomicAdd(&C->samples, (unsigned long long)done);
+}
+
+// Per-tile error estimate for the adaptive tile sampler (one workgroup per tile, fixed summation order so the
+// CPU oracle reproduces every bit): pixel error = sqrt(max(E[l^2] - E[l]^2, 0) / n), unsampled or once-sampled
+// pixels count as 1e3; lane j sums pixels j, j+256, ... of the row-major tile, then a stride-128..1 tree.
+__global__ __launch_bounds__(kBlock) void k_tile_error(DScene S, const float4* __restrict__ accum, const float* __restrict__ m2,
+                                                        float* __restrict__ tile_err, uint32_t* __restrict__ tile_min_count)
+{
+  __shared__ float s_e[kBlock];
+  __shared__ float s_n[kBlock];
+  __shared__ float s_c[kBlock];
+  const uint32_t ts = S.tile_size, tx = (S.width + ts - 1u) / ts;
+  const uint32_t tile = blockIdx.x, x0 = (tile % tx) * ts, y0 = (tile / tx) * ts;
+  float e = 0.f, npx = 0.f, cmin = 3.0e38f;
+  for (uint32_t i = threadIdx.x; i < ts * ts; i += kBlock) {
+    const uint32_t px = x0 + i % ts, py = y0 + i / ts;
+    if (px < S.width && py < S.height) {
+      const size_t pi = (size_t)py * S.width + px;
+      const float4 a = accum[pi];
+      float pe = 1.0e3f;
+      if (a.w >= 2.0f) {
+        const float l = CRH_FMA(0.0722f, a.z, CRH_FMA(0.7152f, a.y, 0.2126f * a.x));
+        pe = crh_sqrt(crh_max(m2[pi] - l * l, 0.f) / a.w);
+      }
+      e += pe; npx += 1.0f; cmin = crh_min(cmin, a.w);
+    }
+  }
+  s_e[threadIdx.x] = e; s_n[threadIdx.x] = npx; s_c[threadIdx.x] = cmin;
+  __syncthreads();
+  for (uint32_t st = kBlock / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      s_e[threadIdx.x] += s_e[threadIdx.x + st]; s_n[threadIdx.x] += s_n[threadIdx.x + st];
+      s_c[threadIdx.x] = crh_min(s_c[threadIdx.x], s_c[threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    tile_err[tile] = s_n[0] > 0.f ? s_e[0] / s_n[0] : 0.f;
+    tile_min_count[tile] = s_n[0] > 0.f ? (uint32_t)s_c[0] : 0u;
+  }
 }
 
 __device__ __forceinline__ float hable(float x)
@@ -886,10 +935,10 @@ __global__ void k_debug_math(int fn, const float* __restrict__ a, const float* _
 
 // ================================================================== launch wrappers
 void launch_raygen(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qsel,
-                   const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds, uint32_t n_samples)
+                   const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds, uint32_t n_samples, int seed_per_tile)
 {
   hipMemsetAsync(Q.counts + qsel, 0, sizeof(uint32_t), L.stream);
-  hipLaunchKernelGGL(k_raygen, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples);
+  hipLaunchKernelGGL(k_raygen, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile);
 }
 void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, DCounters* C)
 {
@@ -908,10 +957,15 @@ void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const D
   if (L.counters) hipLaunchKernelGGL(k_trace_any<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C);
   else            hipLaunchKernelGGL(k_trace_any<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C);
 }
-void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, const uint32_t* d_tile_ids,
+void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,
                        uint32_t n_tiles, uint32_t n_samples, DCounters* C)
 {
-  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, d_tile_ids, n_tiles, n_samples, C);
+  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, m2, d_tile_ids, n_tiles, n_samples, C);
+}
+void launch_tile_error(const Launch& L, const DScene& S, const float4* accum, const float* m2, float* tile_err, uint32_t* tile_min_count,
+                       uint32_t n_tiles_total)
+{
+  hipLaunchKernelGGL(k_tile_error, dim3(n_tiles_total), dim3(kBlock), 0, L.stream, S, accum, m2, tile_err, tile_min_count);
 }
 void launch_tonemap(const Launch& L, const float4* accum, uint8_t* out, uint32_t n, int mode, float exposure, float wp)
 {

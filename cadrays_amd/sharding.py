@@ -23,11 +23,18 @@ def render_shard(backend, rank, world, first_sample, n_samples):
 
 
 def reduce_framebuffer(accum, dst=0):
-    """Sum the per-rank float4 accumulators into rank `dst` (torch.distributed reduce; nccl == RCCL on ROCm)."""
+    """Sum the per-rank float4 accumulators into rank `dst` (torch.distributed reduce; nccl == RCCL on ROCm).
+    The reduce runs on a staging copy: a rank's own accumulator must keep holding only its own tiles, because
+    rendering continues into it (progressive display reduces every few iterations).  Returns the staging tensor
+    (the assembled frame on rank `dst`); the caller's stream is synchronised before returning."""
+    import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
-    return accum
+    out = accum.clone()
+    if dist.is_available() and dist.is_initialized():
+        dist.reduce(out, dst=dst, op=dist.ReduceOp.SUM)
+    if out.is_cuda:
+        torch.cuda.current_stream(out.device).synchronize()
+    return out
 
 
 class DeviceFramebuffer:

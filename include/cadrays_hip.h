@@ -152,6 +152,14 @@ CRH_API int crh_render(crh_ctx* ctx, uint32_t n_iterations);
  * tile_size x tile_size, numbered row-major over ceil(W/ts) x ceil(H/ts). */
 CRH_API int crh_render_tiles(crh_ctx* ctx, const uint32_t* tile_ids, uint32_t n_tiles,
                      uint32_t first_sample, uint32_t n_samples);
+/* Adaptive screen sampling == Graphic3d_RenderingParams::AdaptiveScreenSampling + NbRayTracingTiles
+ * (SettingsWidget.cxx:427-477): with `on`, every crh_render iteration renders +1 sample on `tiles_per_iteration`
+ * tiles drawn with probability proportional to their estimated error instead of on the whole target.
+ * Changing it restarts accumulation. */
+CRH_API int crh_set_adaptive(crh_ctx* ctx, int on, uint32_t tiles_per_iteration);
+/* Per-tile error estimate (mean standard error of the pixel luminance) and per-tile sample count; pass NULL
+ * arrays to query n_tiles.  Needs adaptive mode for a meaningful error. */
+CRH_API int crh_get_tile_stats(crh_ctx* ctx, float* err, uint32_t* counts, uint32_t* n_tiles);
 /* wait for all queued device work of this context */
 CRH_API int crh_sync(crh_ctx* ctx);
 /* == BufferDump(Graphic3d_BT_RGB_RayTraceHdrLeft -> ImgRGBF) (AppGui.cxx:345-349):

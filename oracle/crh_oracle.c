@@ -72,6 +72,8 @@ typedef struct orc_ctx {
   v3* l_vec; float* l_par;
   /* accumulator */
   float* accum;     /* W*H*4 */
+  float* m2;        /* W*H: running mean of squared luminance (adaptive sampling) */
+  int adaptive; uint32_t adaptive_tiles, adaptive_picks;
   crh_stats st;
   char err[256];
 } orc_ctx;
@@ -763,7 +765,7 @@ static void prepare(orc_ctx* c)
   c->eps = c->par.scene_epsilon > 0.f ? c->par.scene_epsilon : crh_max(1.0e-6f, 1.0e-5f * crh_len3(dg));
 }
 
-static void accumulate_px(const orc_ctx* c, float* a, v3 s)
+static void accumulate_px(const orc_ctx* c, float* a, v3 s, float* m2)
 {
   float clampv = c->par.radiance_clamp;
   float r[3] = {s.x, s.y, s.z};
@@ -773,12 +775,17 @@ static void accumulate_px(const orc_ctx* c, float* a, v3 s)
     float v = r[k];
     if (!(v == v)) v = 0.f;                 /* NaN -> 0 */
     if (clampv > 0.f && v > clampv) v = clampv;
+    r[k] = v;
     a[k] = CRH_FMA(v - a[k], w, a[k]);
+  }
+  if (m2) {
+    float l = CRH_FMA(LUMA_B, r[2], CRH_FMA(LUMA_G, r[1], LUMA_R * r[0]));
+    *m2 = CRH_FMA(l * l - *m2, w, *m2);
   }
   a[3] = n + 1.0f;
 }
 
-static int render_tiles(orc_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, uint32_t ns)
+static int render_tiles(orc_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, uint32_t ns, const uint32_t* tile_seeds)
 {
   if (!c->built) return CRH_E_NOTBUILT;
   uint32_t ts = c->par.tile_size ? c->par.tile_size : 32u;
@@ -797,8 +804,8 @@ static int render_tiles(orc_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t
     for (uint32_t s = 0; s < ns; ++s)
       for (uint32_t y = y0; y < y0 + ts && y < c->par.height; ++y)
         for (uint32_t x = x0; x < x0 + ts && x < c->par.width; ++x) {
-          v3 r = path_trace(c, x, y, seeds[s], &st, &cn);
-          accumulate_px(c, &c->accum[4 * ((size_t)y * c->par.width + x)], r);
+          v3 r = path_trace(c, x, y, tile_seeds ? tile_seeds[ti] : seeds[s], &st, &cn);
+          accumulate_px(c, &c->accum[4 * ((size_t)y * c->par.width + x)], r, c->adaptive ? &c->m2[(size_t)y * c->par.width + x] : NULL);
           st.samples++;
         }
     rn += st.rays_nearest; ra += st.rays_any; nn += cn.nodes; tt += cn.tris; na += cn.nodes_any; ta += cn.tris_any; hh += st.shaded_hits; sm += st.samples;
@@ -839,7 +846,7 @@ ORC_API void orc_destroy(orc_ctx* c)
 {
   if (!c) return;
   free(c->pos); free(c->nrm); free(c->uv); free(c->tri); free(c->mats); free(c->lights); free(c->env);
-  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c);
+  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c);
 }
 ORC_API const char* orc_last_error(orc_ctx* c) { return c ? c->err : "null ctx"; }
 
@@ -894,6 +901,7 @@ ORC_API int orc_reset(orc_ctx* c)
 {
   if (!c) return CRH_E_INVALID;
   free(c->accum); c->accum = (float*)calloc((size_t)c->par.width * c->par.height * 4, sizeof(float));
+  free(c->m2); c->m2 = (float*)calloc((size_t)c->par.width * c->par.height, sizeof(float)); c->adaptive_picks = 0;
   memset(&c->st, 0, sizeof c->st);
   return 0;
 }
@@ -909,14 +917,93 @@ ORC_API int orc_build(orc_ctx* c)
   do_build(c); c->built = 1; return orc_reset(c);
 }
 ORC_API int orc_render_tiles(orc_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, uint32_t ns)
-{ if (!c) return CRH_E_INVALID; if (!c->built) return CRH_E_NOTBUILT; prepare(c); return render_tiles(c, tiles, nt, first, ns); }
+{ if (!c) return CRH_E_INVALID; if (!c->built) return CRH_E_NOTBUILT; prepare(c); return render_tiles(c, tiles, nt, first, ns, NULL); }
+/* --- adaptive screen sampling (reference controls at SettingsWidget.cxx:427-477) ---------------------
+ * tile error = mean over the tile's pixels of sqrt(max(E[l^2] - E[l]^2, 0) / n) (1e3 for pixels with n < 2), summed in
+ * the fixed order "lane j of 256 takes pixels j, j+256, .. of the row-major tile, then a stride 128..1 tree". */
+static void tile_stats(const orc_ctx* c, float* err, uint32_t* cnt)
+{
+  uint32_t ts = c->par.tile_size, tx = (c->par.width + ts - 1) / ts, ty = (c->par.height + ts - 1) / ts;
+  for (uint32_t t = 0; t < tx * ty; ++t) {
+    float e[256], np_[256], cm[256];
+    uint32_t x0 = (t % tx) * ts, y0 = (t / tx) * ts;
+    for (uint32_t j = 0; j < 256; ++j) {
+      e[j] = 0.f; np_[j] = 0.f; cm[j] = 3.0e38f;
+      for (uint32_t i = j; i < ts * ts; i += 256) {
+        uint32_t px = x0 + i % ts, py = y0 + i / ts;
+        if (px < c->par.width && py < c->par.height) {
+          const float* a = &c->accum[4 * ((size_t)py * c->par.width + px)];
+          float pe = 1.0e3f;
+          if (a[3] >= 2.0f) {
+            float l = CRH_FMA(LUMA_B, a[2], CRH_FMA(LUMA_G, a[1], LUMA_R * a[0]));
+            pe = crh_sqrt(crh_max(c->m2[(size_t)py * c->par.width + px] - l * l, 0.f) / a[3]);
+          }
+          e[j] += pe; np_[j] += 1.0f; cm[j] = crh_min(cm[j], a[3]);
+        }
+      }
+    }
+    for (uint32_t st = 128; st > 0; st >>= 1)
+      for (uint32_t j = 0; j < st; ++j) { e[j] += e[j + st]; np_[j] += np_[j + st]; cm[j] = crh_min(cm[j], cm[j + st]); }
+    err[t] = np_[0] > 0.f ? e[0] / np_[0] : 0.f;
+    cnt[t] = np_[0] > 0.f ? (uint32_t)cm[0] : 0u;
+  }
+}
+
+static uint32_t radical_inverse2(uint32_t v)
+{
+  uint32_t r = 0;
+  for (int b = 0; b < 32; ++b) { r = (r << 1) | (v & 1u); v >>= 1; }
+  return r;
+}
+
+static int adaptive_iteration(orc_ctx* c)
+{
+  uint32_t ts = c->par.tile_size, nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
+  float* err = (float*)malloc(sizeof(float) * nt); uint32_t* cnt = (uint32_t*)malloc(sizeof(uint32_t) * nt);
+  float* cdf = (float*)malloc(sizeof(float) * nt); uint8_t* picked = (uint8_t*)calloc(nt, 1);
+  tile_stats(c, err, cnt);
+  float acc = 0.f;
+  for (uint32_t i = 0; i < nt; ++i) { acc += err[i] > 0.f ? err[i] : 0.f; cdf[i] = acc; }
+  for (uint32_t k = 0; k < c->adaptive_tiles; ++k) {
+    float u = (float)(radical_inverse2(c->adaptive_picks++) >> 8) * 5.9604644775390625e-8f;
+    uint32_t t = 0;
+    if (!(acc > 0.f)) t = (uint32_t)(u * (float)nt);
+    else { float x = u * acc; while (t < nt && !(cdf[t] > x)) ++t; }     /* first tile whose cdf exceeds x */
+    if (t >= nt) t = nt - 1;
+    picked[t] = 1;
+  }
+  uint32_t n = 0; for (uint32_t i = 0; i < nt; ++i) n += picked[i];
+  uint32_t* tiles = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1)); uint32_t* seeds = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  n = 0;
+  for (uint32_t i = 0; i < nt; ++i) if (picked[i]) { tiles[n] = i; seeds[n] = frame_seed(c->par.seed, cnt[i]); ++n; }
+  int rc = render_tiles(c, tiles, n, 0, 1, seeds);
+  free(err); free(cnt); free(cdf); free(picked); free(tiles); free(seeds);
+  return rc;
+}
+
+ORC_API int orc_set_adaptive(orc_ctx* c, int on, uint32_t tiles_per_iteration)
+{
+  if (!c || (on && !tiles_per_iteration)) return CRH_E_INVALID;
+  c->adaptive = on != 0; if (on) c->adaptive_tiles = tiles_per_iteration;
+  return orc_reset(c);
+}
+ORC_API int orc_get_tile_stats(orc_ctx* c, float* err, uint32_t* counts, uint32_t* n_tiles)
+{
+  if (!c || !c->accum) return CRH_E_INVALID;
+  uint32_t ts = c->par.tile_size, nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
+  if (n_tiles) *n_tiles = nt;
+  if (err && counts) tile_stats(c, err, counts);
+  return 0;
+}
+
 ORC_API int orc_render(orc_ctx* c, uint32_t n)
 {
   if (!c) return CRH_E_INVALID; if (!c->built) return CRH_E_NOTBUILT;
   prepare(c);
+  if (c->adaptive) { for (uint32_t i = 0; i < n; ++i) { int rc = adaptive_iteration(c); if (rc) return rc; } return 0; }
   /* every pixel has the same count when whole frames are rendered: continue from a[3] of pixel 0 */
   uint32_t first = (uint32_t)c->accum[3];
-  return render_tiles(c, NULL, 0, first, n);
+  return render_tiles(c, NULL, 0, first, n, NULL);
 }
 ORC_API int orc_read_accum(orc_ctx* c, float* out) { if (!c || !c->accum) return CRH_E_INVALID; memcpy(out, c->accum, sizeof(float) * 4 * (size_t)c->par.width * c->par.height); return 0; }
 ORC_API int orc_read_hdr(orc_ctx* c, float* out)

@@ -276,3 +276,30 @@ def test_headless_cpp_driver_matches_oracle(tmp_path, Oracle):
     ppm = open(tmp_path / "Output_cornell_5.ppm", "rb").read()
     assert ppm.startswith(b"P6\n96 64\n255\n") and np.array_equal(np.frombuffer(ppm[len(b"P6\n96 64\n255\n"):], np.uint8).reshape(64, 96, 3), o.read_ldr())
     assert float(open(tmp_path / "Output_cornell_5.txt").read()) > 0
+
+
+def test_device_framebuffer_view_and_nccl_reduce(view_cls):
+    """bench.py's multi-GPU plumbing on one GPU: zero-copy torch view of crh_accum_device_ptr + an RCCL
+    (backend 'nccl') reduce in a single-rank process group."""
+    import os, socket
+    import torch
+    import torch.distributed as dist
+    from cadrays_amd import sharding
+    v = view_cls(0).load_scene(scenes.cornell_box(False, 64, 64))
+    v.render(2); v.sync()
+    fb = sharding.DeviceFramebuffer(v)
+    assert fb.tensor.shape == (64, 64, 4) and fb.tensor.is_cuda
+    host = fb.tensor.cpu().numpy()
+    assert np.array_equal(bits(host[..., :3]), bits(v.read_hdr())) and (host[..., 3] == 2).all()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        total = sharding.reduce_framebuffer(fb.tensor, 0)
+        assert torch.equal(total, fb.tensor) and total.data_ptr() != fb.tensor.data_ptr()
+        tiles = sharding.render_shard(v, 0, 1, 2, 1)
+        assert len(tiles) == v.n_tiles()
+        v.sync()
+        assert (fb.tensor[..., 3] == 3).all()
+    finally:
+        dist.destroy_process_group()

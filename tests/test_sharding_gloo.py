@@ -32,9 +32,10 @@ def _worker(rank, world, port, spp, out_path):
             tiles = sharding.render_shard(o, rank, world, step * spp, spp)
         assert len(tiles) > 0 and (tiles % world == rank).all()
         acc = torch.from_numpy(o.read_accum().copy())
-        sharding.reduce_framebuffer(acc, 0)
+        total = sharding.reduce_framebuffer(acc, 0)
+        assert torch.equal(acc, torch.from_numpy(o.read_accum()))      # the rank's own buffer is left untouched
         if rank == 0:
-            np.save(out_path, acc.numpy())
+            np.save(out_path, total.numpy())
     finally:
         dist.destroy_process_group()
 
