@@ -42,6 +42,9 @@ class DeviceFramebuffer:
 
     def __init__(self, view):
         import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("torch sees no GPU: `import torch` must come before the first cadrays_amd.View in the process "
+                               "(torch bundles its own HIP runtime and cannot initialise after the system one)")
         ptr, nbytes = view.accum_device_ptr()
         self.__cuda_array_interface__ = {"shape": (view.height, view.width, 4), "typestr": "<f4",
                                          "data": (ptr, False), "version": 2}

@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401 -- must be imported BEFORE libcadrays_hip.so initialises HIP: torch bundles its own HIP runtime and
+              # finds no GPU when it is loaded into a process where the system runtime is already up (seen on the GPU box)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
