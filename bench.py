@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step (per GPU share)")
     ap.add_argument("--tris", type=int, default=0, help="override triangle count (debug)")
     ap.add_argument("--width", type=int, default=0)
@@ -132,7 +132,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port, not the reference: OCCT has no CPU path tracer) on this box's cores
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and world == 1:          # reported on rank 0 at N = 1 only
         from oracle.pyoracle import Oracle
         ncores = os.cpu_count() or 1
         Oracle.set_threads(ncores)
@@ -171,6 +171,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()                                       # rank 0 may still be in its counting pass
         dist.destroy_process_group()
 
 

@@ -3,7 +3,7 @@
 // One launch per stage and bounce, all on one HIP stream, no host round trip inside an iteration:
 //   k_raygen -> [ k_trace_nearest -> k_shade -> k_trace_any ] x depth -> k_accumulate
 // Stage boundaries exchange path ids through compacted queues built with wave64 ballot + prefix
-// popcount and ONE atomic per wavefront.  Traversal keeps a per-lane stack in LDS (lane-interleaved,
+// popcount and ONE atomic per workgroup; traversal waves are persistent and refill idle lanes.  Traversal keeps a per-lane stack in LDS (lane-interleaved,
 // conflict free), BVH nodes are 128-B float4 records (one L2 line per visit), triangles 48-B records
 // in leaf order.  No MFMA: there is no dense contraction on this path.
 //
@@ -24,20 +24,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
   return v;   // total in lane 0
 }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// Append `value` of every lane with `pred` to a global queue: ballot, prefix popcount, one atomic per wave.
-__device__ __forceinline__ void wave_enqueue(bool pred, uint32_t value, uint32_t* __restrict__ q, uint32_t* __restrict__ count)
-{
-  const unsigned long long mask = __ballot(pred);
-  if (mask == 0ull) return;
-  const uint32_t lane = lane_id();
-  const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
-  base = __shfl(base, leader);
-  if (pred) q[base + prefix] = value;
-}
 
 // Persistent-wave work distribution: each wavefront pulls the next 64 queue entries from a global cursor
 // (one returning atomic per wave per chunk), so the grid only needs to fill the machine once and no
@@ -667,7 +653,15 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
 // ================================================================== shade
 constexpr int kLdsMats = 64;   // materials staged in LDS (8 KB); larger tables are read from HBM/L2
 
-__global__ __launch_bounds__(kBlock) void k_shade(DScene S, DPaths P, uint32_t bounce,
+#ifndef CRH_SHADE_MINWAVES
+#define CRH_SHADE_MINWAVES 0
+#endif
+#if CRH_SHADE_MINWAVES > 0
+#define CRH_SHADE_BOUNDS __launch_bounds__(kBlock, CRH_SHADE_MINWAVES)
+#else
+#define CRH_SHADE_BOUNDS __launch_bounds__(kBlock)
+#endif
+__global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
                                                    const uint32_t* __restrict__ q_in, const uint32_t* __restrict__ count_in,
                                                    uint32_t* __restrict__ q_out, uint32_t* __restrict__ count_out,
                                                    uint32_t* __restrict__ q_sh, uint32_t* __restrict__ count_sh,

@@ -12,5 +12,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUS
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -o p -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$name.log 2>&1
 done
-python3 $REPO/tools_profile_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 $REPO/profiles/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
