@@ -50,8 +50,14 @@ def main():
     import torch
     if world > 1:
         import torch.distributed as dist
+        backend = os.environ.get("CRH_BENCH_BACKEND", "nccl")     # "gloo" + CRH_BENCH_SHARE_DEVICE=1: rehearsal of the N > 1 flow on one GPU
+        if os.environ.get("CRH_BENCH_SHARE_DEVICE") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
 
     from cadrays_amd import scenes, sharding

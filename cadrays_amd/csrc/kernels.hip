@@ -151,13 +151,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     }
     if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
 
-    // ------------------------------------------------------------------ (A) inner nodes until a leaf is in hand
-#if CRH_INNER_STEPS > 0
-#pragma unroll 1
-    for (int step_ = 0; step_ < CRH_INNER_STEPS && have && !(cur & kQLeafBit); ++step_) {
-#else
-    while (have && !(cur & kQLeafBit)) {
-#endif
+    // one inner-node step of this lane: fetch the 128-B node, slab-test and order its children, push / descend / pop
+    auto inner_step = [&]() {
       const float4* np = nodes + 8u * cur;
       const float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
       const float4 rf = np[6];
@@ -208,36 +203,47 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
         else { cur = ovf[sp - kLdsStack]; asm volatile("" : "+v"(cur)); }
       }
-    }
-
-    // ------------------------------------------------------------------ (B) the leaf in hand
-    if (have && (cur & kQLeafBit) && cur != kDone) {
-      const uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t k = 0; k < cnt; ++k) {
-        const float4* tp = tris + 3u * (off + k);
-        const float4 a = tp[0], b = tp[1], c = tp[2];
-        if (COUNT) ++n_tris;
-        const v3 v0 = xyz(a), v1 = xyz(b), v2 = xyz(c);
-        const v3 e0 = crh_sub3(v1, v0), e1 = crh_sub3(v0, v2);
-        const v3 nrm = crh_cross3(e1, e0);
-        const v3 to = crh_sub3(v0, o);
-        const float inv = 1.0f / crh_dot3(nrm, d);
-        const v3 vc = crh_cross3(d, to);
-        const float tt = crh_dot3(nrm, to) * inv;
-        const float uu = crh_dot3(vc, e1) * inv;
-        const float vv = crh_dot3(vc, e0) * inv;
-        if (tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f && tt < best) {
-          best = tt; found = true;
-          hit = make_float4(tt, uu, vv, __int_as_float((int)(off + k)));
-          if (ANY) break;
-        }
+    };
+    // one ray/triangle test of this lane against leaf-order triangle `ti`
+    auto tri_step = [&](uint32_t ti) {
+      const float4* tp = tris + 3u * ti;
+      const float4 a = tp[0], b = tp[1], c = tp[2];
+      if (COUNT) ++n_tris;
+      const v3 v0 = xyz(a), v1 = xyz(b), v2 = xyz(c);
+      const v3 e0 = crh_sub3(v1, v0), e1 = crh_sub3(v0, v2);
+      const v3 nrm = crh_cross3(e1, e0);
+      const v3 to = crh_sub3(v0, o);
+      const float inv = 1.0f / crh_dot3(nrm, d);
+      const v3 vc = crh_cross3(d, to);
+      const float tt = crh_dot3(nrm, to) * inv;
+      const float uu = crh_dot3(vc, e1) * inv;
+      const float vv = crh_dot3(vc, e0) * inv;
+      if (tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f && tt < best) {
+        best = tt; found = true;
+        hit = make_float4(tt, uu, vv, __int_as_float((int)ti));
       }
+    };
+    auto pop = [&]() {
       if ((ANY && found) || sp == 0) cur = kDone;
       else {
         --sp;
         if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
         else { cur = ovf[sp - kLdsStack]; asm volatile("" : "+v"(cur)); }
       }
+    };
+
+    // ------------------------------------------------------------------ (A) inner nodes until a leaf is in hand
+#if CRH_INNER_STEPS > 0
+#pragma unroll 1
+    for (int step_ = 0; step_ < CRH_INNER_STEPS && have && !(cur & kQLeafBit); ++step_) inner_step();
+#else
+    while (have && !(cur & kQLeafBit)) inner_step();
+#endif
+    // ------------------------------------------------------------------ (B) the leaf in hand
+    if (have && (cur & kQLeafBit) && cur != kDone) {
+      const uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+      for (uint32_t k = 0; k < cnt; ++k) { tri_step(off + k); if (ANY && found) break; }
+      pop();
     }
 
     // ------------------------------------------------------------------ (C) retire finished rays

@@ -31,7 +31,10 @@ def reduce_framebuffer(accum, dst=0):
     import torch.distributed as dist
     out = accum.clone()
     if dist.is_available() and dist.is_initialized():
-        dist.reduce(out, dst=dst, op=dist.ReduceOp.SUM)
+        if out.is_cuda and dist.get_backend() == "gloo":       # gloo has no GPU reduce; only used to rehearse the flow on one GPU
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(out, dst=dst, op=dist.ReduceOp.SUM)
     if out.is_cuda:
         torch.cuda.current_stream(out.device).synchronize()
     return out
