@@ -96,6 +96,14 @@ class Backend:
             h, w, _ = env.shape
             self._call("set_envmap", _fp(env), C.c_uint32(w), C.c_uint32(h))
 
+    def set_texture(self, slot, image):
+        if image is None:
+            self._call("set_texture", C.c_uint32(slot), None, C.c_uint32(0), C.c_uint32(0))
+        else:
+            image = np.ascontiguousarray(image, np.float32)
+            h, w, _ = image.shape
+            self._call("set_texture", C.c_uint32(slot), _fp(image), C.c_uint32(w), C.c_uint32(h))
+
     def set_camera(self, cam):
         c = abi.crh_camera()
         c.eye[:] = [float(x) for x in cam.eye]
@@ -125,6 +133,8 @@ class Backend:
         self.set_envmap(scene.env)
         self.set_camera(scene.camera)
         self.set_params(scene.params)
+        for slot, img in enumerate(getattr(scene, "textures", []) or []):
+            self.set_texture(slot, img)
         self.build()
         return self
 

@@ -32,6 +32,8 @@ struct crh_ctx {
   std::vector<crh_bsdf> mats;
   std::vector<crh_light> lights;
   std::vector<float> env; uint32_t envW = 0, envH = 0;
+  struct HostTex { std::vector<float> rgba; uint32_t w = 0, h = 0; };
+  std::vector<HostTex> textures; bool textures_dirty = false;
   crh_camera cam{};
   crh_params par{};
   // ---- built scene
@@ -40,6 +42,7 @@ struct crh_ctx {
   bool built = false;
   // ---- device
   float4 *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_env = nullptr;
+  float4 *d_uvs = nullptr, *d_texels = nullptr; uint4* d_tex_desc = nullptr;
   float4* d_accum = nullptr; uint32_t accumW = 0, accumH = 0;
   float* d_m2 = nullptr;            // running mean of squared luminance (adaptive sampling only)
   float* d_tile_err = nullptr; uint32_t* d_tile_cnt = nullptr; uint32_t tile_stat_cap = 0;
@@ -128,6 +131,7 @@ void fill_scene(const crh_ctx* c, DScene& S)
 {
   std::memset(&S, 0, sizeof S);
   S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = c->d_env;
+  S.uvs = c->d_uvs; S.texels = c->d_texels; S.tex_desc = c->d_tex_desc; S.n_tex = c->d_tex_desc ? (uint32_t)c->textures.size() : 0u;
   S.n_mats = (uint32_t)c->mats.size(); S.n_lights = (uint32_t)c->lights.size(); S.env_w = c->envW; S.env_h = c->envH;
   for (int k = 0; k < 3; ++k) S.bg[k] = c->par.background[k];
   S.env_as_bg = c->par.env_as_background;
@@ -160,6 +164,22 @@ int upload_lights(crh_ctx* c)
     o[4] = s.emission[0]; o[5] = s.emission[1]; o[6] = s.emission[2];
   }
   return dev_upload(c, c->d_lights, l.data(), l.size() * sizeof(float));
+}
+
+int upload_textures(crh_ctx* c)
+{
+  if (!c->textures_dirty) return CRH_OK;
+  std::vector<float> all; std::vector<uint32_t> desc(4 * std::max<size_t>(c->textures.size(), 1), 0u);
+  for (size_t i = 0; i < c->textures.size(); ++i) {
+    desc[4 * i] = (uint32_t)(all.size() / 4); desc[4 * i + 1] = c->textures[i].w; desc[4 * i + 2] = c->textures[i].h;
+    all.insert(all.end(), c->textures[i].rgba.begin(), c->textures[i].rgba.end());
+  }
+  if (all.empty()) all.assign(4, 0.f);
+  int rc;
+  if ((rc = dev_upload(c, c->d_texels, all.data(), all.size() * sizeof(float)))) return rc;
+  if ((rc = dev_upload(c, c->d_tex_desc, desc.data(), desc.size() * sizeof(uint32_t)))) return rc;
+  c->textures_dirty = false;
+  return CRH_OK;
 }
 
 int alloc_accum(crh_ctx* c)
@@ -218,6 +238,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
   if (ns == 0 || nt == 0) return CRH_OK;
   CRH_HIP(hipSetDevice(c->device));
+  { int rc_t = upload_textures(c); if (rc_t) return rc_t; }
   const uint32_t ts = c->par.tile_size, tpp = ts * ts;
   const uint32_t tx = (c->par.width + ts - 1) / ts, ty = (c->par.height + ts - 1) / ts;
   for (uint32_t i = 0; i < nt; ++i) if (tiles[i] >= tx * ty) return fail(c, CRH_E_INVALID, "tile id out of range");
@@ -280,7 +301,8 @@ int tile_stats(crh_ctx* c, std::vector<float>& err, std::vector<uint32_t>& cnt)
 int adaptive_iteration(crh_ctx* c)
 {
   std::vector<float> err; std::vector<uint32_t> cnt;
-  int rc = tile_stats(c, err, cnt); if (rc) return rc;
+  int rc = upload_textures(c); if (rc) return rc;
+  rc = tile_stats(c, err, cnt); if (rc) return rc;
   const uint32_t nt = (uint32_t)err.size();
   std::vector<float> cdf(nt);
   float acc = 0.f;
@@ -359,7 +381,7 @@ void crh_destroy(crh_ctx* c)
   void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o, c->paths.ray_d,
                   c->paths.hit, c->paths.thr, c->paths.rad, c->paths.st, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
                   c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
-                  c->d_m2, c->d_tile_err, c->d_tile_cnt};
+                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc};
   for (void* p : ptrs) if (p) hipFree(p);
   hipStreamDestroy(c->stream);
   delete c;
@@ -434,6 +456,23 @@ int crh_set_envmap(crh_ctx* c, const float* rgb, uint32_t w, uint32_t h)
   return CRH_OK;
 }
 
+int crh_set_texture(crh_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uint32_t h)
+{
+  if (!c || slot >= 4096u) return fail(c, CRH_E_INVALID, "texture slot out of range");
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  if (c->textures.size() <= slot) c->textures.resize(slot + 1);
+  crh_ctx::HostTex& t = c->textures[slot];
+  t.rgba.clear(); t.w = t.h = 0;
+  if (rgb && w && h) {
+    t.rgba.resize(4 * (size_t)w * h);
+    for (size_t i = 0; i < (size_t)w * h; ++i) { t.rgba[4 * i] = rgb[3 * i]; t.rgba[4 * i + 1] = rgb[3 * i + 1]; t.rgba[4 * i + 2] = rgb[3 * i + 2]; t.rgba[4 * i + 3] = 1.f; }
+    t.w = w; t.h = h;
+  }
+  c->textures_dirty = true;
+  return do_reset(c);
+}
+
 int crh_set_camera(crh_ctx* c, const crh_camera* cam) { if (!c || !cam) return fail(c, CRH_E_INVALID, "null camera"); c->cam = *cam; return CRH_OK; }
 
 int crh_set_params(crh_ctx* c, const crh_params* p)
@@ -471,6 +510,14 @@ int crh_build(crh_ctx* c)
   if ((rc = dev_upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode)))) return rc;
   if ((rc = dev_upload(c, c->d_tris, c->h_tris.data(), c->h_tris.size() * sizeof(float)))) return rc;
   if ((rc = dev_upload(c, c->d_shade, sh.data(), sh.size() * sizeof(float)))) return rc;
+  if (!c->uv.empty()) {
+    std::vector<float> uvr(8 * (size_t)std::max(nT, 1u), 0.f);
+    for (uint32_t i = 0; i < nT; ++i) {
+      const uint32_t t = c->bvh.prim_order[i];
+      for (int k = 0; k < 3; ++k) { const int32_t vi = c->tri[4 * t + k]; uvr[8 * (size_t)i + 2 * k] = c->uv[2 * vi]; uvr[8 * (size_t)i + 2 * k + 1] = c->uv[2 * vi + 1]; }
+    }
+    if ((rc = dev_upload(c, c->d_uvs, uvr.data(), uvr.size() * sizeof(float)))) return rc;
+  } else if (c->d_uvs) { CRH_HIP(hipFree(c->d_uvs)); c->d_uvs = nullptr; }
   c->built = true;
   return do_reset(c);
 }
@@ -546,6 +593,27 @@ int crh_read_ldr(crh_ctx* c, uint8_t* out)
   launch_tonemap(L, c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point);
   CRH_HIP(hipMemcpyAsync(out, c->d_scratch, 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
+  return CRH_OK;
+}
+
+int crh_save_accum(crh_ctx* c, float* out, uint32_t* frames_done)
+{
+  if (!c || !out || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null output");
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpy(out, c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyDeviceToHost));
+  if (frames_done) *frames_done = c->frames_done;
+  return CRH_OK;
+}
+
+int crh_load_accum(crh_ctx* c, const float* in, uint32_t frames_done)
+{
+  if (!c || !in || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null input");
+  if (c->adaptive) return fail(c, CRH_E_INVALID, "checkpoints do not carry the adaptive sampler's second moments");
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpy(c->d_accum, in, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyHostToDevice));
+  c->frames_done = frames_done;
   return CRH_OK;
 }
 

@@ -27,6 +27,10 @@ struct DScene {
   const float4* mats;     // 8 x float4 per material (crh_bsdf)
   const float4* lights;   // 2 x float4 per light: {vec.xyz (unit to-light dir | position), is_point}, {emission.rgb, cosmax | radius}
   const float4* env;      // W*H float4 texels, row 0 = zenith; nullptr -> constant background
+  const float4* uvs;      // 2 x float4 per triangle in leaf order: {uv0, uv1}, {uv2, -, -}; nullptr -> no texture coordinates
+  const float4* texels;   // all diffuse textures back to back
+  const uint4*  tex_desc; // per slot: {first texel, width, height, 0}; width 0 = empty slot
+  uint32_t n_tex;
   uint32_t n_mats, n_lights, env_w, env_h;
   float bg[3]; int env_as_bg;
   // camera frame

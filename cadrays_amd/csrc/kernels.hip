@@ -590,6 +590,35 @@ __device__ __forceinline__ v3 offset_origin(v3 p, v3 dir, v3 ng, float eps)
   return crh_madd3(o, ng, s);
 }
 
+// Diffuse texture lookup: bilinear, repeat wrap, row 0 of the image = v 1.  The call site is behind
+// a wave-uniform "any texture bound" test.
+__device__ __forceinline__ v3 sample_texture(const DScene& S, uint32_t slot, uint32_t tri, float bu, float bv, float w0, float sc_s, float sc_t)
+{
+  if (slot >= S.n_tex || !S.uvs) return crh_mk3(1.f, 1.f, 1.f);
+  const uint4 td = S.tex_desc[slot];
+  if (td.y == 0u) return crh_mk3(1.f, 1.f, 1.f);
+  const float4 ua = S.uvs[2u * tri], ub = S.uvs[2u * tri + 1u];
+  const float ss = sc_s != 0.f ? sc_s : 1.0f, st_ = sc_t != 0.f ? sc_t : 1.0f;
+  const float us = CRH_FMA(ub.x, bv, CRH_FMA(ua.z, bu, ua.x * w0)) * ss;
+  const float vs = CRH_FMA(ub.y, bv, CRH_FMA(ua.w, bu, ua.y * w0)) * st_;
+  float uf = (float)(int)us; if (uf > us) uf -= 1.0f;
+  float vf = (float)(int)vs; if (vf > vs) vf -= 1.0f;
+  const float x = CRH_FMA(us - uf, (float)td.y, -0.5f), y = CRH_FMA(1.0f - (vs - vf), (float)td.z, -0.5f);
+  float xf = (float)(int)x; if (xf > x) xf -= 1.0f;
+  float yf = (float)(int)y; if (yf > y) yf -= 1.0f;
+  const float fx = x - xf, fy = y - yf;
+  const int W = (int)td.y, H = (int)td.z;
+  int x0 = (int)xf; if (x0 < 0) x0 += W; if (x0 >= W) x0 -= W;
+  int x1 = x0 + 1; if (x1 >= W) x1 = 0;
+  int y0 = (int)yf; if (y0 < 0) y0 += H; if (y0 >= H) y0 -= H;
+  int y1 = y0 + 1; if (y1 >= H) y1 = 0;
+  const float4* tb = S.texels + td.x;
+  const float4 p00 = tb[y0 * W + x0], p10 = tb[y0 * W + x1], p01 = tb[y1 * W + x0], p11 = tb[y1 * W + x1];
+  return crh_mk3(lerpf(lerpf(p00.x, p10.x, fx), lerpf(p01.x, p11.x, fx), fy),
+                 lerpf(lerpf(p00.y, p10.y, fx), lerpf(p01.y, p11.y, fx), fy),
+                 lerpf(lerpf(p00.z, p10.z, fx), lerpf(p01.z, p11.z, fx), fy));
+}
+
 // ================================================================== path slot <-> pixel
 // Slot layout inside one sample: tile-major, and inside a tile 8x8-pixel blocks so that one wavefront
 // owns one 8x8 block (coherent primary rays, coalesced accumulator rows of 8 float4 = 128 B).
@@ -729,6 +758,10 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
         { const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2], m3 = mp[3], m4 = mp[4];
           bs.Kc = xyz(m0); bs.Rc = m0.w; bs.Kd = xyz(m1); bs.Ks = xyz(m2); bs.Rs = m2.w; bs.Kt = xyz(m3); bs.Le = xyz(m4);
           bs.ab = mp[5]; bs.fc = mp[6]; bs.fb = mp[7]; }
+        if (S.n_tex != 0u) {                                   // wave-uniform: scenes without textures skip the call
+          const int slot = (int)mp[1].w - 1;
+          if (slot >= 0) bs.Kd = crh_mul3(bs.Kd, sample_texture(S, (uint32_t)slot, (uint32_t)hk, h.y, h.z, w0, mp[3].w, mp[4].w));
+        }
         const Frame fr = make_frame(ns);
         const v3 wo = to_local(fr, crh_mk3(-d.x, -d.y, -d.z));
         bs.Fc = fresnel_media(wo.z, bs.fc);

@@ -69,6 +69,8 @@ class BSDF:
     Absorption: np.ndarray = field(default_factory=lambda: np.zeros(4, np.float32))  # rgb + coeff
     FresnelCoat: Fresnel = field(default_factory=lambda: Fresnel.CreateConstant(0.0))
     FresnelBase: Fresnel = field(default_factory=lambda: Fresnel.CreateConstant(1.0))
+    texture: int = -1                 # diffuse (Kd) texture slot; -1 = none   (aspect Kd map, AisMesh.cxx:321-346)
+    texture_scale: tuple = (1.0, 1.0)  # rttexture -scale S T                    (ImportExportPlugin.cxx:679-727)
 
     # -- factories (reference call sites above) ------------------------------------------
     @staticmethod
@@ -157,10 +159,10 @@ class BSDF:
     def to_abi(self):
         m = abi.crh_bsdf()
         m.Kc[:] = [float(x) for x in self.Kc]
-        m.Kd[:] = [float(x) for x in self.Kd] + [0.0]
+        m.Kd[:] = [float(x) for x in self.Kd] + [float(self.texture + 1)]
         m.Ks[:] = [float(x) for x in self.Ks]
-        m.Kt[:] = [float(x) for x in self.Kt] + [0.0]
-        m.Le[:] = [float(x) for x in self.Le] + [0.0]
+        m.Kt[:] = [float(x) for x in self.Kt] + [float(self.texture_scale[0]) if self.texture >= 0 else 0.0]
+        m.Le[:] = [float(x) for x in self.Le] + [float(self.texture_scale[1]) if self.texture >= 0 else 0.0]
         m.Absorption[:] = [float(x) for x in self.Absorption]
         m.FresnelCoat[:] = self.FresnelCoat.Serialize()
         m.FresnelBase[:] = self.FresnelBase.Serialize()

@@ -72,6 +72,7 @@ class Scene:
     camera: Camera = field(default_factory=Camera)
     params: Params = field(default_factory=Params)
     uv: Optional[np.ndarray] = None
+    textures: List[np.ndarray] = field(default_factory=list)   # slot -> (H, W, 3) float32 linear RGB, row 0 = v 1
     name: str = "scene"
 
 

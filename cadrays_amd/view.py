@@ -63,6 +63,18 @@ class View(Backend):
         self._call("get_kernel_timing", C.byref(ms), C.byref(n), C.byref(allms))
         return {"trace_nearest_ms_total": ms.value, "trace_nearest_launches": n.value, "render_ms_total": allms.value}
 
+    def save_accum(self):
+        """checkpoint: (H, W, 4) float32 accumulator (rgb mean + sample count) and the iteration counter"""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        n = C.c_uint32(0)
+        self._call("save_accum", out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n))
+        return out, n.value
+
+    def load_accum(self, rgba, frames_done):
+        rgba = np.ascontiguousarray(rgba, np.float32)
+        assert rgba.shape == (self.height, self.width, 4)
+        self._call("load_accum", rgba.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(int(frames_done)))
+
     def accum_device_ptr(self):
         p, n = C.c_void_p(0), C.c_uint64(0)
         self._call("accum_device_ptr", C.byref(p), C.byref(n))

@@ -34,10 +34,11 @@ typedef struct crh_ctx crh_ctx;
 /* The double-layer material, field-for-field Graphic3d_BSDF as the reference fills
  * and serialises it (MaterialEditor.cxx:281-338, ImportExport.cxx:164-231):
  *   Kc.rgb coat weight, Kc.w coat roughness        (MaterialEditor.cxx:890-896)
- *   Kd.rgb diffuse weight                          (:680)
+ *   Kd.rgb diffuse weight                          (:680); Kd.w = diffuse texture slot + 1 (0 = untextured)
+ *                                                   [the aspect's Kd map, AisMesh.cxx:321-346, rttexture]
  *   Ks.rgb glossy weight,  Ks.w base roughness     (:707-713)
- *   Kt.rgb transmission weight                     (:811)
- *   Le.rgb emission                                (:1068-1089)
+ *   Kt.rgb transmission weight                     (:811); Kt.w = texture scale S (0 = 1)  (rttexture -scale S T,
+ *   Le.rgb emission                                (:1068-1089); Le.w = texture scale T (0 = 1)   ImportExportPlugin.cxx:679-727)
  *   Absorption.rgb colour, .w coefficient          (:817-823)
  *   FresnelCoat / FresnelBase: serialised Graphic3d_Fresnel (MaterialEditor.cxx:209-255):
  *       Schlick    : x,y,z = F0 rgb (x >= 0)
@@ -136,6 +137,10 @@ CRH_API int crh_set_lights(crh_ctx* ctx, const crh_light* l, uint32_t n);
 /* == V3d_View::SetTextureEnv (LightSourcesEditor.cxx:339-354); rgb = W*H*3 linear float
  * lat-long, NULL = constant crh_params.background */
 CRH_API int crh_set_envmap(crh_ctx* ctx, const float* rgb, uint32_t w, uint32_t h);
+/* == Graphic3d_AspectFillArea3d::SetTextureMap (AisMesh.cxx:340-345, ImportExportPlugin.cxx:737-742): linear float RGB
+ * image for texture slot `slot` (row 0 = top, v = 1); NULL clears the slot.  Needs uv in crh_set_geometry.  The
+ * texel multiplies Kd (bilinear, repeat wrap). */
+CRH_API int crh_set_texture(crh_ctx* ctx, uint32_t slot, const float* rgb, uint32_t w, uint32_t h);
 /* == Graphic3d_Camera setters (AppViewer.cxx:993-1042) */
 CRH_API int crh_set_camera(crh_ctx* ctx, const crh_camera* cam);
 /* == ChangeRenderingParams() field writes (SettingsWidget.cxx:263-477) */
@@ -168,6 +173,11 @@ CRH_API int crh_read_hdr(crh_ctx* ctx, float* rgb_out);
 /* == BufferDump(Graphic3d_BT_RGB) (AppViewer.cxx:1259-1261): W*H*3 uint8 after exposure,
  * tone map, gamma 2.2 */
 CRH_API int crh_read_ldr(crh_ctx* ctx, uint8_t* rgb_out);
+/* Accumulator checkpoint / resume (SURVEY.md section 5 "checkpoint / resume", 8f rank 4; the reference only keeps the
+ * image while paused, AppViewer.cxx:916-920,1045): copy out / restore the float4 accumulator (rgb running mean + per-pixel
+ * sample count) together with the whole-frame iteration counter that selects the next frame seed. */
+CRH_API int crh_save_accum(crh_ctx* ctx, float* rgba_out /* W*H*4 */, uint32_t* frames_done);
+CRH_API int crh_load_accum(crh_ctx* ctx, const float* rgba /* W*H*4 */, uint32_t frames_done);
 /* Device address of the float4 accumulator (W*H*4 floats: rgb running mean, a = number of
  * samples accumulated in that pixel) so a host process can hand it to RCCL without a copy.
  * Replaces the zero-copy GL texture id the GUI displays (AppViewer.cxx:1099). */

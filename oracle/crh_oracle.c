@@ -61,6 +61,7 @@ typedef struct orc_ctx {
   float* pos; float* nrm; float* uv; int32_t* tri;
   crh_bsdf* mats; crh_light* lights;
   float* env; uint32_t envW, envH;
+  struct { float* rgb; uint32_t w, h; } tex[64]; uint32_t nTex;
   crh_camera cam; crh_params par;
   /* derived */
   qnode* nodes; uint32_t nNodes; qtri* qtris; uint32_t nQT;
@@ -546,6 +547,35 @@ static void load_bsdf(const orc_ctx* c, int32_t mat, bsdf_t* b)
   memcpy(b->fc, m->FresnelCoat, 16); memcpy(b->fb, m->FresnelBase, 16); memcpy(b->ab, m->Absorption, 16);
 }
 
+/* diffuse texture (reference AisMesh.cxx:321-346, rttexture -scale ImportExportPlugin.cxx:679-727):
+ * Kd *= bilinear texel at the repeat-wrapped, scaled, barycentrically interpolated uv; row 0 of the image is v = 1 */
+static float lerpf(float a, float b, float t);
+static void apply_texture(const orc_ctx* c, const int32_t* ti, float w0, float u, float v, bsdf_t* b)
+{
+  const crh_bsdf* m = &c->mats[(ti[3] >= 0 && (uint32_t)ti[3] < c->nM) ? ti[3] : 0];
+  int slot = (int)m->Kd[3] - 1;
+  if (slot < 0 || (uint32_t)slot >= c->nTex || !c->uv || !c->tex[slot].rgb) return;
+  int W = (int)c->tex[slot].w, H = (int)c->tex[slot].h;
+  const float* t0 = &c->uv[2 * ti[0]]; const float* t1 = &c->uv[2 * ti[1]]; const float* t2 = &c->uv[2 * ti[2]];
+  float ss = m->Kt[3] != 0.f ? m->Kt[3] : 1.0f, st = m->Le[3] != 0.f ? m->Le[3] : 1.0f;
+  float us = CRH_FMA(t2[0], v, CRH_FMA(t1[0], u, t0[0] * w0)) * ss;
+  float vs = CRH_FMA(t2[1], v, CRH_FMA(t1[1], u, t0[1] * w0)) * st;
+  float uf = (float)(int)us; if (uf > us) uf -= 1.0f;
+  float vf = (float)(int)vs; if (vf > vs) vf -= 1.0f;
+  float x = CRH_FMA(us - uf, (float)W, -0.5f), y = CRH_FMA(1.0f - (vs - vf), (float)H, -0.5f);
+  float xf = (float)(int)x; if (xf > x) xf -= 1.0f;
+  float yf = (float)(int)y; if (yf > y) yf -= 1.0f;
+  float fx = x - xf, fy = y - yf;
+  int x0 = (int)xf; if (x0 < 0) x0 += W; if (x0 >= W) x0 -= W; int x1 = x0 + 1; if (x1 >= W) x1 = 0;
+  int y0 = (int)yf; if (y0 < 0) y0 += H; if (y0 >= H) y0 -= H; int y1 = y0 + 1; if (y1 >= H) y1 = 0;
+  const float* img = c->tex[slot].rgb;
+  const float* p00 = &img[3 * (y0 * W + x0)]; const float* p10 = &img[3 * (y0 * W + x1)];
+  const float* p01 = &img[3 * (y1 * W + x0)]; const float* p11 = &img[3 * (y1 * W + x1)];
+  b->Kd = crh_mul3(b->Kd, crh_mk3(lerpf(lerpf(p00[0], p10[0], fx), lerpf(p01[0], p11[0], fx), fy),
+                                  lerpf(lerpf(p00[1], p10[1], fx), lerpf(p01[1], p11[1], fx), fy),
+                                  lerpf(lerpf(p00[2], p10[2], fx), lerpf(p01[2], p11[2], fx), fy)));
+}
+
 /* ================================================================== lights / env (a11, a12) */
 typedef struct { v3 t, b, n; } frame_t;
 static frame_t make_frame(v3 n)
@@ -687,6 +717,7 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
     if (!(crh_dot3(ns, ns) > 0.f)) ns = ng;
     v3 p = crh_madd3(o, d, h.t);
     bsdf_t b; load_bsdf(c, ti[3], &b);
+    apply_texture(c, ti, w0, h.u, h.v, &b);
     frame_t fr = make_frame(ns);
     v3 wo = to_local(&fr, crh_mk3(-d.x, -d.y, -d.z));
     b.Fc = fresnel_media(wo.z, b.fc);
@@ -894,6 +925,14 @@ ORC_API int orc_set_envmap(orc_ctx* c, const float* rgb, uint32_t w, uint32_t h)
   if (!c) return CRH_E_INVALID;
   free(c->env); c->env = NULL; c->envW = c->envH = 0;
   if (rgb && w && h) { c->env = (float*)dup_mem(rgb, sizeof(float) * 3 * (size_t)w * h); c->envW = w; c->envH = h; }
+  return 0;
+}
+ORC_API int orc_set_texture(orc_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uint32_t h)
+{
+  if (!c || slot >= 64u) return CRH_E_INVALID;
+  free(c->tex[slot].rgb); c->tex[slot].rgb = NULL; c->tex[slot].w = c->tex[slot].h = 0;
+  if (rgb && w && h) { c->tex[slot].rgb = (float*)dup_mem(rgb, sizeof(float) * 3 * (size_t)w * h); c->tex[slot].w = w; c->tex[slot].h = h; }
+  if (slot + 1 > c->nTex) c->nTex = slot + 1;
   return 0;
 }
 ORC_API int orc_set_camera(orc_ctx* c, const crh_camera* cam) { if (!c || !cam) return CRH_E_INVALID; c->cam = *cam; return 0; }

@@ -303,3 +303,15 @@ def test_device_framebuffer_view_and_nccl_reduce(view_cls):
         assert (fb.tensor[..., 3] == 3).all()
     finally:
         dist.destroy_process_group()
+
+
+def test_accumulator_checkpoint_resume(view_cls):
+    """pause / export / resume: render 3, checkpoint, restore into a fresh context, render 2 == render 5."""
+    sc = scenes.cornell_box(True, 80, 64)
+    a = view_cls(0).load_scene(sc); a.render(3)
+    ck, n = a.save_accum()
+    assert n == 3 and (ck[..., 3] == 3).all()
+    b = view_cls(0).load_scene(sc); b.load_accum(ck, n); b.render(2)
+    c = view_cls(0).load_scene(sc); c.render(5)
+    assert np.array_equal(bits(b.read_hdr()), bits(c.read_hdr()))
+    assert b.save_accum()[1] == 5
