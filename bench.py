@@ -3,7 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" = one crh_render pass of `--spp` samples per pixel over the rank's tiles of the workload
+A "step" = one crh_render pass of `--spp` (default 32) samples per pixel over the rank's tiles of the workload
 (BASELINE.json config C3: 1 M random triangles, glass + glossy double-layer BSDFs, HDR sky, 1080p).
 At N > 1 (one process per GPU under torch.distributed.run) tiles are interleaved across ranks, every rank
 renders spp*N samples of its tiles per step (fixed per-GPU work -> weak scaling), and each step ends with
@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
-    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step (per GPU share)")
+    ap.add_argument("--spp", type=int, default=32, help="samples per pixel per step (per GPU share)")
     ap.add_argument("--tris", type=int, default=0, help="override triangle count (debug)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -118,7 +118,8 @@ def main():
         v.enable_counters(False)
         assert cs["rays_nearest"] == st["rays_nearest"], "counting pass traced different rays"
         launches = max(kt["trace_nearest_launches"], 1)
-        alg_bytes = 128.0 * cs["nodes_nearest"] + 48.0 * cs["tris_nearest"] + 48.0 * cs["rays_nearest"]
+        # algorithmic bytes of k_trace_nearest: 64-B node per inner visit, 3 x float4 per triangle test, 32-B ray + 16-B hit per ray
+        alg_bytes = 64.0 * cs["nodes_nearest"] + 48.0 * cs["tris_nearest"] + 48.0 * cs["rays_nearest"]
         per_launch = alg_bytes / launches
         avg_ms = kt["trace_nearest_ms_total"] / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -126,9 +127,10 @@ def main():
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if traffic is None and args.config == "C3" and not (args.tris or args.width or args.height) and os.path.exists(pmc_file):
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
-            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
-            if traffic is not None and args.spp != 16:
-                traffic = traffic * args.spp / 16.0
+            pmc = json.load(open(pmc_file))
+            traffic = pmc.get("hbm_bytes_per_launch")
+            if traffic is not None and args.spp != pmc.get("spp_per_step", 32):
+                traffic = traffic * args.spp / pmc.get("spp_per_step", 32)
         roof = {"bound": "hbm", "kernel": "k_trace_nearest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": round(per_launch), "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),

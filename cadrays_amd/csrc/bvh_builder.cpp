@@ -5,10 +5,15 @@
 // the cheapest split by  area(L)*n(L) + area(R)*n(R)  wins, ties to the lower axis, then the lower bin;
 // the partition is stable; leaves hold <= 4 triangles; when the remaining depth budget is only enough
 // for balanced splitting, split at the object median of the widest centroid axis (total order by
-// (centre, index)).  The binary tree is then collapsed by replacing children with grandchildren and
-// numbered in DFS pre-order.  Large subtrees are built by separate threads; the result does not depend
-// on the thread count because every subtree owns a disjoint index range and numbering happens afterwards.
+// (centre, index)).  The binary tree is then collapsed by replacing children with grandchildren, numbered in
+// DFS pre-order, and every 4-wide node is packed into 64 bytes with 8-bit child bounds (crh_bvh_format.h).
+// Large subtrees are built by separate threads; the result does not depend on the thread count because every
+// subtree owns a disjoint index range and numbering happens afterwards.
 #include "bvh_builder.h"
+
+#include <hip/hip_runtime.h>   // this file is compiled as HIP (host part only); crh_math.h needs the HIP attribute macros
+
+#include "../../include/crh_bvh_format.h"
 
 #include <algorithm>
 #include <atomic>
@@ -152,7 +157,6 @@ struct Collapser {
   const std::vector<BNode>& bn;
   std::vector<QNode>& qn;
   static uint32_t leaf_ref(const BNode& b) { return kLeafBit | ((b.hi - b.lo - 1u) << 28) | b.lo; }
-  static float bits(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
   uint32_t run(uint32_t bi) {
     const uint32_t me = (uint32_t)qn.size();
@@ -169,23 +173,14 @@ struct Collapser {
     }
     QNode q; std::memset(&q, 0, sizeof q);
     uint32_t refs[4] = {kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef};
-    for (int k = 0; k < 4; ++k) {
-      if (k < nk) {
-        const Box& cb = bn[kids[k]].box;
-        q.f[0 + k] = cb.mn[0]; q.f[4 + k] = cb.mn[1]; q.f[8 + k] = cb.mn[2];
-        q.f[12 + k] = cb.mx[0]; q.f[16 + k] = cb.mx[1]; q.f[20 + k] = cb.mx[2];
-      } else {
-        q.f[0 + k] = q.f[4 + k] = q.f[8 + k] = 3.0e38f;
-        q.f[12 + k] = q.f[16 + k] = q.f[20 + k] = -3.0e38f;
-      }
-    }
+    float cmin[4][3], cmax[4][3];
     for (int k = 0; k < nk; ++k) {
       const BNode& c = bn[kids[k]];
+      for (int a = 0; a < 3; ++a) { cmin[k][a] = c.box.mn[a]; cmax[k][a] = c.box.mx[a]; }
       if (c.left < 0) refs[k] = c.hi > c.lo ? leaf_ref(c) : kEmptyRef;
       else            refs[k] = run(kids[k]);
     }
-    for (int k = 0; k < 4; ++k) q.f[24 + k] = bits(refs[k]);
-    q.f[28] = bits((uint32_t)nk);
+    crh_pack_node(cmin, cmax, refs, nk, q.w);      // 8-bit child bounds on the node's power-of-two grid
     qn[me] = q;
     return me;
   }

@@ -15,7 +15,7 @@ constexpr int      kMaxDepth  = 40;
 constexpr uint32_t kEmptyRef  = 0xFFFFFFFFu;
 constexpr uint32_t kLeafBit   = 0x80000000u;
 
-struct QNode { float f[32]; };   // 128 B: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] rsv[4]
+struct QNode { uint32_t w[16]; };   // 64 B: origin, grid exponents, 8-bit child bounds, child refs (include/crh_bvh_format.h)
 
 struct QBvh {
   std::vector<QNode>    nodes;       // DFS pre-order

@@ -23,7 +23,7 @@ struct crh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   int grid = 2048;        // streaming / shading kernels: 8 workgroups per CU
-  int grid_trace = 1024;  // traversal kernels: 4 workgroups (= 4 waves/SIMD) per CU -- measured optimum: more rays in
+  int grid_trace = 1280;  // traversal kernels: 5 workgroups (= 5 waves/SIMD) per CU -- measured optimum: more rays in
                           // flight only enlarge the working set the 4 MB-per-XCD L2s have to hold
   std::string err;
   // ---- host copies of the inputs
@@ -58,7 +58,7 @@ struct crh_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> render_ev, trace_ev;
   std::vector<hipEvent_t> ev_pool;
   double seconds_acc = 0.0, trace_ms_acc = 0.0, all_ms_acc = 0.0; uint64_t trace_launches = 0;
-  uint32_t max_paths = 32u << 20;   // path slots per batch (148 B each); more in flight keeps late, sparse bounces busy
+  uint32_t max_paths = 64u << 20;   // path slots per batch (148 B each = 9.5 GB); more in flight keeps late, sparse bounces busy
 };
 
 namespace {
@@ -360,7 +360,7 @@ crh_ctx* crh_create(int device_ordinal)
     delete c; return nullptr;
   }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->grid = prop.multiProcessorCount * 8; c->grid_trace = prop.multiProcessorCount * 4; }
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->grid = prop.multiProcessorCount * 8; c->grid_trace = prop.multiProcessorCount * 5; }
   if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)v; }
   if (const char* e = getenv("CRH_GRID")) { int v = atoi(e); if (v > 0) c->grid = v; }
   if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }

@@ -21,7 +21,7 @@ constexpr int kOvfStack   = 48;    // spill entries per lane (scratch); 16 + 48 
 
 // Scene as the kernels see it.  All arrays are float4-granular so every fetch is one dwordx4.
 struct DScene {
-  const float4* nodes;    // 8 x float4 per node (128 B, one L2 line): minx miny minz maxx maxy maxz ref rsv
+  const float4* nodes;    // 4 x float4 per node (64 B): {origin.xyz, exps}, {qlo xyz}, {qhi xyz}, {refs}  (crh_bvh_format.h)
   const float4* tris;     // 3 x float4 per triangle in leaf order: v0|prim, v1, v2
   const float4* shade;    // 3 x float4 per triangle in leaf order: n0|material, n1, n2
   const float4* mats;     // 8 x float4 per material (crh_bsdf)

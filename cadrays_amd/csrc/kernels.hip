@@ -11,6 +11,8 @@
 // built with -ffp-contract=off) so that results are bit-identical to the CPU oracle.
 #include "kernels.h"
 
+#include "../../include/crh_bvh_format.h"
+
 namespace crh {
 namespace {
 
@@ -66,10 +68,10 @@ __device__ __forceinline__ void block_enqueue(bool pred, uint32_t value, uint32_
 #define CRH_TRACE_BOUNDS __launch_bounds__(kBlock)
 #endif
 #ifndef CRH_INNER_STEPS
-#define CRH_INNER_STEPS 4      // 0: descend until every lane holds a leaf; k > 0: at most k inner steps per round
+#define CRH_INNER_STEPS 3      // 0: descend until every lane holds a leaf; k > 0: at most k inner steps per round
 #endif
 #ifndef CRH_REFILL_IDLE
-#define CRH_REFILL_IDLE 24     // refill a wavefront once this many of its 64 lanes have no ray
+#define CRH_REFILL_IDLE 12     // refill a wavefront once this many of its 64 lanes have no ray
 #endif
 constexpr uint32_t kPoolChunk = 512;   // rays a wavefront takes from the global cursor per atomic
 constexpr uint32_t kDone = 0xFFFFFFFFu;
@@ -151,29 +153,37 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     }
     if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
 
-    // one inner-node step of this lane: fetch the 128-B node, slab-test and order its children, push / descend / pop
+    // one inner-node step of this lane: fetch the 64-B node (4 x dwordx4), slab-test and order its children, push / descend / pop
     auto inner_step = [&]() {
-      const float4* np = nodes + 8u * cur;
-      const float4 mnx = np[0], mny = np[1], mnz = np[2], mxx = np[3], mxy = np[4], mxz = np[5];
-      const float4 rf = np[6];
+      const float4* np = nodes + 4u * cur;
+      const float4 n0 = np[0], n1 = np[1], n2 = np[2], rf = np[3];
       const uint4 refs = make_uint4(__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w));
       if (COUNT) ++n_nodes;
+      // per-node grid: face t = fma(q, step * inv_d, fma(origin, inv_d, -o * inv_d))
+      const uint32_t ew = __float_as_uint(n0.w);
+      const float ax = __uint_as_float((ew & 0xffu) << 23) * ix, ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * iy,
+                  az = __uint_as_float(((ew >> 16) & 0xffu) << 23) * iz;
+      const float bx = CRH_FMA(n0.x, ix, nox), by = CRH_FMA(n0.y, iy, noy), bz = CRH_FMA(n0.z, iz, noz);
+      const uint32_t lx = __float_as_uint(n1.x), ly = __float_as_uint(n1.y), lz = __float_as_uint(n1.z);
+      const uint32_t hx = __float_as_uint(n2.x), hy = __float_as_uint(n2.y), hz = __float_as_uint(n2.z);
       uint32_t key[4];
-#define CRH_CHILD(K, MNX, MNY, MNZ, MXX, MXY, MXZ, REF)                                                    \
+#define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))      /* v_cvt_f32_ubyteK */
+#define CRH_CHILD(K, REF)                                                                                    \
       {                                                                                                     \
-        const float a0 = CRH_FMA(MNX, ix, nox), a1 = CRH_FMA(MXX, ix, nox);                               \
-        const float b0 = CRH_FMA(MNY, iy, noy), b1 = CRH_FMA(MXY, iy, noy);                               \
-        const float c0 = CRH_FMA(MNZ, iz, noz), c1 = CRH_FMA(MXZ, iz, noz);                               \
+        const float a0 = CRH_FMA(CRH_QB(lx, K), ax, bx), a1 = CRH_FMA(CRH_QB(hx, K), ax, bx);             \
+        const float b0 = CRH_FMA(CRH_QB(ly, K), ay, by), b1 = CRH_FMA(CRH_QB(hy, K), ay, by);             \
+        const float c0 = CRH_FMA(CRH_QB(lz, K), az, bz), c1 = CRH_FMA(CRH_QB(hz, K), az, bz);             \
         const float tmin = fmaxf(fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), 0.f);          \
         const float tmx  = fminf(fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)), best);         \
         const int bits = max(__float_as_int(tmin), 0);                                                     \
         key[K] = (REF != kQEmpty && tmin <= tmx) ? (((uint32_t)bits & ~3u) | (uint32_t)K) : 0xFFFFFFFFu;   \
       }
-      CRH_CHILD(0, mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, refs.x)
-      CRH_CHILD(1, mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, refs.y)
-      CRH_CHILD(2, mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, refs.z)
-      CRH_CHILD(3, mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, refs.w)
+      CRH_CHILD(0, refs.x)
+      CRH_CHILD(1, refs.y)
+      CRH_CHILD(2, refs.z)
+      CRH_CHILD(3, refs.w)
 #undef CRH_CHILD
+#undef CRH_QB
       CRH_CE(key[0], key[1]) CRH_CE(key[2], key[3]) CRH_CE(key[0], key[2]) CRH_CE(key[1], key[3]) CRH_CE(key[1], key[2])
       // The sorted keys put the nh hit children first (miss keys have bit 31 set).  Far .. near go onto the
       // stack, the nearest continues in registers.  Common case (room for three entries in the LDS part of

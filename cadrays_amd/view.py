@@ -98,14 +98,14 @@ class View(Backend):
 
 
 def build_bvh_host(pos, tri, threads=0):
-    """Run the product's BVH builder on the host only (no GPU): returns (nodes[n,32] f32, prim_order[nT] u32)."""
+    """Run the product's BVH builder on the host only (no GPU): returns (nodes[n,16] u32-as-f32, prim_order[nT] u32)."""
     lib = load_library()
     pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
     tri = np.ascontiguousarray(tri, np.int32).reshape(-1, 4)
     nn = C.c_uint32(0)
     fp, ip, up = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
     args = (pos.ctypes.data_as(fp), C.c_uint32(len(pos)), tri.ctypes.data_as(ip), C.c_uint32(len(tri)), C.c_int(threads))
-    nodes = np.empty((max(len(tri), 4), 32), np.float32)   # nodes <= max(1, ~nT/2)
+    nodes = np.empty((max(len(tri), 4), 16), np.float32)   # nodes <= max(1, ~nT/2), 64 B each
     order = np.empty(len(tri), np.uint32)
     rc = lib.crh_build_bvh_host(*args, nodes.ctypes.data_as(fp), C.byref(nn), order.ctypes.data_as(up))
     if rc != 0:

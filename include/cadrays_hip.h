@@ -193,7 +193,7 @@ CRH_API int crh_get_stats(crh_ctx* ctx, crh_stats* out);
  * any    : out_vis = n x uint32 (1 = unoccluded up to tmax). */
 CRH_API int crh_trace_nearest(crh_ctx* ctx, const float* rays, uint32_t n, float* out_hit);
 CRH_API int crh_trace_any(crh_ctx* ctx, const float* rays, uint32_t n, uint32_t* out_vis);
-/* Copy out the built QBVH: nodes (32 floats = 128 B each) and the leaf-ordered triangle
+/* Copy out the built QBVH: nodes (16 dwords = 64 B each, layout in crh_bvh_format.h) and the leaf-ordered triangle
  * records (12 floats = 48 B each).  Pass NULL buffers to query the counts. */
 CRH_API int crh_get_bvh(crh_ctx* ctx, float* nodes, uint32_t* n_nodes, float* tris, uint32_t* n_tris);
 /* Host-only: run the BVH builder (no device needed) and copy out nodes / leaf-ordered triangles.

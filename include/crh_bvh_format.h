@@ -1,0 +1,80 @@
+/* crh_bvh_format.h -- the 64-byte 4-wide BVH node and its quantiser (data-format definition shared by the
+ * host builder, the gfx950 traversal kernels and the CPU oracle, like crh_math.h for arithmetic).
+ *
+ * Node = 16 dwords (one half of a 128-B L2 line, four dwordx4 fetches per visit):
+ *   [0..2]  origin.xyz (float)            minimum corner of the union of the child boxes
+ *   [3]     ex | ey<<8 | ez<<16 | n<<24    biased exponent bytes of the per-axis grid step 2^(e-127); n = child count
+ *   [4..6]  qlo_x, qlo_y, qlo_z            byte k = child k's lower bound on the grid:  origin + q * step
+ *   [7]     0
+ *   [8..10] qhi_x, qhi_y, qhi_z            byte k = child k's upper bound
+ *   [11]    0
+ *   [12..15] child references              inner: node index | leaf: 0x80000000 | (count-1)<<28 | first triangle | 0xFFFFFFFF empty
+ * The grid is conservative: origin + qlo*step <= true lower bound, origin + qhi*step >= true upper bound, so the
+ * set of triangles a ray can reach is unchanged; only the number of visits grows slightly (<= 2/255 of the parent
+ * extent per face).  Traversal evaluates a face as  t = fma((float)q, step * inv_d, fma(origin, inv_d, -o * inv_d)).
+ */
+#ifndef CRH_BVH_FORMAT_H
+#define CRH_BVH_FORMAT_H
+
+#include "crh_math.h"
+
+#define CRH_NODE_DWORDS 16
+#define CRH_NODE_BYTES  64
+
+/* biased exponent byte E of the smallest power-of-two step with 255 * 2^(E-127) >= ext */
+CRH_HD uint32_t crh_quant_exp(float ext)
+{
+  if (!(ext > 0.f)) return 1u;
+  int e = (int)(crh_f2u(ext) >> 23) - 7;
+  if (e < 1) e = 1;
+  if (255.0f * crh_u2f((uint32_t)e << 23) < ext) e += 1;
+  if (e > 253) e = 253;
+  return (uint32_t)e;
+}
+CRH_HD float crh_quant_step(uint32_t e) { return crh_u2f(e << 23); }
+
+/* lower bound: largest q in [0,255] with origin + q*step <= lo */
+CRH_HD uint32_t crh_quant_lo(float lo, float origin, uint32_t e)
+{
+  const float step = crh_quant_step(e), inv = crh_u2f((254u - e) << 23);
+  float t = (lo - origin) * inv;
+  int q = t > 0.f ? (t < 255.0f ? (int)t : 255) : 0;
+  while (q > 0 && (double)origin + (double)q * (double)step > (double)lo) --q;
+  return (uint32_t)q;
+}
+/* upper bound: smallest q in [0,255] with origin + q*step >= hi */
+CRH_HD uint32_t crh_quant_hi(float hi, float origin, uint32_t e)
+{
+  const float step = crh_quant_step(e), inv = crh_u2f((254u - e) << 23);
+  float t = (hi - origin) * inv;
+  int q = t > 0.f ? (t < 255.0f ? (int)t : 255) : 0;
+  if ((float)q < t && q < 255) ++q;
+  while (q < 255 && (double)origin + (double)q * (double)step < (double)hi) ++q;
+  return (uint32_t)q;
+}
+
+/* Fill one node from <= 4 child boxes (cmin/cmax: [child][axis]) and references.  out: 16 dwords. */
+CRH_HD void crh_pack_node(const float cmin[4][3], const float cmax[4][3], const uint32_t refs[4], int n_children, uint32_t out[CRH_NODE_DWORDS])
+{
+  float org[3], ext[3]; uint32_t e[3];
+  for (int a = 0; a < 3; ++a) {
+    float lo = 3.0e38f, hi = -3.0e38f;
+    for (int k = 0; k < n_children; ++k) { if (cmin[k][a] < lo) lo = cmin[k][a]; if (cmax[k][a] > hi) hi = cmax[k][a]; }
+    if (n_children == 0) { lo = 0.f; hi = 0.f; }
+    org[a] = lo; ext[a] = hi - lo; e[a] = crh_quant_exp(ext[a]);
+  }
+  out[0] = crh_f2u(org[0]); out[1] = crh_f2u(org[1]); out[2] = crh_f2u(org[2]);
+  out[3] = e[0] | (e[1] << 8) | (e[2] << 16) | ((uint32_t)n_children << 24);
+  for (int a = 0; a < 3; ++a) {
+    uint32_t lo = 0u, hi = 0u;
+    for (int k = 0; k < n_children; ++k) {
+      lo |= crh_quant_lo(cmin[k][a], org[a], e[a]) << (8 * k);
+      hi |= crh_quant_hi(cmax[k][a], org[a], e[a]) << (8 * k);
+    }
+    out[4 + a] = lo; out[8 + a] = hi;
+  }
+  out[7] = 0u; out[11] = 0u;
+  for (int k = 0; k < 4; ++k) out[12 + k] = refs[k];
+}
+
+#endif /* CRH_BVH_FORMAT_H */

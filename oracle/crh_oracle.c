@@ -29,6 +29,7 @@
 #endif
 
 #include "../include/crh_math.h"
+#include "../include/crh_bvh_format.h"
 #include "../include/cadrays_hip.h"
 
 #define ORC_API __attribute__((visibility("default")))
@@ -39,7 +40,7 @@
 #define BVH_MAXDEPTH   40          /* binary depth bound (root = 0); median splits keep it  */
 #define QBVH_EMPTY     0xFFFFFFFFu
 #define QBVH_LEAFBIT   0x80000000u
-#define STACK_MAX      64          /* >= 3 * ceil((BVH_MAXDEPTH+1)/2)                       */
+#define STACK_MAX      64          /* >= 3 * ceil((BVH_MAXDEPTH+1)/2) */
 #define DIR_EPS        1.0e-15f
 #define BSDF_EPS       1.0e-5f     /* roughness / weight threshold ("FLT_EPSILON" in GLSL)  */
 #define MIN_THROUGHPUT 1.0e-3f
@@ -50,7 +51,7 @@
 
 typedef crh_v3 v3;
 
-typedef struct { float f[32]; } qnode;     /* 128 B: minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] ref[4] rsv[4] */
+typedef struct { uint32_t w[CRH_NODE_DWORDS]; } qnode;   /* 64 B, layout in include/crh_bvh_format.h */
 typedef struct { float f[12]; } qtri;      /* 48 B: v0.xyz,prim | v1.xyz,0 | v2.xyz,0 */
 
 typedef struct { uint64_t nodes, tris, nodes_any, tris_any; } trav_counters;
@@ -226,23 +227,14 @@ static uint32_t collapse_rec(collapser* C, uint32_t bi)
   }
   qnode q; memset(&q, 0, sizeof q);
   uint32_t refs[4] = {QBVH_EMPTY, QBVH_EMPTY, QBVH_EMPTY, QBVH_EMPTY};
-  for (int k = 0; k < 4; ++k) {
-    if (k < nk) {
-      const bnode* c = &C->bn[kids[k]];
-      q.f[0 + k] = c->box.mn[0]; q.f[4 + k] = c->box.mn[1]; q.f[8 + k] = c->box.mn[2];
-      q.f[12 + k] = c->box.mx[0]; q.f[16 + k] = c->box.mx[1]; q.f[20 + k] = c->box.mx[2];
-    } else {
-      q.f[0 + k] = q.f[4 + k] = q.f[8 + k] = 3.0e38f;
-      q.f[12 + k] = q.f[16 + k] = q.f[20 + k] = -3.0e38f;
-    }
-  }
+  float cmin[4][3], cmax[4][3];
   for (int k = 0; k < nk; ++k) {
     const bnode* c = &C->bn[kids[k]];
+    for (int a = 0; a < 3; ++a) { cmin[k][a] = c->box.mn[a]; cmax[k][a] = c->box.mx[a]; }
     if (c->left < 0) refs[k] = (c->hi > c->lo) ? leaf_ref(c) : QBVH_EMPTY;
     else             refs[k] = collapse_rec(C, kids[k]);
   }
-  for (int k = 0; k < 4; ++k) q.f[24 + k] = crh_u2f(refs[k]);
-  q.f[28] = crh_u2f((uint32_t)nk);
+  crh_pack_node(cmin, cmax, refs, nk, q.w);
   C->qn[me] = q;
   return me;
 }
@@ -329,13 +321,18 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
       }
     } else {
       const qnode* q = &c->nodes[cur]; if (any_hit) cn->nodes_any++; else cn->nodes++;
+      /* decode the per-node grid: face t = fma(q, step * inv, fma(origin, inv, -o*inv)) */
+      const uint32_t ew = q->w[3];
+      const float ax = crh_quant_step(ew & 0xffu) * ix, ay = crh_quant_step((ew >> 8) & 0xffu) * iy, az = crh_quant_step((ew >> 16) & 0xffu) * iz;
+      const float bx = CRH_FMA(crh_u2f(q->w[0]), ix, nox), by = CRH_FMA(crh_u2f(q->w[1]), iy, noy), bz = CRH_FMA(crh_u2f(q->w[2]), iz, noz);
       uint32_t key[4]; uint32_t rf[4]; int nh = 0;
       for (int k = 0; k < 4; ++k) {
-        uint32_t r = crh_f2u(q->f[24 + k]);
+        uint32_t r = q->w[12 + k];
         if (r == QBVH_EMPTY) continue;
-        float a0 = CRH_FMA(q->f[0 + k], ix, nox),  a1 = CRH_FMA(q->f[12 + k], ix, nox);
-        float b0 = CRH_FMA(q->f[4 + k], iy, noy),  b1 = CRH_FMA(q->f[16 + k], iy, noy);
-        float c0 = CRH_FMA(q->f[8 + k], iz, noz),  c1 = CRH_FMA(q->f[20 + k], iz, noz);
+        const int sh = 8 * k;
+        float a0 = CRH_FMA((float)((q->w[4] >> sh) & 0xffu), ax, bx), a1 = CRH_FMA((float)((q->w[8] >> sh) & 0xffu), ax, bx);
+        float b0 = CRH_FMA((float)((q->w[5] >> sh) & 0xffu), ay, by), b1 = CRH_FMA((float)((q->w[9] >> sh) & 0xffu), ay, by);
+        float c0 = CRH_FMA((float)((q->w[6] >> sh) & 0xffu), az, bz), c1 = CRH_FMA((float)((q->w[10] >> sh) & 0xffu), az, bz);
         float tmin = crh_max(crh_max(crh_max(crh_min(a0, a1), crh_min(b0, b1)), crh_min(c0, c1)), 0.f);
         float tmx  = crh_min(crh_min(crh_min(crh_max(a0, a1), crh_max(b0, b1)), crh_max(c0, c1)), best);
         if (tmin <= tmx) {

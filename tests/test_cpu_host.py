@@ -69,7 +69,7 @@ def test_host_bvh_builder_equals_oracle_bytes(hip_lib, oracle_lib, n, threads):
     assert nodes.shape == on.shape and np.array_equal(nodes.view(np.uint32), on.view(np.uint32))
     assert np.array_equal(ot[:, 3].view(np.uint32)[:n], order)
     # structural invariants: every triangle referenced exactly once, leaves <= 4, children inside parents
-    refs = nodes[:, 24:28].view(np.uint32)
+    refs = nodes[:, 12:16].view(np.uint32)              # 64-B node: dwords 12..15 (include/crh_bvh_format.h)
     leaf = (refs & 0x80000000) != 0
     leaf &= refs != 0xFFFFFFFF
     cnt = ((refs >> 28) & 7) + 1
