@@ -3,7 +3,8 @@
 // One launch per stage and bounce, all on one HIP stream, no host round trip inside an iteration:
 //   k_raygen -> [ k_trace_nearest -> k_shade -> k_trace_any ] x depth -> k_accumulate
 // Stage boundaries exchange path ids through compacted queues built with wave64 ballot + prefix
-// popcount and ONE atomic per workgroup; traversal waves are persistent and refill idle lanes.  Traversal keeps a per-lane stack in LDS (lane-interleaved,
+// popcount, collected in LDS and appended with one atomic per 1024-8192 paths (a single counter word sustains only
+// ~88 atomics/us on MI355X); traversal waves are persistent and refill idle lanes.  Traversal keeps a per-lane stack in LDS (lane-interleaved,
 // conflict free), BVH nodes are 128-B float4 records (one L2 line per visit), triangles 48-B records
 // in leaf order.  No MFMA: there is no dense contraction on this path.
 //
@@ -37,25 +38,16 @@ __device__ __forceinline__ uint32_t wave_next_chunk(uint32_t* __restrict__ curso
   return __shfl(base, 0);
 }
 
-// Workgroup-aggregated append: ballots and prefix popcounts inside each wave, wave totals combined in LDS,
-// ONE global atomic per workgroup per call (4x fewer than per-wave; a single counter word sustains only
-// ~88 atomics/us on MI355X).  Must be called by all kBlock threads.  `sh` = 8 dwords of LDS scratch.
-__device__ __forceinline__ void block_enqueue(bool pred, uint32_t value, uint32_t* __restrict__ q, uint32_t* __restrict__ count, uint32_t* sh)
+// Append to a workgroup-local LDS list: ballot + prefix popcount, one LDS atomic per wavefront.
+__device__ __forceinline__ void lds_append(bool pred, uint32_t value, uint32_t* list, uint32_t* n)
 {
   const unsigned long long mask = __ballot(pred);
-  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
-  const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  if (lane == 0) sh[wv] = (uint32_t)__popcll(mask);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t c0 = sh[0], c1 = sh[1], c2 = sh[2], c3 = sh[3];
-    const uint32_t tot = c0 + c1 + c2 + c3;
-    const uint32_t base = tot ? atomicAdd(count, tot) : 0u;
-    sh[4] = base; sh[5] = base + c0; sh[6] = base + c0 + c1; sh[7] = base + c0 + c1 + c2;
-  }
-  __syncthreads();
-  if (pred) q[sh[4 + wv] + prefix] = value;
-  __syncthreads();
+  if (mask == 0ull) return;
+  const uint32_t lane = lane_id();
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(n, (uint32_t)__popcll(mask));
+  base = __shfl(base, 0);
+  if (pred) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
 // ================================================================== traversal
@@ -73,7 +65,10 @@ __device__ __forceinline__ void block_enqueue(bool pred, uint32_t value, uint32_
 #ifndef CRH_REFILL_IDLE
 #define CRH_REFILL_IDLE 12     // refill a wavefront once this many of its 64 lanes have no ray
 #endif
-constexpr uint32_t kPoolChunk = 512;   // rays a wavefront takes from the global cursor per atomic
+#ifndef CRH_POOL_CHUNK
+#define CRH_POOL_CHUNK 256     // measured: 64 -> 2257, 128 -> 2305, 256 -> 2308, 512 -> 2266, 1024 -> 2136 Mrays/s (big pools starve late bounces)
+#endif
+constexpr uint32_t kPoolChunk = CRH_POOL_CHUNK;   // rays a wavefront takes from the global cursor per atomic
 constexpr uint32_t kDone = 0xFFFFFFFFu;
 
 __device__ __forceinline__ float inv_dir(float d)
@@ -629,6 +624,10 @@ __device__ __forceinline__ v3 sample_texture(const DScene& S, uint32_t slot, uin
                  lerpf(lerpf(p00.z, p10.z, fx), lerpf(p01.z, p11.z, fx), fy));
 }
 
+constexpr uint32_t kGenIters = 32;     // k_raygen: 32 x 256 = 8192 path slots per queue reservation
+static_assert(kGenIters * 4 == 128, "k_raygen scans its 128 (iteration, wave) counters with one wavefront, two per lane");
+constexpr uint32_t kShadeIters = 4;    // k_shade : 4 x 256 = 1024 paths per cursor fetch / queue reservation
+
 // ================================================================== path slot <-> pixel
 // Slot layout inside one sample: tile-major, and inside a tile 8x8-pixel blocks so that one wavefront
 // owns one 8x8 block (coherent primary rays, coalesced accumulator rows of 8 float4 = 128 B).
@@ -650,12 +649,37 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
                                                     const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
                                                     const uint32_t* __restrict__ seeds, uint32_t n_samples, int seed_per_tile)
 {
-  __shared__ uint32_t s_enq[8];
+  // Queue space is reserved ONCE per chunk of kGenIters x 256 slots: pass 1 counts the slots that map to a pixel
+  // inside the image (edge tiles are partial), one atomic reserves the range, pass 2 generates the rays and writes
+  // their ids at exclusive-scan offsets.  (Per-workgroup appends were atomic-rate bound: 261 K atomics per 67 M paths.)
+  __shared__ uint32_t s_cnt[kGenIters * 4];
+  __shared__ uint32_t s_base;
   if (blockIdx.x == 0 && threadIdx.x == 0) { cursors[0] = 0u; cursors[1] = 0u; cursors[2] = 0u; }
   const uint32_t per_sample = n_tiles * S.tile_size * S.tile_size;
   const uint32_t total = per_sample * n_samples;
-  for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {
-    const uint32_t pid = base + threadIdx.x;
+  const uint32_t chunk = kGenIters * kBlock;
+  const uint32_t lane = lane_id(), wv = threadIdx.x >> 6;
+  for (uint32_t cbase = blockIdx.x * chunk; cbase < total; cbase += gridDim.x * chunk) {
+    for (uint32_t it = 0; it < kGenIters; ++it) {
+      const uint32_t pid = cbase + it * kBlock + threadIdx.x;
+      bool valid = pid < total;
+      uint32_t px, py;
+      if (valid) { const uint32_t s = pid / per_sample; valid = slot_pixel(S, tile_ids, pid - s * per_sample, px, py); }
+      const unsigned long long m = __ballot(valid);
+      if (lane == 0) s_cnt[it * 4u + wv] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (wv == 0) {                                  // exclusive scan of the kGenIters*4 (= 128) counters by one wavefront
+      const uint32_t a = s_cnt[2u * lane], b = s_cnt[2u * lane + 1u];
+      uint32_t incl = a + b;
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
+      const uint32_t excl = incl - (a + b);
+      s_cnt[2u * lane] = excl; s_cnt[2u * lane + 1u] = excl + a;
+      if (lane == 63) s_base = incl ? atomicAdd(count, incl) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t it = 0; it < kGenIters; ++it) {
+    const uint32_t pid = cbase + it * kBlock + threadIdx.x;
     bool valid = pid < total;
     uint32_t px = 0, py = 0, s = 0;
     if (valid) { s = pid / per_sample; valid = slot_pixel(S, tile_ids, pid - s * per_sample, px, py); }
@@ -691,7 +715,10 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
       P.rad[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
       P.st[pid] = make_uint2(rng, 0u);
     }
-    block_enqueue(valid, pid, q, count, s_enq);
+    const unsigned long long m = __ballot(valid);
+    if (valid) q[s_base + s_cnt[it * 4u + wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pid;
+    }
+    __syncthreads();
   }
 }
 
@@ -713,8 +740,9 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
                                                    uint32_t* __restrict__ cursors, DCounters* C)
 {
   __shared__ float4 s_mats[kLdsMats * 8];
-  __shared__ uint32_t s_enq[8];
-  __shared__ uint32_t s_base;
+  // survivors / shadow rays of kShadeIters x 256 paths are collected in LDS and appended with ONE global atomic each
+  __shared__ uint32_t s_qc[kShadeIters * kBlock], s_qs[kShadeIters * kBlock];
+  __shared__ uint32_t s_base, s_nc, s_ns, s_gc, s_gs;
   if (blockIdx.x == 0 && threadIdx.x == 0) cursors[0] = 0u;     // nearest-hit cursor of the next bounce
   const bool mats_in_lds = S.n_mats <= (uint32_t)kLdsMats;
   if (mats_in_lds) {
@@ -726,11 +754,13 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
   uint32_t n_shaded = 0;
   for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) s_base = atomicAdd(cursors + 1, (uint32_t)kBlock);
+    if (threadIdx.x == 0) { s_base = atomicAdd(cursors + 1, kShadeIters * (uint32_t)kBlock); s_nc = 0u; s_ns = 0u; }
     __syncthreads();
     const uint32_t base = s_base;
     if (base >= n) break;
-    const uint32_t i = base + threadIdx.x;
+#pragma unroll 1
+    for (uint32_t it = 0; it < kShadeIters; ++it) {
+    const uint32_t i = base + it * kBlock + threadIdx.x;
     bool cont = false, shadow = false;
     uint32_t pid = 0;
     if (i < n) {
@@ -835,8 +865,14 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
         }
       }
     }
-    if (S.n_lights > 0u) block_enqueue(shadow, pid, q_sh, count_sh, s_enq);
-    block_enqueue(cont, pid, q_out, count_out, s_enq);
+    if (S.n_lights > 0u) lds_append(shadow, pid, s_qs, &s_ns);
+    lds_append(cont, pid, s_qc, &s_nc);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { s_gc = s_nc ? atomicAdd(count_out, s_nc) : 0u; s_gs = s_ns ? atomicAdd(count_sh, s_ns) : 0u; }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < s_nc; j += kBlock) q_out[s_gc + j] = s_qc[j];
+    for (uint32_t j = threadIdx.x; j < s_ns; j += kBlock) q_sh[s_gs + j] = s_qs[j];
   }
   n_shaded = wave_sum(n_shaded);
   if (lane_id() == 0 && n_shaded) atomicAdd(&C->shaded_hits, (unsigned long long)n_shaded);
