@@ -248,7 +248,8 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   CRH_HIP(hipMemcpyAsync(c->d_tile_ids, tiles, sizeof(uint32_t) * nt, hipMemcpyHostToDevice, c->stream));
   std::vector<uint32_t> seeds(ns);
   {
-    uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;   // sequential form of frame_seed()
+    // frame seeds: Bullard generator restarted at par.seed, frame n uses next() >> 2
+    uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;
     for (uint32_t i = 0; i < first + ns; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; if (i >= first) seeds[i - first] = hi >> 2; }
   }
   CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice, c->stream));
