@@ -75,6 +75,16 @@ class Backend:
                    to.ctypes.data_as(_i32p) if to is not None else None,
                    _fp(xf), C.c_uint32(0 if xf is None else len(xf)))
 
+    def set_transforms(self, obj_xform):
+        """new per-object 3x4 transforms of a two-level scene: only the top-level tree is rebuilt (ImRaytraceControls.cxx:58-89)"""
+        xf = np.ascontiguousarray(obj_xform, np.float32).reshape(-1, 12)
+        self._call("set_transforms", _fp(xf), C.c_uint32(len(xf)))
+
+    def get_tlas(self):
+        r, n, b = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._call("get_tlas", C.byref(r), C.byref(n), C.byref(b))
+        return {"root": r.value, "n_instances": n.value, "n_blas_nodes": b.value}
+
     def set_materials(self, bsdfs):
         arr = pack_materials(bsdfs)
         self._call("set_materials", arr, C.c_uint32(len(bsdfs)))
@@ -127,7 +137,7 @@ class Backend:
         self.width, self.height, self.tile_size = int(p.width), int(p.height), int(p.tile_size)
 
     def load_scene(self, scene):
-        self.set_geometry(scene.pos, scene.nrm, scene.tri, scene.uv)
+        self.set_geometry(scene.pos, scene.nrm, scene.tri, scene.uv, getattr(scene, "tri_object", None), getattr(scene, "obj_xform", None))
         self.set_materials(scene.materials)
         self.set_lights(scene.lights)
         self.set_envmap(scene.env)

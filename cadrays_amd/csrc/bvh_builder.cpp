@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>   // this file is compiled as HIP (host part only); crh_math.h needs the HIP attribute macros
 
 #include "../../include/crh_bvh_format.h"
+#include "../../include/crh_xform.h"
 
 #include <algorithm>
 #include <atomic>
@@ -45,6 +46,7 @@ struct Builder {
   std::vector<BNode> nodes;
   std::atomic<uint32_t> next{0};
   std::atomic<int> spare_threads{0};
+  uint32_t leaf_max = kLeafSize;       // 4 for triangle trees, 1 for the top-level tree over instances
 
   uint32_t alloc() { return next.fetch_add(1, std::memory_order_relaxed); }
 
@@ -57,7 +59,7 @@ struct Builder {
   // returns the split position, reorders idx[lo,hi)
   uint32_t split(uint32_t lo, uint32_t hi, int depth, const float cmn[3], const float cmx[3]) {
     const uint32_t n = hi - lo;
-    const int need = ceil_log2((n + kLeafSize - 1) / kLeafSize);
+    const int need = ceil_log2((n + leaf_max - 1) / leaf_max);
     const bool force_median = depth + need >= kMaxDepth;
     if (!force_median) {
       float ext[3], inv_ok[3];
@@ -135,7 +137,7 @@ struct Builder {
         }
       }
       nd.box = box;
-      if (hi - lo <= kLeafSize) return;
+      if (hi - lo <= leaf_max) return;
       const uint32_t mid = split(lo, hi, depth, cmn, cmx);
       const uint32_t l = alloc(), r = alloc();
       nodes[me].left = (int32_t)l; nodes[me].right = (int32_t)r;
@@ -156,7 +158,11 @@ struct Builder {
 struct Collapser {
   const std::vector<BNode>& bn;
   std::vector<QNode>& qn;
-  static uint32_t leaf_ref(const BNode& b) { return kLeafBit | ((b.hi - b.lo - 1u) << 28) | b.lo; }
+  bool instances; uint32_t tri_base; const std::vector<uint32_t>& idx;
+  uint32_t leaf_ref(const BNode& b) const {
+    if (instances) return CRH_REF_INSTANCE_TAG | idx[b.lo];
+    return kLeafBit | ((b.hi - b.lo - 1u) << 28) | (b.lo + tri_base);
+  }
 
   uint32_t run(uint32_t bi) {
     const uint32_t me = (uint32_t)qn.size();
@@ -188,16 +194,17 @@ struct Collapser {
 
 }  // namespace
 
-void build_qbvh(const float* pos, const int32_t* tri, uint32_t n, QBvh& out, int threads) {
+uint32_t build_tree(const float* boxes, uint32_t n, uint32_t leaf_max, bool instance_leaves, uint32_t tri_base,
+                    std::vector<QNode>& nodes, std::vector<uint32_t>& order, float bmin[3], float bmax[3], int threads) {
   Builder B;
+  B.leaf_max = leaf_max;
   const uint32_t cap = n ? n : 1;
   for (int a = 0; a < 3; ++a) { B.pmn[a].resize(cap); B.pmx[a].resize(cap); B.cen[a].resize(cap); }
   B.idx.resize(cap); B.tmp.resize(cap);
   Box scene; scene.clear();
   for (uint32_t t = 0; t < n; ++t) {
     for (int a = 0; a < 3; ++a) {
-      const float v0 = pos[3 * tri[4 * t + 0] + a], v1 = pos[3 * tri[4 * t + 1] + a], v2 = pos[3 * tri[4 * t + 2] + a];
-      const float lo = std::min(v0, std::min(v1, v2)), hi = std::max(v0, std::max(v1, v2));
+      const float lo = boxes[6 * (size_t)t + a], hi = boxes[6 * (size_t)t + 3 + a];
       B.pmn[a][t] = lo; B.pmx[a][t] = hi; B.cen[a][t] = (lo + hi) * 0.5f;
       scene.mn[a] = std::min(scene.mn[a], lo); scene.mx[a] = std::max(scene.mx[a], hi);
     }
@@ -209,13 +216,23 @@ void build_qbvh(const float* pos, const int32_t* tri, uint32_t n, QBvh& out, int
   B.spare_threads.store(threads - 1);
   const uint32_t root = B.alloc();
   B.build(root, 0, n, 0);
+  Collapser C{B.nodes, nodes, instance_leaves, tri_base, B.idx};
+  const uint32_t qroot = C.run(root);
+  order.assign(B.idx.begin(), B.idx.begin() + n);
+  for (int a = 0; a < 3; ++a) { bmin[a] = n ? scene.mn[a] : 0.f; bmax[a] = n ? scene.mx[a] : 0.f; }
+  return qroot;
+}
 
+void build_qbvh(const float* pos, const int32_t* tri, uint32_t n, QBvh& out, int threads) {
+  std::vector<float> boxes(6 * (size_t)(n ? n : 1));
+  for (uint32_t t = 0; t < n; ++t)
+    for (int a = 0; a < 3; ++a) {
+      const float v0 = pos[3 * tri[4 * t + 0] + a], v1 = pos[3 * tri[4 * t + 1] + a], v2 = pos[3 * tri[4 * t + 2] + a];
+      boxes[6 * (size_t)t + a] = std::min(v0, std::min(v1, v2)); boxes[6 * (size_t)t + 3 + a] = std::max(v0, std::max(v1, v2));
+    }
   out.nodes.clear();
   out.nodes.reserve(n / 2 + 16);
-  Collapser C{B.nodes, out.nodes};
-  C.run(root);
-  out.prim_order.assign(B.idx.begin(), B.idx.begin() + n);
-  for (int a = 0; a < 3; ++a) { out.bbmin[a] = n ? scene.mn[a] : 0.f; out.bbmax[a] = n ? scene.mx[a] : 0.f; }
+  build_tree(boxes.data(), n, kLeafSize, false, 0, out.nodes, out.prim_order, out.bbmin, out.bbmax, threads);
 }
 
 }  // namespace crh

@@ -26,4 +26,11 @@ struct QBvh {
 // pos: 3*nV floats (world space); tri: 4*nT ints {i0,i1,i2,material}.  threads <= 0: hardware concurrency.
 void build_qbvh(const float* pos, const int32_t* tri, uint32_t n_tris, QBvh& out, int threads = 0);
 
+// One tree over n axis-aligned boxes (6 floats each: min xyz, max xyz), appended to `nodes` (references are indices into
+// `nodes`).  leaf_max = 4 and triangle leaves (first triangle = tri_base + position in `order`) for an object's tree;
+// leaf_max = 1 and instance leaves (CRH_REF_INSTANCE_TAG | box index) for the top-level tree of the two-level BVH.
+// Returns the root's index; order = leaf order of the boxes; bmin/bmax = bounds.
+uint32_t build_tree(const float* boxes, uint32_t n, uint32_t leaf_max, bool instance_leaves, uint32_t tri_base,
+                    std::vector<QNode>& nodes, std::vector<uint32_t>& order, float bmin[3], float bmax[3], int threads = 0);
+
 }  // namespace crh

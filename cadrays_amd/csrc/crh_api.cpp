@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/cadrays_hip.h"
+#include "../../include/crh_xform.h"
 #include "bvh_builder.h"
 #include "kernels.h"
 
@@ -36,6 +37,12 @@ struct crh_ctx {
   std::vector<HostTex> textures; bool textures_dirty = false;
   crh_camera cam{};
   crh_params par{};
+  // ---- two-level mode (per-object transforms)
+  bool two_level = false; uint32_t nO = 0;
+  std::vector<float> xf; std::vector<int32_t> tri_obj;
+  struct Inst { float fwd[12], inv[12], bmin[3], bmax[3]; uint32_t root, obj; };
+  std::vector<Inst> inst; uint32_t n_blas_nodes = 0, root = 0;
+  float4* d_inst = nullptr;
   // ---- built scene
   QBvh bvh;
   std::vector<float> h_tris;      // 12 floats per triangle, leaf order
@@ -131,6 +138,7 @@ void fill_scene(const crh_ctx* c, DScene& S)
 {
   std::memset(&S, 0, sizeof S);
   S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = c->d_env;
+  S.inst = c->d_inst; S.root = c->root; S.two_level = c->two_level ? 1 : 0;
   S.uvs = c->d_uvs; S.texels = c->d_texels; S.tex_desc = c->d_tex_desc; S.n_tex = c->d_tex_desc ? (uint32_t)c->textures.size() : 0u;
   S.n_mats = (uint32_t)c->mats.size(); S.n_lights = (uint32_t)c->lights.size(); S.env_w = c->envW; S.env_h = c->envH;
   for (int k = 0; k < 3; ++k) S.bg[k] = c->par.background[k];
@@ -164,6 +172,26 @@ int upload_lights(crh_ctx* c)
     o[4] = s.emission[0]; o[5] = s.emission[1]; o[6] = s.emission[2];
   }
   return dev_upload(c, c->d_lights, l.data(), l.size() * sizeof(float));
+}
+
+// (Re)build the top-level tree over the instances' world boxes behind the object trees [0, n_blas_nodes) and refresh the
+// instance table on the device.  Object trees and triangle records are not touched.
+int build_tlas(crh_ctx* c)
+{
+  c->bvh.nodes.resize(c->n_blas_nodes);
+  const uint32_t n = (uint32_t)c->inst.size();
+  std::vector<float> boxes(6 * (size_t)std::max(n, 1u), 0.f), table(32 * (size_t)std::max(n, 1u), 0.f);
+  for (uint32_t i = 0; i < n; ++i) {
+    crh_ctx::Inst& in = c->inst[i];
+    std::memcpy(in.fwd, &c->xf[12 * (size_t)in.obj], sizeof in.fwd);
+    if (!crh_xform_inverse(in.fwd, in.inv)) std::memset(in.inv, 0, sizeof in.inv);
+    crh_xform_box(in.fwd, in.bmin, in.bmax, &boxes[6 * (size_t)i], &boxes[6 * (size_t)i + 3]);
+    std::memcpy(&table[32 * (size_t)i], in.inv, 48); std::memcpy(&table[32 * (size_t)i + 12], in.fwd, 48);
+    std::memcpy(&table[32 * (size_t)i + 24], &in.root, 4); std::memcpy(&table[32 * (size_t)i + 25], &in.obj, 4);
+  }
+  std::vector<uint32_t> order;
+  c->root = build_tree(boxes.data(), n, 1, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, 1);
+  return dev_upload(c, c->d_inst, table.data(), table.size() * sizeof(float));
 }
 
 int upload_textures(crh_ctx* c)
@@ -382,7 +410,7 @@ void crh_destroy(crh_ctx* c)
   void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o, c->paths.ray_d,
                   c->paths.hit, c->paths.thr, c->paths.rad, c->paths.st, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
                   c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
-                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc};
+                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst};
   for (void* p : ptrs) if (p) hipFree(p);
   hipStreamDestroy(c->stream);
   delete c;
@@ -402,24 +430,38 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
   c->pos.assign(pos, pos + 3 * (size_t)nV); c->nrm.assign(nrm, nrm + 3 * (size_t)nV);
   if (uv) c->uv.assign(uv, uv + 2 * (size_t)nV); else c->uv.clear();
   c->tri.assign(tri, tri + 4 * (size_t)nT);
-  if (tri_obj && xf) {
-    // flatten per-object 3x4 transforms into world space (two-level BVH: SURVEY.md section 8(f) rank 4)
-    std::vector<uint8_t> done(nV ? nV : 1, 0);
-    for (uint32_t t = 0; t < nT; ++t) {
-      const int32_t ob = tri_obj[t];
-      if (ob < 0 || (uint32_t)ob >= nO) return fail(c, CRH_E_INVALID, "triangle object id out of range");
-      const float* m = &xf[12 * ob];
-      const crh_v3 r0 = crh_mk3(m[0], m[1], m[2]), r1 = crh_mk3(m[4], m[5], m[6]), r2 = crh_mk3(m[8], m[9], m[10]);
-      for (int k = 0; k < 3; ++k) {
-        const int32_t vi = tri[4 * t + k]; if (done[vi]) continue; done[vi] = 1;
-        const crh_v3 p = crh_mk3(pos[3 * vi], pos[3 * vi + 1], pos[3 * vi + 2]), n = crh_mk3(nrm[3 * vi], nrm[3 * vi + 1], nrm[3 * vi + 2]);
-        c->pos[3 * vi + 0] = crh_dot3(r0, p) + m[3]; c->pos[3 * vi + 1] = crh_dot3(r1, p) + m[7]; c->pos[3 * vi + 2] = crh_dot3(r2, p) + m[11];
-        const crh_v3 nn = crh_norm3(crh_mk3(crh_dot3(r0, n), crh_dot3(r1, n), crh_dot3(r2, n)));
-        c->nrm[3 * vi + 0] = nn.x; c->nrm[3 * vi + 1] = nn.y; c->nrm[3 * vi + 2] = nn.z;
-      }
-    }
+  c->two_level = false; c->nO = 0; c->xf.clear(); c->tri_obj.clear();
+  if (tri_obj && xf && nO) {
+    // two-level mode: vertices stay in object space; every object gets its own tree (crh_build), the top-level tree
+    // over the instances carries the transforms (crh_set_transforms rebuilds only that)
+    for (uint32_t t = 0; t < nT; ++t)
+      if (tri_obj[t] < 0 || (uint32_t)tri_obj[t] >= nO) return fail(c, CRH_E_INVALID, "triangle object id out of range");
+    c->two_level = true; c->nO = nO;
+    c->xf.assign(xf, xf + 12 * (size_t)nO); c->tri_obj.assign(tri_obj, tri_obj + nT);
   }
   c->built = false;
+  return CRH_OK;
+}
+
+int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
+{
+  if (!c || !xf) return fail(c, CRH_E_INVALID, "null transforms");
+  if (!c->two_level || nO != c->nO) return fail(c, CRH_E_INVALID, "crh_set_transforms needs a two-level scene with the same object count");
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  c->xf.assign(xf, xf + 12 * (size_t)nO);
+  if (c->built) {
+    int rc = build_tlas(c); if (rc) return rc;
+    if ((rc = dev_upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode)))) return rc;
+  }
+  return do_reset(c);
+}
+
+int crh_get_tlas(crh_ctx* c, uint32_t* root, uint32_t* n_inst, uint32_t* n_blas)
+{
+  if (!c) return CRH_E_INVALID;
+  if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
+  if (root) *root = c->root; if (n_inst) *n_inst = (uint32_t)c->inst.size(); if (n_blas) *n_blas = c->n_blas_nodes;
   return CRH_OK;
 }
 
@@ -493,7 +535,37 @@ int crh_build(crh_ctx* c)
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
   int threads = 0; if (const char* e = getenv("CRH_BUILD_THREADS")) threads = atoi(e);
-  build_qbvh(c->pos.data(), c->tri.data(), nT, c->bvh, threads);
+  std::vector<int32_t> tri_inst(nT ? nT : 1, -1);   // triangle -> instance (two-level only)
+  c->inst.clear(); c->root = 0;
+  if (!c->two_level) {
+    build_qbvh(c->pos.data(), c->tri.data(), nT, c->bvh, threads);
+    c->n_blas_nodes = (uint32_t)c->bvh.nodes.size();
+  } else {
+    // one object-space tree per non-empty object, triangles in input order inside an object
+    std::vector<std::vector<uint32_t>> members(c->nO);
+    for (uint32_t t = 0; t < nT; ++t) members[c->tri_obj[t]].push_back(t);
+    c->bvh.nodes.clear(); c->bvh.prim_order.clear(); c->bvh.prim_order.reserve(nT);
+    std::vector<float> boxes; std::vector<uint32_t> order;
+    uint32_t tri_base = 0;
+    for (uint32_t ob = 0; ob < c->nO; ++ob) {
+      const std::vector<uint32_t>& mem = members[ob];
+      if (mem.empty()) continue;
+      boxes.assign(6 * mem.size(), 0.f);
+      for (size_t i = 0; i < mem.size(); ++i)
+        for (int a = 0; a < 3; ++a) {
+          const uint32_t t = mem[i];
+          const float v0 = c->pos[3 * c->tri[4 * t + 0] + a], v1 = c->pos[3 * c->tri[4 * t + 1] + a], v2 = c->pos[3 * c->tri[4 * t + 2] + a];
+          boxes[6 * i + a] = std::min(v0, std::min(v1, v2)); boxes[6 * i + 3 + a] = std::max(v0, std::max(v1, v2));
+        }
+      crh_ctx::Inst in{}; in.obj = ob;
+      in.root = build_tree(boxes.data(), (uint32_t)mem.size(), kLeafSize, false, tri_base, c->bvh.nodes, order, in.bmin, in.bmax, threads);
+      for (size_t i = 0; i < mem.size(); ++i) { c->bvh.prim_order.push_back(mem[order[i]]); tri_inst[mem[order[i]]] = (int32_t)c->inst.size(); }
+      c->inst.push_back(in);
+      tri_base += (uint32_t)mem.size();
+    }
+    c->n_blas_nodes = (uint32_t)c->bvh.nodes.size();
+    int rc_t = build_tlas(c); if (rc_t) return rc_t;
+  }
   // leaf-ordered triangle and shading records
   c->h_tris.assign(12 * (size_t)std::max(nT, 1u), 0.f);
   std::vector<float> sh(12 * (size_t)std::max(nT, 1u), 0.f);
@@ -506,6 +578,7 @@ int crh_build(crh_ctx* c)
     std::memcpy(&c->h_tris[12 * (size_t)i + 3], &t, 4);
     const int32_t mat = c->tri[4 * t + 3];
     std::memcpy(&sh[12 * (size_t)i + 3], &mat, 4);
+    std::memcpy(&sh[12 * (size_t)i + 7], &tri_inst[t], 4);       // n1.w = instance index (two-level shading fetches its transform)
   }
   int rc;
   if ((rc = dev_upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode)))) return rc;

@@ -17,7 +17,7 @@ constexpr uint32_t kQLeafBit      = 0x80000000u;
 
 constexpr int kBlock      = 256;   // threads per workgroup (4 waves)
 constexpr int kLdsStack   = 16;    // traversal stack entries per lane kept in LDS
-constexpr int kOvfStack   = 48;    // spill entries per lane (scratch); 16 + 48 = 64 >= 3 * quad depth bound
+constexpr int kOvfStack   = 64;    // spill entries per lane (scratch); 16 + 64 = 80 >= 3 * quad depth bound + top-level tree + sentinel
 
 // Scene as the kernels see it.  All arrays are float4-granular so every fetch is one dwordx4.
 struct DScene {
@@ -31,6 +31,9 @@ struct DScene {
   const float4* texels;   // all diffuse textures back to back
   const uint4*  tex_desc; // per slot: {first texel, width, height, 0}; width 0 = empty slot
   uint32_t n_tex;
+  const float4* inst;     // two-level: 8 x float4 per instance: inverse rows (3), forward rows (3), {root, object, -, -}, pad
+  uint32_t root;          // node index traversal starts at (0 for a single-level scene, the top-level root otherwise)
+  int two_level;
   uint32_t n_mats, n_lights, env_w, env_h;
   float bg[3]; int env_as_bg;
   // camera frame

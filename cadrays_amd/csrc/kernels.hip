@@ -13,6 +13,7 @@
 #include "kernels.h"
 
 #include "../../include/crh_bvh_format.h"
+#include "../../include/crh_xform.h"
 
 namespace crh {
 namespace {
@@ -97,8 +98,11 @@ __device__ __forceinline__ uint32_t pick(uint4 r, uint32_t s)
 // load(idx, o, d, tmax, tag) fetches queue entry idx; store(tag, hit, found) commits a finished ray.
 // lds: this lane's column of the workgroup's stack (stride kBlock dwords), 16 entries; deeper entries
 // spill to scratch (never touched on ordinary scenes).
-template <bool ANY, bool COUNT, class Load, class Store>
+// TWO: two-level scene -- traversal starts at the top-level root; an instance leaf re-expresses the ray in the object's
+// space (direction not renormalised, so t keeps its meaning), a sentinel on the stack restores the world ray.
+template <bool ANY, bool COUNT, bool TWO, class Load, class Store>
 __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                             const float4* __restrict__ inst, uint32_t root,
                                              uint32_t* __restrict__ cursor, uint32_t n, uint32_t* lds,
                                              Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris)
 {
@@ -110,6 +114,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   uint32_t cur = kDone, tag = 0;
   int sp = 0;
   v3 o = crh_mk3(0.f, 0.f, 0.f), d = o;
+  v3 wo = o, wd = o;     // world-space ray while inside an object (TWO only)
   float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, best = 0.f;
   float4 hit = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   bool found = false;
@@ -139,7 +144,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           load(pool_next + rank, o, d, tmax, tag);
           ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
           nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
-          best = tmax; found = false; sp = 0; cur = 0u; have = true;
+          if (TWO) { wo = o; wd = d; }
+          best = tmax; found = false; sp = 0; cur = root; have = true;
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
         }
         pool_next += take;
@@ -148,6 +154,24 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     }
     if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
 
+    auto set_ray = [&](v3 no, v3 nd) {
+      o = no; d = nd;
+      ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
+      nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
+    };
+    auto read_top = [&]() {
+      --sp;
+      if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
+      else { cur = ovf[sp - kLdsStack]; asm volatile("" : "+v"(cur)); }
+    };
+    auto pop = [&]() {
+      if ((ANY && found) || sp == 0) { cur = kDone; return; }
+      read_top();
+      if (TWO && cur == CRH_REF_SENTINEL) {          // leaving an object: back to the world-space ray
+        set_ray(wo, wd);
+        if (sp == 0) cur = kDone; else read_top();
+      }
+    };
     // one inner-node step of this lane: fetch the 64-B node (4 x dwordx4), slab-test and order its children, push / descend / pop
     auto inner_step = [&]() {
       const float4* np = nodes + 4u * cur;
@@ -201,13 +225,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         if (nh >= 2) CRH_PUSH(r1)
 #undef CRH_PUSH
       }
-      if (nh >= 1) cur = r0;
-      else if (sp == 0) cur = kDone;
-      else {
-        --sp;
-        if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
-        else { cur = ovf[sp - kLdsStack]; asm volatile("" : "+v"(cur)); }
-      }
+      if (nh >= 1) cur = r0; else pop();
     };
     // one ray/triangle test of this lane against leaf-order triangle `ti`
     auto tri_step = [&](uint32_t ti) {
@@ -228,15 +246,6 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         hit = make_float4(tt, uu, vv, __int_as_float((int)ti));
       }
     };
-    auto pop = [&]() {
-      if ((ANY && found) || sp == 0) cur = kDone;
-      else {
-        --sp;
-        if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
-        else { cur = ovf[sp - kLdsStack]; asm volatile("" : "+v"(cur)); }
-      }
-    };
-
     // ------------------------------------------------------------------ (A) inner nodes until a leaf is in hand
 #if CRH_INNER_STEPS > 0
 #pragma unroll 1
@@ -245,7 +254,17 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     while (have && !(cur & kQLeafBit)) inner_step();
 #endif
     // ------------------------------------------------------------------ (B) the leaf in hand
-    if (have && (cur & kQLeafBit) && cur != kDone) {
+    if (TWO && have && (cur & 0xF0000000u) == CRH_REF_INSTANCE_TAG && cur < CRH_REF_SENTINEL) {
+      // top-level leaf: enter the object (ray := M^-1 ray), mark the stack, continue at the object's root
+      const float4* ip = inst + 8u * (cur & 0x0FFFFFFFu);
+      const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2], meta = ip[6];
+      const float m[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
+      set_ray(crh_xform_point(m, wo), crh_xform_vector(m, wd));
+      const uint32_t mark = CRH_REF_SENTINEL;
+      if (sp < kLdsStack) lds[sp * kBlock] = mark; else ovf[sp - kLdsStack] = mark;
+      ++sp;
+      cur = __float_as_uint(meta.x);
+    } else if (have && (cur & kQLeafBit) && cur != kDone) {
       const uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
       for (uint32_t k = 0; k < cnt; ++k) { tri_step(off + k); if (ANY && found) break; }
       pop();
@@ -256,7 +275,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool TWO>
 __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint32_t* __restrict__ q,
                                                   const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors,
                                                   uint32_t* zero_a, uint32_t* zero_b, DCounters* C)
@@ -269,7 +288,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint3
     atomicAdd(&C->rays_nearest, (unsigned long long)n);
   }
   uint32_t nn = 0, nt = 0;
-  trace_engine<false, COUNT>(S.nodes, S.tris, cursors + 0, n, &stk[threadIdx.x],
+  trace_engine<false, COUNT, TWO>(S.nodes, S.tris, S.inst, S.root, cursors + 0, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
@@ -282,7 +301,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint3
   }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool TWO>
 __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t* __restrict__ q,
                                               const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors, DCounters* C)
 {
@@ -290,7 +309,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
   const uint32_t n = *count;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
   uint32_t nn = 0, nt = 0;
-  trace_engine<true, COUNT>(S.nodes, S.tris, cursors + 2, n, &stk[threadIdx.x],
+  trace_engine<true, COUNT, TWO>(S.nodes, S.tris, S.inst, S.root, cursors + 2, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
@@ -311,13 +330,13 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
 }
 
 // API-level tracing of a caller ray buffer {o.xyz, tmax, d.xyz, -}; `cursor` must be zero at launch
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool TWO>
 __global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict__ rays, uint32_t n, uint32_t* __restrict__ cursor,
                                                float4* __restrict__ out_hit, uint32_t* __restrict__ out_vis, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   uint32_t nn = 0, nt = 0;
-  trace_engine<ANY, COUNT>(S.nodes, S.tris, cursor, n, &stk[threadIdx.x],
+  trace_engine<ANY, COUNT, TWO>(S.nodes, S.tris, S.inst, S.root, cursor, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = idx;
       const float4 o4 = rays[2u * idx], d4 = rays[2u * idx + 1u];
@@ -784,12 +803,21 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
         const float4* tp = S.tris + 3u * (uint32_t)hk;
         const float4* sp = S.shade + 3u * (uint32_t)hk;
         const float4 a = tp[0], b4 = tp[1], c4 = tp[2], s0 = sp[0], s1 = sp[1], s2 = sp[2];
-        const v3 p0 = xyz(a), p1 = xyz(b4), p2 = xyz(c4);
+        v3 p0 = xyz(a), p1 = xyz(b4), p2 = xyz(c4);
+        float M[12];
+        if (S.two_level) {                                   // object -> world through the instance's forward transform
+          const float4* ip = S.inst + 8u * (uint32_t)__float_as_int(s1.w);
+          const float4 f0 = ip[3], f1 = ip[4], f2 = ip[5];
+          M[0] = f0.x; M[1] = f0.y; M[2] = f0.z; M[3] = f0.w; M[4] = f1.x; M[5] = f1.y; M[6] = f1.z; M[7] = f1.w;
+          M[8] = f2.x; M[9] = f2.y; M[10] = f2.z; M[11] = f2.w;
+          p0 = crh_xform_point(M, p0); p1 = crh_xform_point(M, p1); p2 = crh_xform_point(M, p2);
+        }
         const v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
         const float w0 = (1.0f - h.y) - h.z;
         v3 ns = crh_norm3(crh_mk3(CRH_FMA(s2.x, h.z, CRH_FMA(s1.x, h.y, s0.x * w0)),
                                   CRH_FMA(s2.y, h.z, CRH_FMA(s1.y, h.y, s0.y * w0)),
                                   CRH_FMA(s2.z, h.z, CRH_FMA(s1.z, h.y, s0.z * w0))));
+        if (S.two_level) ns = crh_norm3(crh_xform_vector(M, ns));
         if (!(crh_dot3(ns, ns) > 0.f)) ns = ng;
         const v3 p = crh_madd3(o, d, h.x);
         int mat = __float_as_int(s0.w); if (mat < 0 || (uint32_t)mat >= S.n_mats) mat = 0;
@@ -1021,10 +1049,11 @@ void launch_raygen(const Launch& L, const DScene& S, const DPaths& P, const DQue
 }
 void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, DCounters* C)
 {
-  if (L.counters)
-    hipLaunchKernelGGL(k_trace_nearest<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, C);
-  else
-    hipLaunchKernelGGL(k_trace_nearest<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, C);
+#define CRH_LAUNCH_TN(CNT, TWO) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], \
+                                                   Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, C)
+  if (S.two_level) { if (L.counters) CRH_LAUNCH_TN(true, true); else CRH_LAUNCH_TN(false, true); }
+  else             { if (L.counters) CRH_LAUNCH_TN(true, false); else CRH_LAUNCH_TN(false, false); }
+#undef CRH_LAUNCH_TN
 }
 void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, uint32_t bounce, DCounters* C)
 {
@@ -1033,8 +1062,10 @@ void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueu
 }
 void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, DCounters* C)
 {
-  if (L.counters) hipLaunchKernelGGL(k_trace_any<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C);
-  else            hipLaunchKernelGGL(k_trace_any<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C);
+#define CRH_LAUNCH_TA(CNT, TWO) hipLaunchKernelGGL((k_trace_any<CNT, TWO>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C)
+  if (S.two_level) { if (L.counters) CRH_LAUNCH_TA(true, true); else CRH_LAUNCH_TA(false, true); }
+  else             { if (L.counters) CRH_LAUNCH_TA(true, false); else CRH_LAUNCH_TA(false, false); }
+#undef CRH_LAUNCH_TA
 }
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,
                        uint32_t n_tiles, uint32_t n_samples, DCounters* C)
@@ -1058,13 +1089,12 @@ void launch_trace_rays(const Launch& L, const DScene& S, const float4* rays, uin
                        uint32_t* out_vis, uint32_t* cursor, DCounters* C)
 {
   hipMemsetAsync(cursor, 0, sizeof(uint32_t), L.stream);
-  if (any_hit) {
-    if (L.counters) hipLaunchKernelGGL((k_trace_rays<true, true>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C);
-    else            hipLaunchKernelGGL((k_trace_rays<true, false>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C);
-  } else {
-    if (L.counters) hipLaunchKernelGGL((k_trace_rays<false, true>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C);
-    else            hipLaunchKernelGGL((k_trace_rays<false, false>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C);
-  }
+#define CRH_LAUNCH_TR(ANY, CNT, TWO) hipLaunchKernelGGL((k_trace_rays<ANY, CNT, TWO>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C)
+#define CRH_LAUNCH_TR2(ANY, CNT) { if (S.two_level) CRH_LAUNCH_TR(ANY, CNT, true); else CRH_LAUNCH_TR(ANY, CNT, false); }
+  if (any_hit) { if (L.counters) CRH_LAUNCH_TR2(true, true) else CRH_LAUNCH_TR2(true, false) }
+  else         { if (L.counters) CRH_LAUNCH_TR2(false, true) else CRH_LAUNCH_TR2(false, false) }
+#undef CRH_LAUNCH_TR2
+#undef CRH_LAUNCH_TR
 }
 void launch_debug_math(const Launch& L, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n)
 {

@@ -73,6 +73,8 @@ class Scene:
     params: Params = field(default_factory=Params)
     uv: Optional[np.ndarray] = None
     textures: List[np.ndarray] = field(default_factory=list)   # slot -> (H, W, 3) float32 linear RGB, row 0 = v 1
+    tri_object: Optional[np.ndarray] = None   # (nT,) int32 object id per triangle  } two-level BVH: vertices in object space,
+    obj_xform: Optional[np.ndarray] = None    # (nO, 12) row-major 3x4 transforms   } one tree per object + a top-level tree
     name: str = "scene"
 
 

@@ -124,12 +124,19 @@ CRH_API const char* crh_last_error(crh_ctx* ctx);
 
 /* geometry == what AIS Display/SetLocation feeds OpenGl_SceneGeometry: indexed
  * triangle arrays with normals (+uv) and a material id per triangle
- * (AisMesh.cxx:357-423), per-object 3x4 row-major transforms (DataNode.cxx:239-242). */
+ * (AisMesh.cxx:357-423), per-object 3x4 row-major transforms (DataNode.cxx:239-242).
+ * With tri_object + obj_xform the scene is a TWO-LEVEL BVH like OCCT's: vertices are in object space, every
+ * object gets its own tree, a top-level tree over the instances' world boxes carries the transforms (each vertex
+ * must belong to one object).  Without them the arrays are world space and one tree is built. */
 CRH_API int crh_set_geometry(crh_ctx* ctx,
                      const float* pos, const float* nrm, const float* uv, uint32_t n_vertices,
                      const int32_t* tri /* 4*nT: i0,i1,i2,material */, uint32_t n_triangles,
                      const int32_t* tri_object /* nT or NULL */,
                      const float* obj_xform /* 12*nO or NULL */, uint32_t n_objects);
+/* == AIS_InteractiveObject::SetLocalTransformation / the manipulator moving an object (ImRaytraceControls.cxx:58-89,
+ * DataNode.cxx:239-242): new 3x4 transforms for the n_objects of the two-level scene.  Only the top-level tree is
+ * rebuilt (object trees and triangles stay in HBM untouched); restarts accumulation. */
+CRH_API int crh_set_transforms(crh_ctx* ctx, const float* obj_xform /* 12*nO */, uint32_t n_objects);
 /* == Graphic3d_MaterialAspect::SetBSDF + SynchronizeAspects (MaterialEditor.cxx:331-337, Utils.cxx:57-93) */
 CRH_API int crh_set_materials(crh_ctx* ctx, const crh_bsdf* m, uint32_t n);
 /* == V3d_Viewer::SetLightOn/UpdateLights (LightSourcesEditor.cxx:47-87, 401-413) */
@@ -196,6 +203,8 @@ CRH_API int crh_trace_any(crh_ctx* ctx, const float* rays, uint32_t n, uint32_t*
 /* Copy out the built QBVH: nodes (16 dwords = 64 B each, layout in crh_bvh_format.h) and the leaf-ordered triangle
  * records (12 floats = 48 B each).  Pass NULL buffers to query the counts. */
 CRH_API int crh_get_bvh(crh_ctx* ctx, float* nodes, uint32_t* n_nodes, float* tris, uint32_t* n_tris);
+/* Two-level scenes: index of the top-level root in the node array, instance count, number of object-tree nodes. */
+CRH_API int crh_get_tlas(crh_ctx* ctx, uint32_t* root, uint32_t* n_instances, uint32_t* n_blas_nodes);
 /* Host-only: run the BVH builder (no device needed) and copy out nodes / leaf-ordered triangles.
  * Call with NULL outputs to get the counts.  == BVH_BinnedBuilder + CollapseToQuadTree. */
 CRH_API int crh_build_bvh_host(const float* pos, uint32_t n_vertices, const int32_t* tri, uint32_t n_triangles, int threads,

@@ -30,6 +30,7 @@
 
 #include "../include/crh_math.h"
 #include "../include/crh_bvh_format.h"
+#include "../include/crh_xform.h"
 #include "../include/cadrays_hip.h"
 
 #define ORC_API __attribute__((visibility("default")))
@@ -40,7 +41,7 @@
 #define BVH_MAXDEPTH   40          /* binary depth bound (root = 0); median splits keep it  */
 #define QBVH_EMPTY     0xFFFFFFFFu
 #define QBVH_LEAFBIT   0x80000000u
-#define STACK_MAX      64          /* >= 3 * ceil((BVH_MAXDEPTH+1)/2) */
+#define STACK_MAX      96          /* >= 3 * ceil((BVH_MAXDEPTH+1)/2) for one tree, + top-level tree + sentinel */
 #define DIR_EPS        1.0e-15f
 #define BSDF_EPS       1.0e-5f     /* roughness / weight threshold ("FLT_EPSILON" in GLSL)  */
 #define MIN_THROUGHPUT 1.0e-3f
@@ -55,6 +56,7 @@ typedef struct { uint32_t w[CRH_NODE_DWORDS]; } qnode;   /* 64 B, layout in incl
 typedef struct { float f[12]; } qtri;      /* 48 B: v0.xyz,prim | v1.xyz,0 | v2.xyz,0 */
 
 typedef struct { uint64_t nodes, tris, nodes_any, tris_any; } trav_counters;
+typedef struct orc_instance { float fwd[12], inv[12]; float bmin[3], bmax[3]; uint32_t root, obj; } orc_instance;
 
 typedef struct orc_ctx {
   /* inputs */
@@ -66,6 +68,9 @@ typedef struct orc_ctx {
   crh_camera cam; crh_params par;
   /* derived */
   qnode* nodes; uint32_t nNodes; qtri* qtris; uint32_t nQT;
+  /* two-level mode (per-object transforms): object-space BLAS per object + TLAS over instance boxes */
+  int two_level; uint32_t nO; float* xf; int32_t* tri_obj;
+  struct orc_instance* inst; uint32_t nInst; uint32_t nBlasNodes; uint32_t root;
   float bbmin[3], bbmax[3]; float eps;
   int built;
   /* camera frame */
@@ -98,6 +103,7 @@ typedef struct {
   const aabb* pb; const float* cen; /* 3*n */
   uint32_t* idx; uint32_t* tmp;
   bnode* bn; uint32_t nbn, cap;
+  uint32_t leaf_max;            /* 4 for triangle trees, 1 for the top-level tree over instances */
 } builder;
 
 static void aabb_empty(aabb* b) { for (int a = 0; a < 3; ++a) { b->mn[a] = 3.0e38f; b->mx[a] = -3.0e38f; } }
@@ -132,7 +138,7 @@ static uint32_t build_rec(builder* B, uint32_t lo, uint32_t hi, int depth)
   for (uint32_t i = lo; i < hi; ++i) aabb_grow(&box, &B->pb[B->idx[i]]);
   uint32_t n = hi - lo;
   B->bn[me].box = box; B->bn[me].lo = lo; B->bn[me].hi = hi; B->bn[me].left = B->bn[me].right = -1;
-  if (n <= BVH_LEAF) return me;
+  if (n <= B->leaf_max) return me;
 
   /* centroid bounds */
   float cmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -142,7 +148,7 @@ static uint32_t build_rec(builder* B, uint32_t lo, uint32_t hi, int depth)
   }
   uint32_t mid = 0; int done = 0;
   /* depth budget: once balanced median splits are needed to finish within BVH_MAXDEPTH, use them */
-  int need = ceil_log2_u32((n + BVH_LEAF - 1) / BVH_LEAF);
+  int need = ceil_log2_u32((n + B->leaf_max - 1) / B->leaf_max);
   int force_median = (depth + need >= BVH_MAXDEPTH);
 
   if (!force_median) {
@@ -205,10 +211,13 @@ static uint32_t build_rec(builder* B, uint32_t lo, uint32_t hi, int depth)
 
 /* collapse binary -> 4-wide (OCCT BVH_Tree::CollapseToQuadTree idea: children := grandchildren),
  * nodes numbered in DFS pre-order, children visited in slot order. */
-typedef struct { const bnode* bn; qnode* qn; uint32_t nq, capq; } collapser;
+typedef struct { const bnode* bn; qnode* qn; uint32_t nq, capq; int instances; uint32_t tri_base; const uint32_t* idx; } collapser;
 
-static uint32_t leaf_ref(const bnode* b)
-{ return QBVH_LEAFBIT | ((b->hi - b->lo - 1u) << 28) | b->lo; }
+static uint32_t leaf_ref(const collapser* C, const bnode* b)
+{
+  if (C->instances) return CRH_REF_INSTANCE_TAG | C->idx[b->lo];          /* top-level leaf = one instance */
+  return QBVH_LEAFBIT | ((b->hi - b->lo - 1u) << 28) | (b->lo + C->tri_base);
+}
 
 static uint32_t collapse_rec(collapser* C, uint32_t bi)
 {
@@ -231,7 +240,7 @@ static uint32_t collapse_rec(collapser* C, uint32_t bi)
   for (int k = 0; k < nk; ++k) {
     const bnode* c = &C->bn[kids[k]];
     for (int a = 0; a < 3; ++a) { cmin[k][a] = c->box.mn[a]; cmax[k][a] = c->box.mx[a]; }
-    if (c->left < 0) refs[k] = (c->hi > c->lo) ? leaf_ref(c) : QBVH_EMPTY;
+    if (c->left < 0) refs[k] = (c->hi > c->lo) ? leaf_ref(C, c) : QBVH_EMPTY;
     else             refs[k] = collapse_rec(C, kids[k]);
   }
   crh_pack_node(cmin, cmax, refs, nk, q.w);
@@ -239,43 +248,104 @@ static uint32_t collapse_rec(collapser* C, uint32_t bi)
   return me;
 }
 
-static int do_build(orc_ctx* c)
+/* One tree over n primitives with boxes pb[0..n) (centre = box centre): binary build + 4-wide collapse appended to C.
+ * Returns the 4-wide root index; order[0..n) = leaf order; *rootbox = bounds. */
+static uint32_t build_tree(collapser* C, const aabb* pb, uint32_t n, uint32_t leaf_max, int instances, uint32_t tri_base,
+                           uint32_t* order, aabb* rootbox)
 {
-  uint32_t n = c->nT;
-  free(c->nodes); free(c->qtris); c->nodes = NULL; c->qtris = NULL;
-  aabb* pb = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
   float* cen = (float*)malloc(sizeof(float) * 3 * (n ? n : 1));
-  aabb sb; aabb_empty(&sb);
-  for (uint32_t t = 0; t < n; ++t) {
-    aabb b; aabb_empty(&b);
-    for (int k = 0; k < 3; ++k) {
-      const float* p = &c->pos[3 * c->tri[4 * t + k]];
-      for (int a = 0; a < 3; ++a) { if (p[a] < b.mn[a]) b.mn[a] = p[a]; if (p[a] > b.mx[a]) b.mx[a] = p[a]; }
-    }
-    pb[t] = b; aabb_grow(&sb, &b);
-    for (int a = 0; a < 3; ++a) cen[3 * t + a] = (b.mn[a] + b.mx[a]) * 0.5f;
-  }
-  builder B; B.pb = pb; B.cen = cen;
-  B.idx = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
-  B.tmp = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  for (uint32_t t = 0; t < n; ++t) for (int a = 0; a < 3; ++a) cen[3 * t + a] = (pb[t].mn[a] + pb[t].mx[a]) * 0.5f;
+  builder B; B.pb = pb; B.cen = cen; B.leaf_max = leaf_max;
+  B.idx = order; B.tmp = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
   for (uint32_t t = 0; t < n; ++t) B.idx[t] = t;
   B.cap = 1024; B.nbn = 0; B.bn = (bnode*)malloc(sizeof(bnode) * B.cap);
   build_rec(&B, 0, n, 0);
-  collapser C; C.bn = B.bn; C.capq = 1024; C.nq = 0; C.qn = (qnode*)malloc(sizeof(qnode) * C.capq);
-  collapse_rec(&C, 0);
-  c->nodes = C.qn; c->nNodes = C.nq;
-  c->qtris = (qtri*)malloc(sizeof(qtri) * (n ? n : 1)); c->nQT = n;
-  for (uint32_t i = 0; i < n; ++i) {
-    uint32_t t = B.idx[i]; qtri* q = &c->qtris[i];
-    for (int k = 0; k < 3; ++k) {
-      const float* p = &c->pos[3 * c->tri[4 * t + k]];
-      q->f[4 * k + 0] = p[0]; q->f[4 * k + 1] = p[1]; q->f[4 * k + 2] = p[2]; q->f[4 * k + 3] = 0.f;
-    }
-    q->f[3] = crh_u2f(t);
+  if (rootbox) *rootbox = B.bn[0].box;
+  C->bn = B.bn; C->instances = instances; C->tri_base = tri_base; C->idx = order;
+  uint32_t root = collapse_rec(C, 0);
+  free(cen); free(B.tmp); free(B.bn);
+  return root;
+}
+
+static void tri_box(const orc_ctx* c, uint32_t t, aabb* b)
+{
+  aabb_empty(b);
+  for (int k = 0; k < 3; ++k) {
+    const float* p = &c->pos[3 * c->tri[4 * t + k]];
+    for (int a = 0; a < 3; ++a) { if (p[a] < b->mn[a]) b->mn[a] = p[a]; if (p[a] > b->mx[a]) b->mx[a] = p[a]; }
   }
-  if (n) { for (int a = 0; a < 3; ++a) { c->bbmin[a] = sb.mn[a]; c->bbmax[a] = sb.mx[a]; } }
-  else   { for (int a = 0; a < 3; ++a) { c->bbmin[a] = 0.f; c->bbmax[a] = 0.f; } }
-  free(pb); free(cen); free(B.idx); free(B.tmp); free(B.bn);
+}
+static void emit_tri(const orc_ctx* c, qtri* q, uint32_t t)
+{
+  for (int k = 0; k < 3; ++k) {
+    const float* p = &c->pos[3 * c->tri[4 * t + k]];
+    q->f[4 * k + 0] = p[0]; q->f[4 * k + 1] = p[1]; q->f[4 * k + 2] = p[2]; q->f[4 * k + 3] = 0.f;
+  }
+  q->f[3] = crh_u2f(t);
+}
+
+/* (re)build the top-level tree over the instances' world boxes; keeps the BLAS nodes [0, nBlasNodes) */
+static void build_tlas(orc_ctx* c)
+{
+  uint32_t n = c->nInst;
+  aabb* pb = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
+  uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  aabb sb; aabb_empty(&sb);
+  for (uint32_t i = 0; i < n; ++i) {
+    orc_instance* in = &c->inst[i];
+    memcpy(in->fwd, &c->xf[12 * in->obj], sizeof in->fwd);
+    if (!crh_xform_inverse(in->fwd, in->inv)) memset(in->inv, 0, sizeof in->inv);
+    crh_xform_box(in->fwd, in->bmin, in->bmax, pb[i].mn, pb[i].mx);
+    aabb_grow(&sb, &pb[i]);
+  }
+  collapser C; C.qn = c->nodes; C.nq = c->nBlasNodes; C.capq = c->nBlasNodes > 1024 ? c->nBlasNodes : 1024;
+  C.qn = (qnode*)realloc(C.qn, sizeof(qnode) * C.capq);
+  c->root = build_tree(&C, pb, n, 1, 1, 0, order, NULL);
+  c->nodes = C.qn; c->nNodes = C.nq;
+  for (int a = 0; a < 3; ++a) { c->bbmin[a] = n ? sb.mn[a] : 0.f; c->bbmax[a] = n ? sb.mx[a] : 0.f; }
+  free(pb); free(order);
+}
+
+static int do_build(orc_ctx* c)
+{
+  uint32_t n = c->nT;
+  free(c->nodes); free(c->qtris); free(c->inst); c->nodes = NULL; c->qtris = NULL; c->inst = NULL; c->nInst = 0; c->root = 0;
+  c->qtris = (qtri*)malloc(sizeof(qtri) * (n ? n : 1)); c->nQT = n;
+  collapser C; C.capq = 1024; C.nq = 0; C.qn = (qnode*)malloc(sizeof(qnode) * C.capq);
+  if (!c->two_level) {
+    aabb* pb = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
+    uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    for (uint32_t t = 0; t < n; ++t) tri_box(c, t, &pb[t]);
+    aabb sb;
+    build_tree(&C, pb, n, BVH_LEAF, 0, 0, order, &sb);
+    for (uint32_t i = 0; i < n; ++i) emit_tri(c, &c->qtris[i], order[i]);
+    for (int a = 0; a < 3; ++a) { c->bbmin[a] = n ? sb.mn[a] : 0.f; c->bbmax[a] = n ? sb.mx[a] : 0.f; }
+    c->nodes = C.qn; c->nNodes = C.nq; c->nBlasNodes = C.nq;
+    free(pb); free(order);
+    return 0;
+  }
+  /* two-level: one object-space tree per non-empty object (triangles in input order), then the top-level tree */
+  c->inst = (orc_instance*)calloc(c->nO ? c->nO : 1, sizeof(orc_instance));
+  uint32_t* members = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  aabb* pb = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
+  uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  uint32_t tri_base = 0;
+  for (uint32_t ob = 0; ob < c->nO; ++ob) {
+    uint32_t m = 0;
+    for (uint32_t t = 0; t < n; ++t) if ((uint32_t)c->tri_obj[t] == ob) members[m++] = t;
+    if (!m) continue;
+    for (uint32_t i = 0; i < m; ++i) tri_box(c, members[i], &pb[i]);
+    aabb ob_box;
+    orc_instance* in = &c->inst[c->nInst++];
+    in->obj = ob;
+    in->root = build_tree(&C, pb, m, BVH_LEAF, 0, tri_base, order, &ob_box);
+    for (int a = 0; a < 3; ++a) { in->bmin[a] = ob_box.mn[a]; in->bmax[a] = ob_box.mx[a]; }
+    for (uint32_t i = 0; i < m; ++i) emit_tri(c, &c->qtris[tri_base + i], members[order[i]]);
+    tri_base += m;
+  }
+  c->nodes = C.qn; c->nBlasNodes = C.nq; c->nNodes = C.nq;
+  free(members); free(pb); free(order);
+  build_tlas(c);
   return 0;
 }
 
@@ -308,8 +378,20 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
   float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
   float best = tmax; int found = 0;
   h->t = tmax; h->u = 0.f; h->v = 0.f; h->prim = -1;
-  uint32_t cur = 0;
+  const v3 wo = o, wd = d;                       /* the world-space ray (restored when an object is left) */
+  uint32_t cur = c->root;
   for (;;) {
+    if ((cur & 0xF0000000u) == CRH_REF_INSTANCE_TAG) {
+      /* top-level leaf: express the ray in the object's space (direction NOT renormalised, so t is unchanged),
+       * mark the stack, continue at the object's root */
+      const orc_instance* in = &c->inst[cur & 0x0FFFFFFFu];
+      o = crh_xform_point(in->inv, wo); d = crh_xform_vector(in->inv, wd);
+      ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
+      nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
+      stack[sp++] = CRH_REF_SENTINEL;
+      cur = in->root;
+      continue;
+    }
     if (cur & QBVH_LEAFBIT) {
       uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
       for (uint32_t k = 0; k < cnt; ++k) {
@@ -353,6 +435,13 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
     }
     if (sp == 0) break;
     cur = stack[--sp];
+    if (cur == CRH_REF_SENTINEL) {                /* back to world space */
+      o = wo; d = wd;
+      ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
+      nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
+      if (sp == 0) break;
+      cur = stack[--sp];
+    }
   }
   return found;
 }
@@ -705,12 +794,15 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
     v3 p0 = crh_mk3(c->pos[3 * ti[0]], c->pos[3 * ti[0] + 1], c->pos[3 * ti[0] + 2]);
     v3 p1 = crh_mk3(c->pos[3 * ti[1]], c->pos[3 * ti[1] + 1], c->pos[3 * ti[1] + 2]);
     v3 p2 = crh_mk3(c->pos[3 * ti[2]], c->pos[3 * ti[2] + 1], c->pos[3 * ti[2] + 2]);
+    const float* M = c->two_level ? &c->xf[12 * c->tri_obj[h.prim]] : NULL;      /* object -> world */
+    if (M) { p0 = crh_xform_point(M, p0); p1 = crh_xform_point(M, p1); p2 = crh_xform_point(M, p2); }
     v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
     float w0 = (1.0f - h.u) - h.v;
     const float* n0 = &c->nrm[3 * ti[0]]; const float* n1 = &c->nrm[3 * ti[1]]; const float* n2 = &c->nrm[3 * ti[2]];
     v3 ns = crh_norm3(crh_mk3(CRH_FMA(n2[0], h.v, CRH_FMA(n1[0], h.u, n0[0] * w0)),
                                CRH_FMA(n2[1], h.v, CRH_FMA(n1[1], h.u, n0[1] * w0)),
                                CRH_FMA(n2[2], h.v, CRH_FMA(n1[2], h.u, n0[2] * w0))));
+    if (M) ns = crh_norm3(crh_xform_vector(M, ns));          /* rigid + uniform scale (gp_Trsf): the 3x3 part carries normals */
     if (!(crh_dot3(ns, ns) > 0.f)) ns = ng;
     v3 p = crh_madd3(o, d, h.t);
     bsdf_t b; load_bsdf(c, ti[3], &b);
@@ -874,7 +966,7 @@ ORC_API void orc_destroy(orc_ctx* c)
 {
   if (!c) return;
   free(c->pos); free(c->nrm); free(c->uv); free(c->tri); free(c->mats); free(c->lights); free(c->env);
-  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c);
+  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->xf); free(c->tri_obj); free(c->inst); free(c);
 }
 ORC_API const char* orc_last_error(orc_ctx* c) { return c ? c->err : "null ctx"; }
 
@@ -885,32 +977,31 @@ ORC_API int orc_set_geometry(orc_ctx* c, const float* pos, const float* nrm, con
 {
   if (!c || (nV && (!pos || !nrm)) || (nT && !tri)) return CRH_E_INVALID;
   for (uint32_t t = 0; t < nT; ++t) for (int k = 0; k < 3; ++k) if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) { snprintf(c->err, sizeof c->err, "triangle %u index out of range", t); return CRH_E_INVALID; }
-  if (tri_obj && xf) {
-    /* the restatement supports per-object transforms only when each vertex belongs to one object:
-     * positions/normals are flattened to world space here (rigid + uniform scale: normals use the 3x3 part) */
-    float* p2 = (float*)dup_mem(pos, sizeof(float) * 3 * nV); float* n2 = (float*)dup_mem(nrm, sizeof(float) * 3 * nV);
-    uint8_t* done = (uint8_t*)calloc(nV ? nV : 1, 1);
-    for (uint32_t t = 0; t < nT; ++t) {
-      int32_t ob = tri_obj[t]; if (ob < 0 || (uint32_t)ob >= nO) { free(p2); free(n2); free(done); return CRH_E_INVALID; }
-      const float* m = &xf[12 * ob];
-      for (int k = 0; k < 3; ++k) {
-        int32_t vi = tri[4 * t + k]; if (done[vi]) continue; done[vi] = 1;
-        v3 p = crh_mk3(pos[3 * vi], pos[3 * vi + 1], pos[3 * vi + 2]), n = crh_mk3(nrm[3 * vi], nrm[3 * vi + 1], nrm[3 * vi + 2]);
-        p2[3 * vi + 0] = crh_dot3(crh_mk3(m[0], m[1], m[2]), p) + m[3];
-        p2[3 * vi + 1] = crh_dot3(crh_mk3(m[4], m[5], m[6]), p) + m[7];
-        p2[3 * vi + 2] = crh_dot3(crh_mk3(m[8], m[9], m[10]), p) + m[11];
-        v3 nn = crh_norm3(crh_mk3(crh_dot3(crh_mk3(m[0], m[1], m[2]), n), crh_dot3(crh_mk3(m[4], m[5], m[6]), n), crh_dot3(crh_mk3(m[8], m[9], m[10]), n)));
-        n2[3 * vi + 0] = nn.x; n2[3 * vi + 1] = nn.y; n2[3 * vi + 2] = nn.z;
-      }
-    }
-    free(done); free(c->pos); free(c->nrm); c->pos = p2; c->nrm = n2;
-  } else {
-    free(c->pos); free(c->nrm);
-    c->pos = (float*)dup_mem(pos, sizeof(float) * 3 * nV); c->nrm = (float*)dup_mem(nrm, sizeof(float) * 3 * nV);
+  free(c->pos); free(c->nrm); free(c->xf); free(c->tri_obj); c->xf = NULL; c->tri_obj = NULL; c->two_level = 0; c->nO = 0;
+  c->pos = (float*)dup_mem(pos, sizeof(float) * 3 * nV); c->nrm = (float*)dup_mem(nrm, sizeof(float) * 3 * nV);
+  if (tri_obj && xf && nO) {
+    /* two-level mode: vertices stay in object space; each object gets its own tree, instances carry the transforms */
+    for (uint32_t t = 0; t < nT; ++t) if (tri_obj[t] < 0 || (uint32_t)tri_obj[t] >= nO) { snprintf(c->err, sizeof c->err, "triangle %u object id out of range", t); return CRH_E_INVALID; }
+    c->xf = (float*)dup_mem(xf, sizeof(float) * 12 * nO); c->tri_obj = (int32_t*)dup_mem(tri_obj, sizeof(int32_t) * nT);
+    c->two_level = 1; c->nO = nO;
   }
   free(c->uv); c->uv = uv ? (float*)dup_mem(uv, sizeof(float) * 2 * nV) : NULL;
   free(c->tri); c->tri = (int32_t*)dup_mem(tri, sizeof(int32_t) * 4 * nT);
   c->nV = nV; c->nT = nT; c->built = 0;
+  return 0;
+}
+ORC_API int orc_reset(orc_ctx* c);
+ORC_API int orc_set_transforms(orc_ctx* c, const float* xf, uint32_t nO)
+{
+  if (!c || !xf || !c->two_level || nO != c->nO) return CRH_E_INVALID;
+  memcpy(c->xf, xf, sizeof(float) * 12 * nO);
+  if (c->built) build_tlas(c);                      /* object trees are untouched */
+  return orc_reset(c);
+}
+ORC_API int orc_get_tlas(orc_ctx* c, uint32_t* root, uint32_t* n_instances, uint32_t* n_blas_nodes)
+{
+  if (!c || !c->built) return CRH_E_NOTBUILT;
+  if (root) *root = c->root; if (n_instances) *n_instances = c->nInst; if (n_blas_nodes) *n_blas_nodes = c->nBlasNodes;
   return 0;
 }
 ORC_API int orc_set_materials(orc_ctx* c, const crh_bsdf* m, uint32_t n)
