@@ -61,7 +61,7 @@ __device__ __forceinline__ void lds_append(bool pred, uint32_t value, uint32_t* 
 #define CRH_TRACE_BOUNDS __launch_bounds__(kBlock)
 #endif
 #ifndef CRH_INNER_STEPS
-#define CRH_INNER_STEPS 3      // 0: descend until every lane holds a leaf; k > 0: at most k inner steps per round
+#define CRH_INNER_STEPS 2      // 0: descend until every lane holds a leaf; k > 0: at most k inner steps per round
 #endif
 #ifndef CRH_REFILL_IDLE
 #define CRH_REFILL_IDLE 12     // refill a wavefront once this many of its 64 lanes have no ray
