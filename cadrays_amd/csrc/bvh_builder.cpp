@@ -11,8 +11,6 @@
 // subtree owns a disjoint index range and numbering happens afterwards.
 #include "bvh_builder.h"
 
-#include <hip/hip_runtime.h>   // this file is compiled as HIP (host part only); crh_math.h needs the HIP attribute macros
-
 #include "../../include/crh_bvh_format.h"
 #include "../../include/crh_xform.h"
 

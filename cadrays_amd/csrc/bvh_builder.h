@@ -4,13 +4,15 @@
 // the only reference-side evidence is the TBB build option, reference CMakeLists.txt:79).
 #pragma once
 #include <cstdint>
+
+#include "../../include/crh_bvh_format.h"
 #include <vector>
 
 namespace crh {
 
 // spec constants (DESIGN.md "BVH"): must match what the traversal kernels assume
 constexpr int      kBins      = 32;
-constexpr uint32_t kLeafSize  = 1;     // measured on MI355X: 1 -> 2620, 2 -> 2521, 3 -> 2396, 4 -> 2295, 6 -> 2058 Mrays/s (C3)
+constexpr uint32_t kLeafSize  = CRH_BVH_LEAF_SIZE;   // include/crh_bvh_format.h
 constexpr int      kMaxDepth  = 40;
 constexpr uint32_t kEmptyRef  = 0xFFFFFFFFu;
 constexpr uint32_t kLeafBit   = 0x80000000u;

@@ -265,8 +265,12 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       ++sp;
       cur = __float_as_uint(meta.x);
     } else if (have && (cur & kQLeafBit) && cur != kDone) {
-      const uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t k = 0; k < cnt; ++k) { tri_step(off + k); if (ANY && found) break; }
+      const uint32_t off = cur & 0x0FFFFFFFu;
+      if (CRH_BVH_LEAF_SIZE == 1) tri_step(off);               // the builders emit one triangle per leaf
+      else {
+        const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
+        for (uint32_t k = 0; k < cnt; ++k) { tri_step(off + k); if (ANY && found) break; }
+      }
       pop();
     }
 

@@ -19,6 +19,9 @@
 #include "crh_math.h"
 
 #define CRH_NODE_DWORDS 16
+/* triangles per leaf.  Measured on MI355X (C3, Mrays/s): 1 -> 2620, 2 -> 2521, 3 -> 2396, 4 -> 2295, 6 -> 2058: in a
+ * triangle soup a multi-triangle leaf mostly buys failed tests; one extra 64-B inner level is cheaper. */
+#define CRH_BVH_LEAF_SIZE 1
 #define CRH_NODE_BYTES  64
 
 /* biased exponent byte E of the smallest power-of-two step with 255 * 2^(E-127) >= ext */

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>   /* __host__ / __device__ / __forceinline__ */
 #define CRH_HD __host__ __device__ __forceinline__
 #else
 #define CRH_HD static inline __attribute__((always_inline))

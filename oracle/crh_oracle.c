@@ -37,7 +37,7 @@
 
 /* ------------------------------------------------------------------ spec constants */
 #define BVH_NBINS      32          /* OCCT BVH_Constants_NbBinsOptimal [OCCT-ext]           */
-#define BVH_LEAF       1           /* max triangles per leaf (a leaf visit = one triangle test) */
+#define BVH_LEAF       CRH_BVH_LEAF_SIZE   /* max triangles per leaf (include/crh_bvh_format.h) */
 #define BVH_MAXDEPTH   40          /* binary depth bound (root = 0); median splits keep it  */
 #define QBVH_EMPTY     0xFFFFFFFFu
 #define QBVH_LEAFBIT   0x80000000u
