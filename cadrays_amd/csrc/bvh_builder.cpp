@@ -15,6 +15,9 @@
 #include "../../include/crh_xform.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <cstring>
 #include <future>
@@ -54,26 +57,56 @@ struct Builder {
 
   static int ceil_log2(uint32_t v) { int l = 0; uint32_t p = 1; while (p < v) { p <<= 1; ++l; } return l; }
 
+  // ---- parallelism inside one large node (the top levels of the tree would otherwise be serial) -------------------
+  static constexpr uint32_t kParMin = 65536;      // primitives below which a node is processed by one thread
+  static constexpr int kMaxChunks = 64;
+  int grab_threads(uint32_t n) {                  // extra threads for a node of n primitives (0 = stay serial)
+    if (n < kParMin) return 0;
+    const int want = (int)std::min<uint32_t>(n / (kParMin / 2), kMaxChunks) - 1;
+    int have = spare_threads.load();
+    while (have > 0) {
+      const int take = std::min(have, want);
+      if (spare_threads.compare_exchange_weak(have, have - take)) return take;
+    }
+    return 0;
+  }
+  template <class F> static void run_chunks(int chunks, F f) {   // f(chunk) on `chunks` threads, caller included
+    std::vector<std::thread> th;
+    for (int c = 1; c < chunks; ++c) th.emplace_back(f, c);
+    f(0);
+    for (auto& t : th) t.join();
+  }
+
   // returns the split position, reorders idx[lo,hi)
-  uint32_t split(uint32_t lo, uint32_t hi, int depth, const float cmn[3], const float cmx[3]) {
+  uint32_t split(uint32_t lo, uint32_t hi, int depth, const float cmn[3], const float cmx[3], int extra) {
     const uint32_t n = hi - lo;
+    const int chunks = extra + 1;
+    auto c_lo = [&](int c) { return lo + (uint32_t)((uint64_t)n * c / chunks); };
     const int need = ceil_log2((n + leaf_max - 1) / leaf_max);
     const bool force_median = depth + need >= kMaxDepth;
     if (!force_median) {
       float ext[3], inv_ok[3];
       for (int a = 0; a < 3; ++a) { ext[a] = cmx[a] - cmn[a]; inv_ok[a] = ext[a] > 0.f ? 1.f : 0.f; }
-      uint32_t cnt[3][kBins]; Box bb[3][kBins];
-      for (int a = 0; a < 3; ++a) for (int b = 0; b < kBins; ++b) { cnt[a][b] = 0; bb[a][b].clear(); }
-      for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t p = idx[i];
-        const Box pb = prim_box(p);
-        for (int a = 0; a < 3; ++a) {
-          if (inv_ok[a] == 0.f) continue;
-          int b = (int)(((cen[a][p] - cmn[a]) / ext[a]) * (float)kBins);
-          if (b > kBins - 1) b = kBins - 1;
-          cnt[a][b]++; bb[a][b].grow(pb);
+      struct Bins { uint32_t cnt[3][kBins]; Box bb[3][kBins]; };
+      std::vector<Bins> part(chunks);
+      run_chunks(chunks, [&](int c) {
+        Bins& B = part[c];
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < kBins; ++b) { B.cnt[a][b] = 0; B.bb[a][b].clear(); }
+        for (uint32_t i = c_lo(c), e = c_lo(c + 1); i < e; ++i) {
+          const uint32_t p = idx[i];
+          const Box pb = prim_box(p);
+          for (int a = 0; a < 3; ++a) {
+            if (inv_ok[a] == 0.f) continue;
+            int b = (int)(((cen[a][p] - cmn[a]) / ext[a]) * (float)kBins);
+            if (b > kBins - 1) b = kBins - 1;
+            B.cnt[a][b]++; B.bb[a][b].grow(pb);
+          }
         }
-      }
+      });
+      Bins& M = part[0];                               // merge (min / max / integer sums: order-independent)
+      for (int c = 1; c < chunks; ++c)
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < kBins; ++b) if (part[c].cnt[a][b]) { M.cnt[a][b] += part[c].cnt[a][b]; M.bb[a][b].grow(part[c].bb[a][b]); }
+      auto& cnt = M.cnt; auto& bb = M.bb;
       float best = 3.0e38f; int baxis = -1, bsplit = -1;
       for (int a = 0; a < 3; ++a) {
         if (inv_ok[a] == 0.f) continue;
@@ -95,16 +128,29 @@ struct Builder {
       if (baxis >= 0) {
         const std::vector<float>& cc = cen[baxis];
         const float c0 = cmn[baxis], e = ext[baxis];
-        uint32_t nl = 0, nr = 0;
-        uint32_t* right = tmp.data() + lo;            // this subtree's private scratch range
-        for (uint32_t i = lo; i < hi; ++i) {
-          const uint32_t p = idx[i];
+        auto goes_left = [&](uint32_t p) {
           int b = (int)(((cc[p] - c0) / e) * (float)kBins);
           if (b > kBins - 1) b = kBins - 1;
-          if (b <= bsplit) idx[lo + nl++] = p; else right[nr++] = p;
+          return b <= bsplit;
+        };
+        if (chunks == 1) {
+          uint32_t nl = 0, nr = 0;
+          uint32_t* right = tmp.data() + lo;          // this subtree's private scratch range
+          for (uint32_t i = lo; i < hi; ++i) { const uint32_t p = idx[i]; if (goes_left(p)) idx[lo + nl++] = p; else right[nr++] = p; }
+          std::memcpy(&idx[lo + nl], right, sizeof(uint32_t) * nr);
+          return lo + nl;
         }
-        std::memcpy(&idx[lo + nl], right, sizeof(uint32_t) * nr);
-        return lo + nl;
+        // chunked stable partition: count, exclusive prefix, scatter into tmp[lo, hi) at final positions, copy back
+        std::vector<uint32_t> nlc(chunks + 1, 0);
+        run_chunks(chunks, [&](int c) { uint32_t k = 0; for (uint32_t i = c_lo(c), e2 = c_lo(c + 1); i < e2; ++i) k += goes_left(idx[i]); nlc[c + 1] = k; });
+        for (int c = 0; c < chunks; ++c) nlc[c + 1] += nlc[c];
+        const uint32_t NL = nlc[chunks];
+        run_chunks(chunks, [&](int c) {
+          uint32_t l = lo + nlc[c], r = lo + NL + ((c_lo(c) - lo) - nlc[c]);
+          for (uint32_t i = c_lo(c), e2 = c_lo(c + 1); i < e2; ++i) { const uint32_t p = idx[i]; if (goes_left(p)) tmp[l++] = p; else tmp[r++] = p; }
+        });
+        run_chunks(chunks, [&](int c) { std::memcpy(&idx[c_lo(c)], &tmp[c_lo(c)], sizeof(uint32_t) * (c_lo(c + 1) - c_lo(c))); });
+        return lo + NL;
       }
     }
     // object median on the widest centroid axis
@@ -125,18 +171,32 @@ struct Builder {
     for (;;) {
       BNode& nd = nodes[me];
       nd.lo = lo; nd.hi = hi; nd.left = nd.right = -1;
-      Box box; box.clear();
-      float cmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, cmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-      for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t p = idx[i];
-        for (int a = 0; a < 3; ++a) {
-          box.mn[a] = std::min(box.mn[a], pmn[a][p]); box.mx[a] = std::max(box.mx[a], pmx[a][p]);
-          cmn[a] = std::min(cmn[a], cen[a][p]); cmx[a] = std::max(cmx[a], cen[a][p]);
+      const int extra = grab_threads(hi - lo);         // > 0: this node is processed in extra+1 chunks
+      const int chunks = extra + 1;
+      struct Bounds { Box box; float cmn[3], cmx[3]; };
+      std::vector<Bounds> bp(chunks);
+      run_chunks(chunks, [&](int c) {
+        Bounds& b = bp[c]; b.box.clear();
+        for (int a = 0; a < 3; ++a) { b.cmn[a] = 3.0e38f; b.cmx[a] = -3.0e38f; }
+        const uint32_t n_ = hi - lo;
+        for (uint32_t i = lo + (uint32_t)((uint64_t)n_ * c / chunks), e = lo + (uint32_t)((uint64_t)n_ * (c + 1) / chunks); i < e; ++i) {
+          const uint32_t p = idx[i];
+          for (int a = 0; a < 3; ++a) {
+            b.box.mn[a] = std::min(b.box.mn[a], pmn[a][p]); b.box.mx[a] = std::max(b.box.mx[a], pmx[a][p]);
+            b.cmn[a] = std::min(b.cmn[a], cen[a][p]); b.cmx[a] = std::max(b.cmx[a], cen[a][p]);
+          }
         }
+      });
+      Box box = bp[0].box;
+      float cmn[3] = {bp[0].cmn[0], bp[0].cmn[1], bp[0].cmn[2]}, cmx[3] = {bp[0].cmx[0], bp[0].cmx[1], bp[0].cmx[2]};
+      for (int c = 1; c < chunks; ++c) {
+        box.grow(bp[c].box);
+        for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], bp[c].cmn[a]); cmx[a] = std::max(cmx[a], bp[c].cmx[a]); }
       }
       nd.box = box;
-      if (hi - lo <= leaf_max) return;
-      const uint32_t mid = split(lo, hi, depth, cmn, cmx);
+      if (hi - lo <= leaf_max) { spare_threads.fetch_add(extra); return; }
+      const uint32_t mid = split(lo, hi, depth, cmn, cmx, extra);
+      spare_threads.fetch_add(extra);                  // the children may use them (subtree tasks or their own chunks)
       const uint32_t l = alloc(), r = alloc();
       nodes[me].left = (int32_t)l; nodes[me].right = (int32_t)r;
       // hand the left half to another thread when it is big enough and one is free
@@ -162,10 +222,9 @@ struct Collapser {
     return kLeafBit | ((b.hi - b.lo - 1u) << 28) | (b.lo + tri_base);
   }
 
-  uint32_t run(uint32_t bi) {
-    const uint32_t me = (uint32_t)qn.size();
-    qn.emplace_back();
-    uint32_t kids[4]; int nk = 0;
+  // 4-wide children of binary node bi: its grandchildren, a leaf child stays
+  int kids_of(uint32_t bi, uint32_t kids[4]) const {
+    int nk = 0;
     const BNode& b = bn[bi];
     if (b.left < 0) kids[nk++] = bi;
     else {
@@ -175,17 +234,54 @@ struct Collapser {
         else { kids[nk++] = (uint32_t)c.left; kids[nk++] = (uint32_t)c.right; }
       }
     }
+    return nk;
+  }
+
+  // pass 1: number of 4-wide nodes below (and including) the node made from binary node bi -> DFS indices are known
+  // before any node is packed, so subtrees can be packed by different threads
+  std::vector<uint32_t> qcnt;
+  uint32_t count(uint32_t bi) {
+    uint32_t kids[4]; const int nk = kids_of(bi, kids);
+    uint32_t c = 1;
+    for (int k = 0; k < nk; ++k) if (bn[kids[k]].left >= 0) c += count(kids[k]);
+    return qcnt[bi] = c;
+  }
+
+  std::atomic<int>* spare = nullptr;
+  // pass 2: pack node `me` (DFS pre-order index, absolute in qn) from binary node bi and recurse
+  void pack(uint32_t bi, uint32_t me) {
+    uint32_t kids[4]; const int nk = kids_of(bi, kids);
     QNode q; std::memset(&q, 0, sizeof q);
     uint32_t refs[4] = {kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef};
     float cmin[4][3], cmax[4][3];
+    uint32_t next = me + 1;
+    std::vector<std::future<void>> tasks;
     for (int k = 0; k < nk; ++k) {
       const BNode& c = bn[kids[k]];
       for (int a = 0; a < 3; ++a) { cmin[k][a] = c.box.mn[a]; cmax[k][a] = c.box.mx[a]; }
-      if (c.left < 0) refs[k] = c.hi > c.lo ? leaf_ref(c) : kEmptyRef;
-      else            refs[k] = run(kids[k]);
+      if (c.left < 0) { refs[k] = c.hi > c.lo ? leaf_ref(c) : kEmptyRef; continue; }
+      refs[k] = next;
+      const uint32_t child = kids[k], at = next;
+      next += qcnt[child];
+      if (qcnt[child] > 16384u && spare && spare->fetch_sub(1) > 0)
+        tasks.push_back(std::async(std::launch::async, [this, child, at] { pack(child, at); spare->fetch_add(1); }));
+      else {
+        if (qcnt[child] > 16384u && spare) spare->fetch_add(1);
+        pack(child, at);
+      }
     }
     crh_pack_node(cmin, cmax, refs, nk, q.w);      // 8-bit child bounds on the node's power-of-two grid
     qn[me] = q;
+    for (auto& t : tasks) t.get();
+  }
+
+  uint32_t run(uint32_t bi, std::atomic<int>* spare_threads) {
+    qcnt.assign(bn.size(), 0u);
+    const uint32_t total = count(bi);
+    const uint32_t me = (uint32_t)qn.size();
+    qn.resize((size_t)me + total);
+    spare = spare_threads;
+    pack(bi, me);
     return me;
   }
 };
@@ -212,10 +308,14 @@ uint32_t build_tree(const float* boxes, uint32_t n, uint32_t leaf_max, bool inst
   if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
   if (threads < 1) threads = 1;
   B.spare_threads.store(threads - 1);
+  const auto t0_ = std::chrono::steady_clock::now();
   const uint32_t root = B.alloc();
   B.build(root, 0, n, 0);
-  Collapser C{B.nodes, nodes, instance_leaves, tri_base, B.idx};
-  const uint32_t qroot = C.run(root);
+  const auto t1_ = std::chrono::steady_clock::now();
+  Collapser C{B.nodes, nodes, instance_leaves, tri_base, B.idx, {}, nullptr};
+  B.spare_threads.store(threads - 1);
+  const uint32_t qroot = C.run(root, &B.spare_threads);
+  if (getenv("CRH_BUILD_VERBOSE")) fprintf(stderr, "build_tree n=%u: binary %.3f s, collapse+pack %.3f s\n", n, std::chrono::duration<double>(t1_ - t0_).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1_).count());
   order.assign(B.idx.begin(), B.idx.begin() + n);
   for (int a = 0; a < 3; ++a) { bmin[a] = n ? scene.mn[a] : 0.f; bmax[a] = n ? scene.mx[a] : 0.f; }
   return qroot;

@@ -116,6 +116,7 @@ int ensure_paths(crh_ctx* c, uint32_t need)
                    (void**)&c->paths.st, (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c,
                    (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh};
   const size_t sz[] = {16, 16, 16, 16, 16, 8, 16, 16, 16, 4, 4, 4};
+  c->path_cap = 0;                                          // stays 0 if an allocation below fails
   for (int i = 0; i < 12; ++i) {
     if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
     CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
@@ -269,7 +270,14 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   { int rc_t = upload_textures(c); if (rc_t) return rc_t; }
   const uint32_t ts = c->par.tile_size, tpp = ts * ts;
   const uint32_t tx = (c->par.width + ts - 1) / ts, ty = (c->par.height + ts - 1) / ts;
-  for (uint32_t i = 0; i < nt; ++i) if (tiles[i] >= tx * ty) return fail(c, CRH_E_INVALID, "tile id out of range");
+  {
+    std::vector<uint8_t> seen((size_t)tx * ty, 0);          // a tile listed twice would be accumulated by two threads at once
+    for (uint32_t i = 0; i < nt; ++i) {
+      if (tiles[i] >= tx * ty) return fail(c, CRH_E_INVALID, "tile id out of range");
+      if (seen[tiles[i]]) return fail(c, CRH_E_INVALID, "duplicate tile id");
+      seen[tiles[i]] = 1;
+    }
+  }
   // tile ids + frame seeds to the device (stream-ordered behind any kernels still reading the old ones)
   if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; }
   if (ns > c->seed_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * ns)); c->seed_cap = ns; }

@@ -1044,7 +1044,8 @@ ORC_API int orc_build(orc_ctx* c)
   do_build(c); c->built = 1; return orc_reset(c);
 }
 ORC_API int orc_render_tiles(orc_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, uint32_t ns)
-{ if (!c) return CRH_E_INVALID; if (!c->built) return CRH_E_NOTBUILT; prepare(c); return render_tiles(c, tiles, nt, first, ns, NULL); }
+{ if (!c) return CRH_E_INVALID; if (!c->built) return CRH_E_NOTBUILT;
+  for (uint32_t i = 0; i < nt; ++i) for (uint32_t j = 0; j < i; ++j) if (nt <= 4096 && tiles[i] == tiles[j]) { snprintf(c->err, sizeof c->err, "duplicate tile id"); return CRH_E_INVALID; } prepare(c); return render_tiles(c, tiles, nt, first, ns, NULL); }
 /* --- adaptive screen sampling (reference controls at SettingsWidget.cxx:427-477) ---------------------
  * tile error = mean over the tile's pixels of sqrt(max(E[l^2] - E[l]^2, 0) / n) (1e3 for pixels with n < 2), summed in
  * the fixed order "lane j of 256 takes pixels j, j+256, .. of the row-major tile, then a stride 128..1 tree". */

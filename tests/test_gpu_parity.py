@@ -254,6 +254,13 @@ def test_errors(view_cls):
         v.set_params(dataclasses.replace(sc.params, tile_size=12))
     with pytest.raises(BackendError):
         v.set_params(dataclasses.replace(sc.params, max_depth=33))
+    v.load_scene(sc)
+    with pytest.raises(BackendError):
+        v.render_tiles(np.array([0, 1, 1], np.uint32), 0, 1)          # duplicate tile
+    with pytest.raises(BackendError):
+        v.render_tiles(np.array([10 ** 6], np.uint32), 0, 1)          # out of range
+    with pytest.raises(BackendError):
+        v.set_transforms(np.zeros((2, 12), np.float32))               # not a two-level scene
 
 
 def test_headless_cpp_driver_matches_oracle(tmp_path, Oracle):
