@@ -17,7 +17,8 @@ constexpr uint32_t kQLeafBit      = 0x80000000u;
 
 constexpr int kBlock      = 256;   // threads per workgroup (4 waves)
 constexpr int kLdsStack   = 16;    // traversal stack entries per lane kept in LDS
-constexpr int kOvfStack   = 64;    // spill entries per lane (scratch); 16 + 64 = 80 >= 3 * quad depth bound + top-level tree + sentinel
+constexpr int kOvfStack   = 112;   // spill entries per lane (scratch, rarely touched); 16 + 112 = 128 >= 63 (top-level tree: binary depth <= 40
+                                   // -> 21 four-wide levels x 3 pending siblings) + 1 sentinel + 63 (object tree)
 
 // Scene as the kernels see it.  All arrays are float4-granular so every fetch is one dwordx4.
 struct DScene {

@@ -41,7 +41,7 @@
 #define BVH_MAXDEPTH   40          /* binary depth bound (root = 0); median splits keep it  */
 #define QBVH_EMPTY     0xFFFFFFFFu
 #define QBVH_LEAFBIT   0x80000000u
-#define STACK_MAX      96          /* >= 3 * ceil((BVH_MAXDEPTH+1)/2) for one tree, + top-level tree + sentinel */
+#define STACK_MAX      128         /* >= 63 (top-level tree: 21 four-wide levels x 3 pending siblings) + 1 sentinel + 63 (object tree) */
 #define DIR_EPS        1.0e-15f
 #define BSDF_EPS       1.0e-5f     /* roughness / weight threshold ("FLT_EPSILON" in GLSL)  */
 #define MIN_THROUGHPUT 1.0e-3f
