@@ -124,15 +124,17 @@ def main():
         avg_ms = kt["trace_nearest_ms_total"] / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = args.pmc_traffic
+        traffic_source = "--pmc-traffic" if traffic is not None else None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if traffic is None and args.config == "C3" and not (args.tris or args.width or args.height) and os.path.exists(pmc_file):
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
             pmc = json.load(open(pmc_file))
             traffic = pmc.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             if traffic is not None and args.spp != pmc.get("spp_per_step", 32):
                 traffic = traffic * args.spp / pmc.get("spp_per_step", 32)
         roof = {"bound": "hbm", "kernel": "k_trace_nearest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "alg_bytes_per_launch": round(per_launch), "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
                 "kernel_time_share": round(kt["trace_nearest_ms_total"] / max(kt["render_ms_total"], 1e-9), 3),
                 "nodes_per_ray": round(cs["nodes_nearest"] / max(cs["rays_nearest"], 1), 2),
