@@ -65,7 +65,7 @@ struct crh_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> render_ev, trace_ev;
   std::vector<hipEvent_t> ev_pool;
   double seconds_acc = 0.0, trace_ms_acc = 0.0, all_ms_acc = 0.0; uint64_t trace_launches = 0;
-  uint32_t max_paths = 64u << 20;   // path slots per batch (148 B each = 9.5 GB); more in flight keeps late, sparse bounces busy
+  uint32_t max_paths = 64u << 20;   // path slots per batch (140 B each = 9.4 GB); more in flight keeps late, sparse bounces busy
 };
 
 namespace {
@@ -113,11 +113,11 @@ int ensure_paths(crh_ctx* c, uint32_t need)
   if (need <= c->path_cap) return CRH_OK;
   CRH_HIP(hipStreamSynchronize(c->stream));
   void** ptrs[] = {(void**)&c->paths.ray_o, (void**)&c->paths.ray_d, (void**)&c->paths.hit, (void**)&c->paths.thr, (void**)&c->paths.rad,
-                   (void**)&c->paths.st, (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c,
+                   (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c,
                    (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh};
-  const size_t sz[] = {16, 16, 16, 16, 16, 8, 16, 16, 16, 4, 4, 4};
+  const size_t sz[] = {16, 16, 16, 16, 16, 16, 16, 16, 4, 4, 4};
   c->path_cap = 0;                                          // stays 0 if an allocation below fails
-  for (int i = 0; i < 12; ++i) {
+  for (int i = 0; i < 11; ++i) {
     if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
     CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
   }
@@ -416,7 +416,7 @@ void crh_destroy(crh_ctx* c)
   drain_events(c);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o, c->paths.ray_d,
-                  c->paths.hit, c->paths.thr, c->paths.rad, c->paths.st, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
+                  c->paths.hit, c->paths.thr, c->paths.rad, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
                   c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
                   c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst};
   for (void* p : ptrs) if (p) hipFree(p);

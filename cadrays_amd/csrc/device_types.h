@@ -49,12 +49,11 @@ struct DScene {
 
 // Wavefront path state, structure-of-arrays over path slots.
 struct DPaths {
-  float4* ray_o;   // origin.xyz, tmax
-  float4* ray_d;   // direction.xyz, -
+  float4* ray_o;   // origin.xyz, rng state (uint bits)
+  float4* ray_d;   // direction.xyz, flags (uint bits; bit 0: inside a medium)
   float4* hit;     // t, u, v, leaf-order triangle index (int bits; -1 = miss)
   float4* thr;     // throughput.rgb, implicit (BSDF) pdf of the ray that is in flight
   float4* rad;     // radiance.rgb accumulated along the path
-  uint2*  st;      // rng state, flags (bit 0: inside a medium)
   float4* sh_o;    // shadow ray origin.xyz, tmax
   float4* sh_d;    // shadow ray direction.xyz
   float4* sh_c;    // throughput * contribution to add when unoccluded

@@ -295,8 +295,8 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint3
   trace_engine<false, COUNT, TWO>(S.nodes, S.tris, S.inst, S.root, cursors + 0, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
-      const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];
-      o = xyz(o4); d = xyz(d4); tmax = o4.w;
+      const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];      // .w lanes carry the path's rng state / flags, not ray data
+      o = xyz(o4); d = xyz(d4); tmax = CRH_MAXFLOAT;
     },
     [&](uint32_t tag, float4 h, bool) { P.hit[tag] = h; }, nn, nt);
   if (COUNT) {
@@ -732,11 +732,10 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
         o = crh_madd3(crh_madd3(o, S.right, r * cs), S.up, r * sn);
         d = crh_norm3(crh_sub3(focus, o));
       }
-      P.ray_o[pid] = mk4(o, CRH_MAXFLOAT);
-      P.ray_d[pid] = mk4(d, 0.f);
+      P.ray_o[pid] = mk4(o, __uint_as_float(rng));           // .w = rng state
+      P.ray_d[pid] = mk4(d, __uint_as_float(0u));            // .w = flags (bit 0: inside a medium)
       P.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT);
       P.rad[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
-      P.st[pid] = make_uint2(rng, 0u);
     }
     const unsigned long long m = __ballot(valid);
     if (valid) q[s_base + s_cnt[it * 4u + wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pid;
@@ -789,19 +788,17 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
     if (i < n) {
       pid = q_in[i];
       const float4 o4 = P.ray_o[pid], d4 = P.ray_d[pid], h = P.hit[pid], t4 = P.thr[pid];
-      float4 r4 = P.rad[pid];
-      uint2 st = P.st[pid];
+      const uint2 st = make_uint2(__float_as_uint(o4.w), __float_as_uint(d4.w));   // rng state, flags
       const v3 o = xyz(o4), d = xyz(d4);
       v3 W = xyz(t4); float imp_pdf = t4.w;
-      v3 rad = xyz(r4);
       const int hk = __float_as_int(h.w);
       const bool found = hk >= 0;
       float exp_pdf;
       const v3 le = intersect_light(S, o, d, bounce, found ? h.x : CRH_MAXFLOAT, exp_pdf);
       if (le.x > 0.f || le.y > 0.f || le.z > 0.f || !found) {
         const float mis = (bounce == 0u || imp_pdf == CRH_MAXFLOAT) ? 1.0f : (imp_pdf * imp_pdf) / CRH_FMA(exp_pdf, exp_pdf, imp_pdf * imp_pdf);
-        rad = crh_add3(rad, crh_scale3(crh_mul3(W, le), mis));
-        P.rad[pid] = mk4(rad, 0.f);
+        const float4 r4 = P.rad[pid];                        // the radiance record is touched only when something is added
+        P.rad[pid] = mk4(crh_add3(xyz(r4), crh_scale3(crh_mul3(W, le), mis)), 0.f);
       } else {
         ++n_shaded;
         const float4* tp = S.tris + 3u * (uint32_t)hk;
@@ -842,7 +839,10 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
           const float k = -(h.x * bs.ab.w);
           W = crh_mul3(W, crh_mk3(crh_exp(k * (1.0f - bs.ab.x)), crh_exp(k * (1.0f - bs.ab.y)), crh_exp(k * (1.0f - bs.ab.z))));
         }
-        rad = crh_add3(rad, crh_mul3(W, bs.Le));
+        if (bs.Le.x != 0.f || bs.Le.y != 0.f || bs.Le.z != 0.f) {      // emissive surfaces are rare: skip the read-modify-write otherwise
+          const float4 r4 = P.rad[pid];
+          P.rad[pid] = mk4(crh_add3(xyz(r4), crh_mul3(W, bs.Le)), 0.f);
+        }
         uint32_t rng = st.x;
         // ---- next event estimation
         {
@@ -875,7 +875,6 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
             }
           }
         }
-        P.rad[pid] = mk4(rad, 0.f);
         // ---- BSDF sampling + Russian roulette (the last bounce has no successor ray)
         if (!last) {
           v3 wi; bool delta; const v3 Wsel = W;
@@ -888,10 +887,9 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
           if (alive && kr < survive) {
             if (S.rr && bounce >= 3u) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
             const v3 nd2 = crh_norm3(from_local(fr, wi));
-            P.ray_o[pid] = mk4(offset_origin(p, nd2, ng, S.eps), CRH_MAXFLOAT);
-            P.ray_d[pid] = mk4(nd2, 0.f);
+            P.ray_o[pid] = mk4(offset_origin(p, nd2, ng, S.eps), __uint_as_float(rng));
+            P.ray_d[pid] = mk4(nd2, __uint_as_float(inside ? 1u : 0u));
             P.thr[pid] = mk4(W, imp_pdf);
-            P.st[pid] = make_uint2(rng, inside ? 1u : 0u);
             cont = true;
           }
         }
