@@ -54,6 +54,9 @@ struct crh_ctx {
   float* d_m2 = nullptr;            // running mean of squared luminance (adaptive sampling only)
   float* d_tile_err = nullptr; uint32_t* d_tile_cnt = nullptr; uint32_t tile_stat_cap = 0;
   bool adaptive = false; uint32_t adaptive_tiles = 128; uint32_t adaptive_picks = 0;   // NbRayTracingTiles, Halton index
+  // speculative look-ahead for the +1-spp-per-Redraw boundary: frames [pending_first, pending_first + pending_n) are traced
+  // and wait in the path buffer (batch sample index pending_off ...) to be folded in by the next crh_render calls
+  uint32_t lookahead = 1, pending_first = 0, pending_n = 0, pending_off = 0, pending_tiles = 0;
   DPaths paths{}; DQueues queues{}; uint32_t path_cap = 0;
   uint32_t* d_tile_ids = nullptr; uint32_t tile_cap = 0;
   uint32_t* d_seeds = nullptr; uint32_t seed_cap = 0;
@@ -230,7 +233,7 @@ int do_reset(crh_ctx* c)
   int rc = alloc_accum(c); if (rc) return rc;
   CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, c->stream));
   CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, c->stream));
-  c->adaptive_picks = 0;
+  c->adaptive_picks = 0; c->pending_n = 0;
   CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
   drain_events(c);
@@ -239,8 +242,10 @@ int do_reset(crh_ctx* c)
 }
 
 // One batch: `ns` samples of `nt` tiles whose ids sit at d_tiles; seeds at d_seeds.
-int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile = 0)
+int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile = 0,
+              bool accumulate = true)
 {
+  c->pending_n = 0;                                  // the path buffer is about to be overwritten
   Launch L{c->stream, c->grid, c->counters_on};
   Launch LT{c->stream, c->grid_trace, c->counters_on};
   launch_raygen(L, S, c->paths, c->queues, 0, d_tiles, nt, d_seeds, ns, seed_per_tile);
@@ -257,7 +262,7 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
     if (S.n_lights > 0) launch_trace_any(LT, S, c->paths, c->queues, c->d_counters);
     qin = 1 - qin;
   }
-  launch_accumulate(L, S, c->paths, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, ns, c->d_counters);
+  if (accumulate) launch_accumulate(L, S, c->paths, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, c->d_counters);
   CRH_HIP(hipGetLastError());
   return CRH_OK;
 }
@@ -620,6 +625,39 @@ int crh_render(crh_ctx* c, uint32_t n)
   const uint32_t nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
   std::vector<uint32_t> all(nt);
   for (uint32_t i = 0; i < nt; ++i) all[i] = i;
+  if (c->lookahead > 1 && (uint64_t)nt * ts * ts * c->lookahead <= c->max_paths) {
+    // look-ahead: one wide batch of `lookahead` frames is traced at once; each call folds in only the samples it asked for
+    CRH_HIP(hipSetDevice(c->device));
+    while (n > 0) {
+      if (c->pending_n == 0 || c->pending_first != c->frames_done || c->pending_tiles != nt) {
+        int rc_t = upload_textures(c); if (rc_t) return rc_t;
+        const uint32_t k = c->lookahead;
+        if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; }
+        if (k > c->seed_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * k)); c->seed_cap = k; }
+        std::vector<uint32_t> seeds(k);
+        { uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;
+          for (uint32_t i = 0; i < c->frames_done + k; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; if (i >= c->frames_done) seeds[i - c->frames_done] = hi >> 2; } }
+        CRH_HIP(hipMemcpyAsync(c->d_tile_ids, all.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice, c->stream));
+        CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * k, hipMemcpyHostToDevice, c->stream));
+        CRH_HIP(hipStreamSynchronize(c->stream));
+        int rc_p = ensure_paths(c, nt * ts * ts * k); if (rc_p) return rc_p;
+        DScene S; fill_scene(c, S);
+        hipEvent_t e0 = get_event(c), e1 = get_event(c);
+        hipEventRecord(e0, c->stream);
+        int rc_b = run_batch(c, S, c->d_tile_ids, nt, c->d_seeds, k, 0, false); if (rc_b) return rc_b;
+        hipEventRecord(e1, c->stream);
+        c->render_ev.emplace_back(e0, e1);
+        c->pending_first = c->frames_done; c->pending_n = k; c->pending_off = 0; c->pending_tiles = nt;
+      }
+      const uint32_t m = std::min(n, c->pending_n);
+      DScene S; fill_scene(c, S);
+      Launch L{c->stream, c->grid, false};
+      launch_accumulate(L, S, c->paths, c->d_accum, nullptr, c->d_tile_ids, nt, c->pending_off, m, c->d_counters);
+      CRH_HIP(hipGetLastError());
+      c->pending_off += m; c->pending_n -= m; c->pending_first += m; c->frames_done += m; n -= m;
+    }
+    return CRH_OK;
+  }
   int rc = render_impl(c, all.data(), nt, c->frames_done, n);
   if (rc == CRH_OK) c->frames_done += n;
   return rc;
@@ -636,6 +674,13 @@ int crh_set_adaptive(crh_ctx* c, int on, uint32_t tiles_per_iteration)
   if (!c || (on && tiles_per_iteration == 0)) return fail(c, CRH_E_INVALID, "tiles_per_iteration must be > 0");
   c->adaptive = on != 0; if (on) c->adaptive_tiles = tiles_per_iteration;
   return do_reset(c);                                   // like every rendering-parameter change, restarts accumulation
+}
+
+int crh_set_lookahead(crh_ctx* c, uint32_t frames)
+{
+  if (!c || frames == 0) return fail(c, CRH_E_INVALID, "lookahead must be >= 1");
+  c->lookahead = frames; c->pending_n = 0;
+  return CRH_OK;
 }
 
 int crh_get_tile_stats(crh_ctx* c, float* err, uint32_t* counts, uint32_t* n_tiles)
@@ -695,7 +740,7 @@ int crh_load_accum(crh_ctx* c, const float* in, uint32_t frames_done)
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
   CRH_HIP(hipMemcpy(c->d_accum, in, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyHostToDevice));
-  c->frames_done = frames_done;
+  c->frames_done = frames_done; c->pending_n = 0;
   return CRH_OK;
 }
 

@@ -20,9 +20,10 @@ void launch_trace_nearest(const Launch&, const DScene&, const DPaths&, const DQu
 void launch_shade(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, uint32_t bounce, DCounters*);
 // any-hit traversal of the shadow queue; unoccluded contributions are added to the path radiance
 void launch_trace_any(const Launch&, const DScene&, const DPaths&, const DQueues&, DCounters*);
-// clamp + running mean of the finished paths into the float4 accumulator, sample by sample
+// clamp + running mean of the finished paths of batch samples [first_sample, first_sample + n_samples) into the float4
+// accumulator, sample by sample
 void launch_accumulate(const Launch&, const DScene&, const DPaths&, float4* accum, float* m2 /* or nullptr */,
-                       const uint32_t* d_tile_ids, uint32_t n_tiles, uint32_t n_samples, DCounters*);
+                       const uint32_t* d_tile_ids, uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, DCounters*);
 // adaptive tile sampler: per-tile mean standard error and minimum per-pixel sample count (one workgroup per tile)
 void launch_tile_error(const Launch&, const DScene&, const float4* accum, const float* m2, float* tile_err,
                        uint32_t* tile_min_count, uint32_t n_tiles_total);

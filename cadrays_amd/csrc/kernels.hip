@@ -911,8 +911,9 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
 // ================================================================== accumulate / display
 __global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float4* __restrict__ accum, float* __restrict__ m2,
                                                         const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
-                                                        uint32_t n_samples, DCounters* C)
+                                                        uint32_t first_sample, uint32_t n_samples, DCounters* C)
 {
+  // samples [first_sample, first_sample + n_samples) of the batch in the path buffer are folded in, in order
   const uint32_t per_sample = n_tiles * S.tile_size * S.tile_size;
   uint32_t done = 0;
   for (uint32_t local = blockIdx.x * kBlock + threadIdx.x; local < per_sample; local += gridDim.x * kBlock) {
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float
     const size_t pi = (size_t)py * S.width + px;
     float4 a = accum[pi];
     float q = m2 ? m2[pi] : 0.f;
-    for (uint32_t s = 0; s < n_samples; ++s) {
+    for (uint32_t s = first_sample; s < first_sample + n_samples; ++s) {
       const float4 r = P.rad[s * per_sample + local];
       const float w = 1.0f / (a.w + 1.0f);
       float v[3] = {r.x, r.y, r.z};
@@ -1070,9 +1071,9 @@ void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const D
 #undef CRH_LAUNCH_TA
 }
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,
-                       uint32_t n_tiles, uint32_t n_samples, DCounters* C)
+                       uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, DCounters* C)
 {
-  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, m2, d_tile_ids, n_tiles, n_samples, C);
+  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, m2, d_tile_ids, n_tiles, first_sample, n_samples, C);
 }
 void launch_tile_error(const Launch& L, const DScene& S, const float4* accum, const float* m2, float* tile_err, uint32_t* tile_min_count,
                        uint32_t n_tiles_total)

@@ -52,6 +52,10 @@ class View(Backend):
     def sync(self):
         self._call("sync")
 
+    def set_lookahead(self, frames):
+        """trace `frames` Redraw()s ahead in one wide batch; images after every Redraw stay bit-identical"""
+        self._call("set_lookahead", C.c_uint32(int(frames)))
+
     def enable_counters(self, on=True):
         self._call("enable_counters", C.c_int(int(on)))
 

@@ -169,6 +169,12 @@ CRH_API int crh_render_tiles(crh_ctx* ctx, const uint32_t* tile_ids, uint32_t n_
  * tiles drawn with probability proportional to their estimated error instead of on the whole target.
  * Changing it restarts accumulation. */
 CRH_API int crh_set_adaptive(crh_ctx* ctx, int on, uint32_t tiles_per_iteration);
+/* Speculative look-ahead for the +1-spp-per-Redraw() usage (AppViewer.cxx:1045-1047): with frames > 1, crh_render traces the
+ * next `frames` whole-frame samples in ONE wide batch (late bounces stay wide) and keeps their radiance in the path buffer;
+ * each call folds in only the samples it asked for, so the image after every call is bit-identical to frames = 1.  Any
+ * change of scene / camera / parameters, crh_reset, crh_render_tiles or adaptive mode discards what is pending.  Ray
+ * counters include the speculative samples.  frames = 1 (default) disables it. */
+CRH_API int crh_set_lookahead(crh_ctx* ctx, uint32_t frames);
 /* Per-tile error estimate (mean standard error of the pixel luminance) and per-tile sample count; pass NULL
  * arrays to query n_tiles.  Needs adaptive mode for a meaningful error. */
 CRH_API int crh_get_tile_stats(crh_ctx* ctx, float* err, uint32_t* counts, uint32_t* n_tiles);

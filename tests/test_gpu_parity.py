@@ -322,3 +322,20 @@ def test_accumulator_checkpoint_resume(view_cls):
     c = view_cls(0).load_scene(sc); c.render(5)
     assert np.array_equal(bits(b.read_hdr()), bits(c.read_hdr()))
     assert b.save_accum()[1] == 5
+
+
+def test_lookahead_keeps_every_redraw_bit_identical(view_cls):
+    """crh_set_lookahead: the next k Redraw()s are traced in one wide batch; each call still reveals exactly +1 spp."""
+    sc = scenes.cornell_box(True, 96, 80)
+    ref = view_cls(0).load_scene(sc)
+    v = view_cls(0).load_scene(sc); v.set_lookahead(4)
+    for i in range(1, 11):
+        ref.Redraw(); v.Redraw()
+        assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr())), i
+        if i == 6:                                     # a camera change mid-batch discards the speculative samples
+            import dataclasses
+            cam = dataclasses.replace(sc.camera, eye=(0.45, -1.5, 0.55))
+            ref.set_camera(cam); ref.reset(); v.set_camera(cam); v.reset()
+    v.render(7); ref.render(7)                          # a request larger than the look-ahead spans batches
+    assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr()))
+    assert v.stats()["samples"] == ref.stats()["samples"]
