@@ -6,7 +6,7 @@
 //   loop: View->Redraw() once per frame, count frames      src/Launcher/AppViewer.cxx:1045-1071
 //   BufferDump(Graphic3d_BT_RGB) after the last frame      src/Launcher/AppViewer.cxx:1255-1264
 //   write Output_<name>_<n>.png and Output_<name>_<n>.txt (average frame rate)   main.cxx:193-228
-// Here: cadrays_headless <scene.crhscene> <nFrames> [device] writes Output_<name>_<n>.ppm (LDR),
+// Here: cadrays_headless <scene.crhscene> <nFrames> [device] [lookahead] writes Output_<name>_<n>.ppm (LDR),
 // Output_<name>_<n>.pfm (linear HDR, the parity buffer of AppGui.cxx:345-349) and Output_<name>_<n>.txt.
 #include <chrono>
 #include <cstdint>
@@ -37,10 +37,11 @@ int die(crh_ctx* c, const char* what, int rc)
 
 int main(int argc, char** argv)
 {
-  if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene> <nFrames> [device]\n", argv[0]); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene> <nFrames> [device] [lookahead]\n", argv[0]); return 2; }
   const std::string path = argv[1];
   const int n_frames = atoi(argv[2]);
   const int device = argc > 3 ? atoi(argv[3]) : 0;
+  const int lookahead = argc > 4 ? atoi(argv[4]) : 1;      // crh_set_lookahead: frames traced ahead per wide batch
   if (n_frames <= 0) { fprintf(stderr, "nFrames must be > 0\n"); return 2; }
 
   FILE* f = fopen(path.c_str(), "rb");
@@ -65,6 +66,7 @@ int main(int argc, char** argv)
   if ((rc = crh_set_camera(c, &cam))) return die(c, "crh_set_camera", rc);
   if ((rc = crh_set_params(c, &par))) return die(c, "crh_set_params", rc);
   if ((rc = crh_build(c))) return die(c, "crh_build", rc);
+  if (lookahead > 1 && (rc = crh_set_lookahead(c, (uint32_t)lookahead))) return die(c, "crh_set_lookahead", rc);
 
   // the render loop of AppViewer::Run in test mode: one Redraw per frame until MaxFramesCount
   const auto t0 = std::chrono::steady_clock::now();

@@ -272,7 +272,7 @@ def test_headless_cpp_driver_matches_oracle(tmp_path, Oracle):
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
     sc = scenes.cornell_box(True, 96, 64)
     path = save_scene(sc, str(tmp_path / "cornell.crhscene"))
-    out = subprocess.check_output([exe, path, "5"], text=True)
+    out = subprocess.check_output([exe, path, "5", "0", "4"], text=True)      # 5 frames, device 0, look-ahead 4
     info = json.loads(out.strip().splitlines()[-1])
     assert info["frames"] == 5 and info["samples"] == 96 * 64 * 5 and info["fps"] > 0
     with open(tmp_path / "Output_cornell_5.pfm", "rb") as f:
