@@ -108,11 +108,11 @@ class Backend:
 
     def set_texture(self, slot, image):
         if image is None:
-            self._call("set_texture", C.c_uint32(slot), None, C.c_uint32(0), C.c_uint32(0))
+            self._call("set_texture", C.c_uint32(slot), None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(3))
         else:
             image = np.ascontiguousarray(image, np.float32)
-            h, w, _ = image.shape
-            self._call("set_texture", C.c_uint32(slot), _fp(image), C.c_uint32(w), C.c_uint32(h))
+            h, w, ch = image.shape                       # (H, W, 3) RGB or (H, W, 4) RGBA
+            self._call("set_texture", C.c_uint32(slot), _fp(image), C.c_uint32(w), C.c_uint32(h), C.c_uint32(ch))
 
     def set_camera(self, cam):
         c = abi.crh_camera()
@@ -166,6 +166,10 @@ class Backend:
     def set_adaptive(self, on=True, tiles_per_iteration=128):
         """AdaptiveScreenSampling / NbRayTracingTiles (SettingsWidget.cxx:427-477); restarts accumulation."""
         self._call("set_adaptive", C.c_int(int(on)), C.c_uint32(int(tiles_per_iteration)))
+
+    def set_show_tiles(self, on=True):
+        """ShowSamplingTiles (SettingsWidget.cxx:443-449): outline the tiles of the last adaptive iteration in read_ldr()."""
+        self._call("set_show_tiles", C.c_int(int(on)))
 
     def tile_stats(self):
         n = C.c_uint32(0)

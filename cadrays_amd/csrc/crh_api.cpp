@@ -53,6 +53,7 @@ struct crh_ctx {
   float4* d_accum = nullptr; uint32_t accumW = 0, accumH = 0;
   float* d_m2 = nullptr;            // running mean of squared luminance (adaptive sampling only)
   float* d_tile_err = nullptr; uint32_t* d_tile_cnt = nullptr; uint32_t tile_stat_cap = 0;
+  bool show_tiles = false; std::vector<uint8_t> last_picked;                            // ShowSamplingTiles: tiles of the last adaptive iteration
   bool adaptive = false; uint32_t adaptive_tiles = 128; uint32_t adaptive_picks = 0;   // NbRayTracingTiles, Halton index
   // speculative look-ahead for the +1-spp-per-Redraw boundary: frames [pending_first, pending_first + pending_n) are traced
   // and wait in the path buffer (batch sample index pending_off ...) to be folded in by the next crh_render calls
@@ -233,7 +234,7 @@ int do_reset(crh_ctx* c)
   int rc = alloc_accum(c); if (rc) return rc;
   CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, c->stream));
   CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, c->stream));
-  c->adaptive_picks = 0; c->pending_n = 0;
+  c->adaptive_picks = 0; c->pending_n = 0; c->last_picked.clear();
   CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
   drain_events(c);
@@ -361,6 +362,7 @@ int adaptive_iteration(crh_ctx* c)
     if (t >= nt) t = nt - 1;
     picked[t] = 1;
   }
+  c->last_picked = picked;
   std::vector<uint32_t> tiles, seeds; uint32_t maxc = 0;
   for (uint32_t i = 0; i < nt; ++i) if (picked[i]) { tiles.push_back(i); maxc = std::max(maxc, cnt[i]); }
   std::vector<uint32_t> table(maxc + 1);
@@ -512,9 +514,10 @@ int crh_set_envmap(crh_ctx* c, const float* rgb, uint32_t w, uint32_t h)
   return CRH_OK;
 }
 
-int crh_set_texture(crh_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uint32_t h)
+int crh_set_texture(crh_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uint32_t h, uint32_t channels)
 {
   if (!c || slot >= 4096u) return fail(c, CRH_E_INVALID, "texture slot out of range");
+  if (rgb && channels != 3u && channels != 4u) return fail(c, CRH_E_INVALID, "texture channels must be 3 or 4");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
   if (c->textures.size() <= slot) c->textures.resize(slot + 1);
@@ -522,7 +525,10 @@ int crh_set_texture(crh_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uin
   t.rgba.clear(); t.w = t.h = 0;
   if (rgb && w && h) {
     t.rgba.resize(4 * (size_t)w * h);
-    for (size_t i = 0; i < (size_t)w * h; ++i) { t.rgba[4 * i] = rgb[3 * i]; t.rgba[4 * i + 1] = rgb[3 * i + 1]; t.rgba[4 * i + 2] = rgb[3 * i + 2]; t.rgba[4 * i + 3] = 1.f; }
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+      t.rgba[4 * i] = rgb[channels * i]; t.rgba[4 * i + 1] = rgb[channels * i + 1]; t.rgba[4 * i + 2] = rgb[channels * i + 2];
+      t.rgba[4 * i + 3] = channels == 4u ? rgb[4 * i + 3] : 1.f;
+    }
     t.w = w; t.h = h;
   }
   c->textures_dirty = true;
@@ -676,6 +682,13 @@ int crh_set_adaptive(crh_ctx* c, int on, uint32_t tiles_per_iteration)
   return do_reset(c);                                   // like every rendering-parameter change, restarts accumulation
 }
 
+int crh_set_show_tiles(crh_ctx* c, int on)
+{
+  if (!c) return CRH_E_INVALID;
+  c->show_tiles = on != 0;                              // display-only: accumulation goes on
+  return CRH_OK;
+}
+
 int crh_set_lookahead(crh_ctx* c, uint32_t frames)
 {
   if (!c || frames == 0) return fail(c, CRH_E_INVALID, "lookahead must be >= 1");
@@ -715,9 +728,16 @@ int crh_read_ldr(crh_ctx* c, uint8_t* out)
   if (!c || !out || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null output");
   CRH_HIP(hipSetDevice(c->device));
   const uint32_t n = c->par.width * c->par.height;
-  int rc = ensure_scratch(c, 3 * (size_t)n); if (rc) return rc;
+  const uint32_t ts = c->par.tile_size, n_tiles = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
+  const bool overlay = c->show_tiles && c->adaptive && c->last_picked.size() == n_tiles;
+  int rc = ensure_scratch(c, 3 * (size_t)n + (overlay ? n_tiles : 0)); if (rc) return rc;
+  uint8_t* d_mask = nullptr;
+  if (overlay) {
+    d_mask = (uint8_t*)c->d_scratch + 3 * (size_t)n;
+    CRH_HIP(hipMemcpyAsync(d_mask, c->last_picked.data(), n_tiles, hipMemcpyHostToDevice, c->stream));
+  }
   Launch L{c->stream, c->grid, false};
-  launch_tonemap(L, c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point);
+  launch_tonemap(L, c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, d_mask, c->par.width, ts);
   CRH_HIP(hipMemcpyAsync(out, c->d_scratch, 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
   return CRH_OK;

@@ -528,7 +528,7 @@ __device__ bool sample_layered(const Bsdf& b, v3 wo, v3& wi, v3& W, bool& inside
     else { k = crh_mul3(k, fresnel_media(wo.z, b.fb)); wi = mirror; delta = true; }
   } else {
     k = crh_scale3(crh_mul3(b.Kt, L.Tc), L.total / L.pt);
-    const float ior = b.fc.y;
+    const float ior = b.fc.x > -2.5f ? 1.0f : b.fc.y;        // no dielectric coat: index-matched, straight through
     const float eta = wo.z > 0.f ? 1.0f / ior : ior;
     const float sinT2 = (eta * eta) * CRH_FMA(-wo.z, wo.z, 1.0f);
     if (!(sinT2 < 1.0f) || !(L.pt > 0.f)) ok = false;
@@ -620,11 +620,11 @@ __device__ __forceinline__ v3 offset_origin(v3 p, v3 dir, v3 ng, float eps)
 
 // Diffuse texture lookup: bilinear, repeat wrap, row 0 of the image = v 1.  The call site is behind
 // a wave-uniform "any texture bound" test.
-__device__ __forceinline__ v3 sample_texture(const DScene& S, uint32_t slot, uint32_t tri, float bu, float bv, float w0, float sc_s, float sc_t)
+__device__ __forceinline__ float4 sample_texture(const DScene& S, uint32_t slot, uint32_t tri, float bu, float bv, float w0, float sc_s, float sc_t)
 {
-  if (slot >= S.n_tex || !S.uvs) return crh_mk3(1.f, 1.f, 1.f);
+  if (slot >= S.n_tex || !S.uvs) return make_float4(1.f, 1.f, 1.f, 1.f);
   const uint4 td = S.tex_desc[slot];
-  if (td.y == 0u) return crh_mk3(1.f, 1.f, 1.f);
+  if (td.y == 0u) return make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 ua = S.uvs[2u * tri], ub = S.uvs[2u * tri + 1u];
   const float ss = sc_s != 0.f ? sc_s : 1.0f, st_ = sc_t != 0.f ? sc_t : 1.0f;
   const float us = CRH_FMA(ub.x, bv, CRH_FMA(ua.z, bu, ua.x * w0)) * ss;
@@ -642,9 +642,10 @@ __device__ __forceinline__ v3 sample_texture(const DScene& S, uint32_t slot, uin
   int y1 = y0 + 1; if (y1 >= H) y1 = 0;
   const float4* tb = S.texels + td.x;
   const float4 p00 = tb[y0 * W + x0], p10 = tb[y0 * W + x1], p01 = tb[y1 * W + x0], p11 = tb[y1 * W + x1];
-  return crh_mk3(lerpf(lerpf(p00.x, p10.x, fx), lerpf(p01.x, p11.x, fx), fy),
-                 lerpf(lerpf(p00.y, p10.y, fx), lerpf(p01.y, p11.y, fx), fy),
-                 lerpf(lerpf(p00.z, p10.z, fx), lerpf(p01.z, p11.z, fx), fy));
+  return make_float4(lerpf(lerpf(p00.x, p10.x, fx), lerpf(p01.x, p11.x, fx), fy),
+                     lerpf(lerpf(p00.y, p10.y, fx), lerpf(p01.y, p11.y, fx), fy),
+                     lerpf(lerpf(p00.z, p10.z, fx), lerpf(p01.z, p11.z, fx), fy),
+                     lerpf(lerpf(p00.w, p10.w, fx), lerpf(p01.w, p11.w, fx), fy));   // RGB images are stored with alpha 1
 }
 
 constexpr uint32_t kGenIters = 32;     // k_raygen: 32 x 256 = 8192 path slots per queue reservation
@@ -829,7 +830,15 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
           bs.ab = mp[5]; bs.fc = mp[6]; bs.fb = mp[7]; }
         if (S.n_tex != 0u) {                                   // wave-uniform: scenes without textures skip the call
           const int slot = (int)mp[1].w - 1;
-          if (slot >= 0) bs.Kd = crh_mul3(bs.Kd, sample_texture(S, (uint32_t)slot, (uint32_t)hk, h.y, h.z, w0, mp[3].w, mp[4].w));
+          if (slot >= 0) {
+            const float4 tx = sample_texture(S, (uint32_t)slot, (uint32_t)hk, h.y, h.z, w0, mp[3].w, mp[4].w);
+            bs.Kd = crh_mul3(bs.Kd, xyz(tx));
+            if (tx.w != 1.0f) {                                // alpha cut-out: the uncovered part transmits
+              bs.Kd = crh_scale3(bs.Kd, tx.w);
+              const float ia = 1.0f - tx.w;
+              bs.Kt = crh_mk3(CRH_FMA(tx.w, bs.Kt.x, ia), CRH_FMA(tx.w, bs.Kt.y, ia), CRH_FMA(tx.w, bs.Kt.z, ia));
+            }
+          }
         }
         const Frame fr = make_frame(ns);
         const v3 wo = to_local(fr, crh_mk3(-d.x, -d.y, -d.z));
@@ -994,8 +1003,10 @@ __device__ __forceinline__ float hable(float x)
   return (CRH_FMA(x, CRH_FMA(A, x, Cc * B), D * E) / CRH_FMA(x, CRH_FMA(A, x, B), D * F)) - E / F;
 }
 __global__ __launch_bounds__(kBlock) void k_tonemap(const float4* __restrict__ accum, uint8_t* __restrict__ out, uint32_t n,
-                                                     int mode, float exposure, float white_point)
+                                                     int mode, float exposure, float white_point,
+                                                     const uint8_t* __restrict__ tile_mask, uint32_t width, uint32_t tile_size)
 {
+  const uint32_t tiles_x = tile_mask ? (width + tile_size - 1u) / tile_size : 0u;
   const float gain = crh_exp(exposure * 0.69314718056f);
   const float wp = hable(white_point > 0.f ? white_point : 1.0f);
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -1009,6 +1020,12 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float4* __restrict__ a
       if (mode == 1) x = hable(x) / wp;
       x = crh_pow(crh_clamp(x, 0.f, 1.0f), 1.0f / 2.2f);
       out[3u * i + k] = (uint8_t)(int)CRH_FMA(x, 255.0f, 0.5f);
+    }
+    if (tile_mask) {                                     // ShowSamplingTiles: red outline around the tiles just sampled
+      const uint32_t px = i % width, py = i / width, lx = px % tile_size, ly = py % tile_size;
+      if (tile_mask[(py / tile_size) * tiles_x + px / tile_size] && (lx == 0u || ly == 0u || lx == tile_size - 1u || ly == tile_size - 1u)) {
+        out[3u * i] = 255; out[3u * i + 1u] = 0; out[3u * i + 2u] = 0;
+      }
     }
   }
 }
@@ -1080,9 +1097,10 @@ void launch_tile_error(const Launch& L, const DScene& S, const float4* accum, co
 {
   hipLaunchKernelGGL(k_tile_error, dim3(n_tiles_total), dim3(kBlock), 0, L.stream, S, accum, m2, tile_err, tile_min_count);
 }
-void launch_tonemap(const Launch& L, const float4* accum, uint8_t* out, uint32_t n, int mode, float exposure, float wp)
+void launch_tonemap(const Launch& L, const float4* accum, uint8_t* out, uint32_t n, int mode, float exposure, float wp,
+                    const uint8_t* tile_mask, uint32_t width, uint32_t tile_size)
 {
-  hipLaunchKernelGGL(k_tonemap, dim3(L.grid), dim3(kBlock), 0, L.stream, accum, out, n, mode, exposure, wp);
+  hipLaunchKernelGGL(k_tonemap, dim3(L.grid), dim3(kBlock), 0, L.stream, accum, out, n, mode, exposure, wp, tile_mask, width, tile_size);
 }
 void launch_hdr(const Launch& L, const float4* accum, float* out, uint32_t n)
 {

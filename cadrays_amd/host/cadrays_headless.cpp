@@ -47,19 +47,38 @@ int main(int argc, char** argv)
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { perror(path.c_str()); return 1; }
   char magic[4]; uint32_t hdr[7];
-  if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "CRHS", 4) != 0 || fread(hdr, 4, 7, f) != 7 || hdr[0] != 1) { fprintf(stderr, "not a .crhscene v1 file\n"); return 1; }
+  if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "CRHS", 4) != 0 || fread(hdr, 4, 7, f) != 7 || (hdr[0] != 1 && hdr[0] != 2)) { fprintf(stderr, "not a .crhscene v1/v2 file\n"); return 1; }
   const uint32_t nV = hdr[1], nT = hdr[2], nM = hdr[3], nL = hdr[4], eW = hdr[5], eH = hdr[6];
   crh_camera cam; crh_params par;
   std::vector<float> pos, nrm, env; std::vector<int32_t> tri; std::vector<crh_bsdf> mats; std::vector<crh_light> lights;
   bool ok = fread(&cam, sizeof cam, 1, f) == 1 && fread(&par, sizeof par, 1, f) == 1 && read_vec(f, pos, 3 * (size_t)nV) && read_vec(f, nrm, 3 * (size_t)nV) &&
             read_vec(f, tri, 4 * (size_t)nT) && read_vec(f, mats, nM) && read_vec(f, lights, nL) && read_vec(f, env, 3 * (size_t)eW * eH);
+  // version 2: texture coordinates, the two-level (per-object transform) description and the Kd textures
+  struct Tex { uint32_t w = 0, h = 0, ch = 0; std::vector<float> texels; };
+  std::vector<float> uv, xform; std::vector<int32_t> tri_obj; std::vector<Tex> textures; uint32_t nO = 0;
+  if (ok && hdr[0] >= 2) {
+    uint32_t ext[3];
+    ok = fread(ext, 4, 3, f) == 3;
+    if (ok && ext[0]) ok = read_vec(f, uv, 2 * (size_t)nV);
+    if (ok && ext[1]) { nO = ext[1]; ok = read_vec(f, tri_obj, nT) && read_vec(f, xform, 12 * (size_t)nO); }
+    if (ok) textures.resize(ext[2]);
+    for (size_t i = 0; ok && i < textures.size(); ++i) {
+      uint32_t d[3];
+      ok = fread(d, 4, 3, f) == 3;
+      if (ok) { textures[i].w = d[0]; textures[i].h = d[1]; textures[i].ch = d[2]; ok = read_vec(f, textures[i].texels, (size_t)d[0] * d[1] * d[2]); }
+    }
+  }
   fclose(f);
   if (!ok) { fprintf(stderr, "truncated scene file\n"); return 1; }
 
   crh_ctx* c = crh_create(device);                       // == driver + viewer + view + FBO (AppViewer.cxx:601-638)
   if (!c) return die(nullptr, "crh_create", CRH_E_DEVICE);
   int rc;
-  if ((rc = crh_set_geometry(c, pos.data(), nrm.data(), nullptr, nV, tri.data(), nT, nullptr, nullptr, 0))) return die(c, "crh_set_geometry", rc);
+  if ((rc = crh_set_geometry(c, pos.data(), nrm.data(), uv.empty() ? nullptr : uv.data(), nV, tri.data(), nT,
+                             nO ? tri_obj.data() : nullptr, nO ? xform.data() : nullptr, nO))) return die(c, "crh_set_geometry", rc);
+  for (size_t i = 0; i < textures.size(); ++i)
+    if (textures[i].w && (rc = crh_set_texture(c, (uint32_t)i, textures[i].texels.data(), textures[i].w, textures[i].h, textures[i].ch)))
+      return die(c, "crh_set_texture", rc);
   if ((rc = crh_set_materials(c, mats.data(), nM))) return die(c, "crh_set_materials", rc);
   if ((rc = crh_set_lights(c, lights.data(), nL))) return die(c, "crh_set_lights", rc);
   if ((rc = crh_set_envmap(c, env.empty() ? nullptr : env.data(), eW, eH))) return die(c, "crh_set_envmap", rc);

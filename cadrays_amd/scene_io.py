@@ -1,6 +1,8 @@
 """Flat binary scene file (.crhscene) for the headless C++ driver (cadrays_amd/host/cadrays_headless.cpp).
-Layout: magic 'CRHS', version u32, counts {nV, nT, nM, nL, envW, envH} u32, crh_camera, crh_params, then
-pos[3nV] nrm[3nV] f32, tri[4nT] i32, crh_bsdf[nM], crh_light[nL], env[3*envW*envH] f32.
+Layout: magic 'CRHS', version u32 (= 2), counts {nV, nT, nM, nL, envW, envH} u32, crh_camera, crh_params, then
+pos[3nV] nrm[3nV] f32, tri[4nT] i32, crh_bsdf[nM], crh_light[nL], env[3*envW*envH] f32; version 2 appends
+{has_uv, nO, nTex} u32, uv[2nV] f32 if has_uv, tri_object[nT] i32 + obj_xform[12nO] f32 if nO > 0 (two-level scene),
+and per texture slot {w, h, channels} u32 + texels[w*h*channels] f32 (w = 0: empty slot).
 (The reference's own on-disk scene format, model.tcl + PLY, is the 'next' row of SURVEY.md section 8f.)"""
 import ctypes as C
 import struct
@@ -33,7 +35,7 @@ def save_scene(scene, path):
     eh, ew = (env.shape[0], env.shape[1]) if env is not None else (0, 0)
     with open(path, "wb") as f:
         f.write(b"CRHS")
-        f.write(struct.pack("<7I", 1, len(scene.pos), len(scene.tri), len(scene.materials), len(scene.lights), ew, eh))
+        f.write(struct.pack("<7I", 2, len(scene.pos), len(scene.tri), len(scene.materials), len(scene.lights), ew, eh))
         f.write(bytes(cam)); f.write(bytes(par))
         f.write(np.ascontiguousarray(scene.pos, np.float32).tobytes())
         f.write(np.ascontiguousarray(scene.nrm, np.float32).tobytes())
@@ -42,4 +44,19 @@ def save_scene(scene, path):
         f.write(bytes(lights)[:C.sizeof(abi.crh_light) * len(scene.lights)])
         if env is not None:
             f.write(np.ascontiguousarray(env, np.float32).tobytes())
+        uv, tobj, xf = scene.uv, getattr(scene, "tri_object", None), getattr(scene, "obj_xform", None)
+        textures = list(getattr(scene, "textures", None) or [])
+        n_obj = len(xf) if (tobj is not None and xf is not None) else 0
+        f.write(struct.pack("<3I", int(uv is not None), n_obj, len(textures)))
+        if uv is not None:
+            f.write(np.ascontiguousarray(uv, np.float32).tobytes())
+        if n_obj:
+            f.write(np.ascontiguousarray(tobj, np.int32).tobytes())
+            f.write(np.ascontiguousarray(xf, np.float32).reshape(-1).tobytes())
+        for t in textures:
+            if t is None:
+                f.write(struct.pack("<3I", 0, 0, 0))
+            else:
+                t = np.ascontiguousarray(t, np.float32)
+                f.write(struct.pack("<3I", t.shape[1], t.shape[0], t.shape[2])); f.write(t.tobytes())
     return path

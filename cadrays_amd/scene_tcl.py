@@ -275,13 +275,15 @@ def read_ply(path):
     return pos, nrm.astype(np.float32), faces, uv
 
 
-def write_ply(path, pos, nrm, faces):
-    """binary little-endian PLY with normals, the layout assimp's 'plyb' exporter writes (AisMesh.cxx:490)."""
+def write_ply(path, pos, nrm, faces, uv=None):
+    """binary little-endian PLY with normals (and s/t texture coordinates when given), the layout assimp's 'plyb'
+    exporter writes (AisMesh.cxx:490)."""
     with open(path, "wb") as f:
         f.write(("ply\nformat binary_little_endian 1.0\ncomment cadrays-hip\nelement vertex %d\nproperty float x\nproperty float y\n"
-                 "property float z\nproperty float nx\nproperty float ny\nproperty float nz\nelement face %d\n"
-                 "property list uchar int vertex_index\nend_header\n" % (len(pos), len(faces))).encode())
-        f.write(np.concatenate([pos, nrm], 1).astype("<f4").tobytes())
+                 "property float z\nproperty float nx\nproperty float ny\nproperty float nz\n%selement face %d\n"
+                 "property list uchar int vertex_index\nend_header\n"
+                 % (len(pos), "property float s\nproperty float t\n" if uv is not None else "", len(faces))).encode())
+        f.write(np.concatenate([pos, nrm] + ([uv] if uv is not None else []), 1).astype("<f4").tobytes())
         rec = np.zeros(len(faces), np.dtype([("n", "u1"), ("i", "<i4", 3)]))
         rec["n"] = 3; rec["i"] = faces
         f.write(rec.tobytes())
@@ -323,6 +325,8 @@ class _Obj:
         self.R, self.s, self.t = np.eye(3), 1.0, np.zeros(3)
         self.bsdf = BSDF.CreateDiffuse(0.8)
         self.displayed = False
+        self.uv = None                                       # (nV, 2) texture coordinates a mesh brings along (AisMesh.cxx:402-410)
+        self.texture, self.tex_on, self.tex_scale = None, True, (1.0, 1.0)   # rttexture state
 
     def world(self):
         return (self.pos * self.s) @ self.R.T + self.t, self.nrm @ self.R.T
@@ -335,14 +339,15 @@ class SceneBuilder:
         self.root, self.sphere_res = root, sphere_res
         self.objs, self.lights, self.light_colors = {}, [], {}
         self.cam = dict(eye=None, at=None, up=(0, 0, 1), proj=None, fovy=45.0, ortho=False, distance=None, size=None)
-        self.depth, self.env_path, self.unsupported = 5, None, []
+        self.depth, self.env_path, self.unsupported, self.adaptive = 5, None, [], False
         self.commands = {k[4:]: getattr(self, k) for k in dir(self) if k.startswith("cmd_")}
 
     # ---- geometry sources
     def cmd_rtmeshread(self, a):
         path, name = a[0], a[1]
-        pos, nrm, faces, _ = read_ply(path)
+        pos, nrm, faces, uv = read_ply(path)
         self.objs[name] = _Obj(pos, nrm, faces)
+        self.objs[name].uv = uv
         self.objs[name].displayed = True                     # rtmeshread displays what it loads (ImportExportPlugin.cxx:132-354)
 
     def cmd_restore(self, a):
@@ -548,6 +553,30 @@ class SceneBuilder:
         for i, k in enumerate(a):
             if k.lower() == "-raydepth":
                 self.depth = int(a[i + 1])
+            elif k.lower() == "-iss":                          # adaptive screen sampling (CornellBox.tcl:79) -> crh_set_adaptive
+                self.adaptive = True
+
+    def cmd_rttexture(self, a):
+        """rttexture <node> [<image file>] [-scale S T] [-on|-off]   (ImportExportPlugin.cxx:608-752)"""
+        if not 2 <= len(a) <= 5:
+            raise TclError("usage: rttexture <node> [file] [-scale S T] [-on|-off]")
+        if a[0] not in self.objs:
+            raise TclError(f"rttexture: no object {a[0]}")
+        o, i = self.objs[a[0]], 1
+        while i < len(a):
+            k = a[i].lower()
+            if k == "-scale":
+                if i + 2 >= len(a) or not (_NUM.fullmatch(a[i + 1]) and _NUM.fullmatch(a[i + 2])):
+                    raise TclError("rttexture: -scale needs two real values")
+                s, t = float(a[i + 1]), float(a[i + 2])
+                o.tex_scale = (s if s > 0 else 1.0, t if t > 0 else 1.0)
+                i += 3
+            elif k in ("-on", "-off"):
+                o.tex_on = k == "-on"; i += 1
+            else:                                             # like the reference, the file is always the second word
+                if not os.path.exists(a[1]):
+                    raise TclError(f"rttexture: image file {a[1]} not found")
+                o.texture = a[1]; i += 1
 
     def cmd_vtextureenv(self, a):
         self.env_path = a[1] if len(a) > 1 and a[0].lower() == "on" else None
@@ -556,20 +585,33 @@ class SceneBuilder:
         return ""
 
     cmd_vsetdispmode = cmd_vaspects = cmd_vvbo = cmd_rtmodel = cmd_rtgroup = cmd_vfps = cmd_vdump = cmd_vtop = cmd_vaxo = _noop
-    cmd_vzbufftrihedron = cmd_vsetcolor = cmd_vselect = cmd_vupdate = cmd_vrepaint = cmd_rtdisplay = cmd_rttexture = _noop
+    cmd_vzbufftrihedron = cmd_vsetcolor = cmd_vselect = cmd_vupdate = cmd_vrepaint = cmd_rtdisplay = _noop
 
     # ---- result
     def snapshot(self, width=512, height=512, name="tcl_scene"):
-        pos, nrm, tri, mats, nv = [], [], [], [], 0
-        for o in self.objs.values():
+        import dataclasses
+        pos, nrm, tri, mats, uvs, nv = [], [], [], [], [], 0
+        textures, slots = [], {}
+        for oname, o in self.objs.items():
             if not o.displayed or len(o.faces) == 0:
                 continue
             p, n = o.world()
             t = np.empty((len(o.faces), 4), np.int32); t[:, :3] = o.faces + nv; t[:, 3] = len(mats)
-            pos.append(p); nrm.append(n); tri.append(t); mats.append(o.bsdf); nv += len(p)
+            bsdf = o.bsdf
+            if o.texture and o.tex_on:
+                if o.uv is None:                              # CAD shapes get their uv from OCCT's surface parametrisation (DataNode.cxx:214-260)
+                    self.unsupported.append(f"rttexture {oname}: object has no texture coordinates")
+                else:
+                    if o.texture not in slots:
+                        slots[o.texture] = len(textures); textures.append(load_texture(o.texture))
+                    # meshes keep their own uv; -scale only re-parametrises CAD shapes (DataNode.cxx:219-222)
+                    bsdf = dataclasses.replace(bsdf, texture=slots[o.texture], texture_scale=(1.0, 1.0))
+            pos.append(p); nrm.append(n); tri.append(t); mats.append(bsdf); nv += len(p)
+            uvs.append(o.uv if o.uv is not None else np.zeros((len(p), 2), np.float32))
         if not pos:
             raise TclError("no displayed geometry")
         pos = np.concatenate(pos).astype(np.float32); nrm = np.concatenate(nrm).astype(np.float32); tri = np.concatenate(tri)
+        uv = np.concatenate(uvs).astype(np.float32) if textures else None
         c = self.cam
         proj = np.array(c["proj"] if c["proj"] is not None else (0.0, -1.0, 0.0), float)
         if c["eye"] is not None and c["at"] is not None:
@@ -591,11 +633,30 @@ class SceneBuilder:
             lights.append(mk(l["vec"], smoothness=l["sm"], intensity=l["int"], color=l["color"]))
         env = None
         if self.env_path and os.path.exists(self.env_path):
-            from PIL import Image
-            im = np.asarray(Image.open(self.env_path).convert("RGB"), np.float32) / 255.0
-            env = np.ascontiguousarray(im * im)                # OCCT linearises LDR env texels by squaring [OCCT-ext]
-        return Scene(pos, nrm, tri, mats, lights=lights, env=env, camera=cam,
+            env = np.ascontiguousarray(load_texture(self.env_path)[..., :3])   # LDR env texels are linearised by squaring [OCCT-ext]
+        return Scene(pos, nrm, tri, mats, lights=lights, env=env, camera=cam, uv=uv, textures=textures,
                      params=Params(width=width, height=height, max_depth=self.depth), name=name)
+
+
+def load_texture(path):
+    """8-bit image file -> linear float texels the way the path tracer consumes them: rgb squared ("de-gamma for
+    gamma = 2", the same rule as the environment map [OCCT-ext]); an alpha channel is kept as it is (cut-out)."""
+    from PIL import Image
+    im = Image.open(path)
+    if im.mode in ("RGBA", "LA", "PA") or "transparency" in im.info:
+        a = np.asarray(im.convert("RGBA"), np.float32) / 255.0
+        return np.ascontiguousarray(np.concatenate([a[..., :3] * a[..., :3], a[..., 3:]], 2))
+    a = np.asarray(im.convert("RGB"), np.float32) / 255.0
+    return np.ascontiguousarray(a * a)
+
+
+def save_texture(path, texels):
+    """inverse of load_texture up to the 8-bit quantisation"""
+    from PIL import Image
+    t = np.asarray(texels, np.float32)
+    rgb = np.sqrt(np.clip(t[..., :3], 0.0, 1.0))
+    out = rgb if t.shape[2] == 3 else np.concatenate([rgb, np.clip(t[..., 3:], 0.0, 1.0)], 2)
+    Image.fromarray((out * 255.0 + 0.5).astype(np.uint8), "RGB" if t.shape[2] == 3 else "RGBA").save(path)
 
 
 def read_scene(path, width=512, height=512, sphere_res=(48, 24)):
@@ -609,8 +670,15 @@ def read_scene(path, width=512, height=512, sphere_res=(48, 24)):
 
 def write_scene(scene, directory, object_names=None):
     """Write `scene` the way ImportExport::Export does (ImportExport.cxx:350-607): model.tcl + meshes/<name>.ply,
-    one mesh per material."""
+    one mesh per material, + textures/ (Kd maps as `rttexture` lines, ImportExport.cxx:235-264; an LDR environment as
+    `vtextureenv on`, :509)."""
     os.makedirs(os.path.join(directory, "meshes"), exist_ok=True)
+    textures = list(getattr(scene, "textures", None) or [])
+    if textures or (scene.env is not None and float(np.max(scene.env)) <= 1.0):
+        os.makedirs(os.path.join(directory, "textures"), exist_ok=True)
+    for slot, t in enumerate(textures):
+        if t is not None:
+            save_texture(os.path.join(directory, "textures", f"tex{slot}.png"), t)
     lines = ["variable Root [file dirname [file normalize [info script]]]", "", "# Restore exported meshes"]
     names = []
     for m in range(len(scene.materials)):
@@ -619,7 +687,8 @@ def write_scene(scene, directory, object_names=None):
             continue
         used, inv = np.unique(sel[:, :3], return_inverse=True)
         name = (object_names or {}).get(m, f"Mesh{m}")
-        write_ply(os.path.join(directory, "meshes", name + ".ply"), scene.pos[used], scene.nrm[used], inv.reshape(-1, 3).astype(np.int32))
+        write_ply(os.path.join(directory, "meshes", name + ".ply"), scene.pos[used], scene.nrm[used], inv.reshape(-1, 3).astype(np.int32),
+                  scene.uv[used] if scene.uv is not None else None)
         lines.append(f"rtmeshread $Root/meshes/{name}.ply {name} -group ")
         names.append((name, scene.materials[m]))
     g = lambda v: repr(float(np.float32(v)))
@@ -634,6 +703,10 @@ def write_scene(scene, directory, object_names=None):
         for layer, fr in (("coat", b.FresnelCoat), ("base", b.FresnelBase)):
             kind = {"schlick": "Schlick", "constant": "Constant", "conductor": "Conductor", "dielectric": "Dielectric"}[fr.kind]
             lines.append(f"vbsdf {name} -{layer}Fresnel {kind} " + " ".join(g(x) for x in fr.data) + " -noupdate")
+        if b.texture >= 0 and b.texture < len(textures) and textures[b.texture] is not None and scene.uv is not None:
+            lines += ["rtmodel -sync default", f'rttexture {name} "$Root/textures/tex{b.texture}.png"']
+            if tuple(b.texture_scale) != (1.0, 1.0):
+                lines.append(f"rttexture {name} -scale {b.texture_scale[0]!r} {b.texture_scale[1]!r}")
     c = scene.camera
     eye, d = np.array(c.eye, float), np.array(c.dir, float)
     at = eye + d
@@ -649,6 +722,9 @@ def write_scene(scene, directory, object_names=None):
         kind = "positional position" if l.is_point else "directional direction"
         lines.append(f"vlight add {kind} " + " ".join(repr(float(x)) for x in l.vec) + f" smoothness {l.smoothness!r} intensity {l.intensity!r}")
         lines.append(f"rtlight {i} -color " + " ".join(repr(float(x)) for x in l.color))
+    if scene.env is not None and float(np.max(scene.env)) <= 1.0:      # the reference only loads 8-bit png/jpg environments
+        save_texture(os.path.join(directory, "textures", "env.png"), scene.env)
+        lines.append("vtextureenv on $Root/textures/env.png")
     lines.append(f"vrenderparams -ray -gi -rayDepth {scene.params.max_depth}")
     path = os.path.join(directory, "model.tcl")
     with open(path, "w") as f:

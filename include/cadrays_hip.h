@@ -144,10 +144,11 @@ CRH_API int crh_set_lights(crh_ctx* ctx, const crh_light* l, uint32_t n);
 /* == V3d_View::SetTextureEnv (LightSourcesEditor.cxx:339-354); rgb = W*H*3 linear float
  * lat-long, NULL = constant crh_params.background */
 CRH_API int crh_set_envmap(crh_ctx* ctx, const float* rgb, uint32_t w, uint32_t h);
-/* == Graphic3d_AspectFillArea3d::SetTextureMap (AisMesh.cxx:340-345, ImportExportPlugin.cxx:737-742): linear float RGB
- * image for texture slot `slot` (row 0 = top, v = 1); NULL clears the slot.  Needs uv in crh_set_geometry.  The
- * texel multiplies Kd (bilinear, repeat wrap). */
-CRH_API int crh_set_texture(crh_ctx* ctx, uint32_t slot, const float* rgb, uint32_t w, uint32_t h);
+/* == Graphic3d_AspectFillArea3d::SetTextureMap (AisMesh.cxx:340-345, ImportExportPlugin.cxx:737-742): linear float
+ * image for texture slot `slot`, `channels` = 3 (RGB) or 4 (RGBA) floats per texel (row 0 = top, v = 1); NULL clears
+ * the slot.  Needs uv in crh_set_geometry.  The texel (bilinear, repeat wrap) multiplies Kd; the alpha a of an RGBA
+ * image cuts the surface out: Kd *= a, Kt = (1 - a) + a * Kt. */
+CRH_API int crh_set_texture(crh_ctx* ctx, uint32_t slot, const float* texels, uint32_t w, uint32_t h, uint32_t channels);
 /* == Graphic3d_Camera setters (AppViewer.cxx:993-1042) */
 CRH_API int crh_set_camera(crh_ctx* ctx, const crh_camera* cam);
 /* == ChangeRenderingParams() field writes (SettingsWidget.cxx:263-477) */
@@ -169,6 +170,10 @@ CRH_API int crh_render_tiles(crh_ctx* ctx, const uint32_t* tile_ids, uint32_t n_
  * tiles drawn with probability proportional to their estimated error instead of on the whole target.
  * Changing it restarts accumulation. */
 CRH_API int crh_set_adaptive(crh_ctx* ctx, int on, uint32_t tiles_per_iteration);
+/* == Graphic3d_RenderingParams::ShowSamplingTiles ("Show distribution", SettingsWidget.cxx:443-449; debug view of the
+ * adaptive sampler): with `on`, crh_read_ldr outlines in red (255,0,0) the tiles the most recent adaptive iteration
+ * sampled.  Only the LDR read-out changes; the accumulator and crh_read_hdr never see the overlay. */
+CRH_API int crh_set_show_tiles(crh_ctx* ctx, int on);
 /* Speculative look-ahead for the +1-spp-per-Redraw() usage (AppViewer.cxx:1045-1047): with frames > 1, crh_render traces the
  * next `frames` whole-frame samples in ONE wide batch (late bounces stay wide) and keeps their radiance in the path buffer;
  * each call folds in only the samples it asked for, so the image after every call is bit-identical to frames = 1.  Any

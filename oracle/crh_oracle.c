@@ -64,7 +64,7 @@ typedef struct orc_ctx {
   float* pos; float* nrm; float* uv; int32_t* tri;
   crh_bsdf* mats; crh_light* lights;
   float* env; uint32_t envW, envH;
-  struct { float* rgb; uint32_t w, h; } tex[64]; uint32_t nTex;
+  struct { float* rgb; uint32_t w, h, ch; } tex[64]; uint32_t nTex;   /* ch = 3 (RGB) or 4 (RGBA) floats per texel */
   crh_camera cam; crh_params par;
   /* derived */
   qnode* nodes; uint32_t nNodes; qtri* qtris; uint32_t nQT;
@@ -81,6 +81,7 @@ typedef struct orc_ctx {
   float* accum;     /* W*H*4 */
   float* m2;        /* W*H: running mean of squared luminance (adaptive sampling) */
   int adaptive; uint32_t adaptive_tiles, adaptive_picks;
+  int show_tiles; uint8_t* last_picked; uint32_t last_picked_n;   /* ShowSamplingTiles overlay */
   crh_stats st;
   char err[256];
 } orc_ctx;
@@ -607,7 +608,7 @@ static int sample_layered(const bsdf_t* b, v3 wo, v3* wi, v3* W, int* inside, in
     else { k = crh_mul3(k, fresnel_media(wo.z, b->fb)); *wi = mirror; *delta = 1; }
   } else {                                                    /* specular transmission */
     k = crh_scale3(crh_mul3(b->Kt, L.Tc), L.total / L.pt);
-    float ior = b->fc[1];
+    float ior = b->fc[0] > -2.5f ? 1.0f : b->fc[1];         /* no dielectric coat: index-matched, straight through */
     float eta = wo.z > 0.f ? 1.0f / ior : ior;
     float sinT2 = (eta * eta) * CRH_FMA(-wo.z, wo.z, 1.0f);
     if (!(sinT2 < 1.0f) || !(L.pt > 0.f)) ok = 0;
@@ -634,7 +635,8 @@ static void load_bsdf(const orc_ctx* c, int32_t mat, bsdf_t* b)
 }
 
 /* diffuse texture (reference AisMesh.cxx:321-346, rttexture -scale ImportExportPlugin.cxx:679-727):
- * Kd *= bilinear texel at the repeat-wrapped, scaled, barycentrically interpolated uv; row 0 of the image is v = 1 */
+ * Kd *= bilinear texel at the repeat-wrapped, scaled, barycentrically interpolated uv; row 0 of the image is v = 1.
+ * An RGBA texture's alpha a cuts the surface out: Kd *= a, Kt = (1 - a) + a * Kt  (alpha -> transmission) */
 static float lerpf(float a, float b, float t);
 static void apply_texture(const orc_ctx* c, const int32_t* ti, float w0, float u, float v, bsdf_t* b)
 {
@@ -654,12 +656,20 @@ static void apply_texture(const orc_ctx* c, const int32_t* ti, float w0, float u
   float fx = x - xf, fy = y - yf;
   int x0 = (int)xf; if (x0 < 0) x0 += W; if (x0 >= W) x0 -= W; int x1 = x0 + 1; if (x1 >= W) x1 = 0;
   int y0 = (int)yf; if (y0 < 0) y0 += H; if (y0 >= H) y0 -= H; int y1 = y0 + 1; if (y1 >= H) y1 = 0;
-  const float* img = c->tex[slot].rgb;
-  const float* p00 = &img[3 * (y0 * W + x0)]; const float* p10 = &img[3 * (y0 * W + x1)];
-  const float* p01 = &img[3 * (y1 * W + x0)]; const float* p11 = &img[3 * (y1 * W + x1)];
+  const float* img = c->tex[slot].rgb; const int ch = (int)c->tex[slot].ch;
+  const float* p00 = &img[ch * (y0 * W + x0)]; const float* p10 = &img[ch * (y0 * W + x1)];
+  const float* p01 = &img[ch * (y1 * W + x0)]; const float* p11 = &img[ch * (y1 * W + x1)];
   b->Kd = crh_mul3(b->Kd, crh_mk3(lerpf(lerpf(p00[0], p10[0], fx), lerpf(p01[0], p11[0], fx), fy),
                                   lerpf(lerpf(p00[1], p10[1], fx), lerpf(p01[1], p11[1], fx), fy),
                                   lerpf(lerpf(p00[2], p10[2], fx), lerpf(p01[2], p11[2], fx), fy)));
+  if (ch == 4) {
+    float a = lerpf(lerpf(p00[3], p10[3], fx), lerpf(p01[3], p11[3], fx), fy);
+    if (a != 1.0f) {
+      b->Kd = crh_scale3(b->Kd, a);
+      float ia = 1.0f - a;
+      b->Kt = crh_mk3(CRH_FMA(a, b->Kt.x, ia), CRH_FMA(a, b->Kt.y, ia), CRH_FMA(a, b->Kt.z, ia));
+    }
+  }
 }
 
 /* ================================================================== lights / env (a11, a12) */
@@ -966,7 +976,7 @@ ORC_API void orc_destroy(orc_ctx* c)
 {
   if (!c) return;
   free(c->pos); free(c->nrm); free(c->uv); free(c->tri); free(c->mats); free(c->lights); free(c->env);
-  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->xf); free(c->tri_obj); free(c->inst); free(c);
+  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->last_picked); free(c->xf); free(c->tri_obj); free(c->inst); free(c);
 }
 ORC_API const char* orc_last_error(orc_ctx* c) { return c ? c->err : "null ctx"; }
 
@@ -1015,11 +1025,11 @@ ORC_API int orc_set_envmap(orc_ctx* c, const float* rgb, uint32_t w, uint32_t h)
   if (rgb && w && h) { c->env = (float*)dup_mem(rgb, sizeof(float) * 3 * (size_t)w * h); c->envW = w; c->envH = h; }
   return 0;
 }
-ORC_API int orc_set_texture(orc_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uint32_t h)
+ORC_API int orc_set_texture(orc_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uint32_t h, uint32_t channels)
 {
-  if (!c || slot >= 64u) return CRH_E_INVALID;
+  if (!c || slot >= 64u || (rgb && channels != 3u && channels != 4u)) return CRH_E_INVALID;
   free(c->tex[slot].rgb); c->tex[slot].rgb = NULL; c->tex[slot].w = c->tex[slot].h = 0;
-  if (rgb && w && h) { c->tex[slot].rgb = (float*)dup_mem(rgb, sizeof(float) * 3 * (size_t)w * h); c->tex[slot].w = w; c->tex[slot].h = h; }
+  if (rgb && w && h) { c->tex[slot].rgb = (float*)dup_mem(rgb, sizeof(float) * channels * (size_t)w * h); c->tex[slot].w = w; c->tex[slot].h = h; c->tex[slot].ch = channels; }
   if (slot + 1 > c->nTex) c->nTex = slot + 1;
   return 0;
 }
@@ -1029,6 +1039,7 @@ ORC_API int orc_reset(orc_ctx* c)
   if (!c) return CRH_E_INVALID;
   free(c->accum); c->accum = (float*)calloc((size_t)c->par.width * c->par.height * 4, sizeof(float));
   free(c->m2); c->m2 = (float*)calloc((size_t)c->par.width * c->par.height, sizeof(float)); c->adaptive_picks = 0;
+  free(c->last_picked); c->last_picked = NULL; c->last_picked_n = 0;
   memset(&c->st, 0, sizeof c->st);
   return 0;
 }
@@ -1105,7 +1116,8 @@ static int adaptive_iteration(orc_ctx* c)
   n = 0;
   for (uint32_t i = 0; i < nt; ++i) if (picked[i]) { tiles[n] = i; seeds[n] = frame_seed(c->par.seed, cnt[i]); ++n; }
   int rc = render_tiles(c, tiles, n, 0, 1, seeds);
-  free(err); free(cnt); free(cdf); free(picked); free(tiles); free(seeds);
+  free(c->last_picked); c->last_picked = picked; c->last_picked_n = nt;
+  free(err); free(cnt); free(cdf); free(tiles); free(seeds);
   return rc;
 }
 
@@ -1115,6 +1127,7 @@ ORC_API int orc_set_adaptive(orc_ctx* c, int on, uint32_t tiles_per_iteration)
   c->adaptive = on != 0; if (on) c->adaptive_tiles = tiles_per_iteration;
   return orc_reset(c);
 }
+ORC_API int orc_set_show_tiles(orc_ctx* c, int on) { if (!c) return CRH_E_INVALID; c->show_tiles = on != 0; return 0; }
 ORC_API int orc_get_tile_stats(orc_ctx* c, float* err, uint32_t* counts, uint32_t* n_tiles)
 {
   if (!c || !c->accum) return CRH_E_INVALID;
@@ -1146,6 +1159,14 @@ ORC_API int orc_read_ldr(orc_ctx* c, uint8_t* out)
   if (!c || !c->accum) return CRH_E_INVALID;
   size_t n = (size_t)c->par.width * c->par.height;
   for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) out[3 * i + k] = to_ldr(&c->par, c->accum[4 * i + k]);
+  uint32_t ts = c->par.tile_size, tx = (c->par.width + ts - 1) / ts, ty = (c->par.height + ts - 1) / ts;
+  if (c->show_tiles && c->adaptive && c->last_picked && c->last_picked_n == tx * ty)
+    for (uint32_t y = 0; y < c->par.height; ++y) for (uint32_t x = 0; x < c->par.width; ++x) {
+      uint32_t lx = x % ts, ly = y % ts;
+      if (c->last_picked[(y / ts) * tx + x / ts] && (lx == 0 || ly == 0 || lx == ts - 1 || ly == ts - 1)) {
+        uint8_t* o = &out[3 * ((size_t)y * c->par.width + x)]; o[0] = 255; o[1] = 0; o[2] = 0;
+      }
+    }
   return 0;
 }
 ORC_API int orc_get_stats(orc_ctx* c, crh_stats* s) { if (!c || !s) return CRH_E_INVALID; *s = c->st; return 0; }

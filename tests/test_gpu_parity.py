@@ -285,6 +285,27 @@ def test_headless_cpp_driver_matches_oracle(tmp_path, Oracle):
     assert float(open(tmp_path / "Output_cornell_5.txt").read()) > 0
 
 
+def test_headless_cpp_driver_v2_scene_textures_and_object_transforms(tmp_path, Oracle):
+    """.crhscene v2: uv + RGBA / RGB Kd textures + the two-level description travel to the C++ driver"""
+    import dataclasses, json, os, subprocess
+    from cadrays_amd.scene_io import save_scene
+    from test_textures import alpha_room
+    from test_two_level import moved_xforms
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cadrays_amd", "host", "cadrays_headless")
+    sc = alpha_room()
+    tri_obj = sc.tri[:, 3].astype(np.int32)
+    sc = dataclasses.replace(sc, tri_object=tri_obj, obj_xform=moved_xforms(int(tri_obj.max()) + 1))
+    path = save_scene(sc, str(tmp_path / "room.crhscene"))
+    out = subprocess.check_output([exe, path, "3"], text=True)
+    assert json.loads(out.strip().splitlines()[-1])["samples"] == sc.params.width * sc.params.height * 3
+    with open(tmp_path / "Output_room_3.pfm", "rb") as f:
+        f.readline(); w, h = map(int, f.readline().split()); f.readline()
+        img = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]
+    o = Oracle().load_scene(sc); o.render(3)
+    assert np.array_equal(bits(img), bits(o.read_hdr()))
+
+
 def test_device_framebuffer_view_and_nccl_reduce(view_cls):
     """bench.py's multi-GPU plumbing on one GPU: zero-copy torch view of crh_accum_device_ptr + an RCCL
     (backend 'nccl') reduce in a single-rank process group."""

@@ -139,3 +139,76 @@ def test_parsed_scene_renders_bit_exact_on_gpu(tmp_path, hip_lib, oracle_lib):
     v = View(0).load_scene(back); v.render(3)
     o = oracle_lib.Oracle().load_scene(back); o.render(3)
     assert np.array_equal(v.read_hdr().view(np.uint32), o.read_hdr().view(np.uint32))
+
+
+def _textured_export_scene():
+    import dataclasses
+    sc = scenes.cornell_box(True, 64, 64)
+    uv = np.zeros((len(sc.pos), 2), np.float32)
+    uv[:, 0] = sc.pos[:, 0] + 0.25 * sc.pos[:, 2]; uv[:, 1] = sc.pos[:, 1] - 0.5 * sc.pos[:, 2]
+    r = np.random.default_rng(11)
+    q = lambda a: (np.round(np.sqrt(a) * 255.0) / 255.0).astype(np.float32) ** 2     # values an 8-bit file can hold exactly
+    rgb = q(r.random((8, 16, 3)).astype(np.float32))
+    rgba = np.concatenate([q(r.random((4, 4, 3)).astype(np.float32)), (np.round(r.random((4, 4, 1)) * 255) / 255).astype(np.float32)], 2)
+    mats = list(sc.materials)
+    mats[2] = dataclasses.replace(mats[2], texture=0)
+    mats[0] = dataclasses.replace(mats[0], texture=1)
+    env = q(r.random((8, 16, 3)).astype(np.float32))
+    return dataclasses.replace(sc, materials=mats, uv=uv, textures=[rgb, rgba], env=env)
+
+
+def test_textures_and_uv_round_trip_through_the_export_layout(tmp_path):
+    """rttexture lines + textures/*.png + s/t in the PLYs (ImportExport.cxx:235-264, :509; AisMesh.cxx:402-410)"""
+    sc = _textured_export_scene()
+    path = write_scene(sc, str(tmp_path))
+    text = open(path).read()
+    assert 'rttexture Mesh2 "$Root/textures/tex0.png"' in text and "vtextureenv on $Root/textures/env.png" in text
+    assert os.path.exists(tmp_path / "textures" / "tex1.png")
+    back, b = read_scene(path, 64, 64)
+    assert not b.unsupported
+    by_slot = {m.texture: m for m in back.materials if m.texture >= 0}
+    assert len(by_slot) == 2 and len(back.textures) == 2
+    # slots are renumbered in order of first use; compare by content
+    want = {3: sc.textures[0], 4: sc.textures[1]}
+    got = {t.shape[2]: t for t in back.textures}
+    for ch in (3, 4):
+        np.testing.assert_allclose(got[ch], want[ch], atol=1e-6)
+    np.testing.assert_allclose(back.env, sc.env, atol=1e-6)
+    # uv travel with their vertices
+    key = lambda s: sorted(map(tuple, np.round(np.concatenate([s.pos[s.tri[:, :3]].reshape(len(s.tri), 9), s.uv[s.tri[:, :3]].reshape(len(s.tri), 6)], 1), 5).tolist()))
+    assert key(back) == key(sc)
+
+
+def test_rttexture_command_semantics(tmp_path):
+    from cadrays_amd.scene_tcl import save_texture
+    pos, nrm, tri = scenes.gen_scene(4, 2, 1)
+    uv = np.random.default_rng(0).random((len(pos), 2)).astype(np.float32)
+    write_ply(str(tmp_path / "m.ply"), pos, nrm, tri[:, :3], uv)
+    write_ply(str(tmp_path / "n.ply"), pos, nrm, tri[:, :3])
+    save_texture(str(tmp_path / "t.png"), np.full((2, 2, 3), 0.25, np.float32))
+    s = tmp_path / "s.tcl"
+    s.write_text(f'''
+      rtmeshread {tmp_path}/m.ply A
+      rtmeshread {tmp_path}/n.ply B
+      box c 1 1 1
+      vdisplay c
+      rttexture A "{tmp_path}/t.png"
+      rttexture A -scale 2 3
+      rttexture B {tmp_path}/t.png
+      rttexture c {tmp_path}/t.png
+      vrenderparams -ray -gi -rayDepth 7 -iss
+    ''')
+    sc, b = read_scene(str(s), 32, 32)
+    assert b.adaptive and sc.params.max_depth == 7
+    assert sc.materials[0].texture == 0 and sc.materials[0].texture_scale == (1.0, 1.0)   # meshes keep their uv: -scale re-parametrises CAD shapes only
+    assert sc.materials[1].texture == -1 and sc.materials[2].texture == -1
+    assert len(b.unsupported) == 2 and all("no texture coordinates" in u for u in b.unsupported)
+    np.testing.assert_allclose(sc.textures[0], 0.25, atol=2e-3)
+    assert np.array_equal(sc.uv[:len(pos)], uv) and not sc.uv[len(pos):].any()
+    # -off keeps the map but disables it; a missing file is an error like the reference's NoImageFile
+    s.write_text(f'rtmeshread {tmp_path}/m.ply A\nrttexture A {tmp_path}/t.png\nrttexture A -off\n')
+    sc2, _ = read_scene(str(s), 32, 32)
+    assert sc2.materials[0].texture == -1 and sc2.uv is None
+    s.write_text(f'rtmeshread {tmp_path}/m.ply A\nrttexture A {tmp_path}/missing.png\n')
+    with pytest.raises(TclError):
+        read_scene(str(s), 32, 32)

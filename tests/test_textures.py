@@ -91,3 +91,59 @@ def test_textured_room_gpu_bit_exact(hip_lib, oracle_lib):
     v.set_texture(0, None); v.render(2)
     o2 = oracle_lib.Oracle().load_scene(dataclasses.replace(sc, textures=[None, sc.textures[1]])); o2.render(2)
     assert np.array_equal(v.read_hdr().view(np.uint32), o2.read_hdr().view(np.uint32))
+
+
+# ---- RGBA textures: alpha cuts the surface out (Kd *= a, Kt = (1 - a) + a * Kt)
+def alpha_quad_scene(alpha_tex, res=16):
+    """textured quad (white RGB) in front of a black-ish floor, lit by a unit sky from everywhere"""
+    sc = textured_quad(alpha_tex, kd=0.9, res=res)
+    return sc
+
+
+def test_alpha_one_is_bitwise_the_rgb_texture(oracle_lib):
+    rgb = quadrant_texture() * 0.8 + 0.1
+    rgba = np.concatenate([rgb, np.ones((8, 8, 1), np.float32)], 2)
+    a = oracle_lib.Oracle().load_scene(textured_quad(rgb)); a.render(3)
+    b = oracle_lib.Oracle().load_scene(textured_quad(rgba)); b.render(3)
+    assert np.array_equal(a.read_hdr(), b.read_hdr())
+
+
+def test_alpha_zero_is_invisible_and_half_alpha_mixes(oracle_lib):
+    """under a unit sky: an opaque Lambert plane returns Kd, a fully cut-out one the sky itself (1), alpha 0.5 the mean"""
+    def run(alpha):
+        t = np.ones((4, 4, 4), np.float32); t[..., 3] = alpha
+        sc = textured_quad(t, kd=0.6, res=16)
+        sc = dataclasses.replace(sc, params=dataclasses.replace(sc.params, max_depth=4))
+        o = oracle_lib.Oracle().load_scene(sc); o.render(64)
+        return o.read_hdr()[4:12, 4:12].mean()
+    assert abs(run(1.0) - 0.6) < 1e-5
+    assert abs(run(0.0) - 1.0) < 1e-5
+    assert abs(run(0.5) - 0.8) < 0.02                      # 0.5 * Kd + 0.5 * transmitted sky, stochastic lobe choice
+
+
+def alpha_room():
+    sc = textured_room()
+    r = np.random.default_rng(5)
+    t = sc.textures[0]
+    a = (r.random(t.shape[:2] + (1,)) > 0.4).astype(np.float32) * 0.75 + 0.25 * r.random(t.shape[:2] + (1,)).astype(np.float32)
+    return dataclasses.replace(sc, textures=[np.concatenate([t, a.astype(np.float32)], 2), sc.textures[1]])
+
+
+def test_set_texture_rejects_bad_channel_count(oracle_lib):
+    o = oracle_lib.Oracle()
+    with pytest.raises(Exception):
+        o.set_texture(0, np.ones((4, 4, 2), np.float32))
+
+
+@pytest.mark.gpu
+def test_alpha_room_gpu_bit_exact(hip_lib, oracle_lib):
+    from cadrays_amd.view import View
+    sc = alpha_room()
+    v = View(0).load_scene(sc); v.render(4)
+    o = oracle_lib.Oracle().load_scene(sc); o.render(4)
+    a, b = v.read_hdr(), o.read_hdr()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    p = oracle_lib.Oracle().load_scene(textured_room()); p.render(4)
+    assert not np.array_equal(b, p.read_hdr())              # the alpha channel did change the light transport
+    with pytest.raises(Exception):
+        v.set_texture(0, np.ones((4, 4, 2), np.float32))
