@@ -72,6 +72,8 @@ __device__ __forceinline__ void lds_append(bool pred, uint32_t value, uint32_t* 
 constexpr uint32_t kPoolChunk = CRH_POOL_CHUNK;   // rays a wavefront takes from the global cursor per atomic
 constexpr uint32_t kDone = 0xFFFFFFFFu;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float inv_dir(float d)
 { return 1.0f / (crh_abs(d) < kDirEps ? (d < 0.f ? -kDirEps : kDirEps) : d); }
 
@@ -183,17 +185,21 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float ax = __uint_as_float((ew & 0xffu) << 23) * ix, ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * iy,
                   az = __uint_as_float(((ew >> 16) & 0xffu) << 23) * iz;
       const float bx = CRH_FMA(n0.x, ix, nox), by = CRH_FMA(n0.y, iy, noy), bz = CRH_FMA(n0.z, iz, noz);
-      const uint32_t lx = __float_as_uint(n1.x), ly = __float_as_uint(n1.y), lz = __float_as_uint(n1.z);
-      const uint32_t hx = __float_as_uint(n2.x), hy = __float_as_uint(n2.y), hz = __float_as_uint(n2.z);
+      // Along a negative direction the far plane is the one the ray enters through: swap the lo / hi byte words of that axis
+      // once per node instead of a min + max per child and axis (fma is monotonic in q, so the values are the same bits).
+      const bool sx = ix < 0.f, sy = iy < 0.f, sz = iz < 0.f;
+      const uint32_t lx = __float_as_uint(sx ? n2.x : n1.x), ly = __float_as_uint(sy ? n2.y : n1.y), lz = __float_as_uint(sz ? n2.z : n1.z);
+      const uint32_t hx = __float_as_uint(sx ? n1.x : n2.x), hy = __float_as_uint(sy ? n1.y : n2.y), hz = __float_as_uint(sz ? n1.z : n2.z);
+      const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
       uint32_t key[4];
 #define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))      /* v_cvt_f32_ubyteK */
 #define CRH_CHILD(K, REF)                                                                                    \
       {                                                                                                     \
-        const float a0 = CRH_FMA(CRH_QB(lx, K), ax, bx), a1 = CRH_FMA(CRH_QB(hx, K), ax, bx);             \
-        const float b0 = CRH_FMA(CRH_QB(ly, K), ay, by), b1 = CRH_FMA(CRH_QB(hy, K), ay, by);             \
-        const float c0 = CRH_FMA(CRH_QB(lz, K), az, bz), c1 = CRH_FMA(CRH_QB(hz, K), az, bz);             \
-        const float tmin = fmaxf(fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), 0.f);          \
-        const float tmx  = fminf(fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1)), best);         \
+        const f32x2 tx = __builtin_elementwise_fma((f32x2){CRH_QB(lx, K), CRH_QB(hx, K)}, ax2, bx2);      /* v_pk_fma_f32: entry, exit */ \
+        const f32x2 ty = __builtin_elementwise_fma((f32x2){CRH_QB(ly, K), CRH_QB(hy, K)}, ay2, by2);      \
+        const f32x2 tz = __builtin_elementwise_fma((f32x2){CRH_QB(lz, K), CRH_QB(hz, K)}, az2, bz2);      \
+        const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
+        const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), best);                                    \
         const int bits = max(__float_as_int(tmin), 0);                                                     \
         key[K] = (REF != kQEmpty && tmin <= tmx) ? (((uint32_t)bits & ~3u) | (uint32_t)K) : 0xFFFFFFFFu;   \
       }
