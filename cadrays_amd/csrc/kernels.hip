@@ -741,8 +741,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
       }
       P.ray_o[pid] = mk4(o, __uint_as_float(rng));           // .w = rng state
       P.ray_d[pid] = mk4(d, __uint_as_float(0u));            // .w = flags (bit 0: inside a medium)
-      P.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT);
-      P.rad[pid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // throughput (1,1,1 | no pending pdf) and radiance (0) are NOT written here: every generated path goes through
+      // the bounce-0 k_shade, which takes them as constants and writes the radiance record unconditionally
     }
     const unsigned long long m = __ballot(valid);
     if (valid) q[s_base + s_cnt[it * 4u + wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pid;
@@ -780,6 +780,8 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
   }
   const uint32_t n = *count_in;
   const bool last = bounce + 1u >= S.max_depth;
+  const bool first = bounce == 0u;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t n_shaded = 0;
   for (;;) {
     __syncthreads();
@@ -794,7 +796,8 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
     uint32_t pid = 0;
     if (i < n) {
       pid = q_in[i];
-      const float4 o4 = P.ray_o[pid], d4 = P.ray_d[pid], h = P.hit[pid], t4 = P.thr[pid];
+      const float4 o4 = P.ray_o[pid], d4 = P.ray_d[pid], h = P.hit[pid];
+      const float4 t4 = first ? make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT) : P.thr[pid];     // k_raygen leaves thr / rad unwritten
       const uint2 st = make_uint2(__float_as_uint(o4.w), __float_as_uint(d4.w));   // rng state, flags
       const v3 o = xyz(o4), d = xyz(d4);
       v3 W = xyz(t4); float imp_pdf = t4.w;
@@ -804,7 +807,7 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
       const v3 le = intersect_light(S, o, d, bounce, found ? h.x : CRH_MAXFLOAT, exp_pdf);
       if (le.x > 0.f || le.y > 0.f || le.z > 0.f || !found) {
         const float mis = (bounce == 0u || imp_pdf == CRH_MAXFLOAT) ? 1.0f : (imp_pdf * imp_pdf) / CRH_FMA(exp_pdf, exp_pdf, imp_pdf * imp_pdf);
-        const float4 r4 = P.rad[pid];                        // the radiance record is touched only when something is added
+        const float4 r4 = first ? zero4 : P.rad[pid];        // the radiance record is touched only when something is added
         P.rad[pid] = mk4(crh_add3(xyz(r4), crh_scale3(crh_mul3(W, le), mis)), 0.f);
       } else {
         ++n_shaded;
@@ -855,9 +858,9 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
           W = crh_mul3(W, crh_mk3(crh_exp(k * (1.0f - bs.ab.x)), crh_exp(k * (1.0f - bs.ab.y)), crh_exp(k * (1.0f - bs.ab.z))));
         }
         if (bs.Le.x != 0.f || bs.Le.y != 0.f || bs.Le.z != 0.f) {      // emissive surfaces are rare: skip the read-modify-write otherwise
-          const float4 r4 = P.rad[pid];
+          const float4 r4 = first ? zero4 : P.rad[pid];
           P.rad[pid] = mk4(crh_add3(xyz(r4), crh_mul3(W, bs.Le)), 0.f);
-        }
+        } else if (first) P.rad[pid] = zero4;                          // bounce 0 initialises the record
         uint32_t rng = st.x;
         // ---- next event estimation
         {
