@@ -5,6 +5,8 @@
 // There is NO CPU fallback: every entry point that renders or traces launches the gfx950 kernels and
 // reports CRH_E_DEVICE when the HIP runtime refuses.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>     // types only: the library is loaded with dlopen on the first multi-device crh_reduce
 
 #include <algorithm>
 #include <cstdio>
@@ -52,6 +54,9 @@ struct crh_ctx {
   float4 *d_uvs = nullptr, *d_texels = nullptr; uint4* d_tex_desc = nullptr;
   float4* d_accum = nullptr; uint32_t accumW = 0, accumH = 0;
   float* d_m2 = nullptr;            // running mean of squared luminance (adaptive sampling only)
+  // crh_reduce: the frame assembled from all shards lives beside the root's own accumulator (rendering continues into that)
+  float4* d_assembled = nullptr; float4* d_peer_stage = nullptr; uint32_t assembledW = 0, assembledH = 0; bool assembled_valid = false;
+  std::vector<ncclComm_t> comms; std::vector<crh_ctx*> comm_ctxs;      // RCCL communicators of the last multi-device group (kept on the root)
   float* d_tile_err = nullptr; uint32_t* d_tile_cnt = nullptr; uint32_t tile_stat_cap = 0;
   bool show_tiles = false; std::vector<uint8_t> last_picked;                            // ShowSamplingTiles: tiles of the last adaptive iteration
   bool adaptive = false; uint32_t adaptive_tiles = 128; uint32_t adaptive_picks = 0;   // NbRayTracingTiles, Halton index
@@ -234,7 +239,7 @@ int do_reset(crh_ctx* c)
   int rc = alloc_accum(c); if (rc) return rc;
   CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, c->stream));
   CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, c->stream));
-  c->adaptive_picks = 0; c->pending_n = 0; c->last_picked.clear();
+  c->adaptive_picks = 0; c->pending_n = 0; c->last_picked.clear(); c->assembled_valid = false;
   CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
   drain_events(c);
@@ -384,6 +389,118 @@ int adaptive_iteration(crh_ctx* c)
   return CRH_OK;
 }
 
+
+// ---- RCCL, loaded on first use (a single-GPU host never pays for it; a Python host that already loaded torch's librccl
+// gets that copy back from dlopen by SONAME)
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl()
+{
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) { api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
+    if (api.lib) {
+      api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+      api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+      api.Reduce = (decltype(api.Reduce))dlsym(api.lib, "ncclReduce");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.CommInitAll || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Reduce) api.lib = nullptr;
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+
+void release_comms(crh_ctx* c)
+{
+  if (c->comms.empty()) return;
+  if (RcclApi* R = rccl()) for (ncclComm_t m : c->comms) if (m) R->CommDestroy(m);
+  c->comms.clear(); c->comm_ctxs.clear();
+}
+
+#define CRH_NCCL(call)                                                                                   \
+  do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) {                                                \
+      char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s", #call, R->GetErrorString ? R->GetErrorString(r_) : "rccl error"); \
+      c->err = b_; return CRH_E_DEVICE; } } while (0)
+
+int reduce_impl(crh_ctx* const* ctxs, uint32_t n, uint32_t root)
+{
+  crh_ctx* c = ctxs[root];                                   // errors are reported on the root
+  const uint32_t W = c->par.width, H = c->par.height;
+  const size_t n4 = (size_t)W * H;
+  std::vector<int> devs(n);
+  bool distinct = true;
+  for (uint32_t i = 0; i < n; ++i) {
+    crh_ctx* x = ctxs[i];
+    if (!x || !x->d_accum || x->par.width != W || x->par.height != H) return fail(c, CRH_E_INVALID, "crh_reduce: every context needs an accumulator of the root's size");
+    for (uint32_t j = 0; j < i; ++j) { if (ctxs[j] == x) return fail(c, CRH_E_INVALID, "crh_reduce: context listed twice"); if (ctxs[j]->device == x->device) distinct = false; }
+    devs[i] = x->device;
+  }
+  CRH_HIP(hipSetDevice(c->device));
+  if (!c->d_assembled || c->assembledW != W || c->assembledH != H) {
+    if (c->d_assembled) { CRH_HIP(hipFree(c->d_assembled)); c->d_assembled = nullptr; }
+    if (c->d_peer_stage) { CRH_HIP(hipFree(c->d_peer_stage)); c->d_peer_stage = nullptr; }
+    CRH_HIP(hipMalloc((void**)&c->d_assembled, sizeof(float4) * n4));
+    c->assembledW = W; c->assembledH = H;
+  }
+  // every shard's queued rendering must have landed before its accumulator is read by another stream / device
+  for (uint32_t i = 0; i < n; ++i) { CRH_HIP(hipSetDevice(ctxs[i]->device)); CRH_HIP(hipStreamSynchronize(ctxs[i]->stream)); }
+
+  // CRH_REDUCE_RCCL_SINGLE=1 sends even a one-context group through RCCL (exercises the library binding on a 1-GPU box)
+  RcclApi* R = (distinct && (n > 1 || getenv("CRH_REDUCE_RCCL_SINGLE"))) ? rccl() : nullptr;
+  if (R) {
+    // one process, one communicator per context, a single grouped ncclReduce: on xGMI the peers' contributions arrive
+    // over distinct links; message = W*H*16 B (33 MB at 1080p, 133 MB at 4K)
+    if (c->comm_ctxs.size() != n || !std::equal(c->comm_ctxs.begin(), c->comm_ctxs.end(), ctxs)) {
+      release_comms(c);
+      c->comms.assign(n, nullptr);
+      CRH_NCCL(R->CommInitAll(c->comms.data(), (int)n, devs.data()));
+      c->comm_ctxs.assign(ctxs, ctxs + n);
+    }
+    CRH_NCCL(R->GroupStart());
+    for (uint32_t i = 0; i < n; ++i) {
+      hipSetDevice(ctxs[i]->device);
+      ncclResult_t r = R->Reduce(ctxs[i]->d_accum, i == root ? (void*)c->d_assembled : (void*)ctxs[i]->d_accum, 4 * n4, ncclFloat, ncclSum, (int)root,
+                                 c->comms[i], ctxs[i]->stream);
+      if (r != ncclSuccess) { R->GroupEnd(); c->err = "ncclReduce failed"; return CRH_E_DEVICE; }
+    }
+    CRH_NCCL(R->GroupEnd());
+    for (uint32_t i = 0; i < n; ++i) { CRH_HIP(hipSetDevice(ctxs[i]->device)); CRH_HIP(hipStreamSynchronize(ctxs[i]->stream)); }
+    CRH_HIP(hipSetDevice(c->device));
+  } else {
+    // contexts that share a device (rehearsal of the sharded flow on one GPU) or no RCCL in the process: the root pulls
+    // every shard (peer copy when it lives on another device) and adds it in context order -- same sums, since every pixel
+    // is non-zero in exactly one shard
+    CRH_HIP(hipMemcpyAsync(c->d_assembled, c->d_accum, sizeof(float4) * n4, hipMemcpyDeviceToDevice, c->stream));
+    Launch L{c->stream, c->grid, false};
+    for (uint32_t i = 0; i < n; ++i) {
+      if (i == root) continue;
+      const float4* src = ctxs[i]->d_accum;
+      if (ctxs[i]->device != c->device) {
+        if (!c->d_peer_stage) CRH_HIP(hipMalloc((void**)&c->d_peer_stage, sizeof(float4) * n4));
+        CRH_HIP(hipMemcpyPeerAsync(c->d_peer_stage, c->device, ctxs[i]->d_accum, ctxs[i]->device, sizeof(float4) * n4, c->stream));
+        src = c->d_peer_stage;
+      }
+      launch_add4(L, c->d_assembled, src, (uint32_t)n4);
+    }
+    CRH_HIP(hipGetLastError());
+    CRH_HIP(hipStreamSynchronize(c->stream));
+  }
+  c->assembled_valid = true;
+  return CRH_OK;
+}
+
 }  // namespace
 
 // =============================================================================================== C ABI
@@ -427,6 +544,9 @@ void crh_destroy(crh_ctx* c)
                   c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
                   c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (c->d_assembled) hipFree(c->d_assembled);
+  if (c->d_peer_stage) hipFree(c->d_peer_stage);
+  release_comms(c);
   hipStreamDestroy(c->stream);
   delete c;
 }
@@ -621,6 +741,7 @@ int crh_render(crh_ctx* c, uint32_t n)
 {
   if (!c) return CRH_E_INVALID;
   if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
+  c->assembled_valid = false;                            // reads show this context's own accumulator again
   if (c->adaptive) {
     CRH_HIP(hipSetDevice(c->device));
     for (uint32_t i = 0; i < n; ++i) { int rc = adaptive_iteration(c); if (rc) return rc; }
@@ -672,6 +793,7 @@ int crh_render(crh_ctx* c, uint32_t n)
 int crh_render_tiles(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, uint32_t ns)
 {
   if (!c || (nt && !tiles)) return fail(c, CRH_E_INVALID, "null tile list");
+  c->assembled_valid = false;
   return render_impl(c, tiles, nt, first, ns);
 }
 
@@ -717,7 +839,7 @@ int crh_read_hdr(crh_ctx* c, float* out)
   const uint32_t n = c->par.width * c->par.height;
   int rc = ensure_scratch(c, sizeof(float) * 3 * (size_t)n); if (rc) return rc;
   Launch L{c->stream, c->grid, false};
-  launch_hdr(L, c->d_accum, (float*)c->d_scratch, n);
+  launch_hdr(L, c->assembled_valid ? c->d_assembled : c->d_accum, (float*)c->d_scratch, n);
   CRH_HIP(hipMemcpyAsync(out, c->d_scratch, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
   return CRH_OK;
@@ -737,7 +859,7 @@ int crh_read_ldr(crh_ctx* c, uint8_t* out)
     CRH_HIP(hipMemcpyAsync(d_mask, c->last_picked.data(), n_tiles, hipMemcpyHostToDevice, c->stream));
   }
   Launch L{c->stream, c->grid, false};
-  launch_tonemap(L, c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, d_mask, c->par.width, ts);
+  launch_tonemap(L, c->assembled_valid ? c->d_assembled : c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, d_mask, c->par.width, ts);
   CRH_HIP(hipMemcpyAsync(out, c->d_scratch, 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
   return CRH_OK;
@@ -748,7 +870,7 @@ int crh_save_accum(crh_ctx* c, float* out, uint32_t* frames_done)
   if (!c || !out || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null output");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
-  CRH_HIP(hipMemcpy(out, c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyDeviceToHost));
+  CRH_HIP(hipMemcpy(out, c->assembled_valid ? c->d_assembled : c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyDeviceToHost));
   if (frames_done) *frames_done = c->frames_done;
   return CRH_OK;
 }
@@ -760,7 +882,7 @@ int crh_load_accum(crh_ctx* c, const float* in, uint32_t frames_done)
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
   CRH_HIP(hipMemcpy(c->d_accum, in, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyHostToDevice));
-  c->frames_done = frames_done; c->pending_n = 0;
+  c->frames_done = frames_done; c->pending_n = 0; c->assembled_valid = false;
   return CRH_OK;
 }
 
@@ -769,6 +891,12 @@ int crh_accum_device_ptr(crh_ctx* c, void** p, uint64_t* nbytes)
   if (!c || !p || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator");
   *p = c->d_accum; if (nbytes) *nbytes = sizeof(float4) * (uint64_t)c->par.width * c->par.height;
   return CRH_OK;
+}
+
+int crh_reduce(crh_ctx* const* ctxs, uint32_t n, uint32_t root)
+{
+  if (!ctxs || n == 0 || root >= n || !ctxs[root]) return CRH_E_INVALID;
+  return reduce_impl(ctxs, n, root);
 }
 
 int crh_enable_counters(crh_ctx* c, int on) { if (!c) return CRH_E_INVALID; c->counters_on = on != 0; return CRH_OK; }

@@ -30,6 +30,7 @@ void launch_tile_error(const Launch&, const DScene&, const float4* accum, const 
 void launch_tonemap(const Launch&, const float4* accum, uint8_t* out_rgb, uint32_t n_pixels, int mode, float exposure, float white_point,
                     const uint8_t* tile_mask /* nullptr: no overlay */, uint32_t width, uint32_t tile_size);
 void launch_hdr(const Launch&, const float4* accum, float* out_rgb, uint32_t n_pixels);
+void launch_add4(const Launch&, float4* dst, const float4* src, uint32_t n_float4);
 // API-level ray tracing on a plain ray buffer (8 floats per ray)
 void launch_trace_rays(const Launch&, const DScene&, const float4* rays, uint32_t n, int any_hit,
                        float4* out_hit, uint32_t* out_vis, uint32_t* d_cursor, DCounters*);

@@ -1046,6 +1046,16 @@ __global__ __launch_bounds__(kBlock) void k_hdr(const float4* __restrict__ accum
   }
 }
 
+// dst += src over n float4 (the same-device leg of crh_reduce: disjoint tile support, so every pixel adds zeros to one value)
+__global__ __launch_bounds__(kBlock) void k_add4(float4* __restrict__ dst, const float4* __restrict__ src, uint32_t n)
+{
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float4 a = dst[i]; const float4 b = src[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    dst[i] = a;
+  }
+}
+
 __global__ void k_debug_math(int fn, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                              float* __restrict__ out2, uint32_t n)
 {
@@ -1114,6 +1124,10 @@ void launch_tonemap(const Launch& L, const float4* accum, uint8_t* out, uint32_t
 void launch_hdr(const Launch& L, const float4* accum, float* out, uint32_t n)
 {
   hipLaunchKernelGGL(k_hdr, dim3(L.grid), dim3(kBlock), 0, L.stream, accum, out, n);
+}
+void launch_add4(const Launch& L, float4* dst, const float4* src, uint32_t n)
+{
+  hipLaunchKernelGGL(k_add4, dim3(L.grid), dim3(kBlock), 0, L.stream, dst, src, n);
 }
 void launch_trace_rays(const Launch& L, const DScene& S, const float4* rays, uint32_t n, int any_hit, float4* out_hit,
                        uint32_t* out_vis, uint32_t* cursor, DCounters* C)

@@ -6,14 +6,18 @@
 //   loop: View->Redraw() once per frame, count frames      src/Launcher/AppViewer.cxx:1045-1071
 //   BufferDump(Graphic3d_BT_RGB) after the last frame      src/Launcher/AppViewer.cxx:1255-1264
 //   write Output_<name>_<n>.png and Output_<name>_<n>.txt (average frame rate)   main.cxx:193-228
-// Here: cadrays_headless <scene.crhscene> <nFrames> [device] [lookahead] writes Output_<name>_<n>.ppm (LDR),
+// Here: cadrays_headless <scene.crhscene> <nFrames> [device] [lookahead] [gpus] writes Output_<name>_<n>.ppm (LDR),
 // Output_<name>_<n>.pfm (linear HDR, the parity buffer of AppGui.cxx:345-349) and Output_<name>_<n>.txt.
+// gpus > 1: one context per GPU (devices device .. device+gpus-1; CRH_HEADLESS_SHARE_DEVICE=1 keeps them all on `device`),
+// screen tiles interleaved across the contexts, one host thread per context, crh_reduce (RCCL over xGMI) assembles the
+// frame on context 0 -- bit-identical to the one-GPU image.
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cadrays_hip.h"
@@ -26,23 +30,17 @@ template <class T> bool read_vec(FILE* f, std::vector<T>& v, size_t n)
   return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
 
-int die(crh_ctx* c, const char* what, int rc)
-{
-  fprintf(stderr, "cadrays_headless: %s failed (%d): %s\n", what, rc, c ? crh_last_error(c) : "");
-  if (c) crh_destroy(c);
-  return 1;
-}
-
 }  // namespace
 
 int main(int argc, char** argv)
 {
-  if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene> <nFrames> [device] [lookahead]\n", argv[0]); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene> <nFrames> [device] [lookahead] [gpus]\n", argv[0]); return 2; }
   const std::string path = argv[1];
   const int n_frames = atoi(argv[2]);
   const int device = argc > 3 ? atoi(argv[3]) : 0;
   const int lookahead = argc > 4 ? atoi(argv[4]) : 1;      // crh_set_lookahead: frames traced ahead per wide batch
-  if (n_frames <= 0) { fprintf(stderr, "nFrames must be > 0\n"); return 2; }
+  const int n_gpus = argc > 5 ? atoi(argv[5]) : 1;
+  if (n_frames <= 0 || n_gpus <= 0) { fprintf(stderr, "nFrames and gpus must be > 0\n"); return 2; }
 
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { perror(path.c_str()); return 1; }
@@ -71,35 +69,66 @@ int main(int argc, char** argv)
   fclose(f);
   if (!ok) { fprintf(stderr, "truncated scene file\n"); return 1; }
 
-  crh_ctx* c = crh_create(device);                       // == driver + viewer + view + FBO (AppViewer.cxx:601-638)
-  if (!c) return die(nullptr, "crh_create", CRH_E_DEVICE);
+  // one context per GPU (== driver + viewer + view + FBO, AppViewer.cxx:601-638), each holding the whole scene
+  const bool share = getenv("CRH_HEADLESS_SHARE_DEVICE") != nullptr;
+  std::vector<crh_ctx*> ctx((size_t)n_gpus, nullptr);
+  auto die_all = [&](crh_ctx* c, const char* what, int rc) {
+    fprintf(stderr, "cadrays_headless: %s failed (%d): %s\n", what, rc, c ? crh_last_error(c) : "");
+    for (crh_ctx* x : ctx) if (x) crh_destroy(x);
+    return 1;
+  };
   int rc;
-  if ((rc = crh_set_geometry(c, pos.data(), nrm.data(), uv.empty() ? nullptr : uv.data(), nV, tri.data(), nT,
-                             nO ? tri_obj.data() : nullptr, nO ? xform.data() : nullptr, nO))) return die(c, "crh_set_geometry", rc);
-  for (size_t i = 0; i < textures.size(); ++i)
-    if (textures[i].w && (rc = crh_set_texture(c, (uint32_t)i, textures[i].texels.data(), textures[i].w, textures[i].h, textures[i].ch)))
-      return die(c, "crh_set_texture", rc);
-  if ((rc = crh_set_materials(c, mats.data(), nM))) return die(c, "crh_set_materials", rc);
-  if ((rc = crh_set_lights(c, lights.data(), nL))) return die(c, "crh_set_lights", rc);
-  if ((rc = crh_set_envmap(c, env.empty() ? nullptr : env.data(), eW, eH))) return die(c, "crh_set_envmap", rc);
-  if ((rc = crh_set_camera(c, &cam))) return die(c, "crh_set_camera", rc);
-  if ((rc = crh_set_params(c, &par))) return die(c, "crh_set_params", rc);
-  if ((rc = crh_build(c))) return die(c, "crh_build", rc);
-  if (lookahead > 1 && (rc = crh_set_lookahead(c, (uint32_t)lookahead))) return die(c, "crh_set_lookahead", rc);
+  for (int g = 0; g < n_gpus; ++g) {
+    crh_ctx* c = ctx[(size_t)g] = crh_create(share ? device : device + g);
+    if (!c) return die_all(nullptr, "crh_create", CRH_E_DEVICE);
+    if ((rc = crh_set_geometry(c, pos.data(), nrm.data(), uv.empty() ? nullptr : uv.data(), nV, tri.data(), nT,
+                               nO ? tri_obj.data() : nullptr, nO ? xform.data() : nullptr, nO))) return die_all(c, "crh_set_geometry", rc);
+    for (size_t i = 0; i < textures.size(); ++i)
+      if (textures[i].w && (rc = crh_set_texture(c, (uint32_t)i, textures[i].texels.data(), textures[i].w, textures[i].h, textures[i].ch)))
+        return die_all(c, "crh_set_texture", rc);
+    if ((rc = crh_set_materials(c, mats.data(), nM))) return die_all(c, "crh_set_materials", rc);
+    if ((rc = crh_set_lights(c, lights.data(), nL))) return die_all(c, "crh_set_lights", rc);
+    if ((rc = crh_set_envmap(c, env.empty() ? nullptr : env.data(), eW, eH))) return die_all(c, "crh_set_envmap", rc);
+    if ((rc = crh_set_camera(c, &cam))) return die_all(c, "crh_set_camera", rc);
+    if ((rc = crh_set_params(c, &par))) return die_all(c, "crh_set_params", rc);
+    if ((rc = crh_build(c))) return die_all(c, "crh_build", rc);
+    if (n_gpus == 1 && lookahead > 1 && (rc = crh_set_lookahead(c, (uint32_t)lookahead))) return die_all(c, "crh_set_lookahead", rc);
+  }
+  crh_ctx* c = ctx[0];
 
-  // the render loop of AppViewer::Run in test mode: one Redraw per frame until MaxFramesCount
   const auto t0 = std::chrono::steady_clock::now();
-  for (int frame = 0; frame < n_frames; ++frame)
-    if ((rc = crh_render(c, 1))) return die(c, "crh_render", rc);
-  if ((rc = crh_sync(c))) return die(c, "crh_sync", rc);
+  if (n_gpus == 1) {
+    // the render loop of AppViewer::Run in test mode: one Redraw per frame until MaxFramesCount
+    for (int frame = 0; frame < n_frames; ++frame)
+      if ((rc = crh_render(c, 1))) return die_all(c, "crh_render", rc);
+    if ((rc = crh_sync(c))) return die_all(c, "crh_sync", rc);
+  } else {
+    // tile t -> context t mod gpus (the RT tile entry point, SettingsWidget.cxx:451-476); every context renders all
+    // frames of its own tiles with the one-GPU RNG, so the assembled image does not depend on the GPU count
+    const uint32_t ts = par.tile_size, n_tiles = ((par.width + ts - 1) / ts) * ((par.height + ts - 1) / ts);
+    std::vector<int> rcs((size_t)n_gpus, 0);
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_gpus; ++g)
+      th.emplace_back([&, g] {
+        std::vector<uint32_t> mine;
+        for (uint32_t t = (uint32_t)g; t < n_tiles; t += (uint32_t)n_gpus) mine.push_back(t);
+        int r = mine.empty() ? 0 : crh_render_tiles(ctx[(size_t)g], mine.data(), (uint32_t)mine.size(), 0, (uint32_t)n_frames);
+        if (!r) r = crh_sync(ctx[(size_t)g]);
+        rcs[(size_t)g] = r;
+      });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < n_gpus; ++g) if (rcs[(size_t)g]) return die_all(ctx[(size_t)g], "crh_render_tiles", rcs[(size_t)g]);
+    if ((rc = crh_reduce(ctx.data(), (uint32_t)n_gpus, 0))) return die_all(c, "crh_reduce", rc);
+  }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const double fps = n_frames / secs;
 
   std::vector<uint8_t> ldr(3 * (size_t)par.width * par.height);
   std::vector<float> hdr_img(3 * (size_t)par.width * par.height);
-  if ((rc = crh_read_ldr(c, ldr.data()))) return die(c, "crh_read_ldr", rc);   // BufferDump(Graphic3d_BT_RGB)
-  if ((rc = crh_read_hdr(c, hdr_img.data()))) return die(c, "crh_read_hdr", rc);   // Graphic3d_BT_RGB_RayTraceHdrLeft
-  crh_stats st; crh_get_stats(c, &st);
+  if ((rc = crh_read_ldr(c, ldr.data()))) return die_all(c, "crh_read_ldr", rc);   // BufferDump(Graphic3d_BT_RGB)
+  if ((rc = crh_read_hdr(c, hdr_img.data()))) return die_all(c, "crh_read_hdr", rc);   // Graphic3d_BT_RGB_RayTraceHdrLeft
+  crh_stats st{}; 
+  for (crh_ctx* x : ctx) { crh_stats s1; crh_get_stats(x, &s1); st.rays_nearest += s1.rays_nearest; st.rays_any += s1.rays_any; st.samples += s1.samples; }
 
   std::string stem = path; const size_t sl = stem.find_last_of('/'); std::string dir = sl == std::string::npos ? "." : stem.substr(0, sl);
   std::string name = sl == std::string::npos ? stem : stem.substr(sl + 1); const size_t dot = name.find_last_of('.'); if (dot != std::string::npos) name = name.substr(0, dot);
@@ -111,9 +140,9 @@ int main(int argc, char** argv)
     fclose(o);
   }
   if (FILE* o = fopen((base + ".txt").c_str(), "w")) { fprintf(o, "%g", fps); fclose(o); }
-  printf("{\"scene\": \"%s\", \"frames\": %d, \"fps\": %.4f, \"seconds\": %.6f, \"rays_nearest\": %llu, \"rays_any\": %llu, \"samples\": %llu, \"mrays_per_s\": %.3f}\n",
-         name.c_str(), n_frames, fps, secs, (unsigned long long)st.rays_nearest, (unsigned long long)st.rays_any, (unsigned long long)st.samples,
+  printf("{\"scene\": \"%s\", \"gpus\": %d, \"frames\": %d, \"fps\": %.4f, \"seconds\": %.6f, \"rays_nearest\": %llu, \"rays_any\": %llu, \"samples\": %llu, \"mrays_per_s\": %.3f}\n",
+         name.c_str(), n_gpus, n_frames, fps, secs, (unsigned long long)st.rays_nearest, (unsigned long long)st.rays_any, (unsigned long long)st.samples,
          (double)(st.rays_nearest + st.rays_any) / secs / 1e6);
-  crh_destroy(c);
+  for (crh_ctx* x : ctx) crh_destroy(x);
   return 0;
 }

@@ -14,7 +14,7 @@ import dataclasses
 import numpy as np
 
 from ._lib import load_library
-from .binding import Backend
+from .binding import Backend, BackendError
 
 BT_RGB = "Graphic3d_BT_RGB"                             # AppViewer.cxx:1259-1261
 BT_RGB_RayTraceHdrLeft = "Graphic3d_BT_RGB_RayTraceHdrLeft"   # AppGui.cxx:349
@@ -83,6 +83,18 @@ class View(Backend):
         p, n = C.c_void_p(0), C.c_uint64(0)
         self._call("accum_device_ptr", C.byref(p), C.byref(n))
         return p.value, n.value
+
+    @staticmethod
+    def reduce(views, root=0):
+        """crh_reduce: assemble the tile-sharded frame of `views` (one context per GPU) on views[root]; that view's
+        read_hdr / read_ldr / save_accum return the assembled frame until it renders again"""
+        lib = views[root]._lib
+        arr = (C.c_void_p * len(views))(*[v._ctx.value for v in views])
+        lib.crh_reduce.restype = C.c_int
+        rc = lib.crh_reduce(arr, C.c_uint32(len(views)), C.c_uint32(int(root)))
+        if rc != 0:
+            msg = views[root]._fn("last_error")(views[root]._ctx)
+            raise BackendError(f"crh_reduce -> {rc}: {msg.decode() if msg else ''}")
 
     def bench_trace(self, rays, any_hit=False, repeat=10):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

@@ -200,6 +200,16 @@ CRH_API int crh_load_accum(crh_ctx* ctx, const float* rgba /* W*H*4 */, uint32_t
  * samples accumulated in that pixel) so a host process can hand it to RCCL without a copy.
  * Replaces the zero-copy GL texture id the GUI displays (AppViewer.cxx:1099). */
 CRH_API int crh_accum_device_ptr(crh_ctx* ctx, void** dev_ptr, uint64_t* n_bytes);
+/* The exchange step of the tile-sharded multi-GPU render (the reference is single-GPU, its frame is
+ * simply the FBO of AppViewer.cxx:1099): sums the float4 accumulators of `n` contexts -- one per GPU, each holding only
+ * its own tiles and zeros elsewhere, so the sum is exact -- into an assembled frame on ctxs[root].  Contexts on distinct
+ * devices: one grouped ncclReduce over RCCL / xGMI (librccl is loaded on first use); contexts sharing a device, or a
+ * process without RCCL: peer copies + adds on the root.  Until the next crh_render* / crh_reset / crh_load_accum of the
+ * root, its crh_read_hdr / crh_read_ldr / crh_save_accum return the assembled frame; no context's own accumulator is
+ * modified, so rendering continues (progressive display reduces every few iterations).  One host thread calls it after
+ * the per-context render threads have returned.  (One process per GPU instead: hand crh_accum_device_ptr to the
+ * process group's reduce -- bench.py does that through torch.distributed.) */
+CRH_API int crh_reduce(crh_ctx* const* ctxs, uint32_t n, uint32_t root);
 /* counters since the last crh_reset; collecting node/triangle counters needs
  * crh_enable_counters(ctx, 1) (slower kernels) */
 CRH_API int crh_enable_counters(crh_ctx* ctx, int on);

@@ -283,6 +283,15 @@ def test_headless_cpp_driver_matches_oracle(tmp_path, Oracle):
     ppm = open(tmp_path / "Output_cornell_5.ppm", "rb").read()
     assert ppm.startswith(b"P6\n96 64\n255\n") and np.array_equal(np.frombuffer(ppm[len(b"P6\n96 64\n255\n"):], np.uint8).reshape(64, 96, 3), o.read_ldr())
     assert float(open(tmp_path / "Output_cornell_5.txt").read()) > 0
+    # gpus = 3: one context per "GPU" (all on device 0 here), host thread per context, tiles interleaved, crh_reduce on context 0
+    env = dict(os.environ, CRH_HEADLESS_SHARE_DEVICE="1")
+    out = subprocess.check_output([exe, path, "5", "0", "1", "3"], text=True, env=env)
+    info = json.loads(out.strip().splitlines()[-1])
+    assert info["gpus"] == 3 and info["samples"] == 96 * 64 * 5
+    with open(tmp_path / "Output_cornell_5.pfm", "rb") as f:
+        assert f.readline() == b"PF\n"; f.readline(); f.readline()
+        img3 = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]
+    assert np.array_equal(bits(img3), bits(o.read_hdr()))
 
 
 def test_headless_cpp_driver_v2_scene_textures_and_object_transforms(tmp_path, Oracle):
@@ -360,3 +369,34 @@ def test_lookahead_keeps_every_redraw_bit_identical(view_cls):
     v.render(7); ref.render(7)                          # a request larger than the look-ahead spans batches
     assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr()))
     assert v.stats()["samples"] == ref.stats()["samples"]
+
+
+def test_crh_reduce_assembles_tile_shards(view_cls, monkeypatch):
+    """C-ABI exchange step: three contexts render interleaved tiles, crh_reduce assembles the frame on the root
+    bit-identically to a one-context render; own accumulators stay untouched and rendering continues afterwards."""
+    from cadrays_amd import sharding
+    sc = scenes.cornell_box(True, 100, 76)
+    full = view_cls(0).load_scene(sc); full.render(6)
+    ref3, ref6 = None, full.read_hdr()
+    half = view_cls(0).load_scene(sc); half.render(3); ref3 = half.read_hdr()
+    vs = [view_cls(0).load_scene(sc) for _ in range(3)]
+    for r, v in enumerate(vs):
+        sharding.render_shard(v, r, 3, 0, 3)
+    own_before = vs[1].save_accum()[0].copy()
+    view_cls.reduce(vs, root=1)
+    assert np.array_equal(bits(vs[1].read_hdr()), bits(ref3))
+    assert np.array_equal(vs[1].read_ldr(), half.read_ldr())
+    for r, v in enumerate(vs):                                                           # rendering continues into the own shards
+        sharding.render_shard(v, r, 3, 3, 3)
+    own_after = vs[1].save_accum()[0]
+    mask = own_before[..., 3] > 0
+    assert mask.any() and not mask.all() and np.array_equal(own_after[..., 3] > 0, mask)   # the root's accumulator holds only its own tiles
+    view_cls.reduce(vs, root=0)
+    assert np.array_equal(bits(vs[0].read_hdr()), bits(ref6))
+    # a one-context group through RCCL itself (the multi-device leg cannot run on a 1-GPU box)
+    monkeypatch.setenv("CRH_REDUCE_RCCL_SINGLE", "1")
+    view_cls.reduce([full], root=0)
+    assert np.array_equal(bits(full.read_hdr()), bits(ref6))
+    from cadrays_amd.binding import BackendError
+    with pytest.raises(BackendError):
+        view_cls.reduce([vs[0], vs[0]], root=0)
