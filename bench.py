@@ -84,6 +84,8 @@ def main():
             v.sync()                                          # the accumulator is written on the context's own stream
             sharding.reduce_framebuffer(fb.tensor, 0)         # RCCL reduce of a staging copy; returns synchronised
 
+    if dist is not None:                                      # RCCL builds its rings / channels on first use: keep that out of the
+        sharding.reduce_framebuffer(fb.tensor, 0)             # timed steps even when the caller asks for --warmup 0
     for i in range(args.warmup):
         step(i)
     barrier()
