@@ -46,6 +46,8 @@ class crh_stats(C.Structure):
 
 assert C.sizeof(crh_bsdf) == 128 and C.sizeof(crh_light) == 32
 
+NODE_DWORDS = 16          # CRH_NODE_DWORDS of include/crh_bvh_format.h: 4-wide BVH node, 12 dwords used on a 64-B stride
+
 # every symbol include/cadrays_hip.h declares (tests check the built library exports them all)
 EXPORTS = [
     "crh_create", "crh_destroy", "crh_last_error", "crh_set_geometry", "crh_set_transforms", "crh_set_materials",

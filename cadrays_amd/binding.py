@@ -213,7 +213,7 @@ class Backend:
     def get_bvh(self):
         nn, nt = C.c_uint32(0), C.c_uint32(0)
         self._call("get_bvh", None, C.byref(nn), None, C.byref(nt))
-        nodes = np.empty((nn.value, 16), np.float32)      # 64-B nodes (include/crh_bvh_format.h)
+        nodes = np.empty((nn.value, abi.NODE_DWORDS), np.float32)      # 64-B stride nodes (include/crh_bvh_format.h)
         tris = np.empty((nt.value, 12), np.float32)
         self._call("get_bvh", _fp(nodes), C.byref(nn), _fp(tris), C.byref(nt))
         return nodes, tris

@@ -3,10 +3,11 @@
 // Build rules (DESIGN.md "BVH"): triangle box centre = (min+max)*0.5; at each node all three axes are
 // binned in one pass over SoA primitive arrays (32 bins, bin = int(((c - cmin) / extent) * 32), clamped);
 // the cheapest split by  area(L)*n(L) + area(R)*n(R)  wins, ties to the lower axis, then the lower bin;
-// the partition is stable; leaves hold <= 4 triangles; when the remaining depth budget is only enough
+// the partition is stable; leaves hold ONE triangle; when the remaining depth budget is only enough
 // for balanced splitting, split at the object median of the widest centroid axis (total order by
-// (centre, index)).  The binary tree is then collapsed by replacing children with grandchildren, numbered in
-// DFS pre-order, and every 4-wide node is packed into 64 bytes with 8-bit child bounds (crh_bvh_format.h).
+// (centre, index)).  The binary tree is then collapsed by replacing children with grandchildren; the inner
+// children of a node get consecutive indices and the triangles of its leaf children consecutive positions, so
+// every 4-wide node packs into 48 bytes with 8-bit child bounds and two base references (crh_bvh_format.h).
 // Large subtrees are built by separate threads; the result does not depend on the thread count because every
 // subtree owns a disjoint index range and numbering happens afterwards.
 #include "bvh_builder.h"
@@ -47,7 +48,7 @@ struct Builder {
   std::vector<BNode> nodes;
   std::atomic<uint32_t> next{0};
   std::atomic<int> spare_threads{0};
-  uint32_t leaf_max = kLeafSize;       // 4 for triangle trees, 1 for the top-level tree over instances
+  uint32_t leaf_max = kLeafSize;       // one primitive per leaf (triangle trees and the top-level tree over instances alike)
 
   uint32_t alloc() { return next.fetch_add(1, std::memory_order_relaxed); }
 
@@ -216,15 +217,13 @@ struct Builder {
 struct Collapser {
   const std::vector<BNode>& bn;
   std::vector<QNode>& qn;
-  bool instances; uint32_t tri_base; const std::vector<uint32_t>& idx;
-  uint32_t leaf_ref(const BNode& b) const {
-    if (instances) return CRH_REF_INSTANCE_TAG | idx[b.lo];
-    return kLeafBit | ((b.hi - b.lo - 1u) << 28) | (b.lo + tri_base);
-  }
+  bool instances; uint32_t leaf0; const std::vector<uint32_t>& idx; std::vector<uint32_t>& order;
 
-  // 4-wide children of binary node bi: its grandchildren, a leaf child stays
-  int kids_of(uint32_t bi, uint32_t kids[4]) const {
-    int nk = 0;
+  // 4-wide children of binary node bi (its grandchildren, a leaf child stays) in SLOT order: inner children first, then
+  // the leaves, each group in collapse order; a leaf without primitives (empty scene) is dropped.  Returns the child
+  // count, ni = number of inner children.
+  int slots_of(uint32_t bi, uint32_t slot[4], int& ni) const {
+    uint32_t kids[4]; int nk = 0;
     const BNode& b = bn[bi];
     if (b.left < 0) kids[nk++] = bi;
     else {
@@ -234,44 +233,52 @@ struct Collapser {
         else { kids[nk++] = (uint32_t)c.left; kids[nk++] = (uint32_t)c.right; }
       }
     }
-    return nk;
+    int nc = 0;
+    for (int k = 0; k < nk; ++k) if (bn[kids[k]].left >= 0) slot[nc++] = kids[k];
+    ni = nc;
+    for (int k = 0; k < nk; ++k) if (bn[kids[k]].left < 0 && bn[kids[k]].hi > bn[kids[k]].lo) slot[nc++] = kids[k];
+    return nc;
   }
 
-  // pass 1: number of 4-wide nodes below (and including) the node made from binary node bi -> DFS indices are known
-  // before any node is packed, so subtrees can be packed by different threads
+  // pass 1: number of 4-wide nodes below (and including) the node made from binary node bi.  With it -- and one primitive
+  // per leaf, so a subtree's leaf count is hi - lo -- every node index and leaf position follows from prefix sums, before
+  // any node is packed: subtrees can be packed by different threads and the numbering equals the sequential "take the
+  // next free block when a node is expanded" rule of the format (crh_bvh_format.h).
   std::vector<uint32_t> qcnt;
   uint32_t count(uint32_t bi) {
-    uint32_t kids[4]; const int nk = kids_of(bi, kids);
+    uint32_t slot[4]; int ni; slots_of(bi, slot, ni);
     uint32_t c = 1;
-    for (int k = 0; k < nk; ++k) if (bn[kids[k]].left >= 0) c += count(kids[k]);
+    for (int k = 0; k < ni; ++k) c += count(slot[k]);
     return qcnt[bi] = c;
   }
 
   std::atomic<int>* spare = nullptr;
-  // pass 2: pack node `me` (DFS pre-order index, absolute in qn) from binary node bi and recurse
-  void pack(uint32_t bi, uint32_t me) {
-    uint32_t kids[4]; const int nk = kids_of(bi, kids);
+  // pass 2: pack node `me` from binary node bi; nb = first node index of the block holding its descendants,
+  // lb = first leaf position of its subtree
+  void pack(uint32_t bi, uint32_t me, uint32_t nb, uint32_t lb) {
+    uint32_t slot[4]; int ni; const int nc = slots_of(bi, slot, ni);
     QNode q; std::memset(&q, 0, sizeof q);
-    uint32_t refs[4] = {kEmptyRef, kEmptyRef, kEmptyRef, kEmptyRef};
     float cmin[4][3], cmax[4][3];
-    uint32_t next = me + 1;
-    std::vector<std::future<void>> tasks;
-    for (int k = 0; k < nk; ++k) {
-      const BNode& c = bn[kids[k]];
+    for (int k = 0; k < nc; ++k) {
+      const BNode& c = bn[slot[k]];
       for (int a = 0; a < 3; ++a) { cmin[k][a] = c.box.mn[a]; cmax[k][a] = c.box.mx[a]; }
-      if (c.left < 0) { refs[k] = c.hi > c.lo ? leaf_ref(c) : kEmptyRef; continue; }
-      refs[k] = next;
-      const uint32_t child = kids[k], at = next;
-      next += qcnt[child];
+      if (k >= ni) order[lb + (uint32_t)(k - ni) - leaf0] = idx[c.lo];          // one primitive per leaf
+    }
+    crh_pack_node(cmin, cmax, ni, nc, nb, (instances ? CRH_REF_INSTANCE_TAG : CRH_LEAF_TAG) | lb, q.w);   // 8-bit child bounds on the node's power-of-two grid
+    qn[me] = q;
+    std::vector<std::future<void>> tasks;
+    uint32_t next_nb = nb + (uint32_t)ni, next_lb = lb + (uint32_t)(nc - ni);
+    for (int k = 0; k < ni; ++k) {
+      const uint32_t child = slot[k], at = nb + (uint32_t)k, cnb = next_nb, clb = next_lb;
+      next_nb += qcnt[child] - 1u;
+      next_lb += bn[child].hi - bn[child].lo;
       if (qcnt[child] > 16384u && spare && spare->fetch_sub(1) > 0)
-        tasks.push_back(std::async(std::launch::async, [this, child, at] { pack(child, at); spare->fetch_add(1); }));
+        tasks.push_back(std::async(std::launch::async, [this, child, at, cnb, clb] { pack(child, at, cnb, clb); spare->fetch_add(1); }));
       else {
         if (qcnt[child] > 16384u && spare) spare->fetch_add(1);
-        pack(child, at);
+        pack(child, at, cnb, clb);
       }
     }
-    crh_pack_node(cmin, cmax, refs, nk, q.w);      // 8-bit child bounds on the node's power-of-two grid
-    qn[me] = q;
     for (auto& t : tasks) t.get();
   }
 
@@ -281,17 +288,17 @@ struct Collapser {
     const uint32_t me = (uint32_t)qn.size();
     qn.resize((size_t)me + total);
     spare = spare_threads;
-    pack(bi, me);
+    pack(bi, me, me + 1u, leaf0);
     return me;
   }
 };
 
 }  // namespace
 
-uint32_t build_tree(const float* boxes, uint32_t n, uint32_t leaf_max, bool instance_leaves, uint32_t tri_base,
+uint32_t build_tree(const float* boxes, uint32_t n, bool instance_leaves, uint32_t leaf0,
                     std::vector<QNode>& nodes, std::vector<uint32_t>& order, float bmin[3], float bmax[3], int threads) {
   Builder B;
-  B.leaf_max = leaf_max;
+  B.leaf_max = 1;                      // the node format holds one primitive per leaf
   const uint32_t cap = n ? n : 1;
   for (int a = 0; a < 3; ++a) { B.pmn[a].resize(cap); B.pmx[a].resize(cap); B.cen[a].resize(cap); }
   B.idx.resize(cap); B.tmp.resize(cap);
@@ -312,11 +319,11 @@ uint32_t build_tree(const float* boxes, uint32_t n, uint32_t leaf_max, bool inst
   const uint32_t root = B.alloc();
   B.build(root, 0, n, 0);
   const auto t1_ = std::chrono::steady_clock::now();
-  Collapser C{B.nodes, nodes, instance_leaves, tri_base, B.idx, {}, nullptr};
+  order.assign(n, 0u);
+  Collapser C{B.nodes, nodes, instance_leaves, leaf0, B.idx, order, {}, nullptr};
   B.spare_threads.store(threads - 1);
   const uint32_t qroot = C.run(root, &B.spare_threads);
   if (getenv("CRH_BUILD_VERBOSE")) fprintf(stderr, "build_tree n=%u: binary %.3f s, collapse+pack %.3f s\n", n, std::chrono::duration<double>(t1_ - t0_).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1_).count());
-  order.assign(B.idx.begin(), B.idx.begin() + n);
   for (int a = 0; a < 3; ++a) { bmin[a] = n ? scene.mn[a] : 0.f; bmax[a] = n ? scene.mx[a] : 0.f; }
   return qroot;
 }
@@ -330,7 +337,7 @@ void build_qbvh(const float* pos, const int32_t* tri, uint32_t n, QBvh& out, int
     }
   out.nodes.clear();
   out.nodes.reserve(n / 2 + 16);
-  build_tree(boxes.data(), n, kLeafSize, false, 0, out.nodes, out.prim_order, out.bbmin, out.bbmax, threads);
+  build_tree(boxes.data(), n, false, 0, out.nodes, out.prim_order, out.bbmin, out.bbmax, threads);
 }
 
 }  // namespace crh

@@ -17,10 +17,10 @@ constexpr int      kMaxDepth  = 40;
 constexpr uint32_t kEmptyRef  = 0xFFFFFFFFu;
 constexpr uint32_t kLeafBit   = 0x80000000u;
 
-struct QNode { uint32_t w[16]; };   // 64 B: origin, grid exponents, 8-bit child bounds, child refs (include/crh_bvh_format.h)
+struct QNode { uint32_t w[CRH_NODE_DWORDS]; };   // 64-B stride, 48 B used: origin, grid exponents + child counts, 8-bit child bounds, child / leaf base (include/crh_bvh_format.h)
 
 struct QBvh {
-  std::vector<QNode>    nodes;       // DFS pre-order
+  std::vector<QNode>    nodes;       // root first; the inner children of a node are consecutive
   std::vector<uint32_t> prim_order;  // leaf order -> input triangle index
   float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
 };
@@ -29,10 +29,10 @@ struct QBvh {
 void build_qbvh(const float* pos, const int32_t* tri, uint32_t n_tris, QBvh& out, int threads = 0);
 
 // One tree over n axis-aligned boxes (6 floats each: min xyz, max xyz), appended to `nodes` (references are indices into
-// `nodes`).  leaf_max = 4 and triangle leaves (first triangle = tri_base + position in `order`) for an object's tree;
-// leaf_max = 1 and instance leaves (CRH_REF_INSTANCE_TAG | box index) for the top-level tree of the two-level BVH.
-// Returns the root's index; order = leaf order of the boxes; bmin/bmax = bounds.
-uint32_t build_tree(const float* boxes, uint32_t n, uint32_t leaf_max, bool instance_leaves, uint32_t tri_base,
+// `nodes`).  One box per leaf; leaf references are CRH_LEAF_TAG | (leaf0 + position) for an object's tree and
+// CRH_REF_INSTANCE_TAG | (leaf0 + position) for the top-level tree of the two-level BVH.
+// Returns the root's index; order[position] = box at that leaf position; bmin/bmax = bounds.
+uint32_t build_tree(const float* boxes, uint32_t n, bool instance_leaves, uint32_t leaf0,
                     std::vector<QNode>& nodes, std::vector<uint32_t>& order, float bmin[3], float bmax[3], int threads = 0);
 
 }  // namespace crh

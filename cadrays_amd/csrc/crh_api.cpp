@@ -148,7 +148,7 @@ void fill_scene(const crh_ctx* c, DScene& S)
 {
   std::memset(&S, 0, sizeof S);
   S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = c->d_env;
-  S.inst = c->d_inst; S.root = c->root; S.two_level = c->two_level ? 1 : 0;
+  S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * c->inst.size() : nullptr; S.root = c->root; S.two_level = c->two_level ? 1 : 0;
   S.uvs = c->d_uvs; S.texels = c->d_texels; S.tex_desc = c->d_tex_desc; S.n_tex = c->d_tex_desc ? (uint32_t)c->textures.size() : 0u;
   S.n_mats = (uint32_t)c->mats.size(); S.n_lights = (uint32_t)c->lights.size(); S.env_w = c->envW; S.env_h = c->envH;
   for (int k = 0; k < 3; ++k) S.bg[k] = c->par.background[k];
@@ -190,7 +190,9 @@ int build_tlas(crh_ctx* c)
 {
   c->bvh.nodes.resize(c->n_blas_nodes);
   const uint32_t n = (uint32_t)c->inst.size();
-  std::vector<float> boxes(6 * (size_t)std::max(n, 1u), 0.f), table(32 * (size_t)std::max(n, 1u), 0.f);
+  // instance table: n records in instance order (shading looks the hit triangle's instance up) followed by the same n
+  // records in top-level LEAF order (a top-level leaf reference is a position in that order)
+  std::vector<float> boxes(6 * (size_t)std::max(n, 1u), 0.f), table(64 * (size_t)std::max(n, 1u), 0.f);
   for (uint32_t i = 0; i < n; ++i) {
     crh_ctx::Inst& in = c->inst[i];
     std::memcpy(in.fwd, &c->xf[12 * (size_t)in.obj], sizeof in.fwd);
@@ -200,7 +202,8 @@ int build_tlas(crh_ctx* c)
     std::memcpy(&table[32 * (size_t)i + 24], &in.root, 4); std::memcpy(&table[32 * (size_t)i + 25], &in.obj, 4);
   }
   std::vector<uint32_t> order;
-  c->root = build_tree(boxes.data(), n, 1, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, 1);
+  c->root = build_tree(boxes.data(), n, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, 1);
+  for (uint32_t p = 0; p < n; ++p) std::memcpy(&table[32 * (size_t)(n + p)], &table[32 * (size_t)order[p]], 128);
   return dev_upload(c, c->d_inst, table.data(), table.size() * sizeof(float));
 }
 
@@ -697,7 +700,7 @@ int crh_build(crh_ctx* c)
           boxes[6 * i + a] = std::min(v0, std::min(v1, v2)); boxes[6 * i + 3 + a] = std::max(v0, std::max(v1, v2));
         }
       crh_ctx::Inst in{}; in.obj = ob;
-      in.root = build_tree(boxes.data(), (uint32_t)mem.size(), kLeafSize, false, tri_base, c->bvh.nodes, order, in.bmin, in.bmax, threads);
+      in.root = build_tree(boxes.data(), (uint32_t)mem.size(), false, tri_base, c->bvh.nodes, order, in.bmin, in.bmax, threads);
       for (size_t i = 0; i < mem.size(); ++i) { c->bvh.prim_order.push_back(mem[order[i]]); tri_inst[mem[order[i]]] = (int32_t)c->inst.size(); }
       c->inst.push_back(in);
       tri_base += (uint32_t)mem.size();

@@ -22,7 +22,7 @@ constexpr int kOvfStack   = 112;   // spill entries per lane (scratch, rarely to
 
 // Scene as the kernels see it.  All arrays are float4-granular so every fetch is one dwordx4.
 struct DScene {
-  const float4* nodes;    // 4 x float4 per node (64 B): {origin.xyz, exps}, {qlo xyz}, {qhi xyz}, {refs}  (crh_bvh_format.h)
+  const float4* nodes;    // 3 x float4 used per node (64-B stride): {origin.xyz, exps | child counts}, {qlo xyz, qhi x}, {qhi yz, child base, leaf base}  (crh_bvh_format.h)
   const float4* tris;     // 3 x float4 per triangle in leaf order: v0|prim, v1, v2
   const float4* shade;    // 3 x float4 per triangle in leaf order: n0|material, n1, n2
   const float4* mats;     // 8 x float4 per material (crh_bsdf)
@@ -33,6 +33,7 @@ struct DScene {
   const uint4*  tex_desc; // per slot: {first texel, width, height, 0}; width 0 = empty slot
   uint32_t n_tex;
   const float4* inst;     // two-level: 8 x float4 per instance: inverse rows (3), forward rows (3), {root, object, -, -}, pad
+  const float4* inst_leaf;  // the same records in top-level leaf order (a top-level leaf reference is a position in this list)
   uint32_t root;          // node index traversal starts at (0 for a single-level scene, the top-level root otherwise)
   int two_level;
   uint32_t n_mats, n_lights, env_w, env_h;

@@ -5,8 +5,8 @@
 // Stage boundaries exchange path ids through compacted queues built with wave64 ballot + prefix
 // popcount, collected in LDS and appended with one atomic per 1024-8192 paths (a single counter word sustains only
 // ~88 atomics/us on MI355X); traversal waves are persistent and refill idle lanes.  Traversal keeps a per-lane stack in LDS (lane-interleaved,
-// conflict free), BVH nodes are 128-B float4 records (one L2 line per visit), triangles 48-B records
-// in leaf order.  No MFMA: there is no dense contraction on this path.
+// conflict free), BVH nodes are 48-B records with 8-bit child bounds and implicit child references (three dwordx4 fetches per
+// visit), triangles 48-B records in leaf order.  No MFMA: there is no dense contraction on this path.
 //
 // Arithmetic follows DESIGN.md "Algorithm spec" operation by operation (fma only where written;
 // built with -ffp-contract=off) so that results are bit-identical to the CPU oracle.
@@ -76,15 +76,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float inv_dir(float d)
 { return 1.0f / (crh_abs(d) < kDirEps ? (d < 0.f ? -kDirEps : kDirEps) : d); }
-
-// select r[s & 3] without branches: two selects on bit 0, one on bit 1
-__device__ __forceinline__ uint32_t pick(uint4 r, uint32_t s)
-{
-  const bool b0 = (s & 1u) != 0u, b1 = (s & 2u) != 0u;
-  const uint32_t lo = b0 ? r.y : r.x;
-  const uint32_t hi = b0 ? r.w : r.z;
-  return b1 ? hi : lo;
-}
 
 #define CRH_CE(a, b) { const uint32_t lo_ = min(a, b); const uint32_t hi_ = max(a, b); a = lo_; b = hi_; }
 
@@ -174,26 +165,29 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         if (sp == 0) cur = kDone; else read_top();
       }
     };
-    // one inner-node step of this lane: fetch the 64-B node (4 x dwordx4), slab-test and order its children, push / descend / pop
+    // one inner-node step of this lane: fetch the 48-B node (3 x dwordx4), slab-test and order its children, push / descend / pop
     auto inner_step = [&]() {
-      const float4* np = nodes + 4u * cur;
-      const float4 n0 = np[0], n1 = np[1], n2 = np[2], rf = np[3];
-      const uint4 refs = make_uint4(__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w));
+      const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;
+      const float4 n0 = np[0], n1 = np[1], n2 = np[2];
       if (COUNT) ++n_nodes;
       // per-node grid: face t = fma(q, step * inv_d, fma(origin, inv_d, -o * inv_d))
       const uint32_t ew = __float_as_uint(n0.w);
       const float ax = __uint_as_float((ew & 0xffu) << 23) * ix, ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * iy,
                   az = __uint_as_float(((ew >> 16) & 0xffu) << 23) * iz;
       const float bx = CRH_FMA(n0.x, ix, nox), by = CRH_FMA(n0.y, iy, noy), bz = CRH_FMA(n0.z, iz, noz);
+      // child references are implicit: slots < ni are the consecutive inner nodes from child_base, the others the leaves
+      // with consecutive references from leaf_base (crh_bvh_format.h): ref(slot) = (slot < ni ? child_base : leaf_base - ni) + slot
+      const uint32_t ni = (ew >> 24) & 7u, nch = ew >> 28;
+      const uint32_t base_inner = __float_as_uint(n2.z), base_leaf = __float_as_uint(n2.w) - ni;
       // Along a negative direction the far plane is the one the ray enters through: swap the lo / hi byte words of that axis
       // once per node instead of a min + max per child and axis (fma is monotonic in q, so the values are the same bits).
       const bool sx = ix < 0.f, sy = iy < 0.f, sz = iz < 0.f;
-      const uint32_t lx = __float_as_uint(sx ? n2.x : n1.x), ly = __float_as_uint(sy ? n2.y : n1.y), lz = __float_as_uint(sz ? n2.z : n1.z);
-      const uint32_t hx = __float_as_uint(sx ? n1.x : n2.x), hy = __float_as_uint(sy ? n1.y : n2.y), hz = __float_as_uint(sz ? n1.z : n2.z);
+      const uint32_t lx = __float_as_uint(sx ? n1.w : n1.x), ly = __float_as_uint(sy ? n2.x : n1.y), lz = __float_as_uint(sz ? n2.y : n1.z);
+      const uint32_t hx = __float_as_uint(sx ? n1.x : n1.w), hy = __float_as_uint(sy ? n1.y : n2.x), hz = __float_as_uint(sz ? n1.z : n2.y);
       const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
       uint32_t key[4];
 #define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))      /* v_cvt_f32_ubyteK */
-#define CRH_CHILD(K, REF)                                                                                    \
+#define CRH_CHILD(K)                                                                                         \
       {                                                                                                     \
         const f32x2 tx = __builtin_elementwise_fma((f32x2){CRH_QB(lx, K), CRH_QB(hx, K)}, ax2, bx2);      /* v_pk_fma_f32: entry, exit */ \
         const f32x2 ty = __builtin_elementwise_fma((f32x2){CRH_QB(ly, K), CRH_QB(hy, K)}, ay2, by2);      \
@@ -201,12 +195,12 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
         const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), best);                                    \
         const int bits = max(__float_as_int(tmin), 0);                                                     \
-        key[K] = (REF != kQEmpty && tmin <= tmx) ? (((uint32_t)bits & ~3u) | (uint32_t)K) : 0xFFFFFFFFu;   \
+        key[K] = ((uint32_t)K < nch && tmin <= tmx) ? (((uint32_t)bits & ~3u) | (uint32_t)K) : 0xFFFFFFFFu;   \
       }
-      CRH_CHILD(0, refs.x)
-      CRH_CHILD(1, refs.y)
-      CRH_CHILD(2, refs.z)
-      CRH_CHILD(3, refs.w)
+      CRH_CHILD(0)
+      CRH_CHILD(1)
+      CRH_CHILD(2)
+      CRH_CHILD(3)
 #undef CRH_CHILD
 #undef CRH_QB
       CRH_CE(key[0], key[1]) CRH_CE(key[2], key[3]) CRH_CE(key[0], key[2]) CRH_CE(key[1], key[3]) CRH_CE(key[1], key[2])
@@ -214,7 +208,9 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       // stack, the nearest continues in registers.  Common case (room for three entries in the LDS part of
       // the stack): three UNCONDITIONAL stores -- hit children land at sp + (nh-1-j), the others in the dead
       // slots above the new top -- so the step has no per-child branches.
-      const uint32_t r0 = pick(refs, key[0]), r1 = pick(refs, key[1]), r2 = pick(refs, key[2]), r3 = pick(refs, key[3]);
+#define CRH_REF(KEY) (((((KEY) & 3u) < ni) ? base_inner : base_leaf) + ((KEY) & 3u))
+      const uint32_t r0 = CRH_REF(key[0]), r1 = CRH_REF(key[1]), r2 = CRH_REF(key[2]), r3 = CRH_REF(key[3]);
+#undef CRH_REF
       const int nh = 4 + ((((int)key[0] >> 31) + ((int)key[1] >> 31)) + (((int)key[2] >> 31) + ((int)key[3] >> 31)));
       if (__builtin_expect(sp <= kLdsStack - 3, 1)) {
         uint32_t* top = lds + sp * kBlock;
@@ -271,12 +267,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       ++sp;
       cur = __float_as_uint(meta.x);
     } else if (have && (cur & kQLeafBit) && cur != kDone) {
-      const uint32_t off = cur & 0x0FFFFFFFu;
-      if (CRH_BVH_LEAF_SIZE == 1) tri_step(off);               // the builders emit one triangle per leaf
-      else {
-        const uint32_t cnt = ((cur >> 28) & 7u) + 1u;
-        for (uint32_t k = 0; k < cnt; ++k) { tri_step(off + k); if (ANY && found) break; }
-      }
+      tri_step(cur & 0x0FFFFFFFu);                               // one triangle per leaf (crh_bvh_format.h)
       pop();
     }
 
@@ -298,7 +289,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint3
     atomicAdd(&C->rays_nearest, (unsigned long long)n);
   }
   uint32_t nn = 0, nt = 0;
-  trace_engine<false, COUNT, TWO>(S.nodes, S.tris, S.inst, S.root, cursors + 0, n, &stk[threadIdx.x],
+  trace_engine<false, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, cursors + 0, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];      // .w lanes carry the path's rng state / flags, not ray data
@@ -319,7 +310,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
   const uint32_t n = *count;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
   uint32_t nn = 0, nt = 0;
-  trace_engine<true, COUNT, TWO>(S.nodes, S.tris, S.inst, S.root, cursors + 2, n, &stk[threadIdx.x],
+  trace_engine<true, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, cursors + 2, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
@@ -346,7 +337,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   uint32_t nn = 0, nt = 0;
-  trace_engine<ANY, COUNT, TWO>(S.nodes, S.tris, S.inst, S.root, cursor, n, &stk[threadIdx.x],
+  trace_engine<ANY, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, cursor, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = idx;
       const float4 o4 = rays[2u * idx], d4 = rays[2u * idx + 1u];

@@ -13,6 +13,7 @@ import dataclasses
 
 import numpy as np
 
+from . import abi
 from ._lib import load_library
 from .binding import Backend, BackendError
 
@@ -121,7 +122,7 @@ def build_bvh_host(pos, tri, threads=0):
     nn = C.c_uint32(0)
     fp, ip, up = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
     args = (pos.ctypes.data_as(fp), C.c_uint32(len(pos)), tri.ctypes.data_as(ip), C.c_uint32(len(tri)), C.c_int(threads))
-    nodes = np.empty((max(len(tri), 4), 16), np.float32)   # nodes <= max(1, ~nT/2), 64 B each
+    nodes = np.empty((max(len(tri), 4), abi.NODE_DWORDS), np.float32)   # nodes <= max(1, ~nT/2), 64 B each
     order = np.empty(len(tri), np.uint32)
     rc = lib.crh_build_bvh_host(*args, nodes.ctypes.data_as(fp), C.byref(nn), order.ctypes.data_as(up))
     if rc != 0:

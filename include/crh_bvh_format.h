@@ -1,14 +1,22 @@
-/* crh_bvh_format.h -- the 64-byte 4-wide BVH node and its quantiser (data-format definition shared by the
+/* crh_bvh_format.h -- the 4-wide BVH node (48 bytes of payload on a 64-byte stride) and its quantiser (data-format definition shared by the
  * host builder, the gfx950 traversal kernels and the CPU oracle, like crh_math.h for arithmetic).
  *
- * Node = 16 dwords (one half of a 128-B L2 line, four dwordx4 fetches per visit):
+ * Node = 12 dwords = THREE dwordx4 fetches per visit (per-lane divergent loads cost ~0.7 TA cycles per lane and
+ * instruction on MI355X -- tools/ubench/ta_rate.hip -- so the fourth fetch of the former explicit-reference node was
+ * ~20 % of the address-processing time of a visit).  Nodes sit on a 64-B stride (dwords 12..15 are padding that is never
+ * fetched): packed at 48 B half of them straddle two 64-B sectors, which costs more HBM traffic than the smaller array
+ * saves (measured, Mrays/s at 64-B / 48-B stride: C3 2890 / 2836, C5 -- 10 M triangles, HBM-bound -- 2104 / 1955).
  *   [0..2]  origin.xyz (float)            minimum corner of the union of the child boxes
- *   [3]     ex | ey<<8 | ez<<16 | n<<24    biased exponent bytes of the per-axis grid step 2^(e-127); n = child count
+ *   [3]     ex | ey<<8 | ez<<16 | n_inner<<24 | n_children<<28
+ *                                          biased exponent bytes of the per-axis grid step 2^(e-127); child counts
  *   [4..6]  qlo_x, qlo_y, qlo_z            byte k = child k's lower bound on the grid:  origin + q * step
- *   [7]     0
- *   [8..10] qhi_x, qhi_y, qhi_z            byte k = child k's upper bound
- *   [11]    0
- *   [12..15] child references              inner: node index | leaf: 0x80000000 | (count-1)<<28 | first triangle | 0xFFFFFFFF empty
+ *   [7..9]  qhi_x, qhi_y, qhi_z            byte k = child k's upper bound
+ *   [10]    child_base                     slots 0 .. n_inner-1 are inner nodes child_base + slot (consecutive indices)
+ *   [11]    leaf_base                      slots n_inner .. n_children-1 are leaves with references leaf_base + (slot - n_inner):
+ *                                          0x80000000 | triangle (ONE leaf-order triangle per leaf, consecutive triangles),
+ *                                          or 0xF0000000 | position in the top-level tree's leaf-ordered instance list
+ * Child references are therefore implicit: the builders number the inner children of a node consecutively and place
+ * the triangles of its leaf children consecutively (inner children first, then leaves, each in collapse order).
  * The grid is conservative: origin + qlo*step <= true lower bound, origin + qhi*step >= true upper bound, so the
  * set of triangles a ray can reach is unchanged; only the number of visits grows slightly (<= 2/255 of the parent
  * extent per face).  Traversal evaluates a face as  t = fma((float)q, step * inv_d, fma(origin, inv_d, -o * inv_d)).
@@ -18,11 +26,17 @@
 
 #include "crh_math.h"
 
-#define CRH_NODE_DWORDS 16
-/* triangles per leaf.  Measured on MI355X (C3, Mrays/s): 1 -> 2620, 2 -> 2521, 3 -> 2396, 4 -> 2295, 6 -> 2058: in a
- * triangle soup a multi-triangle leaf mostly buys failed tests; one extra 64-B inner level is cheaper. */
+#ifndef CRH_NODE_DWORDS
+#define CRH_NODE_DWORDS 16          /* dwords between consecutive nodes (12 are used) */
+#endif
+/* triangles per leaf -- fixed by the format (a leaf reference is one triangle index).  Measured on MI355X with the
+ * former explicit-reference node (C3, Mrays/s): 1 -> 2620, 2 -> 2521, 3 -> 2396, 4 -> 2295, 6 -> 2058: in a
+ * triangle soup a multi-triangle leaf mostly buys failed tests; one extra inner level is cheaper. */
 #define CRH_BVH_LEAF_SIZE 1
-#define CRH_NODE_BYTES  64
+#define CRH_NODE_BYTES  (4 * CRH_NODE_DWORDS)
+#define CRH_LEAF_TAG      0x80000000u
+#define CRH_NODE_NINNER(w3)    (((w3) >> 24) & 7u)
+#define CRH_NODE_NCHILDREN(w3) (((w3) >> 28) & 7u)
 
 /* biased exponent byte E of the smallest power-of-two step with 255 * 2^(E-127) >= ext */
 CRH_HD uint32_t crh_quant_exp(float ext)
@@ -56,8 +70,9 @@ CRH_HD uint32_t crh_quant_hi(float hi, float origin, uint32_t e)
   return (uint32_t)q;
 }
 
-/* Fill one node from <= 4 child boxes (cmin/cmax: [child][axis]) and references.  out: 16 dwords. */
-CRH_HD void crh_pack_node(const float cmin[4][3], const float cmax[4][3], const uint32_t refs[4], int n_children, uint32_t out[CRH_NODE_DWORDS])
+/* Fill one node from <= 4 child boxes (cmin/cmax: [slot][axis], inner children first) and the two bases.  out: 12 dwords. */
+CRH_HD void crh_pack_node(const float cmin[4][3], const float cmax[4][3], int n_inner, int n_children, uint32_t child_base,
+                          uint32_t leaf_base, uint32_t out[CRH_NODE_DWORDS])
 {
   float org[3], ext[3]; uint32_t e[3];
   for (int a = 0; a < 3; ++a) {
@@ -67,17 +82,24 @@ CRH_HD void crh_pack_node(const float cmin[4][3], const float cmax[4][3], const 
     org[a] = lo; ext[a] = hi - lo; e[a] = crh_quant_exp(ext[a]);
   }
   out[0] = crh_f2u(org[0]); out[1] = crh_f2u(org[1]); out[2] = crh_f2u(org[2]);
-  out[3] = e[0] | (e[1] << 8) | (e[2] << 16) | ((uint32_t)n_children << 24);
+  out[3] = e[0] | (e[1] << 8) | (e[2] << 16) | ((uint32_t)n_inner << 24) | ((uint32_t)n_children << 28);
   for (int a = 0; a < 3; ++a) {
     uint32_t lo = 0u, hi = 0u;
     for (int k = 0; k < n_children; ++k) {
       lo |= crh_quant_lo(cmin[k][a], org[a], e[a]) << (8 * k);
       hi |= crh_quant_hi(cmax[k][a], org[a], e[a]) << (8 * k);
     }
-    out[4 + a] = lo; out[8 + a] = hi;
+    out[4 + a] = lo; out[7 + a] = hi;
   }
-  out[7] = 0u; out[11] = 0u;
-  for (int k = 0; k < 4; ++k) out[12 + k] = refs[k];
+  out[10] = child_base; out[11] = leaf_base;
+  for (int k = 12; k < CRH_NODE_DWORDS; ++k) out[k] = 0u;
+}
+
+/* reference of the child in `slot` (< n_children) of a packed node */
+CRH_HD uint32_t crh_node_child_ref(const uint32_t w[CRH_NODE_DWORDS], uint32_t slot)
+{
+  const uint32_t ni = CRH_NODE_NINNER(w[3]);
+  return slot < ni ? w[10] + slot : w[11] + (slot - ni);
 }
 
 #endif /* CRH_BVH_FORMAT_H */

@@ -71,6 +71,7 @@ typedef struct orc_ctx {
   /* two-level mode (per-object transforms): object-space BLAS per object + TLAS over instance boxes */
   int two_level; uint32_t nO; float* xf; int32_t* tri_obj;
   struct orc_instance* inst; uint32_t nInst; uint32_t nBlasNodes; uint32_t root;
+  uint32_t* tlas_order;          /* instance at top-level leaf position i */
   float bbmin[3], bbmax[3]; float eps;
   int built;
   /* camera frame */
@@ -210,20 +211,14 @@ static uint32_t build_rec(builder* B, uint32_t lo, uint32_t hi, int depth)
   return me;
 }
 
-/* collapse binary -> 4-wide (OCCT BVH_Tree::CollapseToQuadTree idea: children := grandchildren),
- * nodes numbered in DFS pre-order, children visited in slot order. */
-typedef struct { const bnode* bn; qnode* qn; uint32_t nq, capq; int instances; uint32_t tri_base; const uint32_t* idx; } collapser;
+/* collapse binary -> 4-wide (OCCT BVH_Tree::CollapseToQuadTree idea: children := grandchildren).  Child references
+ * are implicit in the 48-B node (crh_bvh_format.h): when a node is expanded, its inner children take the next free
+ * node indices (one consecutive block) and the primitives of its leaf children the next free leaf positions; then the
+ * inner children are expanded in slot order.  Slots: inner children first, then leaves, each in collapse order. */
+typedef struct { const bnode* bn; qnode* qn; uint32_t nq, capq; int instances; uint32_t next_leaf, leaf0; const uint32_t* idx; uint32_t* order; } collapser;
 
-static uint32_t leaf_ref(const collapser* C, const bnode* b)
+static void collapse_rec(collapser* C, uint32_t bi, uint32_t me)
 {
-  if (C->instances) return CRH_REF_INSTANCE_TAG | C->idx[b->lo];          /* top-level leaf = one instance */
-  return QBVH_LEAFBIT | ((b->hi - b->lo - 1u) << 28) | (b->lo + C->tri_base);
-}
-
-static uint32_t collapse_rec(collapser* C, uint32_t bi)
-{
-  if (C->nq == C->capq) { C->capq *= 2; C->qn = (qnode*)realloc(C->qn, sizeof(qnode) * C->capq); }
-  uint32_t me = C->nq++;
   uint32_t kids[4]; int nk = 0;
   const bnode* b = &C->bn[bi];
   if (b->left < 0) { kids[nk++] = bi; }
@@ -235,36 +230,45 @@ static uint32_t collapse_rec(collapser* C, uint32_t bi)
       else { kids[nk++] = (uint32_t)c->left; kids[nk++] = (uint32_t)c->right; }
     }
   }
-  qnode q; memset(&q, 0, sizeof q);
-  uint32_t refs[4] = {QBVH_EMPTY, QBVH_EMPTY, QBVH_EMPTY, QBVH_EMPTY};
+  uint32_t slot[4]; int ni = 0, nc = 0;
+  for (int k = 0; k < nk; ++k) if (C->bn[kids[k]].left >= 0) slot[nc++] = kids[k];
+  ni = nc;
+  for (int k = 0; k < nk; ++k) { const bnode* c = &C->bn[kids[k]]; if (c->left < 0 && c->hi > c->lo) slot[nc++] = kids[k]; }   /* an empty leaf (no primitives at all) is dropped */
+  const uint32_t child_base = C->nq;
+  while (C->nq + (uint32_t)ni > C->capq) { C->capq *= 2; C->qn = (qnode*)realloc(C->qn, sizeof(qnode) * C->capq); }
+  C->nq += (uint32_t)ni;
+  const uint32_t leaf_base = (C->instances ? CRH_REF_INSTANCE_TAG : CRH_LEAF_TAG) | C->next_leaf;
   float cmin[4][3], cmax[4][3];
-  for (int k = 0; k < nk; ++k) {
-    const bnode* c = &C->bn[kids[k]];
+  for (int k = 0; k < nc; ++k) {
+    const bnode* c = &C->bn[slot[k]];
     for (int a = 0; a < 3; ++a) { cmin[k][a] = c->box.mn[a]; cmax[k][a] = c->box.mx[a]; }
-    if (c->left < 0) refs[k] = (c->hi > c->lo) ? leaf_ref(C, c) : QBVH_EMPTY;
-    else             refs[k] = collapse_rec(C, kids[k]);
+    if (k >= ni) C->order[C->next_leaf++ - C->leaf0] = C->idx[c->lo];      /* one primitive per leaf */
   }
-  crh_pack_node(cmin, cmax, refs, nk, q.w);
+  qnode q; memset(&q, 0, sizeof q);
+  crh_pack_node(cmin, cmax, ni, nc, child_base, leaf_base, q.w);
   C->qn[me] = q;
-  return me;
+  for (int k = 0; k < ni; ++k) collapse_rec(C, slot[k], child_base + (uint32_t)k);
 }
 
 /* One tree over n primitives with boxes pb[0..n) (centre = box centre): binary build + 4-wide collapse appended to C.
- * Returns the 4-wide root index; order[0..n) = leaf order; *rootbox = bounds. */
-static uint32_t build_tree(collapser* C, const aabb* pb, uint32_t n, uint32_t leaf_max, int instances, uint32_t tri_base,
+ * Leaves are numbered from leaf0; returns the 4-wide root index; order[0..n) = primitive at leaf position leaf0 + i;
+ * *rootbox = bounds. */
+static uint32_t build_tree(collapser* C, const aabb* pb, uint32_t n, uint32_t leaf_max, int instances, uint32_t leaf0,
                            uint32_t* order, aabb* rootbox)
 {
   float* cen = (float*)malloc(sizeof(float) * 3 * (n ? n : 1));
   for (uint32_t t = 0; t < n; ++t) for (int a = 0; a < 3; ++a) cen[3 * t + a] = (pb[t].mn[a] + pb[t].mx[a]) * 0.5f;
   builder B; B.pb = pb; B.cen = cen; B.leaf_max = leaf_max;
-  B.idx = order; B.tmp = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  B.idx = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1)); B.tmp = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
   for (uint32_t t = 0; t < n; ++t) B.idx[t] = t;
   B.cap = 1024; B.nbn = 0; B.bn = (bnode*)malloc(sizeof(bnode) * B.cap);
   build_rec(&B, 0, n, 0);
   if (rootbox) *rootbox = B.bn[0].box;
-  C->bn = B.bn; C->instances = instances; C->tri_base = tri_base; C->idx = order;
-  uint32_t root = collapse_rec(C, 0);
-  free(cen); free(B.tmp); free(B.bn);
+  C->bn = B.bn; C->instances = instances; C->next_leaf = leaf0; C->leaf0 = leaf0; C->idx = B.idx; C->order = order;
+  if (C->nq == C->capq) { C->capq *= 2; C->qn = (qnode*)realloc(C->qn, sizeof(qnode) * C->capq); }
+  uint32_t root = C->nq++;
+  collapse_rec(C, 0, root);
+  free(cen); free(B.tmp); free(B.idx); free(B.bn);
   return root;
 }
 
@@ -304,7 +308,8 @@ static void build_tlas(orc_ctx* c)
   c->root = build_tree(&C, pb, n, 1, 1, 0, order, NULL);
   c->nodes = C.qn; c->nNodes = C.nq;
   for (int a = 0; a < 3; ++a) { c->bbmin[a] = n ? sb.mn[a] : 0.f; c->bbmax[a] = n ? sb.mx[a] : 0.f; }
-  free(pb); free(order);
+  free(c->tlas_order); c->tlas_order = order;
+  free(pb);
 }
 
 static int do_build(orc_ctx* c)
@@ -385,7 +390,7 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
     if ((cur & 0xF0000000u) == CRH_REF_INSTANCE_TAG) {
       /* top-level leaf: express the ray in the object's space (direction NOT renormalised, so t is unchanged),
        * mark the stack, continue at the object's root */
-      const orc_instance* in = &c->inst[cur & 0x0FFFFFFFu];
+      const orc_instance* in = &c->inst[c->tlas_order[cur & 0x0FFFFFFFu]];
       o = crh_xform_point(in->inv, wo); d = crh_xform_vector(in->inv, wd);
       ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
       nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
@@ -394,13 +399,11 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
       continue;
     }
     if (cur & QBVH_LEAFBIT) {
-      uint32_t off = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t k = 0; k < cnt; ++k) {
-        float t, u, v; if (any_hit) cn->tris_any++; else cn->tris++;
-        if (tri_test(&c->qtris[off + k], o, d, best, &t, &u, &v)) {
-          best = t; found = 1; h->t = t; h->u = u; h->v = v; h->prim = (int32_t)crh_f2u(c->qtris[off + k].f[3]);
-          if (any_hit) return 1;
-        }
+      const uint32_t off = cur & 0x0FFFFFFFu;                  /* one triangle per leaf */
+      float t, u, v; if (any_hit) cn->tris_any++; else cn->tris++;
+      if (tri_test(&c->qtris[off], o, d, best, &t, &u, &v)) {
+        best = t; found = 1; h->t = t; h->u = u; h->v = v; h->prim = (int32_t)crh_f2u(c->qtris[off].f[3]);
+        if (any_hit) return 1;
       }
     } else {
       const qnode* q = &c->nodes[cur]; if (any_hit) cn->nodes_any++; else cn->nodes++;
@@ -409,13 +412,13 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
       const float ax = crh_quant_step(ew & 0xffu) * ix, ay = crh_quant_step((ew >> 8) & 0xffu) * iy, az = crh_quant_step((ew >> 16) & 0xffu) * iz;
       const float bx = CRH_FMA(crh_u2f(q->w[0]), ix, nox), by = CRH_FMA(crh_u2f(q->w[1]), iy, noy), bz = CRH_FMA(crh_u2f(q->w[2]), iz, noz);
       uint32_t key[4]; uint32_t rf[4]; int nh = 0;
-      for (int k = 0; k < 4; ++k) {
-        uint32_t r = q->w[12 + k];
-        if (r == QBVH_EMPTY) continue;
+      const int nch = (int)CRH_NODE_NCHILDREN(ew);
+      for (int k = 0; k < nch; ++k) {
+        uint32_t r = crh_node_child_ref(q->w, (uint32_t)k);
         const int sh = 8 * k;
-        float a0 = CRH_FMA((float)((q->w[4] >> sh) & 0xffu), ax, bx), a1 = CRH_FMA((float)((q->w[8] >> sh) & 0xffu), ax, bx);
-        float b0 = CRH_FMA((float)((q->w[5] >> sh) & 0xffu), ay, by), b1 = CRH_FMA((float)((q->w[9] >> sh) & 0xffu), ay, by);
-        float c0 = CRH_FMA((float)((q->w[6] >> sh) & 0xffu), az, bz), c1 = CRH_FMA((float)((q->w[10] >> sh) & 0xffu), az, bz);
+        float a0 = CRH_FMA((float)((q->w[4] >> sh) & 0xffu), ax, bx), a1 = CRH_FMA((float)((q->w[7] >> sh) & 0xffu), ax, bx);
+        float b0 = CRH_FMA((float)((q->w[5] >> sh) & 0xffu), ay, by), b1 = CRH_FMA((float)((q->w[8] >> sh) & 0xffu), ay, by);
+        float c0 = CRH_FMA((float)((q->w[6] >> sh) & 0xffu), az, bz), c1 = CRH_FMA((float)((q->w[9] >> sh) & 0xffu), az, bz);
         float tmin = crh_max(crh_max(crh_max(crh_min(a0, a1), crh_min(b0, b1)), crh_min(c0, c1)), 0.f);
         float tmx  = crh_min(crh_min(crh_min(crh_max(a0, a1), crh_max(b0, b1)), crh_max(c0, c1)), best);
         if (tmin <= tmx) {
@@ -976,7 +979,7 @@ ORC_API void orc_destroy(orc_ctx* c)
 {
   if (!c) return;
   free(c->pos); free(c->nrm); free(c->uv); free(c->tri); free(c->mats); free(c->lights); free(c->env);
-  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->last_picked); free(c->xf); free(c->tri_obj); free(c->inst); free(c);
+  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->last_picked); free(c->xf); free(c->tri_obj); free(c->inst); free(c->tlas_order); free(c);
 }
 ORC_API const char* orc_last_error(orc_ctx* c) { return c ? c->err : "null ctx"; }
 

@@ -17,7 +17,8 @@ _LIB = None
 def build(force=False):
     so = os.path.join(_HERE, "libcrh_oracle.so")
     src = os.path.join(_HERE, "crh_oracle.c")
-    hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("crh_math.h", "cadrays_hip.h")]
+    inc = os.path.join(_HERE, "..", "include")
+    hdrs = [os.path.join(inc, h) for h in sorted(os.listdir(inc)) if h.endswith(".h")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in [src] + hdrs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libcrh_oracle.so"])

@@ -68,14 +68,15 @@ def test_host_bvh_builder_equals_oracle_bytes(hip_lib, oracle_lib, n, threads):
     on, ot = o.get_bvh()
     assert nodes.shape == on.shape and np.array_equal(nodes.view(np.uint32), on.view(np.uint32))
     assert np.array_equal(ot[:, 3].view(np.uint32)[:n], order)
-    # structural invariants: every triangle referenced exactly once, leaves <= 4, children inside parents
-    refs = nodes[:, 12:16].view(np.uint32)              # 64-B node: dwords 12..15 (include/crh_bvh_format.h)
-    leaf = (refs & 0x80000000) != 0
-    leaf &= refs != 0xFFFFFFFF
-    cnt = ((refs >> 28) & 7) + 1
-    assert cnt[leaf].sum() == n and (cnt[leaf] <= 4).all()
-    inner = (~leaf) & (refs != 0xFFFFFFFF)
-    assert sorted(refs[inner].tolist()) == list(range(1, len(nodes)))
+    # structural invariants of the 48-B node (include/crh_bvh_format.h): slots < n_inner are the consecutive nodes from
+    # child_base, the others one-triangle leaves at consecutive positions from leaf_base; every node and triangle once
+    w = nodes.view(np.uint32)
+    ni, nch = (w[:, 3] >> 24) & 7, (w[:, 3] >> 28) & 7
+    assert (ni <= nch).all() and (nch <= 4).all()
+    inner = np.concatenate([w[i, 10] + np.arange(ni[i], dtype=np.uint32) for i in range(len(w))]) if len(w) else np.zeros(0, np.uint32)
+    leaves = np.concatenate([w[i, 11] + np.arange(nch[i] - ni[i], dtype=np.uint32) for i in range(len(w))]) if len(w) else np.zeros(0, np.uint32)
+    assert sorted(inner.tolist()) == list(range(1, len(nodes)))
+    assert ((leaves & 0xF0000000) == 0x80000000).all() and sorted((leaves & 0x0FFFFFFF).tolist()) == list(range(n))
 
 
 def test_host_bvh_degenerate_inputs(hip_lib, oracle_lib):
