@@ -120,8 +120,8 @@ def main():
         v.enable_counters(False)
         assert cs["rays_nearest"] == st["rays_nearest"], "counting pass traced different rays"
         launches = max(kt["trace_nearest_launches"], 1)
-        # algorithmic bytes of k_trace_nearest: 64-B node per inner visit, 3 x float4 per triangle test, 32-B ray + 16-B hit per ray
-        alg_bytes = 64.0 * cs["nodes_nearest"] + 48.0 * cs["tris_nearest"] + 48.0 * cs["rays_nearest"]
+        # algorithmic bytes of k_trace_nearest: 3 x float4 of node per inner visit, 3 x float4 per triangle test, 32-B ray + 16-B hit per ray
+        alg_bytes = 48.0 * cs["nodes_nearest"] + 48.0 * cs["tris_nearest"] + 48.0 * cs["rays_nearest"]
         per_launch = alg_bytes / launches
         avg_ms = kt["trace_nearest_ms_total"] / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
