@@ -724,7 +724,12 @@ int crh_build(crh_ctx* c)
   }
   int rc;
   if ((rc = dev_upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode)))) return rc;
-  if ((rc = dev_upload(c, c->d_tris, c->h_tris.data(), c->h_tris.size() * sizeof(float)))) return rc;
+  if (kTriStride == 3) { if ((rc = dev_upload(c, c->d_tris, c->h_tris.data(), c->h_tris.size() * sizeof(float)))) return rc; }
+  else {
+    std::vector<float> padded(4 * (size_t)kTriStride * std::max(nT, 1u), 0.f);
+    for (size_t i = 0; i < (size_t)nT; ++i) std::memcpy(&padded[4 * (size_t)kTriStride * i], &c->h_tris[12 * i], 48);
+    if ((rc = dev_upload(c, c->d_tris, padded.data(), padded.size() * sizeof(float)))) return rc;
+  }
   if ((rc = dev_upload(c, c->d_shade, sh.data(), sh.size() * sizeof(float)))) return rc;
   if (!c->uv.empty()) {
     std::vector<float> uvr(8 * (size_t)std::max(nT, 1u), 0.f);
