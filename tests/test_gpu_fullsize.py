@@ -81,3 +81,49 @@ def test_c2_full_size_shadow_rays(hip_lib):
     v.reset(); v.render(2)
     assert np.array_equal(bits(v.read_hdr()), bits(a))
     assert np.isfinite(a).all() and a.max() <= 30.0 * (1 + 1e-6)
+
+
+def test_c5_full_size_deep_bvh_properties(hip_lib):
+    """C5 (10 M triangles, 3840x2160): the HBM-resident deep BVH.  8-way tile shards == whole frame bit-for-bit, two runs
+    identical, nearest / any-hit consistent, and a handful of rays agree with a brute-force test against all 10 M triangles."""
+    from cadrays_amd.view import View
+    sc = scenes.baseline_config("C5")
+    assert len(sc.tri) == 10_000_000 and (sc.params.width, sc.params.height) == (3840, 2160)
+    v = View(0).load_scene(sc)
+    nodes, _ = v.get_bvh()
+    w3 = nodes.view(np.uint32)[:, 3]
+    assert (((w3 >> 24) & 7) <= ((w3 >> 28) & 7)).all() and 3_000_000 < len(nodes) < 10_000_000
+    v.render(1); a = v.read_hdr(); st = v.stats()
+    assert st["samples"] == 3840 * 2160 and np.isfinite(a).all() and a.min() >= 0
+    v.reset()
+    tiles = np.arange(v.n_tiles(), dtype=np.uint32)
+    for r in range(8):                                                        # the 8-GPU shard pattern of BASELINE config 5
+        v.render_tiles(tiles[r::8], 0, 1)
+    assert np.array_equal(bits(v.read_hdr()), bits(a))
+    r = np.random.default_rng(5)
+    n = 200_000
+    o = (r.random((n, 3)) * 2 - 1).astype(np.float32)
+    d = r.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.zeros((n, 8), np.float32); rays[:, :3] = o; rays[:, 3] = 1e15; rays[:, 4:7] = d
+    h = v.trace_nearest(rays)
+    hit = h[:, 3].view(np.int32) >= 0
+    assert hit.mean() > 0.9
+    short = rays.copy(); short[:, 3] = np.where(hit, h[:, 0] * (1 - 1e-3), 1e15)
+    assert (v.trace_any(short) == 1).all()
+    # brute force, float64, all triangles: the nearest t of 6 rays
+    p = sc.pos.astype(np.float64).reshape(-1, 3)
+    v0, v1, v2 = p[sc.tri[:, 0]], p[sc.tri[:, 1]], p[sc.tri[:, 2]]
+    e1, e2 = v1 - v0, v2 - v0
+    for i in range(6):
+        oo, dd = o[i].astype(np.float64), d[i].astype(np.float64)
+        pv = np.cross(dd, e2); det = (e1 * pv).sum(1)
+        ok = np.abs(det) > 1e-300
+        inv = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+        tv = oo - v0; uu = (tv * pv).sum(1) * inv
+        qv = np.cross(tv, e1); vv = (qv @ dd) * inv; tt = (qv * e2).sum(1) * inv
+        good = ok & (uu >= 0) & (vv >= 0) & (uu + vv <= 1) & (tt >= 0)
+        if good.any():
+            k = int(np.argmin(np.where(good, tt, np.inf)))
+            assert hit[i] and abs(h[i, 0] - tt[k]) <= 1e-4 * max(1.0, tt[k]), (i, h[i], tt[k], k)
+        else:
+            assert not hit[i]
