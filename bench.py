@@ -3,7 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" = one crh_render pass of `--spp` (default 32) samples per pixel over the rank's tiles of the workload
+A "step" = one crh_render pass of `--spp` (default: one full 256 M-path batch = 128 samples per pixel at 1080p) over the rank's tiles of the workload
 (BASELINE.json config C3: 1 M random triangles, glass + glossy double-layer BSDFs, HDR sky, 1080p).
 At N > 1 (one process per GPU under torch.distributed.run) tiles are interleaved across ranks, every rank
 renders spp*N samples of its tiles per step (fixed per-GPU work -> weak scaling), and each step ends with
@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
-    ap.add_argument("--spp", type=int, default=32, help="samples per pixel per step (per GPU share)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (per GPU share); 0 = what fills one 256 M-path batch (128 at 1080p, 32 at 4K)")
     ap.add_argument("--tris", type=int, default=0, help="override triangle count (debug)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -69,6 +69,8 @@ def main():
     build_s = time.time() - t0
     fb = sharding.DeviceFramebuffer(v) if world > 1 else None
     tiles = sharding.tiles_for_rank(v.n_tiles(), rank, world)
+    if args.spp <= 0:                     # one full path batch per step: 2^28 slots / (tiles x 32 x 32 pixels)
+        args.spp = max(1, (256 << 20) // (v.n_tiles() * sc.params.tile_size ** 2))
     spp_step = args.spp * world          # fixed per-GPU work: 1/N of the tiles, N x the samples
 
     def barrier():
