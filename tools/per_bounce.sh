@@ -9,11 +9,13 @@ out = []
 for r in rows:
     n = r['Kernel_Name']
     import re; m = re.search(r'k_[a-z_]+', n); short = m.group(0) if m else n[:40]
-    out.append((short, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6))
+    out.append((short, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6, int(r['Start_Timestamp']), int(r['End_Timestamp'])))
 # print the launches of the timed step: find the second k_raygen
-idx = [i for i, (n, _) in enumerate(out) if 'k_raygen' in n]
+idx = [i for i, o_ in enumerate(out) if 'k_raygen' in o_[0]]
 print('raygen launches at', idx)
 s = idx[1]; e = idx[2] if len(idx) > 2 else len(out)
-for n, ms in out[s:e]:
-    print('%-42s %8.3f ms' % (n, ms))
+prev_end = None
+for n, ms, st, en in out[s:e]:
+    print('%-42s %8.3f ms   gap before %7.1f us' % (n, ms, (st - prev_end) / 1e3 if prev_end else 0.0))
+    prev_end = en
 PY
