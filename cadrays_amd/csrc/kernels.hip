@@ -63,6 +63,9 @@ __device__ __forceinline__ void lds_append(bool pred, uint32_t value, uint32_t* 
 #ifndef CRH_INNER_STEPS
 #define CRH_INNER_STEPS 2      // 0: descend until every lane holds a leaf; k > 0: at most k inner steps per round
 #endif
+#ifndef CRH_POOL_DIV
+#define CRH_POOL_DIV 2
+#endif
 #ifndef CRH_REFILL_IDLE
 #define CRH_REFILL_IDLE 12     // refill a wavefront once this many of its 64 lanes have no ray
 #endif
@@ -111,7 +114,10 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, best = 0.f;
   float4 hit = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   bool found = false;
-  // wave-uniform pool state
+  // wave-uniform pool state.  Chunk per atomic: kPoolChunk for long queues (one cursor word sustains ~88 atomics/us); short
+  // queues are cut finer so that every wavefront gets work -- a 75 K-ray launch in 256-ray chunks would keep 292 of the 5120
+  // wavefronts busy with four 64-ray generations each (0.5 ms) instead of 1170 with one (CRH_POOL_DIV chunks per wavefront).
+  const uint32_t chunk = min(kPoolChunk, max(64u, ((n / (gridDim.x * (uint32_t)(kBlock / 64) * (uint32_t)CRH_POOL_DIV)) + 63u) & ~63u));
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
 
@@ -122,10 +128,10 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       for (int round = 0; round < 2 && idle != 0ull; ++round) {
         if (pool_next == pool_end) {
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(cursor, kPoolChunk);
+          if (lane == 0) base = atomicAdd(cursor, chunk);
           base = __shfl(base, 0);
           if (base >= n) { exhausted = true; break; }
-          pool_next = base; pool_end = min(base + kPoolChunk, n);
+          pool_next = base; pool_end = min(base + chunk, n);
         }
         const uint32_t avail = pool_end - pool_next;
         const uint32_t want = (uint32_t)__popcll(idle);
