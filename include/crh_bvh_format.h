@@ -11,12 +11,14 @@
  *                                          biased exponent bytes of the per-axis grid step 2^(e-127); child counts
  *   [4..6]  qlo_x, qlo_y, qlo_z            byte k = child k's lower bound on the grid:  origin + q * step
  *   [7..9]  qhi_x, qhi_y, qhi_z            byte k = child k's upper bound
- *   [10]    child_base                     slots 0 .. n_inner-1 are inner nodes child_base + slot (consecutive indices)
+ *   [10]    child_base                     slots 0 .. n_inner-1 are inner nodes child_base + slot (consecutive indices); 0 if n_inner = 0
  *   [11]    leaf_base                      slots n_inner .. n_children-1 are leaves with references leaf_base + (slot - n_inner):
  *                                          0x80000000 | triangle (ONE leaf-order triangle per leaf, consecutive triangles),
  *                                          or 0xF0000000 | position in the top-level tree's leaf-ordered instance list
  * Child references are therefore implicit: the builders number the inner children of a node consecutively and place
  * the triangles of its leaf children consecutively (inner children first, then leaves, each in collapse order).
+ * Pair alignment: a block of >= 2 inner children starts on an EVEN node index (an all-zero slot is skipped when needed),
+ * so the first two siblings share one 128-B L2 line.
  * The grid is conservative: origin + qlo*step <= true lower bound, origin + qhi*step >= true upper bound, so the
  * set of triangles a ray can reach is unchanged; only the number of visits grows slightly (<= 2/255 of the parent
  * extent per face).  Traversal evaluates a face as  t = fma((float)q, step * inv_d, fma(origin, inv_d, -o * inv_d)).

@@ -234,8 +234,9 @@ static void collapse_rec(collapser* C, uint32_t bi, uint32_t me)
   for (int k = 0; k < nk; ++k) if (C->bn[kids[k]].left >= 0) slot[nc++] = kids[k];
   ni = nc;
   for (int k = 0; k < nk; ++k) { const bnode* c = &C->bn[kids[k]]; if (c->left < 0 && c->hi > c->lo) slot[nc++] = kids[k]; }   /* an empty leaf (no primitives at all) is dropped */
+  while (C->nq + (uint32_t)ni + 1u > C->capq) { C->capq *= 2; C->qn = (qnode*)realloc(C->qn, sizeof(qnode) * C->capq); }
+  if (ni >= 2 && (C->nq & 1u)) { memset(&C->qn[C->nq], 0, sizeof(qnode)); C->nq++; }    /* pair alignment: a block of >= 2 inner children starts on an even index (one zero slot skipped) */
   const uint32_t child_base = C->nq;
-  while (C->nq + (uint32_t)ni > C->capq) { C->capq *= 2; C->qn = (qnode*)realloc(C->qn, sizeof(qnode) * C->capq); }
   C->nq += (uint32_t)ni;
   const uint32_t leaf_base = (C->instances ? CRH_REF_INSTANCE_TAG : CRH_LEAF_TAG) | C->next_leaf;
   float cmin[4][3], cmax[4][3];
@@ -245,7 +246,7 @@ static void collapse_rec(collapser* C, uint32_t bi, uint32_t me)
     if (k >= ni) C->order[C->next_leaf++ - C->leaf0] = C->idx[c->lo];      /* one primitive per leaf */
   }
   qnode q; memset(&q, 0, sizeof q);
-  crh_pack_node(cmin, cmax, ni, nc, child_base, leaf_base, q.w);
+  crh_pack_node(cmin, cmax, ni, nc, ni ? child_base : 0u, leaf_base, q.w);      /* no inner children: the field is 0 */
   C->qn[me] = q;
   for (int k = 0; k < ni; ++k) collapse_rec(C, slot[k], child_base + (uint32_t)k);
 }
