@@ -29,6 +29,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Path state is touched once per stage and never reused: streaming (non-temporal) accesses keep the L2 / Infinity Cache for the
+// BVH, triangle and shading records that ARE reused (traversal kernel: +0.9 % C3, +0.7 % C5; the same treatment of the shading
+// kernel's state accesses: -0.5 % C3, +0.1 % C2, not kept).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p)
+{ const f32x4 v = __builtin_nontemporal_load((const f32x4*)p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st_stream(float4* p, float4 v)
+{ const f32x4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (f32x4*)p); }
+
+
 // Persistent-wave work distribution: each wavefront pulls the next 64 queue entries from a global cursor
 // (one returning atomic per wave per chunk), so the grid only needs to fill the machine once and no
 // workgroup is left running a statically assigned share after the others have drained.
@@ -298,10 +308,10 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint3
   trace_engine<false, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, cursors + 0, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
-      const float4 o4 = P.ray_o[tag], d4 = P.ray_d[tag];      // .w lanes carry the path's rng state / flags, not ray data
+      const float4 o4 = ld_stream(&P.ray_o[tag]), d4 = ld_stream(&P.ray_d[tag]);      // .w lanes carry the path's rng state / flags, not ray data
       o = xyz(o4); d = xyz(d4); tmax = CRH_MAXFLOAT;
     },
-    [&](uint32_t tag, float4 h, bool) { P.hit[tag] = h; }, nn, nt);
+    [&](uint32_t tag, float4 h, bool) { st_stream(&P.hit[tag], h); }, nn, nt);
   if (COUNT) {
     nn = wave_sum(nn); nt = wave_sum(nt);
     if (lane_id() == 0) { atomicAdd(&C->nodes_nearest, (unsigned long long)nn); atomicAdd(&C->tris_nearest, (unsigned long long)nt); }
