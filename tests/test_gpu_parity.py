@@ -400,3 +400,18 @@ def test_crh_reduce_assembles_tile_shards(view_cls, monkeypatch):
     from cadrays_amd.binding import BackendError
     with pytest.raises(BackendError):
         view_cls.reduce([vs[0], vs[0]], root=0)
+
+
+@pytest.mark.parametrize("max_paths", [1024, 5000, 70000])
+def test_small_path_budget_splits_batches_identically(view_cls, monkeypatch, max_paths):
+    """CRH_MAX_PATHS below one frame: the render is cut into tile groups and sample batches; the image must not change
+    (accumulation strictly in sample order) and the counters must add up."""
+    sc = scenes.cornell_box(True, 100, 76)
+    ref = view_cls(0).load_scene(sc); ref.enable_counters(True); ref.reset(); ref.render(5)
+    monkeypatch.setenv("CRH_MAX_PATHS", str(max_paths))
+    v = view_cls(0).load_scene(sc); v.enable_counters(True); v.reset()
+    v.render(2); v.render(3)
+    assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr()))
+    a, b = v.stats(), ref.stats()
+    for k in ("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "shaded_hits", "samples"):
+        assert a[k] == b[k], k
