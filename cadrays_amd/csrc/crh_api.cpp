@@ -125,12 +125,13 @@ int ensure_paths(crh_ctx* c, uint32_t need)
 {
   if (need <= c->path_cap) return CRH_OK;
   CRH_HIP(hipStreamSynchronize(c->stream));
-  void** ptrs[] = {(void**)&c->paths.ray_o, (void**)&c->paths.ray_d, (void**)&c->paths.hit, (void**)&c->paths.thr, (void**)&c->paths.rad,
+  void** ptrs[] = {(void**)&c->paths.ray_o[0], (void**)&c->paths.ray_d[0], (void**)&c->paths.hit, (void**)&c->paths.thr[0], (void**)&c->paths.rad,
                    (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c,
-                   (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh};
-  const size_t sz[] = {16, 16, 16, 16, 16, 16, 16, 16, 4, 4, 4};
+                   (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh,
+                   (void**)&c->paths.ray_o[1], (void**)&c->paths.ray_d[1], (void**)&c->paths.thr[1]};
+  const size_t sz[] = {16, 16, 16, 16, 16, 16, 16, 16, 4, 4, 4, 16, 16, 16};
   c->path_cap = 0;                                          // stays 0 if an allocation below fails
-  for (int i = 0; i < 11; ++i) {
+  for (int i = 0; i < 14; ++i) {
     if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
     CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
   }
@@ -546,8 +547,8 @@ void crh_destroy(crh_ctx* c)
   hipStreamSynchronize(c->stream);
   drain_events(c);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
-  void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o, c->paths.ray_d,
-                  c->paths.hit, c->paths.thr, c->paths.rad, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
+  void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o[0], c->paths.ray_d[0], c->paths.ray_o[1], c->paths.ray_d[1], c->paths.thr[1],
+                  c->paths.hit, c->paths.thr[0], c->paths.rad, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
                   c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
                   c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst};
   for (void* p : ptrs) if (p) hipFree(p);

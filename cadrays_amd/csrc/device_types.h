@@ -53,16 +53,20 @@ struct DScene {
   int two_sided, coherent, rr;
 };
 
-// Wavefront path state, structure-of-arrays over path slots.
+// Wavefront path state, structure-of-arrays.  A queue entry is a POSITION in these arrays, not a pixel slot: k_raygen puts
+// path slot s at position s; every k_shade chunk (1024 consecutive queue entries) writes its survivors, in order, over the
+// positions of its own first entries in the OTHER ray buffer (ping-pong by bounce), so the live paths stay packed in runs of
+// consecutive positions and every stage reads and writes whole cache lines however few paths survive.  The pixel slot
+// travels in ray_d.w; only the radiance record is addressed by it.
 struct DPaths {
-  float4* ray_o;   // origin.xyz, rng state (uint bits)
-  float4* ray_d;   // direction.xyz, flags (uint bits; bit 0: inside a medium)
-  float4* hit;     // t, u, v, leaf-order triangle index (int bits; -1 = miss)
-  float4* thr;     // throughput.rgb, implicit (BSDF) pdf of the ray that is in flight
-  float4* rad;     // radiance.rgb accumulated along the path
-  float4* sh_o;    // shadow ray origin.xyz, tmax
-  float4* sh_d;    // shadow ray direction.xyz
-  float4* sh_c;    // throughput * contribution to add when unoccluded
+  float4* ray_o[2];  // origin.xyz, rng state (uint bits)                                   [bounce parity][position]
+  float4* ray_d[2];  // direction.xyz, (path slot << 1) | inside-a-medium flag (uint bits)
+  float4* thr[2];    // throughput.rgb, implicit (BSDF) pdf of the ray that is in flight
+  float4* hit;       // t, u, v, leaf-order triangle index (int bits; -1 = miss)             [position]
+  float4* rad;       // radiance.rgb accumulated along the path                            [path slot]
+  float4* sh_o;      // shadow ray origin.xyz, tmax                                         [position]
+  float4* sh_d;      // shadow ray direction.xyz
+  float4* sh_c;      // throughput * contribution to add when unoccluded, path slot (uint bits)
 };
 
 struct DCounters {          // device-side mirror of crh_stats

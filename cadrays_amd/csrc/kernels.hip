@@ -61,6 +61,19 @@ __device__ __forceinline__ void lds_append(bool pred, uint32_t value, uint32_t* 
   if (pred) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
 }
 
+// Rank of this lane among the `pred` lanes of the workgroup's running list (ballot + prefix popcount, one LDS atomic per
+// wavefront); only meaningful where pred holds.
+__device__ __forceinline__ uint32_t lds_rank(bool pred, uint32_t* n)
+{
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0ull) return 0u;
+  const uint32_t lane = lane_id();
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(n, (uint32_t)__popcll(mask));
+  base = __shfl(base, 0);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
 // ================================================================== traversal
 #ifndef CRH_TRACE_MINWAVES
 #define CRH_TRACE_MINWAVES 0
@@ -293,7 +306,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
 }
 
 template <bool COUNT, bool TWO>
-__global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint32_t* __restrict__ q,
+__global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, int cur, const uint32_t* __restrict__ q,
                                                   const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors,
                                                   uint32_t* zero_a, uint32_t* zero_b, DCounters* C)
 {
@@ -305,10 +318,11 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, const uint3
     atomicAdd(&C->rays_nearest, (unsigned long long)n);
   }
   uint32_t nn = 0, nt = 0;
+  const float4* __restrict__ ray_o = P.ray_o[cur]; const float4* __restrict__ ray_d = P.ray_d[cur];
   trace_engine<false, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, cursors + 0, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
-      const float4 o4 = ld_stream(&P.ray_o[tag]), d4 = ld_stream(&P.ray_d[tag]);      // .w lanes carry the path's rng state / flags, not ray data
+      const float4 o4 = ld_stream(&ray_o[tag]), d4 = ld_stream(&ray_d[tag]);      // .w lanes carry the path's rng state / slot + flags, not ray data
       o = xyz(o4); d = xyz(d4); tmax = CRH_MAXFLOAT;
     },
     [&](uint32_t tag, float4 h, bool) { st_stream(&P.hit[tag], h); }, nn, nt);
@@ -335,9 +349,10 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
     [&](uint32_t tag, float4, bool occluded) {
       if (!occluded) {
         const float4 c = P.sh_c[tag];
-        float4 r = P.rad[tag];
+        const uint32_t slot = __float_as_uint(c.w);
+        float4 r = P.rad[slot];
         r.x += c.x; r.y += c.y; r.z += c.z;
-        P.rad[tag] = r;
+        P.rad[slot] = r;
       }
     }, nn, nt);
   if (COUNT) {
@@ -746,8 +761,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
         o = crh_madd3(crh_madd3(o, S.right, r * cs), S.up, r * sn);
         d = crh_norm3(crh_sub3(focus, o));
       }
-      P.ray_o[pid] = mk4(o, __uint_as_float(rng));           // .w = rng state
-      P.ray_d[pid] = mk4(d, __uint_as_float(0u));            // .w = flags (bit 0: inside a medium)
+      P.ray_o[0][pid] = mk4(o, __uint_as_float(rng));           // .w = rng state; position = path slot at bounce 0
+      P.ray_d[0][pid] = mk4(d, __uint_as_float(pid << 1));      // .w = (path slot << 1) | inside-a-medium flag
       // throughput (1,1,1 | no pending pdf) and radiance (0) are NOT written here: every generated path goes through
       // the bounce-0 k_shade, which takes them as constants and writes the radiance record unconditionally
     }
@@ -769,7 +784,7 @@ constexpr int kLdsMats = 64;   // materials staged in LDS (8 KB); larger tables 
 #else
 #define CRH_SHADE_BOUNDS __launch_bounds__(kBlock)
 #endif
-__global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
+__global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t bounce,
                                                    const uint32_t* __restrict__ q_in, const uint32_t* __restrict__ count_in,
                                                    uint32_t* __restrict__ q_out, uint32_t* __restrict__ count_out,
                                                    uint32_t* __restrict__ q_sh, uint32_t* __restrict__ count_sh,
@@ -788,6 +803,8 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
   const uint32_t n = *count_in;
   const bool last = bounce + 1u >= S.max_depth;
   const bool first = bounce == 0u;
+  const float4* __restrict__ in_o = P.ray_o[cur]; const float4* __restrict__ in_d = P.ray_d[cur]; const float4* __restrict__ in_t = P.thr[cur];
+  float4* __restrict__ out_o = P.ray_o[1 - cur]; float4* __restrict__ out_d = P.ray_d[1 - cur]; float4* __restrict__ out_t = P.thr[1 - cur];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t n_shaded = 0;
   for (;;) {
@@ -800,12 +817,13 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
     for (uint32_t it = 0; it < kShadeIters; ++it) {
     const uint32_t i = base + it * kBlock + threadIdx.x;
     bool cont = false, shadow = false;
-    uint32_t pid = 0;
+    float4 n_o = zero4, n_d = zero4, n_t = zero4, s_o = zero4, s_d = zero4, s_c = zero4;     // successor ray / shadow ray, stored after the ranks are known
     if (i < n) {
-      pid = q_in[i];
-      const float4 o4 = P.ray_o[pid], d4 = P.ray_d[pid], h = P.hit[pid];
-      const float4 t4 = first ? make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT) : P.thr[pid];     // k_raygen leaves thr / rad unwritten
-      const uint2 st = make_uint2(__float_as_uint(o4.w), __float_as_uint(d4.w));   // rng state, flags
+      const uint32_t pos = q_in[i];
+      const float4 o4 = in_o[pos], d4 = in_d[pos], h = P.hit[pos];
+      const float4 t4 = first ? make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT) : in_t[pos];     // k_raygen leaves thr / rad unwritten
+      const uint32_t pid = __float_as_uint(d4.w) >> 1;                              // the path's slot (radiance record, pixel)
+      const uint2 st = make_uint2(__float_as_uint(o4.w), __float_as_uint(d4.w) & 1u);   // rng state, flags
       const v3 o = xyz(o4), d = xyz(d4);
       v3 W = xyz(t4); float imp_pdf = t4.w;
       const int hk = __float_as_int(h.w);
@@ -894,9 +912,9 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
             const v3 wc = crh_mul3(W, contrib);
             if (contrib.x > kMinContrib || contrib.y > kMinContrib || contrib.z > kMinContrib) {
               shadow = true;
-              P.sh_o[pid] = mk4(offset_origin(p, ld, ng, S.eps), dist);
-              P.sh_d[pid] = mk4(ld, 0.f);
-              P.sh_c[pid] = mk4(wc, 0.f);
+              s_o = mk4(offset_origin(p, ld, ng, S.eps), dist);
+              s_d = mk4(ld, 0.f);
+              s_c = mk4(wc, __uint_as_float(pid));
             }
           }
         }
@@ -912,16 +930,24 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, uint32_t bounce,
           if (alive && kr < survive) {
             if (S.rr && bounce >= 3u) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
             const v3 nd2 = crh_norm3(from_local(fr, wi));
-            P.ray_o[pid] = mk4(offset_origin(p, nd2, ng, S.eps), __uint_as_float(rng));
-            P.ray_d[pid] = mk4(nd2, __uint_as_float(inside ? 1u : 0u));
-            P.thr[pid] = mk4(W, imp_pdf);
+            n_o = mk4(offset_origin(p, nd2, ng, S.eps), __uint_as_float(rng));
+            n_d = mk4(nd2, __uint_as_float((pid << 1) | (inside ? 1u : 0u)));
+            n_t = mk4(W, imp_pdf);
             cont = true;
           }
         }
       }
     }
-    if (S.n_lights > 0u) lds_append(shadow, pid, s_qs, &s_ns);
-    lds_append(cont, pid, s_qc, &s_nc);
+    // The r-th shadow ray / survivor of this chunk takes the position of the chunk's r-th input entry (in the other ray buffer for
+    // survivors): positions stay packed in runs, no two chunks ever share one, and no global atomic is needed to find them.
+    if (S.n_lights > 0u) {
+      const uint32_t r = lds_rank(shadow, &s_ns);
+      if (shadow) { const uint32_t ps = q_in[base + r]; s_qs[r] = ps; P.sh_o[ps] = s_o; P.sh_d[ps] = s_d; P.sh_c[ps] = s_c; }
+    }
+    {
+      const uint32_t r = lds_rank(cont, &s_nc);
+      if (cont) { const uint32_t pn = q_in[base + r]; s_qc[r] = pn; out_o[pn] = n_o; out_d[pn] = n_d; out_t[pn] = n_t; }
+    }
     }
     __syncthreads();
     if (threadIdx.x == 0) { s_gc = s_nc ? atomicAdd(count_out, s_nc) : 0u; s_gs = s_ns ? atomicAdd(count_sh, s_ns) : 0u; }
@@ -1095,7 +1121,7 @@ void launch_raygen(const Launch& L, const DScene& S, const DPaths& P, const DQue
 }
 void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, DCounters* C)
 {
-#define CRH_LAUNCH_TN(CNT, TWO) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qin], \
+#define CRH_LAUNCH_TN(CNT, TWO) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, qin, Q.q[qin], \
                                                    Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, C)
   if (S.two_level) { if (L.counters) CRH_LAUNCH_TN(true, true); else CRH_LAUNCH_TN(false, true); }
   else             { if (L.counters) CRH_LAUNCH_TN(true, false); else CRH_LAUNCH_TN(false, false); }
@@ -1103,7 +1129,7 @@ void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, con
 }
 void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, uint32_t bounce, DCounters* C)
 {
-  hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, bounce, Q.q[qin], Q.counts + qin,
+  hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, qin, bounce, Q.q[qin], Q.counts + qin,
                      Q.q[1 - qin], Q.counts + (1 - qin), Q.q_sh, Q.counts + 2, Q.counts + 4, C);
 }
 void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, DCounters* C)
