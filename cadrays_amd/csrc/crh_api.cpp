@@ -74,7 +74,7 @@ struct crh_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> render_ev, trace_ev;
   std::vector<hipEvent_t> ev_pool;
   double seconds_acc = 0.0, trace_ms_acc = 0.0, all_ms_acc = 0.0; uint64_t trace_launches = 0;
-  // path slots per batch (140 B each = 37.6 GB of the 288 GB; allocated on demand, so small renders stay small).  Every launch of
+  // path slots per batch (188 B each = 50 GB of the 288 GB; allocated on demand, so small renders stay small).  Every launch of
   // the wavefront schedule ends in a drain phase whose length does not depend on the launch's size (~0.24 ms per launch on C3), so
   // the batch is made as wide as the memory comfortably allows: 32 M / 64 M / 128 M / 256 M / 512 M slots -> 2745 / 2960 / 3114 /
   // 3205 / 3243 Mrays/s on C3
