@@ -26,8 +26,8 @@ struct crh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   int grid = 2048;        // streaming / shading kernels: 8 workgroups per CU
-  int grid_trace = 1280;  // traversal kernels: 5 workgroups (= 5 waves/SIMD) per CU -- measured optimum: more rays in
-                          // flight only enlarge the working set the 4 MB-per-XCD L2s have to hold
+  int grid_trace = 1536;  // traversal kernels: 6 workgroups (= 6 waves/SIMD) per CU -- measured: 4 / 5 / 6 / 7 / 8 per CU -> 3300 / 3424 /
+                          // 3448 / 3448 / 3443 Mrays/s on C3 (more rays in flight enlarge the working set the 4 MB-per-XCD L2s hold)
   std::string err;
   // ---- host copies of the inputs
   std::vector<float> pos, nrm, uv;
@@ -529,7 +529,7 @@ crh_ctx* crh_create(int device_ordinal)
     delete c; return nullptr;
   }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->grid = prop.multiProcessorCount * 8; c->grid_trace = prop.multiProcessorCount * 5; }
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->grid = prop.multiProcessorCount * 8; c->grid_trace = prop.multiProcessorCount * 6; }
   if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)v; }
   if (const char* e = getenv("CRH_GRID")) { int v = atoi(e); if (v > 0) c->grid = v; }
   if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }
