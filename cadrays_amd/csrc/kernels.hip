@@ -2,11 +2,13 @@
 //
 // One launch per stage and bounce, all on one HIP stream, no host round trip inside an iteration:
 //   k_raygen -> [ k_trace_nearest -> k_shade -> k_trace_any ] x depth -> k_accumulate
-// Stage boundaries exchange path ids through compacted queues built with wave64 ballot + prefix
-// popcount, collected in LDS and appended with one atomic per 1024-8192 paths (a single counter word sustains only
-// ~88 atomics/us on MI355X); traversal waves are persistent and refill idle lanes.  Traversal keeps a per-lane stack in LDS (lane-interleaved,
-// conflict free), BVH nodes are 48-B records with 8-bit child bounds and implicit child references (three dwordx4 fetches per
-// visit), triangles 48-B records in leaf order.  No MFMA: there is no dense contraction on this path.
+// Stage boundaries exchange path-state POSITIONS through compacted queues built with wave64 ballot + prefix popcount,
+// collected in LDS and appended with one atomic per 1024-8192 paths (a single counter word sustains only ~88 atomics/us on
+// MI355X); the state itself is kept packed in runs (every shade chunk writes its survivors over its own first input
+// positions in the other ray buffer), so all stages move whole cache lines at every bounce.  Traversal waves are persistent
+// and refill idle lanes; they keep a per-lane stack in LDS (lane-interleaved, conflict free); BVH nodes are 48-B records on a
+// 64-B stride with 8-bit child bounds and implicit child references (three dwordx4 fetches per visit), triangles 48-B records
+// on a 64-B stride in leaf order.  No MFMA: there is no dense contraction on this path.
 //
 // Arithmetic follows DESIGN.md "Algorithm spec" operation by operation (fma only where written;
 // built with -ffp-contract=off) so that results are bit-identical to the CPU oracle.
