@@ -90,6 +90,14 @@ namespace {
 
 int fail(crh_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
 
+// The boundary takes finite numbers only (coordinates additionally |x| <= 1e30, so that box centres and extents stay finite):
+// NaN / Inf would otherwise reach the BVH builder's binning and the kernels' float -> int conversions.
+bool all_finite(const float* v, size_t n, float limit = 3.0e38f)
+{
+  for (size_t i = 0; i < n; ++i) if (!(v[i] >= -limit && v[i] <= limit)) return false;
+  return true;
+}
+
 template <class T> int dev_upload(crh_ctx* c, T*& dptr, const void* src, size_t bytes)
 {
   if (dptr) { CRH_HIP(hipFree(dptr)); dptr = nullptr; }
@@ -567,6 +575,9 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
   if (!c) return CRH_E_INVALID;
   if ((nV && (!pos || !nrm)) || (nT && !tri)) return fail(c, CRH_E_INVALID, "null geometry array");
   if (nT >= (1u << 28)) return fail(c, CRH_E_INVALID, "too many triangles (limit 2^28)");
+  if (!all_finite(pos, 3 * (size_t)nV, 1.0e30f) || !all_finite(nrm, 3 * (size_t)nV) || (uv && !all_finite(uv, 2 * (size_t)nV)) ||
+      (xf && !all_finite(xf, 12 * (size_t)nO, 1.0e30f)))
+    return fail(c, CRH_E_INVALID, "geometry holds a NaN / Inf (or a coordinate beyond 1e30)");
   for (uint32_t t = 0; t < nT; ++t)
     for (int k = 0; k < 3; ++k)
       if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) { char b[96]; snprintf(b, sizeof b, "triangle %u index out of range", t); return fail(c, CRH_E_INVALID, b); }
@@ -590,6 +601,7 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
 {
   if (!c || !xf) return fail(c, CRH_E_INVALID, "null transforms");
   if (!c->two_level || nO != c->nO) return fail(c, CRH_E_INVALID, "crh_set_transforms needs a two-level scene with the same object count");
+  if (!all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return fail(c, CRH_E_INVALID, "transform holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
   c->xf.assign(xf, xf + 12 * (size_t)nO);
@@ -611,6 +623,7 @@ int crh_get_tlas(crh_ctx* c, uint32_t* root, uint32_t* n_inst, uint32_t* n_blas)
 int crh_set_materials(crh_ctx* c, const crh_bsdf* m, uint32_t n)
 {
   if (!c || (n && !m)) return fail(c, CRH_E_INVALID, "null materials");
+  if (!all_finite((const float*)m, 32 * (size_t)n)) return fail(c, CRH_E_INVALID, "material holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
   c->mats.assign(m, m + n);
@@ -620,6 +633,7 @@ int crh_set_materials(crh_ctx* c, const crh_bsdf* m, uint32_t n)
 int crh_set_lights(crh_ctx* c, const crh_light* l, uint32_t n)
 {
   if (!c || (n && !l)) return fail(c, CRH_E_INVALID, "null lights");
+  if (!all_finite((const float*)l, 8 * (size_t)n, 1.0e30f)) return fail(c, CRH_E_INVALID, "light holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
   c->lights.assign(l, l + n);
@@ -629,6 +643,7 @@ int crh_set_lights(crh_ctx* c, const crh_light* l, uint32_t n)
 int crh_set_envmap(crh_ctx* c, const float* rgb, uint32_t w, uint32_t h)
 {
   if (!c) return CRH_E_INVALID;
+  if (rgb && w && h && !all_finite(rgb, 3 * (size_t)w * h)) return fail(c, CRH_E_INVALID, "environment map holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
   c->envW = c->envH = 0;
@@ -646,6 +661,7 @@ int crh_set_texture(crh_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uin
 {
   if (!c || slot >= 4096u) return fail(c, CRH_E_INVALID, "texture slot out of range");
   if (rgb && channels != 3u && channels != 4u) return fail(c, CRH_E_INVALID, "texture channels must be 3 or 4");
+  if (rgb && w && h && !all_finite(rgb, (size_t)channels * w * h)) return fail(c, CRH_E_INVALID, "texture holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
   if (c->textures.size() <= slot) c->textures.resize(slot + 1);
@@ -663,13 +679,22 @@ int crh_set_texture(crh_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uin
   return do_reset(c);
 }
 
-int crh_set_camera(crh_ctx* c, const crh_camera* cam) { if (!c || !cam) return fail(c, CRH_E_INVALID, "null camera"); c->cam = *cam; return CRH_OK; }
+int crh_set_camera(crh_ctx* c, const crh_camera* cam)
+{
+  if (!c || !cam) return fail(c, CRH_E_INVALID, "null camera");
+  const float f[] = {cam->eye[0], cam->eye[1], cam->eye[2], cam->dir[0], cam->dir[1], cam->dir[2], cam->up[0], cam->up[1], cam->up[2],
+                     cam->fovy_deg, cam->aspect, cam->ortho_scale, cam->aperture_radius, cam->focal_dist};
+  if (!all_finite(f, sizeof f / sizeof f[0], 1.0e30f)) return fail(c, CRH_E_INVALID, "camera holds a NaN / Inf");
+  c->cam = *cam; return CRH_OK;
+}
 
 int crh_set_params(crh_ctx* c, const crh_params* p)
 {
   if (!c || !p) return fail(c, CRH_E_INVALID, "null params");
   if (!p->width || !p->height || p->max_depth < 1 || p->max_depth > 32) return fail(c, CRH_E_INVALID, "width/height must be > 0 and max_depth in 1..32");
   if (p->tile_size < 8 || (p->tile_size & 7u) || p->tile_size > 1024) return fail(c, CRH_E_INVALID, "tile_size must be a multiple of 8 in 8..1024");
+  { const float f[] = {p->radiance_clamp, p->exposure, p->white_point, p->background[0], p->background[1], p->background[2], p->scene_epsilon};
+    if (!all_finite(f, sizeof f / sizeof f[0])) return fail(c, CRH_E_INVALID, "params hold a NaN / Inf"); }
   c->par = *p;
   return do_reset(c);
 }
@@ -966,6 +991,7 @@ int crh_build_bvh_host(const float* pos, uint32_t nV, const int32_t* tri, uint32
 {
   if ((nT && (!pos || !tri)) || !n_nodes) return CRH_E_INVALID;
   for (uint32_t t = 0; t < nT; ++t) for (int k = 0; k < 3; ++k) if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) return CRH_E_INVALID;
+  if (nV && !all_finite(pos, 3 * (size_t)nV, 1.0e30f)) return CRH_E_INVALID;
   QBvh b; build_qbvh(pos, tri, nT, b, threads);
   *n_nodes = (uint32_t)b.nodes.size();
   if (nodes) std::memcpy(nodes, b.nodes.data(), b.nodes.size() * sizeof(QNode));

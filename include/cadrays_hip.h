@@ -4,7 +4,8 @@
  * Every entry point cites the reference call (file:line under /root/reference) it
  * replaces; see INTEGRATION.md for the shim a CADRays maintainer would add.
  *
- * Conventions: plain C, opaque handle, int status (0 = ok, negative = CRH_E_*),
+ * Conventions: plain C, opaque handle, int status (0 = ok, negative = CRH_E_*), every float handed over must be finite
+ * (coordinates, transforms, light and camera vectors additionally |x| <= 1e30) -- NaN / Inf inputs are rejected with CRH_E_INVALID,
  * caller owns all input buffers (copied during the call), the module owns device
  * memory, one host thread per context, one context per GPU.  No torch types.
  */

@@ -984,6 +984,12 @@ ORC_API void orc_destroy(orc_ctx* c)
 }
 ORC_API const char* orc_last_error(orc_ctx* c) { return c ? c->err : "null ctx"; }
 
+/* the boundary takes finite numbers only (same rule as the product: include/cadrays_hip.h) */
+static int all_finite(const float* v, size_t n, float limit)
+{
+  for (size_t i = 0; i < n; ++i) if (!(v[i] >= -limit && v[i] <= limit)) return 0;
+  return 1;
+}
 static void* dup_mem(const void* p, size_t n) { void* r = malloc(n ? n : 1); if (p && n) memcpy(r, p, n); return r; }
 
 ORC_API int orc_set_geometry(orc_ctx* c, const float* pos, const float* nrm, const float* uv, uint32_t nV,
@@ -991,6 +997,8 @@ ORC_API int orc_set_geometry(orc_ctx* c, const float* pos, const float* nrm, con
 {
   if (!c || (nV && (!pos || !nrm)) || (nT && !tri)) return CRH_E_INVALID;
   for (uint32_t t = 0; t < nT; ++t) for (int k = 0; k < 3; ++k) if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) { snprintf(c->err, sizeof c->err, "triangle %u index out of range", t); return CRH_E_INVALID; }
+  if (!all_finite(pos, 3 * (size_t)nV, 1.0e30f) || !all_finite(nrm, 3 * (size_t)nV, 3.0e38f) || (uv && !all_finite(uv, 2 * (size_t)nV, 3.0e38f)) ||
+      (xf && !all_finite(xf, 12 * (size_t)nO, 1.0e30f))) { snprintf(c->err, sizeof c->err, "geometry holds a NaN / Inf (or a coordinate beyond 1e30)"); return CRH_E_INVALID; }
   free(c->pos); free(c->nrm); free(c->xf); free(c->tri_obj); c->xf = NULL; c->tri_obj = NULL; c->two_level = 0; c->nO = 0;
   c->pos = (float*)dup_mem(pos, sizeof(float) * 3 * nV); c->nrm = (float*)dup_mem(nrm, sizeof(float) * 3 * nV);
   if (tri_obj && xf && nO) {
@@ -1007,7 +1015,7 @@ ORC_API int orc_set_geometry(orc_ctx* c, const float* pos, const float* nrm, con
 ORC_API int orc_reset(orc_ctx* c);
 ORC_API int orc_set_transforms(orc_ctx* c, const float* xf, uint32_t nO)
 {
-  if (!c || !xf || !c->two_level || nO != c->nO) return CRH_E_INVALID;
+  if (!c || !xf || !c->two_level || nO != c->nO || !all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return CRH_E_INVALID;
   memcpy(c->xf, xf, sizeof(float) * 12 * nO);
   if (c->built) build_tlas(c);                      /* object trees are untouched */
   return orc_reset(c);
@@ -1019,12 +1027,12 @@ ORC_API int orc_get_tlas(orc_ctx* c, uint32_t* root, uint32_t* n_instances, uint
   return 0;
 }
 ORC_API int orc_set_materials(orc_ctx* c, const crh_bsdf* m, uint32_t n)
-{ if (!c || (n && !m)) return CRH_E_INVALID; free(c->mats); c->mats = (crh_bsdf*)dup_mem(m, sizeof(crh_bsdf) * n); c->nM = n; return 0; }
+{ if (!c || (n && !m) || !all_finite((const float*)m, 32 * (size_t)n, 3.0e38f)) return CRH_E_INVALID; free(c->mats); c->mats = (crh_bsdf*)dup_mem(m, sizeof(crh_bsdf) * n); c->nM = n; return 0; }
 ORC_API int orc_set_lights(orc_ctx* c, const crh_light* l, uint32_t n)
-{ if (!c || (n && !l)) return CRH_E_INVALID; free(c->lights); c->lights = (crh_light*)dup_mem(l, sizeof(crh_light) * n); c->nL = n; return 0; }
+{ if (!c || (n && !l) || !all_finite((const float*)l, 8 * (size_t)n, 1.0e30f)) return CRH_E_INVALID; free(c->lights); c->lights = (crh_light*)dup_mem(l, sizeof(crh_light) * n); c->nL = n; return 0; }
 ORC_API int orc_set_envmap(orc_ctx* c, const float* rgb, uint32_t w, uint32_t h)
 {
-  if (!c) return CRH_E_INVALID;
+  if (!c || (rgb && w && h && !all_finite(rgb, 3 * (size_t)w * h, 3.0e38f))) return CRH_E_INVALID;
   free(c->env); c->env = NULL; c->envW = c->envH = 0;
   if (rgb && w && h) { c->env = (float*)dup_mem(rgb, sizeof(float) * 3 * (size_t)w * h); c->envW = w; c->envH = h; }
   return 0;
@@ -1037,7 +1045,14 @@ ORC_API int orc_set_texture(orc_ctx* c, uint32_t slot, const float* rgb, uint32_
   if (slot + 1 > c->nTex) c->nTex = slot + 1;
   return 0;
 }
-ORC_API int orc_set_camera(orc_ctx* c, const crh_camera* cam) { if (!c || !cam) return CRH_E_INVALID; c->cam = *cam; return 0; }
+ORC_API int orc_set_camera(orc_ctx* c, const crh_camera* cam)
+{
+  if (!c || !cam) return CRH_E_INVALID;
+  const float f[] = {cam->eye[0], cam->eye[1], cam->eye[2], cam->dir[0], cam->dir[1], cam->dir[2], cam->up[0], cam->up[1], cam->up[2],
+                     cam->fovy_deg, cam->aspect, cam->ortho_scale, cam->aperture_radius, cam->focal_dist};
+  if (!all_finite(f, sizeof f / sizeof f[0], 1.0e30f)) return CRH_E_INVALID;
+  c->cam = *cam; return 0;
+}
 ORC_API int orc_reset(orc_ctx* c)
 {
   if (!c) return CRH_E_INVALID;
@@ -1050,6 +1065,8 @@ ORC_API int orc_reset(orc_ctx* c)
 ORC_API int orc_set_params(orc_ctx* c, const crh_params* p)
 {
   if (!c || !p || !p->width || !p->height || p->max_depth < 1 || p->max_depth > 32) return CRH_E_INVALID;
+  { const float f[] = {p->radiance_clamp, p->exposure, p->white_point, p->background[0], p->background[1], p->background[2], p->scene_epsilon};
+    if (!all_finite(f, sizeof f / sizeof f[0], 3.0e38f)) return CRH_E_INVALID; }
   c->par = *p; return orc_reset(c);
 }
 ORC_API int orc_build(orc_ctx* c)

@@ -84,6 +84,38 @@ def test_host_bvh_builder_equals_oracle_bytes(hip_lib, oracle_lib, n, threads):
     assert ((leaves & 0xF0000000) == 0x80000000).all() and sorted((leaves & 0x0FFFFFFF).tolist()) == list(range(n))
 
 
+def test_non_finite_inputs_are_rejected_not_crashed_on(hip_lib, oracle_lib):
+    """NaN / Inf / overflowing coordinates used to reach the builder's binning (a segfault); the boundary rejects them now,
+    on both sides, and keeps building extreme-but-finite scenes."""
+    import ctypes as C
+    from cadrays_amd.view import build_bvh_host
+    from cadrays_amd.binding import BackendError
+    pos, nrm, tri = scenes.gen_scene(3000, 3, 2)
+    for bad in (np.nan, np.inf, -np.inf, 2e30):
+        p = pos.copy(); p[7] = bad; p[100, 1] = bad
+        with pytest.raises(RuntimeError):
+            build_bvh_host(p, tri, 2)
+        o = oracle_lib.Oracle()
+        with pytest.raises(BackendError):
+            o.set_geometry(p, nrm, tri)
+        if not np.isfinite(bad):
+            with pytest.raises(BackendError):
+                o.set_geometry(pos, p, tri)                   # normals: any finite value goes
+    for ok in (1e30, -1e30, 1e-45, 0.0):
+        p = pos.copy(); p[7] = ok; p[100, 1] = ok
+        nodes, order = build_bvh_host(p, tri, 2)
+        assert sorted(order.tolist()) == list(range(3000))
+        o = oracle_lib.Oracle(); o.set_geometry(p, nrm, tri); o.set_materials([BSDF.CreateDiffuse(0.5)] * 2); o.build()
+        assert np.array_equal(nodes.view(np.uint32), o.get_bvh()[0].view(np.uint32))
+    o = oracle_lib.Oracle()
+    sc = scenes.cornell_box(False, 32, 32)
+    import dataclasses
+    with pytest.raises(BackendError):
+        o.set_camera(dataclasses.replace(sc.camera, eye=(np.nan, 0.0, 0.0)))
+    with pytest.raises(BackendError):
+        o.set_params(dataclasses.replace(sc.params, exposure=np.inf))
+
+
 def test_host_bvh_degenerate_inputs(hip_lib, oracle_lib):
     """identical triangles (zero centroid extent -> median by index) and a thin line of triangles."""
     from cadrays_amd.view import build_bvh_host

@@ -261,6 +261,13 @@ def test_errors(view_cls):
         v.render_tiles(np.array([10 ** 6], np.uint32), 0, 1)          # out of range
     with pytest.raises(BackendError):
         v.set_transforms(np.zeros((2, 12), np.float32))               # not a two-level scene
+    nanpos = sc.pos.copy(); nanpos[3, 1] = np.nan
+    with pytest.raises(BackendError):
+        v.set_geometry(nanpos, sc.nrm, sc.tri)                        # NaN vertex: rejected at the boundary
+    with pytest.raises(BackendError):
+        v.set_camera(dataclasses.replace(sc.camera, dir=(0.0, np.inf, 0.0)))
+    v.load_scene(sc); v.render(1)                                      # the context is still usable
+    assert np.isfinite(v.read_hdr()).all()
 
 
 def test_headless_cpp_driver_matches_oracle(tmp_path, Oracle):
