@@ -581,6 +581,10 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
   for (uint32_t t = 0; t < nT; ++t)
     for (int k = 0; k < 3; ++k)
       if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) { char b[96]; snprintf(b, sizeof b, "triangle %u index out of range", t); return fail(c, CRH_E_INVALID, b); }
+  if (tri_obj && xf && nO)
+    for (uint32_t t = 0; t < nT; ++t)
+      if (tri_obj[t] < 0 || (uint32_t)tri_obj[t] >= nO) return fail(c, CRH_E_INVALID, "triangle object id out of range");
+  // every check passed: only now is the context's state replaced
   c->pos.assign(pos, pos + 3 * (size_t)nV); c->nrm.assign(nrm, nrm + 3 * (size_t)nV);
   if (uv) c->uv.assign(uv, uv + 2 * (size_t)nV); else c->uv.clear();
   c->tri.assign(tri, tri + 4 * (size_t)nT);
@@ -588,8 +592,6 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
   if (tri_obj && xf && nO) {
     // two-level mode: vertices stay in object space; every object gets its own tree (crh_build), the top-level tree
     // over the instances carries the transforms (crh_set_transforms rebuilds only that)
-    for (uint32_t t = 0; t < nT; ++t)
-      if (tri_obj[t] < 0 || (uint32_t)tri_obj[t] >= nO) return fail(c, CRH_E_INVALID, "triangle object id out of range");
     c->two_level = true; c->nO = nO;
     c->xf.assign(xf, xf + 12 * (size_t)nO); c->tri_obj.assign(tri_obj, tri_obj + nT);
   }
