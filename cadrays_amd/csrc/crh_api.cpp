@@ -538,7 +538,7 @@ crh_ctx* crh_create(int device_ordinal)
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->grid = prop.multiProcessorCount * 8; c->grid_trace = prop.multiProcessorCount * 6; }
-  if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)v; }
+  if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)std::min<long>(v, 1l << 30); }   // a path slot travels in 31 bits
   if (const char* e = getenv("CRH_GRID")) { int v = atoi(e); if (v > 0) c->grid = v; }
   if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }
   // reference defaults: GI on, depth as vrenderparams default, two-sided (SettingsWidget.cxx:65-90)
@@ -694,6 +694,7 @@ int crh_set_params(crh_ctx* c, const crh_params* p)
 {
   if (!c || !p) return fail(c, CRH_E_INVALID, "null params");
   if (!p->width || !p->height || p->max_depth < 1 || p->max_depth > 32) return fail(c, CRH_E_INVALID, "width/height must be > 0 and max_depth in 1..32");
+  if (p->width > 32768u || p->height > 32768u || (uint64_t)p->width * p->height > (1ull << 28)) return fail(c, CRH_E_INVALID, "render target too large (limit 32768 per side, 2^28 pixels)");
   if (p->tile_size < 8 || (p->tile_size & 7u) || p->tile_size > 1024) return fail(c, CRH_E_INVALID, "tile_size must be a multiple of 8 in 8..1024");
   { const float f[] = {p->radiance_clamp, p->exposure, p->white_point, p->background[0], p->background[1], p->background[2], p->scene_epsilon};
     if (!all_finite(f, sizeof f / sizeof f[0])) return fail(c, CRH_E_INVALID, "params hold a NaN / Inf"); }
