@@ -135,7 +135,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   uint32_t cur = kDone, tag = 0;
   int sp = 0;
   v3 o = crh_mk3(0.f, 0.f, 0.f), d = o;
-  v3 wo = o, wd = o;     // world-space ray while inside an object (TWO only)
+  v3 wo = o, wd = o;     // world-space ray while inside an object (TWO only) ...
+  float wix = 0.f, wiy = 0.f, wiz = 0.f, wnox = 0.f, wnoy = 0.f, wnoz = 0.f;   // ... and its reciprocal direction / -o * inv (restored, not recomputed, on leaving)
   float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, best = 0.f;
   float4 hit = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   bool found = false;
@@ -168,7 +169,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           load(pool_next + rank, o, d, tmax, tag);
           ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
           nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
-          if (TWO) { wo = o; wd = d; }
+          if (TWO) { wo = o; wd = d; wix = ix; wiy = iy; wiz = iz; wnox = nox; wnoy = noy; wnoz = noz; }
           best = tmax; found = false; sp = 0; cur = root; have = true;
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
         }
@@ -192,7 +193,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       if ((ANY && found) || sp == 0) { cur = kDone; return; }
       read_top();
       if (TWO && cur == CRH_REF_SENTINEL) {          // leaving an object: back to the world-space ray
-        set_ray(wo, wd);
+        o = wo; d = wd; ix = wix; iy = wiy; iz = wiz; nox = wnox; noy = wnoy; noz = wnoz;      // same values set_ray(wo, wd) would recompute
         if (sp == 0) cur = kDone; else read_top();
       }
     };
