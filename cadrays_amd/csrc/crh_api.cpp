@@ -213,6 +213,10 @@ int build_tlas(crh_ctx* c)
     crh_xform_box(in.fwd, in.bmin, in.bmax, &boxes[6 * (size_t)i], &boxes[6 * (size_t)i + 3]);
     std::memcpy(&table[32 * (size_t)i], in.inv, 48); std::memcpy(&table[32 * (size_t)i + 12], in.fwd, 48);
     std::memcpy(&table[32 * (size_t)i + 24], &in.root, 4); std::memcpy(&table[32 * (size_t)i + 25], &in.obj, 4);
+    const float* iv = in.inv;                    // meta.z = 1: the inverse's 3x3 part is exactly the identity (translation only)
+    const uint32_t pure_translation = (iv[0] == 1.f && iv[5] == 1.f && iv[10] == 1.f && iv[1] == 0.f && iv[2] == 0.f && iv[4] == 0.f &&
+                                       iv[6] == 0.f && iv[8] == 0.f && iv[9] == 0.f) ? 1u : 0u;
+    std::memcpy(&table[32 * (size_t)i + 26], &pure_translation, 4);
   }
   std::vector<uint32_t> order;
   c->root = build_tree(boxes.data(), n, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, 1);

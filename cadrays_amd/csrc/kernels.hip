@@ -293,7 +293,11 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float4* ip = inst + 8u * (cur & 0x0FFFFFFFu);
       const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2], meta = ip[6];
       const float m[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
-      set_ray(crh_xform_point(m, wo), crh_xform_vector(m, wd));
+      o = crh_xform_point(m, wo); d = crh_xform_vector(m, wd);
+      // an instance that is only translated (inverse 3x3 == identity exactly, flagged by the host) leaves |d| and its signs
+      // unchanged, so the reciprocals are the world ray's: three IEEE divisions saved on the common "placed, not rotated" part
+      if (__float_as_uint(meta.z) == 0u) { ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z); }
+      nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
       const uint32_t mark = CRH_REF_SENTINEL;
       if (sp < kLdsStack) lds[sp * kBlock] = mark; else ovf[sp - kLdsStack] = mark;
       ++sp;

@@ -145,3 +145,37 @@ def test_hip_set_transforms_rebuilds_only_the_top_level(hip_lib, oracle_lib):
     t0 = time.time(); w.set_transforms(xf2); t_move = time.time() - t0
     w.render(1)
     assert np.isfinite(w.read_hdr()).all() and t_move < t_build
+
+
+@pytest.mark.gpu
+def test_translated_only_instances_and_signed_zero_directions(hip_lib, oracle_lib):
+    """Instances whose inverse 3x3 part is exactly the identity reuse the world ray's reciprocal direction on the GPU; the
+    oracle always recomputes.  Axis-parallel rays with -0 / +0 direction components are where a shortcut could differ."""
+    import torch  # noqa: F401
+    from cadrays_amd.view import View
+    sc = object_scene()
+    n = len(sc.obj_xform)
+    xf = np.tile(rigid(), (n, 1))
+    for k in range(n):
+        xf[k] = rigid(0.0, (0, 0, 1), (0.01 * k, -0.02 * k, 0.005 * k))
+    sc = dataclasses.replace(sc, obj_xform=xf)
+    v = View(0).load_scene(sc); o = oracle_lib.Oracle().load_scene(sc)
+    r = np.random.default_rng(3)
+    m = 20000
+    rays = np.zeros((m, 8), np.float32)
+    rays[:, 0:3] = r.random((m, 3)); rays[:, 3] = 1e15
+    d = r.normal(size=(m, 3)).astype(np.float32)
+    d[: m // 2] = 0.0                                                   # first half: axis-parallel, with signed zeros
+    ax = r.integers(0, 3, m // 2); sg = r.choice([-1.0, 1.0], m // 2).astype(np.float32)
+    d[np.arange(m // 2), ax] = sg
+    zs = r.choice([0.0, -0.0], (m // 2, 3)).astype(np.float32)
+    d[: m // 2] = np.where(d[: m // 2] == 0.0, zs, d[: m // 2])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 4:7] = d
+    assert np.array_equal(v.trace_nearest(rays).view(np.uint32), o.trace_nearest(rays).view(np.uint32))
+    assert np.array_equal(v.trace_any(rays), o.trace_any(rays))
+    for cam_dir in ((0.0, 1.0, 0.0), (-0.0, 1.0, -0.0)):
+        s2 = dataclasses.replace(sc, camera=dataclasses.replace(sc.camera, dir=cam_dir, is_ortho=True, ortho_scale=0.6))
+        a = View(0).load_scene(s2); b = oracle_lib.Oracle().load_scene(s2)
+        a.render(2); b.render(2)
+        assert np.array_equal(a.read_hdr().view(np.uint32), b.read_hdr().view(np.uint32))
