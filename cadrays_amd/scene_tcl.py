@@ -182,6 +182,11 @@ class MiniTcl:
                     i += 1; continue
                 break
             return ""
+        if name == "foreach":                                   # foreach var list body
+            for item in a[1].split():
+                self.vars[a[0]] = item
+                self.eval(a[2])
+            return ""
         if name == "eval":
             return self.eval(" ".join(a))
         if name == "lrepeat":
@@ -194,7 +199,7 @@ class MiniTcl:
             return self.vars.get("Root", ".")       # [file dirname [file normalize [info script]]]
         if name == "info":
             return self.vars.get("__script__", "")
-        if name in ("pload", "source", "vinit", "catch"):
+        if name in ("pload", "source", "catch") or (name == "vinit" and "vinit" not in self.cmds):
             return ""
         if name in self.cmds:
             return self.cmds[name](a) or ""
@@ -337,9 +342,15 @@ class SceneBuilder:
 
     def __init__(self, root=".", sphere_res=(48, 24)):
         self.root, self.sphere_res = root, sphere_res
-        self.objs, self.lights, self.light_colors = {}, [], {}
+        self.objs, self.light_colors = {}, {}
+        # a fresh V3d viewer owns a directional headlight (0) and an ambient light (1) [OCCT-ext]; the reference's start-up
+        # script edits them in place (AppGui.cxx:956-957: `vlight del 1`, `vlight change 0 head 0 direction -0.25 -1 -1 ...`)
+        self.lights = [dict(kind="directional", vec=(0.0, 0.0, -1.0), sm=0.0, int=1.0, head=1, color=(1.0, 1.0, 1.0)),
+                       dict(kind="ambient", vec=(0.0, 0.0, 0.0), sm=0.0, int=1.0, head=0, color=(1.0, 1.0, 1.0))]
         self.cam = dict(eye=None, at=None, up=(0, 0, 1), proj=None, fovy=45.0, ortho=False, distance=None, size=None)
         self.depth, self.env_path, self.unsupported, self.adaptive = 5, None, [], False
+        self.view_size = None                    # (w, h) of `vinit ... w=.. h=..`
+        self.on_vfps = self.on_vdump = None      # hooks of a live host (cadrays_amd/run_script.py): vfps N renders, vdump writes
         self.commands = {k[4:]: getattr(self, k) for k in dir(self) if k.startswith("cmd_")}
 
     # ---- geometry sources
@@ -584,7 +595,24 @@ class SceneBuilder:
     def _noop(self, a):
         return ""
 
-    cmd_vsetdispmode = cmd_vaspects = cmd_vvbo = cmd_rtmodel = cmd_rtgroup = cmd_vfps = cmd_vdump = cmd_vtop = cmd_vaxo = _noop
+    def cmd_vinit(self, a):                                   # vinit name=View1 w=128 h=128  (data/other/preview.tcl:10)
+        kv = dict(x.split("=", 1) for x in a if "=" in x)
+        if "w" in kv and "h" in kv:
+            self.view_size = (int(kv["w"]), int(kv["h"]))
+
+    def cmd_vsetlocation(self, a):                            # vsetlocation [-noupdate] name x y z  (preview.tcl:22)
+        args = [x for x in a if x != "-noupdate"]
+        self.objs[args[0]].t = np.array([float(x) for x in args[1:4]])
+
+    def cmd_vfps(self, a):                                    # vfps N: render N frames (preview.tcl:63); a no-op without a live host
+        n = int(a[0]) if a else 100
+        return self.on_vfps(n) if self.on_vfps else ""
+
+    def cmd_vdump(self, a):                                   # vdump file: write the current image (preview.tcl:64)
+        return self.on_vdump(a[0]) if self.on_vdump and a else ""
+
+    cmd_incmesh = _noop                                       # B-Rep tessellation: the primitives here are born as meshes
+    cmd_vsetdispmode = cmd_vaspects = cmd_vvbo = cmd_rtmodel = cmd_rtgroup = cmd_vtop = cmd_vaxo = _noop
     cmd_vzbufftrihedron = cmd_vsetcolor = cmd_vselect = cmd_vupdate = cmd_vrepaint = cmd_rtdisplay = _noop
 
     # ---- result
@@ -630,7 +658,13 @@ class SceneBuilder:
             if not l or l["kind"] not in ("directional", "positional"):
                 continue                                       # ambient / spot are ignored by the path tracer (LightSourcesEditor.cxx:157-178)
             mk = Light.directional if l["kind"] == "directional" else Light.positional
-            lights.append(mk(l["vec"], smoothness=l["sm"], intensity=l["int"], color=l["color"]))
+            vec = np.array(l["vec"], float)
+            if l.get("head"):                                  # headlight: given in eye space (x right, y up, z towards the viewer)
+                fwd = (at - eye) / (np.linalg.norm(at - eye) or 1.0)
+                right = np.cross(fwd, np.array(c["up"], float)); right /= np.linalg.norm(right) or 1.0
+                upv = np.cross(right, fwd)
+                vec = vec[0] * right + vec[1] * upv - vec[2] * fwd + (eye if l["kind"] == "positional" else 0.0)
+            lights.append(mk(tuple(vec), smoothness=l["sm"], intensity=l["int"], color=l["color"]))
         env = None
         if self.env_path and os.path.exists(self.env_path):
             env = np.ascontiguousarray(load_texture(self.env_path)[..., :3])   # LDR env texels are linearised by squaring [OCCT-ext]

@@ -212,3 +212,46 @@ def test_rttexture_command_semantics(tmp_path):
     s.write_text(f'rtmeshread {tmp_path}/m.ply A\nrttexture A {tmp_path}/missing.png\n')
     with pytest.raises(TclError):
         read_scene(str(s), 32, 32)
+
+
+@pytest.mark.gpu
+def test_script_host_runs_vfps_and_vdump_like_the_reference_test_mode(tmp_path, hip_lib, oracle_lib):
+    """`CADRays <script.tcl> <nFrames>` (main.cxx:164-228): the script's own vfps / vdump are honoured live, then nFrames more
+    Redraws end in Output_<name>_<n>.png / .txt; every image equals the oracle's LDR read-out of the same scene state."""
+    import torch  # noqa: F401
+    from PIL import Image
+    from cadrays_amd.run_script import ScriptHost
+    from cadrays_amd.view import View
+    script = tmp_path / "demo.tcl"
+    script.write_text('''
+vinit name=View1 w=48 h=40
+box floor -2 -2 -0.1 4 4 0.1
+psphere ball 0.5
+vdisplay floor ball
+vsetlocation ball 0 0 0.5
+vbsdf floor -kd 0.6
+vlight del 1
+vlight change 0 head 0 direction -0.25 -1 -1 sm 0.3 int 10
+vcamera -persp
+vviewparams -eye 3 -3 2 -at 0 0 0.4 -up 0 0 1
+vrenderparams -ray -gi -rayDepth 4
+foreach m {gold glass plaster} {
+  vsetmaterial ball $m
+  vfps 3
+  vdump "D:/somewhere/$m.png"
+}
+''')
+    host = ScriptHost(lambda: View(0), str(tmp_path))
+    info = host.run(str(script), 2)
+    assert info["frames"] == 3 * 3 + 2 and len(info["images"]) == 4 and not info["unsupported"]
+    assert float((tmp_path / "Output_demo_2.txt").read_text()) > 0
+
+    class OView(oracle_lib.Oracle):
+        def Redraw(self):
+            self.render(1)
+    ref = tmp_path / "ref"; ref.mkdir()
+    ScriptHost(lambda: OView(), str(ref)).run(str(script), 2)
+    for name in ("gold.png", "glass.png", "plaster.png", "Output_demo_2.png"):
+        a, b = np.asarray(Image.open(tmp_path / name)), np.asarray(Image.open(ref / name))
+        assert a.shape == (40, 48, 3) and np.array_equal(a, b), name
+    assert not np.array_equal(np.asarray(Image.open(tmp_path / "gold.png")), np.asarray(Image.open(tmp_path / "glass.png")))
