@@ -280,6 +280,81 @@ def read_ply(path):
     return pos, nrm.astype(np.float32), faces, uv
 
 
+def _finish_mesh(pos, faces, nrm=None, uv=None, smooth=False):
+    """what the reference asks assimp for (MeshImporter.cxx:73-91): triangles, and normals where the file has none --
+    smooth (area-weighted vertex normals, -gensmooth) or per-face (vertices duplicated per triangle)"""
+    pos = np.asarray(pos, np.float32).reshape(-1, 3); faces = np.asarray(faces, np.int32).reshape(-1, 3)
+    if nrm is not None:
+        return pos, np.asarray(nrm, np.float32).reshape(-1, 3), faces, uv
+    fn = np.cross(pos[faces[:, 1]] - pos[faces[:, 0]], pos[faces[:, 2]] - pos[faces[:, 0]]).astype(np.float64)
+    if smooth:
+        nrm = np.zeros((len(pos), 3))
+        for k in range(3):
+            np.add.at(nrm, faces[:, k], fn)
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+        return pos, nrm.astype(np.float32), faces, uv
+    fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-30)
+    flat = faces.reshape(-1)
+    return (pos[flat], np.repeat(fn, 3, axis=0).astype(np.float32), np.arange(len(flat), dtype=np.int32).reshape(-1, 3),
+            None if uv is None else uv[flat])
+
+
+def read_obj(path, smooth=False):
+    """Wavefront OBJ: v / vn / vt / f (polygons fan-triangulated, negative indices, v//vn and v/vt/vn forms); one mesh"""
+    v, vn, vt, corners, faces = [], [], [], {}, []
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "v":
+                v.append([float(x) for x in t[1:4]])
+            elif t[0] == "vn":
+                vn.append([float(x) for x in t[1:4]])
+            elif t[0] == "vt":
+                vt.append([float(x) for x in (t[1:3] + ["0"])[:2]])
+            elif t[0] == "f":
+                idx = []
+                for c in t[1:]:
+                    parts = (c.split("/") + ["", ""])[:3]
+                    key = tuple((int(x) - 1 if int(x) > 0 else n + int(x)) if x else -1 for x, n in zip(parts, (len(v), len(vt), len(vn))))
+                    idx.append(corners.setdefault(key, len(corners)))
+                for k in range(1, len(idx) - 1):
+                    faces.append((idx[0], idx[k], idx[k + 1]))
+    keys = sorted(corners, key=corners.get)
+    pos = np.array([v[k[0]] for k in keys], np.float32).reshape(-1, 3)
+    has_n = bool(keys) and all(k[2] >= 0 for k in keys)
+    has_t = bool(keys) and all(k[1] >= 0 for k in keys)
+    nrm = np.array([vn[k[2]] for k in keys], np.float32) if has_n else None
+    uv = np.array([vt[k[1]] for k in keys], np.float32) if has_t else None
+    return _finish_mesh(pos, faces, nrm, uv, smooth)
+
+
+def read_stl(path, smooth=False):
+    """STL, binary or ascii; vertices are welded by exact coordinates when smooth normals are asked for"""
+    with open(path, "rb") as f:
+        data = f.read()
+    n_bin = struct.unpack_from("<I", data, 80)[0] if len(data) >= 84 else -1
+    if n_bin >= 0 and 84 + 50 * n_bin == len(data):
+        rec = np.frombuffer(data, np.dtype([("n", "<3f4"), ("v", "<9f4"), ("a", "<u2")]), n_bin, 84)
+        tri = rec["v"].reshape(-1, 3, 3).astype(np.float32)
+    else:
+        nums = re.findall(rb"vertex\s+(\S+)\s+(\S+)\s+(\S+)", data)
+        tri = np.array(nums, dtype=np.float64).astype(np.float32).reshape(-1, 3, 3)
+    pos = tri.reshape(-1, 3)
+    faces = np.arange(len(pos), dtype=np.int32).reshape(-1, 3)
+    if smooth and len(pos):
+        uniq, inv = np.unique(pos, axis=0, return_inverse=True)
+        pos, faces = uniq, inv.reshape(-1, 3).astype(np.int32)
+    return _finish_mesh(pos, faces, None, None, smooth)
+
+
+# rtmeshread -up: the model-space axis that becomes +Z (reference MeshImporter.cxx:28-34)
+_UP_FLIP = {"X": lambda p: np.stack([-p[:, 2], p[:, 1], p[:, 0]], 1), "Y": lambda p: np.stack([p[:, 0], -p[:, 2], p[:, 1]], 1),
+            "Z": lambda p: p, "-X": lambda p: np.stack([p[:, 2], p[:, 1], -p[:, 0]], 1),
+            "-Y": lambda p: np.stack([p[:, 0], p[:, 2], -p[:, 1]], 1), "-Z": lambda p: np.stack([-p[:, 0], p[:, 1], -p[:, 2]], 1)}
+
+
 def write_ply(path, pos, nrm, faces, uv=None):
     """binary little-endian PLY with normals (and s/t texture coordinates when given), the layout assimp's 'plyb'
     exporter writes (AisMesh.cxx:490)."""
@@ -356,7 +431,21 @@ class SceneBuilder:
     # ---- geometry sources
     def cmd_rtmeshread(self, a):
         path, name = a[0], a[1]
-        pos, nrm, faces, uv = read_ply(path)
+        flags = [x.lower() for x in a[2:]]
+        smooth = "-gensmooth" in flags or "-gs" in flags       # options as the plugin parses them (ImportExportPlugin.cxx:195-215)
+        up = a[2:][flags.index("-up") + 1].upper().lstrip("+") if "-up" in flags and flags.index("-up") + 1 < len(flags) else "Z"
+        if up not in _UP_FLIP:
+            raise TclError(f"rtmeshread: -up {up}: expected X|Y|Z|-X|-Y|-Z")
+        ext = os.path.splitext(path)[1].lower()
+        if ext == ".obj":
+            pos, nrm, faces, uv = read_obj(path, smooth)
+        elif ext == ".stl":
+            pos, nrm, faces, uv = read_stl(path, smooth)
+        elif ext == ".ply":
+            pos, nrm, faces, uv = read_ply(path)
+        else:
+            raise TclError(f"rtmeshread: {ext or path} files are not supported (ply, obj, stl are)")
+        pos, nrm = _UP_FLIP[up](np.asarray(pos, np.float64)), _UP_FLIP[up](np.asarray(nrm, np.float64))
         self.objs[name] = _Obj(pos, nrm, faces)
         self.objs[name].uv = uv
         self.objs[name].displayed = True                     # rtmeshread displays what it loads (ImportExportPlugin.cxx:132-354)

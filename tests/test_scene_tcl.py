@@ -255,3 +255,39 @@ foreach m {gold glass plaster} {
         a, b = np.asarray(Image.open(tmp_path / name)), np.asarray(Image.open(ref / name))
         assert a.shape == (40, 48, 3) and np.array_equal(a, b), name
     assert not np.array_equal(np.asarray(Image.open(tmp_path / "gold.png")), np.asarray(Image.open(tmp_path / "glass.png")))
+
+
+def test_rtmeshread_obj_stl_and_up_axis(tmp_path):
+    """OBJ and STL through rtmeshread, per-face vs -gensmooth normals (MeshImporter.cxx:73-91) and the -up mapping
+    (MeshImporter.cxx:28-34)."""
+    import struct
+    from cadrays_amd.scene_tcl import MiniTcl, SceneBuilder, read_obj, read_stl
+    # a unit square in the XY plane as two triangles + a quad OBJ with texture coordinates and negative indices
+    (tmp_path / "q.obj").write_text("# quad\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\n")
+    pos, nrm, faces, uv = read_obj(str(tmp_path / "q.obj"))
+    assert faces.shape == (2, 3) and len(pos) == 6 and np.allclose(nrm, [0, 0, 1]) and uv.shape == (6, 2)
+    pos, nrm, faces, uv = read_obj(str(tmp_path / "q.obj"), smooth=True)
+    assert len(pos) == 4 and np.allclose(nrm, [0, 0, 1])
+    (tmp_path / "n.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 -1\nf -3//1 -2//1 -1//1\n")
+    pos, nrm, faces, uv = read_obj(str(tmp_path / "n.obj"))
+    assert np.allclose(nrm, [0, 0, -1]) and uv is None and faces.tolist() == [[0, 1, 2]]
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[1, 0, 0], [1, 1, 0], [0, 1, 0]]], np.float32)
+    with open(tmp_path / "b.stl", "wb") as f:
+        f.write(b"\0" * 80 + struct.pack("<I", 2))
+        for t in tri:
+            f.write(struct.pack("<12fH", 0, 0, 1, *t.reshape(-1), 0))
+    (tmp_path / "a.stl").write_text("solid s\n" + "".join(
+        "facet normal 0 0 1\nouter loop\n" + "".join("vertex %g %g %g\n" % tuple(v) for v in t) + "endloop\nendfacet\n" for t in tri) + "endsolid s\n")
+    for name in ("b.stl", "a.stl"):
+        pos, nrm, faces, _ = read_stl(str(tmp_path / name))
+        assert pos.shape == (6, 3) and np.allclose(nrm, [0, 0, 1]) and np.allclose(pos.reshape(2, 3, 3), tri)
+        pos, nrm, faces, _ = read_stl(str(tmp_path / name), smooth=True)
+        assert pos.shape == (4, 3)
+    b = SceneBuilder(str(tmp_path))
+    t = MiniTcl(b.commands, {})
+    t.eval(f"rtmeshread {tmp_path}/q.obj A\nrtmeshread {tmp_path}/b.stl B -gensmooth -up Y\nrtmeshread {tmp_path}/q.obj C -up -X")
+    assert b.objs["A"].displayed and np.allclose(b.objs["A"].nrm, [0, 0, 1])
+    assert np.allclose(b.objs["B"].nrm, [0, -1, 0]) and np.allclose(b.objs["B"].pos[:, 1], 0)          # (x, y, z) -> (x, -z, y)
+    assert np.allclose(b.objs["C"].nrm, [1, 0, 0])                                                      # (x, y, z) -> (z, y, -x)
+    with pytest.raises(TclError):
+        t.eval(f"rtmeshread {tmp_path}/q.fbx D")
