@@ -599,7 +599,7 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
     c->two_level = true; c->nO = nO;
     c->xf.assign(xf, xf + 12 * (size_t)nO); c->tri_obj.assign(tri_obj, tri_obj + nT);
   }
-  c->built = false;
+  c->built = false; c->pending_n = 0;
   return CRH_OK;
 }
 
@@ -632,7 +632,7 @@ int crh_set_materials(crh_ctx* c, const crh_bsdf* m, uint32_t n)
   if (!all_finite((const float*)m, 32 * (size_t)n)) return fail(c, CRH_E_INVALID, "material holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
-  c->mats.assign(m, m + n);
+  c->mats.assign(m, m + n); c->pending_n = 0;
   return dev_upload(c, c->d_mats, c->mats.data(), sizeof(crh_bsdf) * n);
 }
 
@@ -642,7 +642,7 @@ int crh_set_lights(crh_ctx* c, const crh_light* l, uint32_t n)
   if (!all_finite((const float*)l, 8 * (size_t)n, 1.0e30f)) return fail(c, CRH_E_INVALID, "light holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
-  c->lights.assign(l, l + n);
+  c->lights.assign(l, l + n); c->pending_n = 0;
   return upload_lights(c);
 }
 
@@ -652,7 +652,7 @@ int crh_set_envmap(crh_ctx* c, const float* rgb, uint32_t w, uint32_t h)
   if (rgb && w && h && !all_finite(rgb, 3 * (size_t)w * h)) return fail(c, CRH_E_INVALID, "environment map holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
-  c->envW = c->envH = 0;
+  c->envW = c->envH = 0; c->pending_n = 0;
   if (c->d_env) { CRH_HIP(hipFree(c->d_env)); c->d_env = nullptr; }
   if (rgb && w && h) {
     std::vector<float> t(4 * (size_t)w * h);
@@ -681,7 +681,7 @@ int crh_set_texture(crh_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uin
     }
     t.w = w; t.h = h;
   }
-  c->textures_dirty = true;
+  c->textures_dirty = true; c->pending_n = 0;
   return do_reset(c);
 }
 
@@ -691,7 +691,8 @@ int crh_set_camera(crh_ctx* c, const crh_camera* cam)
   const float f[] = {cam->eye[0], cam->eye[1], cam->eye[2], cam->dir[0], cam->dir[1], cam->dir[2], cam->up[0], cam->up[1], cam->up[2],
                      cam->fovy_deg, cam->aspect, cam->ortho_scale, cam->aperture_radius, cam->focal_dist};
   if (!all_finite(f, sizeof f / sizeof f[0], 1.0e30f)) return fail(c, CRH_E_INVALID, "camera holds a NaN / Inf");
-  c->cam = *cam; return CRH_OK;
+  c->cam = *cam; c->pending_n = 0;                      // samples traced ahead with the old camera are dropped
+  return CRH_OK;
 }
 
 int crh_set_params(crh_ctx* c, const crh_params* p)

@@ -74,6 +74,7 @@ typedef struct orc_ctx {
   uint32_t* tlas_order;          /* instance at top-level leaf position i */
   float bbmin[3], bbmax[3]; float eps;
   int built;
+  uint32_t frames_done;          /* whole-frame iterations since the last restart: orc_render continues from here (like crh_render) */
   /* camera frame */
   v3 c_eye, c_fwd, c_right, c_up; float c_tanh, c_aspect;
   /* lights prepared: vec = to-light dir (directional, normalized) or position; param = cosmax or radius */
@@ -1056,6 +1057,7 @@ ORC_API int orc_set_camera(orc_ctx* c, const crh_camera* cam)
 ORC_API int orc_reset(orc_ctx* c)
 {
   if (!c) return CRH_E_INVALID;
+  c->frames_done = 0;
   free(c->accum); c->accum = (float*)calloc((size_t)c->par.width * c->par.height * 4, sizeof(float));
   free(c->m2); c->m2 = (float*)calloc((size_t)c->par.width * c->par.height, sizeof(float)); c->adaptive_picks = 0;
   free(c->last_picked); c->last_picked = NULL; c->last_picked_n = 0;
@@ -1162,9 +1164,10 @@ ORC_API int orc_render(orc_ctx* c, uint32_t n)
 {
   if (!c) return CRH_E_INVALID; if (!c->built) return CRH_E_NOTBUILT;
   prepare(c);
-  if (c->adaptive) { for (uint32_t i = 0; i < n; ++i) { int rc = adaptive_iteration(c); if (rc) return rc; } return 0; }
-  /* every pixel has the same count when whole frames are rendered: continue from a[3] of pixel 0 */
-  uint32_t first = (uint32_t)c->accum[3];
+  if (c->adaptive) { for (uint32_t i = 0; i < n; ++i) { int rc = adaptive_iteration(c); if (rc) return rc; } c->frames_done += n; return 0; }
+  /* whole frames continue from the iteration counter, whatever orc_render_tiles did to individual tiles in between */
+  uint32_t first = c->frames_done;
+  c->frames_done += n;
   return render_tiles(c, NULL, 0, first, n, NULL);
 }
 ORC_API int orc_read_accum(orc_ctx* c, float* out) { if (!c || !c->accum) return CRH_E_INVALID; memcpy(out, c->accum, sizeof(float) * 4 * (size_t)c->par.width * c->par.height); return 0; }

@@ -123,3 +123,49 @@ def test_random_scene_bit_exact(view_cls, Oracle, seed):
     gs, cs = v.stats(), o.stats()
     for k in ("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "nodes_any", "tris_any", "shaded_hits", "samples"):
         assert gs[k] == cs[k], (seed, k, gs[k], cs[k])
+
+
+@pytest.mark.parametrize("seed", range(1, 49))
+def test_random_call_sequences_keep_both_sides_in_step(view_cls, Oracle, seed):
+    """State handling of the boundary under arbitrary call orders: renders, Redraws with speculative look-ahead, tile
+    subsets, resets, and camera / material / light / environment / parameter changes WITHOUT a reset in between (the
+    accumulation simply continues, pending look-ahead samples must be dropped).  After every step the images agree bit for bit."""
+    import dataclasses
+    r = np.random.default_rng(1000 + seed)
+    sc = random_scene(seed + 200)
+    sc = dataclasses.replace(sc, tri_object=None, obj_xform=None, params=dataclasses.replace(sc.params, max_depth=min(sc.params.max_depth, 6)))
+    v = view_cls(0).load_scene(sc); o = Oracle().load_scene(sc)
+    v.set_lookahead(int(r.choice([1, 3, 8])))
+    par, cam = sc.params, sc.camera
+    done = 0                                             # whole-frame iterations since the last restart (what crh_render continues from)
+    for step in range(14):
+        op = int(r.integers(0, 10))
+        if op <= 2:
+            n = int(r.integers(1, 4)); v.render(n); o.render(n); done += n
+        elif op == 3:
+            for _ in range(int(r.integers(1, 4))):
+                v.Redraw(); o.render(1); done += 1
+        elif op == 4:
+            tiles = np.arange(v.n_tiles(), dtype=np.uint32)
+            sel = tiles[r.random(len(tiles)) < 0.5]
+            if len(sel):
+                v.render_tiles(sel, done, 1); o.render_tiles(sel, done, 1)
+        elif op == 5:
+            v.reset(); o.reset(); done = 0
+        elif op == 6:
+            eye = np.array(cam.eye) * (1 + 0.05 * r.normal()); cam = dataclasses.replace(cam, eye=tuple(eye), fovy_deg=float(r.choice([30.0, 60.0])))
+            v.set_camera(cam); o.set_camera(cam)
+        elif op == 7:
+            mats = [random_bsdf(r, len(sc.textures)) for _ in sc.materials]
+            v.set_materials(mats); o.set_materials(mats)
+        elif op == 8:
+            lights = [Light.directional(r.normal(size=3), 0.2, 3.0)] if r.random() < 0.7 else []
+            env = scenes.procedural_sky(16, 8, int(seed + step)) if r.random() < 0.5 else None
+            v.set_lights(lights); o.set_lights(lights); v.set_envmap(env); o.set_envmap(env)
+        else:
+            par = dataclasses.replace(par, width=int(r.integers(9, 60)), height=int(r.integers(9, 40)), max_depth=int(r.choice([1, 3, 6])),
+                                      radiance_clamp=float(r.choice([0.0, 5.0])), tile_size=int(r.choice([8, 16, 32])))
+            v.set_params(par); o.set_params(par); done = 0
+        g, c = v.read_hdr(), o.read_hdr()
+        assert np.array_equal(bits(g), bits(c)), (seed, step, op)
+    assert np.array_equal(v.read_ldr(), o.read_ldr())
