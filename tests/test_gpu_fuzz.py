@@ -169,3 +169,41 @@ def test_random_call_sequences_keep_both_sides_in_step(view_cls, Oracle, seed):
         g, c = v.read_hdr(), o.read_hdr()
         assert np.array_equal(bits(g), bits(c)), (seed, step, op)
     assert np.array_equal(v.read_ldr(), o.read_ldr())
+
+
+@pytest.mark.parametrize("seed", range(1, 25))
+def test_random_sequences_two_level_adaptive_checkpoint(view_cls, Oracle, seed):
+    """The rarer state transitions: object transforms moved between renders (top-level rebuild), adaptive screen sampling
+    switched on and off, accumulator checkpoints restored into a fresh context -- still bit-identical to the oracle."""
+    import dataclasses
+    r = np.random.default_rng(5000 + seed)
+    sc = None
+    for s in range(seed * 7, seed * 7 + 200):                       # a two-level scene from the generator
+        cand = random_scene(s)
+        if cand.tri_object is not None:
+            sc = cand; break
+    sc = dataclasses.replace(sc, params=dataclasses.replace(sc.params, max_depth=min(sc.params.max_depth, 5), width=40, height=24, tile_size=8))
+    v = view_cls(0).load_scene(sc); o = Oracle().load_scene(sc)
+    v.set_lookahead(int(r.choice([1, 4])))
+    xf = sc.obj_xform.copy()
+    adaptive = False
+    for step in range(10):
+        op = int(r.integers(0, 6))
+        if op <= 1:
+            n = int(r.integers(1, 4)); v.render(n); o.render(n)
+        elif op == 2:
+            xf = xf.copy(); k = int(r.integers(0, len(xf))); xf[k, 3::4] += (0.05 * r.normal(size=3)).astype(np.float32)
+            v.set_transforms(xf); o.set_transforms(xf)
+        elif op == 3:
+            adaptive = not adaptive
+            v.set_adaptive(adaptive, 6); o.set_adaptive(adaptive, 6)
+        elif op == 4 and not adaptive:
+            acc, frames = v.save_accum()
+            w = view_cls(0).load_scene(dataclasses.replace(sc, obj_xform=xf)); w.load_accum(acc, frames)
+            w.set_lookahead(int(r.choice([1, 4])))
+            v = w                                                     # carry on in the restored context
+        else:
+            v.reset(); o.reset()
+        assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), (seed, step, op)
+    v.render(2); o.render(2)
+    assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr()))
