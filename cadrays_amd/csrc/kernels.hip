@@ -685,7 +685,10 @@ __device__ __forceinline__ float4 sample_texture(const DScene& S, uint32_t slot,
 
 constexpr uint32_t kGenIters = 32;     // k_raygen: 32 x 256 = 8192 path slots per queue reservation
 static_assert(kGenIters * 4 == 128, "k_raygen scans its 128 (iteration, wave) counters with one wavefront, two per lane");
-constexpr uint32_t kShadeIters = 4;    // k_shade : 4 x 256 = 1024 paths per cursor fetch / queue reservation
+#ifndef CRH_SHADE_ITERS
+#define CRH_SHADE_ITERS 4
+#endif
+constexpr uint32_t kShadeIters = CRH_SHADE_ITERS;    // k_shade : 4 x 256 = 1024 paths per cursor fetch / queue reservation
 
 // ================================================================== path slot <-> pixel
 // Slot layout inside one sample: tile-major, and inside a tile 8x8-pixel blocks so that one wavefront
