@@ -1,53 +1,204 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the path-tracing hot path.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config C3|C2|C4|C5|C1] [--scaling weak|strong]
 
-A "step" = one crh_render pass of `--spp` (default: one full 256 M-path batch = 128 samples per pixel at 1080p) over the rank's tiles of the workload
-(BASELINE.json config C3: 1 M random triangles, glass + glossy double-layer BSDFs, HDR sky, 1080p).
-At N > 1 (one process per GPU under torch.distributed.run) tiles are interleaved across ranks, every rank
-renders spp*N samples of its tiles per step (fixed per-GPU work -> weak scaling), and each step ends with
-the RCCL reduce of the float4 framebuffer to rank 0.  Inputs are resident in HBM before the timed region.
+A "step" = one crh_render_tiles pass over the rank's tiles of the workload (default BASELINE.json config C3: 1 M random
+triangles, glass + glossy double-layer BSDFs, HDR sky, 1080p; `--spp` samples per pixel per step, default one full
+256 M-path batch = 128 spp at 1080p).  Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0): metric Mrays/s (nearest-hit + any-hit rays actually traced, whole job),
-plus `roofline` for the dominant kernel (k_trace_nearest; HIP-event kernel time measured inside the timed
-region, algorithmic bytes from the deterministic counters) and `cpu_baseline` (the CPU oracle timed on this
-box's cores on a bounded tile sample of the same workload).
+N > 1: one process per GPU.  Under `python -m torch.distributed.run` (WORLD_SIZE set) this process is one of the ranks;
+started by hand as `python bench.py --gpus N` it SPAWNS the N rank processes itself -- before torch or the HIP runtime is
+touched in the parent, which only waits for them -- so the advertised command measures N GPUs.  Tiles are interleaved
+across ranks (tile t -> rank t mod N, cadrays_amd/sharding.py), no collective while rendering, and every step ends with
+the RCCL reduce of the float4 framebuffer to rank 0.
+  --scaling weak   (default) per-GPU work fixed: every rank renders spp*N samples of its 1/N of the tiles per step
+  --scaling strong the job is fixed: every rank renders spp samples of its 1/N of the tiles; `--config C4` = C3's scene,
+                   4096 spp per step, strong (BASELINE.json configs[3])
+
+Prints ONE JSON line (rank 0): metric Mrays/s (nearest-hit + any-hit rays actually traced, whole job), `roofline` for the
+dominant kernel (k_trace_nearest: HIP-event kernel time measured inside the timed region, algorithmic bytes from the
+deterministic counters, memory-side traffic from the committed rocprofv3 --pmc passes when they belong to THIS build) and
+`cpu_baseline` (the CPU oracle timed on this box's cores on a bounded tile sample of the same workload).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak, ~6.3 TB/s achievable (float4 copy); Infinity Cache 256 MiB
+HBM_PEAK_GBPS = 8000.0
+HBM_ACHIEVABLE_GBPS = 6300.0
+INFINITY_CACHE_BYTES = 256 << 20
+NODE_BYTES_FETCHED = 48          # 3 x dwordx4 of the 64-B-stride node are fetched per inner visit (SURVEY 8d assumed 128 B)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+PMC_HASH_FILES = ("cadrays_amd/csrc/kernels.hip", "include/crh_bvh_format.h")
 
 
-def main():
+def kernel_source_hash():
+    """Identity of the traversal kernel + node format a PMC measurement belongs to."""
+    h = hashlib.sha256()
+    for rel in PMC_HASH_FILES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_entry(config, spp, modified):
+    """(entry, reason): the committed counter figures of `config` if they were taken on this build of the kernel."""
+    if modified:
+        return None, "workload overridden on the command line (--tris/--width/--height): no PMC pass of this command"
+    if not os.path.exists(PMC_FILE):
+        return None, "profiles/pmc_traffic.json missing"
+    pmc = json.load(open(PMC_FILE))
+    ent = (pmc.get("configs") or {}).get(config)
+    if ent is None:
+        return None, f"profiles/pmc_traffic.json has no entry for {config}"
+    have, want = ent.get("source_hash"), kernel_source_hash()
+    if have != want:
+        return None, f"stale: PMC passes were taken on kernel build {have}, this is {want} (re-run profiles/pmc_collect.sh)"
+    if ent.get("spp_per_step") != spp:
+        return None, f"PMC passes used {ent.get('spp_per_step')} spp per step, this run {spp}"
+    return ent, None
+
+
+def roofline_report(config, spp, modified, alg_bytes_per_launch, avg_ms, scene_bytes, extra):
+    """The dominant kernel against the memory roofline.  `achieved` is the ALGORITHMIC rate (bytes the
+    traversal must fetch per launch / launch time); when the scene fits the 256 MiB Infinity Cache the bound is not HBM and the
+    algorithmic rate is not comparable with the HBM peak (L2 / Infinity-Cache hits serve part of it), so `frac` is then taken
+    from what actually crossed the L2's memory side (min(algorithmic, counter traffic)) -- or is null without counters."""
+    alg_gbps = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    resident = scene_bytes <= INFINITY_CACHE_BYTES
+    ent, reason = pmc_entry(config, spp, modified)
+    r = {"kernel": "k_trace_nearest", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+         "bound": "l2-miss/fabric gather (Infinity-Cache resident)" if resident else "hbm",
+         "scene_bytes": int(scene_bytes), "alg_gbps": round(alg_gbps, 1),
+         "alg_frac_of_hbm_peak": round(alg_gbps / HBM_PEAK_GBPS, 4),
+         "alg_bytes_per_launch": round(alg_bytes_per_launch), "node_bytes_per_visit": NODE_BYTES_FETCHED,
+         "alg_formula": "48 B fetched per inner-node visit (3 x dwordx4 of a 64-B-stride node; SURVEY 8d assumed 128-B nodes) + 48 B per triangle test + 48 B per ray (32-B ray read, 16-B hit write)",
+         "avg_launch_ms": round(avg_ms, 4)}
+    r.update(extra)
+    if ent is not None:
+        traffic = float(ent["hbm_bytes_per_launch"])
+        t_gbps = traffic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        hit, miss = ent.get("tcc_hit_per_launch"), ent.get("tcc_miss_per_launch")
+        r.update({"traffic": traffic, "traffic_source": ent.get("how", "profiles/pmc_traffic.json"),
+                  "traffic_gbps": round(t_gbps, 1), "traffic_frac_of_peak": round(t_gbps / HBM_PEAK_GBPS, 4),
+                  "traffic_frac_of_achievable": round(t_gbps / HBM_ACHIEVABLE_GBPS, 4),
+                  "traffic_over_alg": round(traffic / max(alg_bytes_per_launch, 1.0), 3),
+                  "l2_hit_rate": round(hit / (hit + miss), 3) if hit and miss else None,
+                  "pmc_avg_launch_ms": ent.get("avg_launch_ms")})
+        if resident:
+            r["achieved"] = round(min(alg_gbps, t_gbps), 1)
+            r["achieved_basis"] = "min(algorithmic, memory-side counter traffic): bytes that were both needed and crossed the L2's memory side"
+        else:
+            r["achieved"] = round(alg_gbps, 1)
+            r["achieved_basis"] = "algorithmic bytes / kernel time (traffic_over_alg > 1 = over-fetch)"
+        r["frac"] = round(r["achieved"] / HBM_PEAK_GBPS, 4)
+    else:
+        r.update({"traffic": None, "traffic_reason": reason, "l2_hit_rate": None})
+        r["achieved"] = round(alg_gbps, 1)
+        r["achieved_basis"] = "algorithmic bytes / kernel time"
+        if resident:
+            r["frac"] = None
+            r["frac_reason"] = "scene is Infinity-Cache resident and there is no counter traffic for this build: the algorithmic rate is not comparable with the HBM peak"
+        else:
+            r["frac"] = round(alg_gbps / HBM_PEAK_GBPS, 4)
+    return r
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start N fresh rank processes (this parent has not imported torch nor
+    touched the HIP runtime, and never does) and wait for them.  Rank 0 prints the JSON line on the inherited stdout."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, CRH_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                deadline = time.time() + 30.0          # a rank died: the others would wait in a collective forever
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.05)
+    return rc
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (per GPU share); 0 = what fills one 256 M-path batch (128 at 1080p, 32 at 4K)")
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step; 0 = what fills one 256 M-path batch (128 at 1080p, 32 at 4K); C4: 4096")
     ap.add_argument("--tris", type=int, default=0, help="override triangle count (debug)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-interactive", action="store_true", help="skip the 1-spp-per-Redraw figure")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes per launch from a separate rocprofv3 --pmc pass")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.scaling is None:
+        args.scaling = "strong" if args.config == "C4" else "weak"
+    if args.steps is None:
+        args.steps = 1 if args.config == "C4" else 4
+    return args
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))          # nothing GPU-related has been imported yet
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+    if os.environ.get("CRH_BENCH_RANK_PROBE") == "1":
+        # launcher self-test (tests/test_bench_cli.py, CPU): rendezvous over gloo, one all-reduce, rank 0 reports what it saw
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"probe": True, "n_gpus": world, "rccl_ranks": dist.get_world_size(), "sum": int(t.item()),
+                              "spawned": os.environ.get("CRH_BENCH_SPAWNED") == "1"}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    import numpy as np
     import torch
+    dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("CRH_BENCH_BACKEND", "nccl")     # "gloo" + CRH_BENCH_SHARE_DEVICE=1: rehearsal of the N > 1 flow on one GPU
@@ -63,15 +214,16 @@ def main():
     from cadrays_amd import scenes, sharding
     from cadrays_amd.view import View
 
-    sc = scenes.baseline_config(args.config, args.width or None, args.height or None, args.tris or None)
+    scene_cfg = "C3" if args.config == "C4" else args.config
+    sc = scenes.baseline_config(scene_cfg, args.width or None, args.height or None, args.tris or None)
     t0 = time.time()
     v = View(local).load_scene(sc)
     build_s = time.time() - t0
     fb = sharding.DeviceFramebuffer(v) if world > 1 else None
     tiles = sharding.tiles_for_rank(v.n_tiles(), rank, world)
-    if args.spp <= 0:                     # one full path batch per step: 2^28 slots / (tiles x 32 x 32 pixels)
-        args.spp = max(1, (256 << 20) // (v.n_tiles() * sc.params.tile_size ** 2))
-    spp_step = args.spp * world          # fixed per-GPU work: 1/N of the tiles, N x the samples
+    if args.spp <= 0:                     # one full path batch per step: 2^28 slots / (tiles x 32 x 32 pixels); C4: the named 4096 spp
+        args.spp = 4096 if args.config == "C4" else max(1, (256 << 20) // (v.n_tiles() * sc.params.tile_size ** 2))
+    spp_step = args.spp * world if args.scaling == "weak" else args.spp      # samples per pixel each rank renders per step
 
     def barrier():
         v.sync()
@@ -86,8 +238,10 @@ def main():
             v.sync()                                          # the accumulator is written on the context's own stream
             sharding.reduce_framebuffer(fb.tensor, 0)         # RCCL reduce of a staging copy; returns synchronised
 
+    rccl_ranks = 1
     if dist is not None:                                      # RCCL builds its rings / channels on first use: keep that out of the
         sharding.reduce_framebuffer(fb.tensor, 0)             # timed steps even when the caller asks for --warmup 0
+        rccl_ranks = dist.get_world_size()                    # as seen after the first reduce
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -103,10 +257,11 @@ def main():
     kt = v.kernel_timing()
     st = v.stats()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        dev = torch.device(f"cuda:{local}") if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        cnt = torch.tensor([st["rays_nearest"], st["rays_any"], st["samples"]], dtype=torch.float64, device=f"cuda:{local}")
+        cnt = torch.tensor([st["rays_nearest"], st["rays_any"], st["samples"]], dtype=torch.float64, device=dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         rays_n, rays_a, samples = (float(x) for x in cnt.tolist())
     else:
@@ -122,71 +277,110 @@ def main():
         v.enable_counters(False)
         assert cs["rays_nearest"] == st["rays_nearest"], "counting pass traced different rays"
         launches = max(kt["trace_nearest_launches"], 1)
-        # algorithmic bytes of k_trace_nearest: 3 x float4 of node per inner visit, 3 x float4 per triangle test, 32-B ray + 16-B hit per ray
-        alg_bytes = 48.0 * cs["nodes_nearest"] + 48.0 * cs["tris_nearest"] + 48.0 * cs["rays_nearest"]
-        per_launch = alg_bytes / launches
+        alg_bytes = float(NODE_BYTES_FETCHED) * cs["nodes_nearest"] + 48.0 * cs["tris_nearest"] + 48.0 * cs["rays_nearest"]
         avg_ms = kt["trace_nearest_ms_total"] / launches
-        achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = args.pmc_traffic
-        traffic_source = "--pmc-traffic" if traffic is not None else None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if traffic is None and args.config == "C3" and not (args.tris or args.width or args.height) and os.path.exists(pmc_file):
-            # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same command
-            pmc = json.load(open(pmc_file))
-            traffic = pmc.get("hbm_bytes_per_launch")
-            traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-            if traffic is not None and args.spp != pmc.get("spp_per_step", 32):
-                traffic = traffic * args.spp / pmc.get("spp_per_step", 32)
-        roof = {"bound": "hbm", "kernel": "k_trace_nearest", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "alg_bytes_per_launch": round(per_launch), "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
-                "kernel_time_share": round(kt["trace_nearest_ms_total"] / max(kt["render_ms_total"], 1e-9), 3),
-                "nodes_per_ray": round(cs["nodes_nearest"] / max(cs["rays_nearest"], 1), 2),
-                "tris_per_ray": round(cs["tris_nearest"] / max(cs["rays_nearest"], 1), 2)}
+        mem = v.scene_bytes()
+        roof = roofline_report(args.config if world == 1 else f"{args.config}@{world}", spp_step, bool(args.tris or args.width or args.height),
+                               alg_bytes / launches, avg_ms, mem["nodes"] + mem["triangles"], {
+            "launches": int(launches),
+            "kernel_time_share": round(kt["trace_nearest_ms_total"] / max(kt["render_ms_total"], 1e-9), 3),
+            "nodes_per_ray": round(cs["nodes_nearest"] / max(cs["rays_nearest"], 1), 2),
+            "tris_per_ray": round(cs["tris_nearest"] / max(cs["rays_nearest"], 1), 2),
+            "scene_bytes_detail": mem})
+
+    # ---- the reference's interactive regime (one Redraw() = +1 spp per call, AppViewer.cxx:1045-1047), reported beside `value`
+    interactive = None
+    if rank == 0 and world == 1 and not args.no_interactive:
+        interactive = {}
+        for k in (1, 16):
+            v.set_lookahead(k); v.reset()
+            for _ in range(2 * k):
+                v.Redraw()
+            v.sync()
+            n_fr = max(32, 4 * k)
+            t1 = time.perf_counter()
+            for _ in range(n_fr):
+                v.Redraw()
+            v.sync()
+            interactive[f"redraw_per_s_lookahead_{k}"] = round(n_fr / (time.perf_counter() - t1), 1)
+        v.set_lookahead(1); v.reset()
+        interactive["note"] = "one crh_render(1) per call over the whole frame, no read-back; NOT part of `value`"
 
     # ---- CPU baseline: the oracle (a port, not the reference: OCCT has no CPU path tracer) on this box's cores
     cpu = None
     if rank == 0 and not args.no_cpu and world == 1:          # reported on rank 0 at N = 1 only
-        from oracle.pyoracle import Oracle
-        ncores = os.cpu_count() or 1
-        Oracle.set_threads(ncores)
-        o = Oracle().load_scene(sc)
-        nt = o.n_tiles()
-        sample = np.unique(np.linspace(0, nt - 1, 32).astype(np.uint32))
-        o.render_tiles(sample, 0, 1)                      # calibration (also warms the threads)
-        s0 = o.stats()
-        rate = (s0["rays_nearest"] + s0["rays_any"]) / max(s0["seconds"], 1e-9)
-        per_tile = (s0["rays_nearest"] + s0["rays_any"]) / len(sample)
-        want = int(min(nt, max(32, rate * args.cpu_seconds / max(per_tile, 1))))
-        sample = np.unique(np.linspace(0, nt - 1, want).astype(np.uint32))
-        # first pass at 1 spp re-measures the rate with all threads busy; then size spp for ~cpu_seconds
-        o.reset(); o.render_tiles(sample, 0, 1)
-        s1 = o.stats()
-        rate = (s1["rays_nearest"] + s1["rays_any"]) / max(s1["seconds"], 1e-9)
-        spp_cpu = int(max(1, min(64, rate * args.cpu_seconds / max(s1["rays_nearest"] + s1["rays_any"], 1))))
-        o.reset(); o.render_tiles(sample, 0, spp_cpu)
-        s1 = o.stats()
-        cpu = {"value": round((s1["rays_nearest"] + s1["rays_any"]) / s1["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": ncores,
-               "kind": "port", "sample": f"{len(sample)} of {nt} 32x32 tiles of the same workload, {spp_cpu} spp, {s1['seconds']:.1f} s, OpenMP oracle"}
+        cpu = cpu_baseline(sc, args.cpu_seconds)
 
     if rank == 0:
         mrays = (rays_n + rays_a) / dt / 1e6
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {len(sc.tri)} random triangles, {len(sc.materials)} BSDF(s), "
                                    f"{'HDR sky env' if sc.env is not None else 'constant env'}, {len(sc.lights)} light(s), "
                                    f"{sc.params.width}x{sc.params.height}, depth {sc.params.max_depth}",
-                       "spp_per_step": spp_step, "tiles_per_rank": int(len(tiles)), "parallelism": f"tiles x{n_gpus} + RCCL reduce" if n_gpus > 1 else "single GPU",
+                       "spp_per_step_per_rank": spp_step, "spp_per_step_whole_frame": spp_step if args.scaling == "strong" or world == 1 else args.spp,
+                       "tiles_per_rank": int(len(tiles)), "parallelism": f"tiles x{n_gpus} + RCCL reduce" if n_gpus > 1 else "single GPU",
+                       "rccl_ranks": int(rccl_ranks), "backend": backend,
                        "msamples_per_s": round(samples / dt / 1e6, 3), "rays_nearest": int(rays_n), "rays_any": int(rays_a),
-                       "build_upload_s": round(build_s, 2), "host_cores": os.cpu_count()},
+                       "build_upload_s": round(build_s, 2), "host_cores": os.cpu_count(), "interactive": interactive},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()                                       # rank 0 may still be in its counting pass
         dist.destroy_process_group()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sc, seconds):
+    """The CPU oracle on a bounded tile sample of the same workload: the parity build (what the tests compare against) and,
+    when built, the fast build (-O3 -march=native, contraction allowed, counters compiled out; oracle/Makefile)."""
+    import numpy as np
+    from oracle import pyoracle
+    ncores = os.cpu_count() or 1
+    out = None
+    for kind in ("fast", "parity"):
+        try:
+            Or = pyoracle.oracle_class(kind)
+        except (OSError, AttributeError, RuntimeError):
+            continue
+        Or.set_threads(ncores)
+        o = Or().load_scene(sc)
+        nt = o.n_tiles()
+        budget = seconds if kind == "fast" or out is None else max(4.0, seconds / 3)
+        sample = np.unique(np.linspace(0, nt - 1, 32).astype(np.uint32))
+        o.render_tiles(sample, 0, 1)                      # calibration (also warms the threads)
+        s0 = o.stats()
+        rate = (s0["rays_nearest"] + s0["rays_any"]) / max(s0["seconds"], 1e-9)
+        per_tile = (s0["rays_nearest"] + s0["rays_any"]) / len(sample)
+        want = int(min(nt, max(32, rate * budget / max(per_tile, 1))))
+        sample = np.unique(np.linspace(0, nt - 1, want).astype(np.uint32))
+        # first pass at 1 spp re-measures the rate with all threads busy; then size spp for ~budget seconds
+        o.reset(); o.render_tiles(sample, 0, 1)
+        s1 = o.stats()
+        rate = (s1["rays_nearest"] + s1["rays_any"]) / max(s1["seconds"], 1e-9)
+        spp_cpu = int(max(1, min(64, rate * budget / max(s1["rays_nearest"] + s1["rays_any"], 1))))
+        o.reset(); o.render_tiles(sample, 0, spp_cpu)
+        s1 = o.stats()
+        leg = {"value": round((s1["rays_nearest"] + s1["rays_any"]) / s1["seconds"] / 1e6, 3), "unit": "Mrays/s",
+               "sample": f"{len(sample)} of {nt} 32x32 tiles of the same workload, {spp_cpu} spp, {s1['seconds']:.1f} s, OpenMP oracle ({kind} build)"}
+        if out is None:
+            out = {"value": leg["value"], "unit": "Mrays/s", "cores": ncores, "kind": "port", "sample": leg["sample"],
+                   "cpu_model": cpu_model(), "build": kind}
+        out[f"{kind}_build"] = leg
+        o.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -122,6 +122,14 @@ void drain_events(crh_ctx* c)
   c->trace_ev.clear();
 }
 
+// Event pairs wait in the context until someone asks for the times; an interactive loop that never does (one crh_render(1)
+// per GUI frame, adaptive or look-ahead) must not grow the lists without bound: fold them in every 4096 pairs.
+int trim_events(crh_ctx* c)
+{
+  if (c->render_ev.size() + c->trace_ev.size() > 4096) { CRH_HIP(hipStreamSynchronize(c->stream)); drain_events(c); }
+  return CRH_OK;
+}
+
 uint32_t frame_seed(uint32_t seed, uint32_t n)   // Bullard generator, SURVEY.md a14
 {
   uint32_t hi = seed, lo = seed ^ 0x49616E42u, r = 0;
@@ -338,8 +346,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   }
   hipEventRecord(e1, c->stream);
   c->render_ev.emplace_back(e0, e1);
-  if (c->render_ev.size() + c->trace_ev.size() > 4096) { CRH_HIP(hipStreamSynchronize(c->stream)); drain_events(c); }
-  return CRH_OK;
+  return trim_events(c);
 }
 
 // ---- adaptive screen sampling (reference: AdaptiveScreenSampling / NbRayTracingTiles, SettingsWidget.cxx:427-477) ----------
@@ -406,7 +413,7 @@ int adaptive_iteration(crh_ctx* c)
   rc = run_batch(c, S, c->d_tile_ids, n, c->d_seeds, 1, 1); if (rc) return rc;
   hipEventRecord(e1, c->stream);
   c->render_ev.emplace_back(e0, e1);
-  return CRH_OK;
+  return trim_events(c);
 }
 
 
@@ -820,6 +827,7 @@ int crh_render(crh_ctx* c, uint32_t n)
         int rc_b = run_batch(c, S, c->d_tile_ids, nt, c->d_seeds, k, 0, false); if (rc_b) return rc_b;
         hipEventRecord(e1, c->stream);
         c->render_ev.emplace_back(e0, e1);
+        { int rc_e = trim_events(c); if (rc_e) return rc_e; }
         c->pending_first = c->frames_done; c->pending_n = k; c->pending_off = 0; c->pending_tiles = nt;
       }
       const uint32_t m = std::min(n, c->pending_n);
@@ -1046,6 +1054,26 @@ int crh_debug_math(crh_ctx* c, int fn, const float* a, const float* b, float* ou
   CRH_HIP(hipGetLastError());
   CRH_HIP(hipMemcpyAsync(out, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost, c->stream));
   CRH_HIP(hipMemcpyAsync(out2, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  return CRH_OK;
+}
+
+int crh_debug_bsdf(crh_ctx* c, int fn, const crh_bsdf* m, const float* a, const float* b, float* out, uint32_t n, int two_sided)
+{
+  if (!c || !m || !a || !out || !n || fn < 0 || fn > 3 || (fn != 3 && !b)) return fail(c, CRH_E_INVALID, "bad debug_bsdf arguments");
+  CRH_HIP(hipSetDevice(c->device));
+  const size_t per_out = fn == 2 ? 8 : (fn == 1 ? 1 : 3);
+  const size_t in_b = sizeof(float) * 3 * (size_t)n, out_b = sizeof(float) * per_out * (size_t)n;
+  int rc = ensure_scratch(c, 256 + 2 * in_b + out_b); if (rc) return rc;
+  char* base = (char*)c->d_scratch;
+  float* d_a = (float*)(base + 256); float* d_b = (float*)(base + 256 + in_b); float* d_o = (float*)(base + 256 + 2 * in_b);
+  CRH_HIP(hipMemcpyAsync(base, m, sizeof(crh_bsdf), hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipMemcpyAsync(d_a, a, in_b, hipMemcpyHostToDevice, c->stream));
+  if (b) CRH_HIP(hipMemcpyAsync(d_b, b, in_b, hipMemcpyHostToDevice, c->stream));
+  Launch L{c->stream, c->grid, false};
+  launch_debug_bsdf(L, fn, (const float4*)base, d_a, d_b, d_o, n, two_sided);
+  CRH_HIP(hipGetLastError());
+  CRH_HIP(hipMemcpyAsync(out, d_o, out_b, hipMemcpyDeviceToHost, c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
   return CRH_OK;
 }

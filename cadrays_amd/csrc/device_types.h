@@ -9,6 +9,7 @@ namespace crh {
 
 // ---- spec constants -----------------------------------------------------------------
 constexpr float    kDirEps        = 1.0e-15f;
+constexpr float    kSlabGuard     = 4.76837158203125e-7f;   // 2^-21: guard band of the slab test per unit of |1/d| x reach
 constexpr float    kBsdfEps       = 1.0e-5f;
 constexpr float    kMinThroughput = 1.0e-3f;
 constexpr float    kMinContrib    = 1.0e-2f;

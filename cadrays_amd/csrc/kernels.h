@@ -35,5 +35,7 @@ void launch_add4(const Launch&, float4* dst, const float4* src, uint32_t n_float
 void launch_trace_rays(const Launch&, const DScene&, const float4* rays, uint32_t n, int any_hit,
                        float4* out_hit, uint32_t* out_vis, uint32_t* d_cursor, DCounters*);
 void launch_debug_math(const Launch&, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n);
+// test hook: eval / pdf / sample / Fresnel of the layered BSDF on caller-supplied local directions (m: 8 x float4 = crh_bsdf)
+void launch_debug_bsdf(const Launch&, int fn, const float4* m, const float* a, const float* b, float* out, uint32_t n, int two_sided);
 
 }  // namespace crh

@@ -136,8 +136,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   int sp = 0;
   v3 o = crh_mk3(0.f, 0.f, 0.f), d = o;
   v3 wo = o, wd = o;     // world-space ray while inside an object (TWO only) ...
-  float wix = 0.f, wiy = 0.f, wiz = 0.f, wnox = 0.f, wnoy = 0.f, wnoz = 0.f;   // ... and its reciprocal direction / -o * inv (restored, not recomputed, on leaving)
-  float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, best = 0.f;
+  float wix = 0.f, wiy = 0.f, wiz = 0.f;   // ... and its reciprocal direction (restored, not recomputed, on leaving)
+  float ix = 0.f, iy = 0.f, iz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, best = 0.f;   // g = |1/d| * 2^-21: the slab test's guard band per unit of distance
   float4 hit = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   bool found = false;
   // wave-uniform pool state.  Chunk per atomic: kPoolChunk for long queues (one cursor word sustains ~88 atomics/us); short
@@ -168,8 +168,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           float tmax;
           load(pool_next + rank, o, d, tmax, tag);
           ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
-          nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
-          if (TWO) { wo = o; wd = d; wix = ix; wiy = iy; wiz = iz; wnox = nox; wnoy = noy; wnoz = noz; }
+          gx = crh_abs(ix) * kSlabGuard; gy = crh_abs(iy) * kSlabGuard; gz = crh_abs(iz) * kSlabGuard;
+          if (TWO) { wo = o; wd = d; wix = ix; wiy = iy; wiz = iz; }
           best = tmax; found = false; sp = 0; cur = root; have = true;
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
         }
@@ -179,11 +179,6 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     }
     if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
 
-    auto set_ray = [&](v3 no, v3 nd) {
-      o = no; d = nd;
-      ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
-      nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
-    };
     auto read_top = [&]() {
       --sp;
       if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
@@ -193,7 +188,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       if ((ANY && found) || sp == 0) { cur = kDone; return; }
       read_top();
       if (TWO && cur == CRH_REF_SENTINEL) {          // leaving an object: back to the world-space ray
-        o = wo; d = wd; ix = wix; iy = wiy; iz = wiz; nox = wnox; noy = wnoy; noz = wnoz;      // same values set_ray(wo, wd) would recompute
+        o = wo; d = wd; ix = wix; iy = wiy; iz = wiz;                                            // the saved reciprocals are the bits inv_dir(wd) would recompute
+        gx = crh_abs(ix) * kSlabGuard; gy = crh_abs(iy) * kSlabGuard; gz = crh_abs(iz) * kSlabGuard;
         if (sp == 0) cur = kDone; else read_top();
       }
     };
@@ -202,11 +198,18 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;
       const float4 n0 = np[0], n1 = np[1], n2 = np[2];
       if (COUNT) ++n_nodes;
-      // per-node grid: face t = fma(q, step * inv_d, fma(origin, inv_d, -o * inv_d))
+      // per-node grid: face t = fma(q, step * inv_d, (origin - o) * inv_d -+ guard) -- the difference is taken BEFORE the
+      // multiplication (fma(origin, inv_d, -o * inv_d) cancels catastrophically when |o * inv_d| >> t: a ray grazing a box
+      // corner was culled by 2e-5 of t), and the entry / exit planes move apart by guard = 2^-21 * |inv_d| * L with
+      // L = |D|_1 + 256 * largest step >= the distance to anything in the node: twice the worst rounding error of this
+      // evaluation, so a child box the exact ray touches is never culled
       const uint32_t ew = __float_as_uint(n0.w);
-      const float ax = __uint_as_float((ew & 0xffu) << 23) * ix, ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * iy,
-                  az = __uint_as_float(((ew >> 16) & 0xffu) << 23) * iz;
-      const float bx = CRH_FMA(n0.x, ix, nox), by = CRH_FMA(n0.y, iy, noy), bz = CRH_FMA(n0.z, iz, noz);
+      const float stx = __uint_as_float((ew & 0xffu) << 23), sty = __uint_as_float(((ew >> 8) & 0xffu) << 23), stz = __uint_as_float(((ew >> 16) & 0xffu) << 23);
+      const float ax = stx * ix, ay = sty * iy, az = stz * iz;
+      const float ddx = n0.x - o.x, ddy = n0.y - o.y, ddz = n0.z - o.z;
+      const float bx = ddx * ix, by = ddy * iy, bz = ddz * iz;
+      const float reach = CRH_FMA(fmaxf(fmaxf(stx, sty), stz), 256.0f, (crh_abs(ddx) + crh_abs(ddy)) + crh_abs(ddz));
+      const float ex = reach * gx, ey = reach * gy, ez = reach * gz;
       // child references are implicit: slots < ni are the consecutive inner nodes from child_base, the others the leaves
       // with consecutive references from leaf_base (crh_bvh_format.h): ref(slot) = (slot < ni ? child_base : leaf_base - ni) + slot
       const uint32_t ni = (ew >> 24) & 7u, nch = ew >> 28;
@@ -216,7 +219,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const bool sx = ix < 0.f, sy = iy < 0.f, sz = iz < 0.f;
       const uint32_t lx = __float_as_uint(sx ? n1.w : n1.x), ly = __float_as_uint(sy ? n2.x : n1.y), lz = __float_as_uint(sz ? n2.y : n1.z);
       const uint32_t hx = __float_as_uint(sx ? n1.x : n1.w), hy = __float_as_uint(sy ? n1.y : n2.x), hz = __float_as_uint(sz ? n1.z : n2.y);
-      const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
+      const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx - ex, bx + ex}, by2 = {by - ey, by + ey}, bz2 = {bz - ez, bz + ez};
       uint32_t key[4];
 #define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))      /* v_cvt_f32_ubyteK */
 #define CRH_CHILD(K)                                                                                         \
@@ -296,8 +299,10 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       o = crh_xform_point(m, wo); d = crh_xform_vector(m, wd);
       // an instance that is only translated (inverse 3x3 == identity exactly, flagged by the host) leaves |d| and its signs
       // unchanged, so the reciprocals are the world ray's: three IEEE divisions saved on the common "placed, not rotated" part
-      if (__float_as_uint(meta.z) == 0u) { ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z); }
-      nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
+      if (__float_as_uint(meta.z) == 0u) {
+        ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
+        gx = crh_abs(ix) * kSlabGuard; gy = crh_abs(iy) * kSlabGuard; gz = crh_abs(iz) * kSlabGuard;
+      }
       const uint32_t mark = CRH_REF_SENTINEL;
       if (sp < kLdsStack) lds[sp * kBlock] = mark; else ovf[sp - kLdsStack] = mark;
       ++sp;
@@ -662,8 +667,11 @@ __device__ __forceinline__ float4 sample_texture(const DScene& S, uint32_t slot,
   if (td.y == 0u) return make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 ua = S.uvs[2u * tri], ub = S.uvs[2u * tri + 1u];
   const float ss = sc_s != 0.f ? sc_s : 1.0f, st_ = sc_t != 0.f ? sc_t : 1.0f;
-  const float us = CRH_FMA(ub.x, bv, CRH_FMA(ua.z, bu, ua.x * w0)) * ss;
-  const float vs = CRH_FMA(ub.y, bv, CRH_FMA(ua.w, bu, ua.y * w0)) * st_;
+  float us = CRH_FMA(ub.x, bv, CRH_FMA(ua.z, bu, ua.x * w0)) * ss;
+  float vs = CRH_FMA(ub.y, bv, CRH_FMA(ua.w, bu, ua.y * w0)) * st_;
+  // beyond 2^22 a float has no fraction left worth sampling and (int) would saturate (texel index out of range): wrap to 0
+  if (!(crh_abs(us) < 4194304.0f)) us = 0.f;
+  if (!(crh_abs(vs) < 4194304.0f)) vs = 0.f;
   float uf = (float)(int)us; if (uf > us) uf -= 1.0f;
   float vf = (float)(int)vs; if (vf > vs) vf -= 1.0f;
   const float x = CRH_FMA(us - uf, (float)td.y, -0.5f), y = CRH_FMA(1.0f - (vs - vf), (float)td.z, -0.5f);
@@ -1120,6 +1128,44 @@ __global__ void k_debug_math(int fn, const float* __restrict__ a, const float* _
   }
 }
 
+// Test hook behind crh_debug_bsdf: the layered BSDF functions k_shade uses, evaluated on caller-supplied directions (local
+// frame, z = shading normal) so that the analytic known-answer tests (pdf integrates to 1, sample weight = f cos / pdf,
+// Fresnel limits, Snell) run on the gfx950 code itself and not only on the CPU oracle.
+//   fn 0: out[3i..]   = eval_layered(wi, wo)            (f * cos)
+//   fn 1: out[i]      = pdf_layered(wo, wi, W = 1)
+//   fn 2: out[8i..]   = sample_layered with rng state bits(b[3i]), inside flag b[3i+1] != 0: wi.xyz, weight.xyz,
+//                       flags (1 alive | 2 delta | 4 inside after), rng state after (uint bits)
+//   fn 3: out[3i..]   = fresnel_media(a[3i], m.FresnelCoat)
+__global__ void k_debug_bsdf(int fn, const float4* __restrict__ m, const float* __restrict__ a, const float* __restrict__ b,
+                             float* __restrict__ out, uint32_t n, int two_sided)
+{
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const v3 wo = crh_mk3(a[3u * i], a[3u * i + 1u], a[3u * i + 2u]);
+    Bsdf bs;
+    bs.Kc = xyz(m[0]); bs.Rc = m[0].w; bs.Kd = xyz(m[1]); bs.Ks = xyz(m[2]); bs.Rs = m[2].w; bs.Kt = xyz(m[3]); bs.Le = xyz(m[4]);
+    bs.ab = m[5]; bs.fc = m[6]; bs.fb = m[7];
+    bs.Fc = fresnel_media(wo.z, bs.fc);
+    const v3 one = crh_mk3(1.0f, 1.0f, 1.0f);
+    if (fn == 0) {
+      const v3 r = eval_layered(bs, crh_mk3(b[3u * i], b[3u * i + 1u], b[3u * i + 2u]), wo, two_sided);
+      out[3u * i] = r.x; out[3u * i + 1u] = r.y; out[3u * i + 2u] = r.z;
+    } else if (fn == 1) {
+      out[i] = pdf_layered(bs, wo, crh_mk3(b[3u * i], b[3u * i + 1u], b[3u * i + 2u]), one, two_sided);
+    } else if (fn == 2) {
+      uint32_t rng = __float_as_uint(b[3u * i]);
+      bool inside = b[3u * i + 1u] != 0.f, delta = false;
+      v3 W = one, wi = crh_mk3(0.f, 0.f, 0.f);
+      const bool alive = sample_layered(bs, wo, wi, W, inside, delta, rng, two_sided);
+      float* o = out + 8u * i;
+      o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; o[3] = W.x; o[4] = W.y; o[5] = W.z;
+      o[6] = (float)((alive ? 1 : 0) | (delta ? 2 : 0) | (inside ? 4 : 0)); o[7] = __uint_as_float(rng);
+    } else {
+      const v3 r = fresnel_media(wo.x, bs.fc);
+      out[3u * i] = r.x; out[3u * i + 1u] = r.y; out[3u * i + 2u] = r.z;
+    }
+  }
+}
+
 }  // namespace
 
 // ================================================================== launch wrappers
@@ -1186,6 +1232,11 @@ void launch_trace_rays(const Launch& L, const DScene& S, const float4* rays, uin
 void launch_debug_math(const Launch& L, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n)
 {
   hipLaunchKernelGGL(k_debug_math, dim3(L.grid), dim3(kBlock), 0, L.stream, fn, a, b, out, out2, n);
+}
+
+void launch_debug_bsdf(const Launch& L, int fn, const float4* m, const float* a, const float* b, float* out, uint32_t n, int two_sided)
+{
+  hipLaunchKernelGGL(k_debug_bsdf, dim3(L.grid), dim3(kBlock), 0, L.stream, fn, m, a, b, out, n, two_sided);
 }
 
 }  // namespace crh

@@ -39,7 +39,9 @@ class ScriptHost:
         w, h = self.size or self.builder.view_size or (512, 512)
         sc = self.builder.snapshot(w, h, "script")
         key = (sc.pos.tobytes(), sc.tri.tobytes(), b"".join(bytes(m.to_abi()) for m in sc.materials), repr(sc.lights), repr(sc.camera),
-               repr(sc.params), None if sc.env is None else sc.env.tobytes())
+               repr(sc.params), None if sc.env is None else sc.env.tobytes(),
+               sc.nrm.tobytes(), None if sc.uv is None else sc.uv.tobytes(), tuple(t.tobytes() for t in (sc.textures or [])),
+               None if sc.tri_object is None else sc.tri_object.tobytes(), None if sc.obj_xform is None else sc.obj_xform.tobytes())
         if key != self._scene_key:
             if self.view is None:
                 self.view = self.view_factory()

@@ -80,6 +80,13 @@ class View(Backend):
         assert rgba.shape == (self.height, self.width, 4)
         self._call("load_accum", rgba.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(int(frames_done)))
 
+    def scene_bytes(self):
+        """HBM residency of the built scene: 64-B-stride nodes, 64-B-stride triangle records, 48-B shading records"""
+        nn, nt = C.c_uint32(0), C.c_uint32(0)
+        self._call("get_bvh", None, C.byref(nn), None, C.byref(nt))
+        return {"nodes": 4 * abi.NODE_DWORDS * nn.value, "triangles": 64 * nt.value, "shading": 48 * nt.value,
+                "n_nodes": nn.value, "n_triangles": nt.value}
+
     def accum_device_ptr(self):
         p, n = C.c_void_p(0), C.c_uint64(0)
         self._call("accum_device_ptr", C.byref(p), C.byref(n))
@@ -112,6 +119,19 @@ class View(Backend):
         self._call("debug_math", C.c_int(fn), a.ctypes.data_as(fp), b.ctypes.data_as(fp), out.ctypes.data_as(fp),
                    out2.ctypes.data_as(fp), C.c_uint32(a.size))
         return out, out2
+
+
+    def debug_bsdf(self, fn, bsdf, a, b=None, two_sided=True):
+        """crh_debug_bsdf: fn 0 eval (f cos), 1 pdf, 2 sample, 3 Fresnel of the coat on the device; a, b: (n, 3) float32"""
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), np.float32).reshape(-1, 3)
+        n = len(a)
+        out = np.empty((n, {0: 3, 1: 1, 2: 8, 3: 3}[fn]), np.float32)
+        m = bsdf.to_abi()
+        fp = C.POINTER(C.c_float)
+        self._call("debug_bsdf", C.c_int(fn), C.byref(m), a.ctypes.data_as(fp), b.ctypes.data_as(fp), out.ctypes.data_as(fp),
+                   C.c_uint32(n), C.c_int(int(two_sided)))
+        return out
 
 
 def build_bvh_host(pos, tri, threads=0):

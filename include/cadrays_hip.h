@@ -241,6 +241,15 @@ CRH_API int crh_bench_trace(crh_ctx* ctx, const float* rays, uint32_t n, int any
  * (fn: 0 sincos2pi, 1 exp, 2 log, 3 pow(a,b), 4 acos, 5 atan2(a,b), 6 sincos, 7 sqrt, 8 a/b, 9 rng stream
  * of seed (a-bits, b-bits)).  The parity tests require bit equality with the CPU build. */
 CRH_API int crh_debug_math(crh_ctx* ctx, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n);
+/* Test hook: the layered BSDF functions of the shading kernel on caller-supplied directions in the local frame (z = shading
+ * normal), n items, so that the analytic known-answer tests run on the gfx950 code itself (reference input contract:
+ * Graphic3d_BSDF, MaterialEditor.cxx:281-338).  a = wo (3 floats per item; fn 3: a[3i] = cos theta).
+ *   fn 0  b = wi;                                  out[3i..] = f(wo, wi) * cos
+ *   fn 1  b = wi;                                  out[i]    = pdf(wo -> wi) with path weight (1,1,1)
+ *   fn 2  b[3i] = rng state (uint bits), b[3i+1] != 0: inside a medium;
+ *                                                  out[8i..] = wi.xyz, weight.xyz, flags (1 alive | 2 delta | 4 inside after), rng after
+ *   fn 3  b unused;                                out[3i..] = Fresnel(a[3i], m->FresnelCoat) */
+CRH_API int crh_debug_bsdf(crh_ctx* ctx, int fn, const crh_bsdf* m, const float* a, const float* b, float* out, uint32_t n, int two_sided);
 CRH_API int crh_enable_kernel_timing(crh_ctx* ctx, int on);
 CRH_API int crh_get_kernel_timing(crh_ctx* ctx, double* trace_ms_total, uint64_t* trace_launches,
                           double* all_ms_total);

@@ -43,6 +43,7 @@
 #define QBVH_LEAFBIT   0x80000000u
 #define STACK_MAX      128         /* >= 63 (top-level tree: 21 four-wide levels x 3 pending siblings) + 1 sentinel + 63 (object tree) */
 #define DIR_EPS        1.0e-15f
+#define SLAB_GUARD     4.76837158203125e-7f   /* 2^-21 */
 #define BSDF_EPS       1.0e-5f     /* roughness / weight threshold ("FLT_EPSILON" in GLSL)  */
 #define MIN_THROUGHPUT 1.0e-3f
 #define MIN_CONTRIB    1.0e-2f
@@ -56,6 +57,13 @@ typedef struct { uint32_t w[CRH_NODE_DWORDS]; } qnode;   /* 64 B, layout in incl
 typedef struct { float f[12]; } qtri;      /* 48 B: v0.xyz,prim | v1.xyz,0 | v2.xyz,0 */
 
 typedef struct { uint64_t nodes, tris, nodes_any, tris_any; } trav_counters;
+/* ORC_FAST (oracle/Makefile, libcrh_oracle_fast.so): the honest CPU-baseline build of bench.py -- -O3 -march=native, contraction
+ * allowed, node / triangle visit counters compiled out, 8x8-pixel work items.  Never used as the parity checker. */
+#ifdef ORC_FAST
+#define ORC_COUNT(x) ((void)0)
+#else
+#define ORC_COUNT(x) (x)
+#endif
 typedef struct orc_instance { float fwd[12], inv[12]; float bmin[3], bmax[3]; uint32_t root, obj; } orc_instance;
 
 typedef struct orc_ctx {
@@ -383,7 +391,7 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
 {
   uint32_t stack[STACK_MAX]; int sp = 0;
   float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
-  float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
+  float gx = crh_abs(ix) * SLAB_GUARD, gy = crh_abs(iy) * SLAB_GUARD, gz = crh_abs(iz) * SLAB_GUARD;
   float best = tmax; int found = 0;
   h->t = tmax; h->u = 0.f; h->v = 0.f; h->prim = -1;
   const v3 wo = o, wd = d;                       /* the world-space ray (restored when an object is left) */
@@ -395,34 +403,43 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
       const orc_instance* in = &c->inst[c->tlas_order[cur & 0x0FFFFFFFu]];
       o = crh_xform_point(in->inv, wo); d = crh_xform_vector(in->inv, wd);
       ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
-      nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
+      gx = crh_abs(ix) * SLAB_GUARD; gy = crh_abs(iy) * SLAB_GUARD; gz = crh_abs(iz) * SLAB_GUARD;
       stack[sp++] = CRH_REF_SENTINEL;
       cur = in->root;
       continue;
     }
     if (cur & QBVH_LEAFBIT) {
       const uint32_t off = cur & 0x0FFFFFFFu;                  /* one triangle per leaf */
-      float t, u, v; if (any_hit) cn->tris_any++; else cn->tris++;
+      float t, u, v; ORC_COUNT(any_hit ? cn->tris_any++ : cn->tris++);
       if (tri_test(&c->qtris[off], o, d, best, &t, &u, &v)) {
         best = t; found = 1; h->t = t; h->u = u; h->v = v; h->prim = (int32_t)crh_f2u(c->qtris[off].f[3]);
         if (any_hit) return 1;
       }
     } else {
-      const qnode* q = &c->nodes[cur]; if (any_hit) cn->nodes_any++; else cn->nodes++;
-      /* decode the per-node grid: face t = fma(q, step * inv, fma(origin, inv, -o*inv)) */
+      const qnode* q = &c->nodes[cur]; ORC_COUNT(any_hit ? cn->nodes_any++ : cn->nodes++);
+      /* decode the per-node grid: face t = fma(q, step * inv, (origin - o) * inv -+ guard), where the
+       * entry / exit planes are moved apart by guard = 2^-21 * |inv| * reach, reach = |origin - o|_1 + 256 * largest step */
       const uint32_t ew = q->w[3];
-      const float ax = crh_quant_step(ew & 0xffu) * ix, ay = crh_quant_step((ew >> 8) & 0xffu) * iy, az = crh_quant_step((ew >> 16) & 0xffu) * iz;
-      const float bx = CRH_FMA(crh_u2f(q->w[0]), ix, nox), by = CRH_FMA(crh_u2f(q->w[1]), iy, noy), bz = CRH_FMA(crh_u2f(q->w[2]), iz, noz);
+      const float stx = crh_quant_step(ew & 0xffu), sty = crh_quant_step((ew >> 8) & 0xffu), stz = crh_quant_step((ew >> 16) & 0xffu);
+      const float ax = stx * ix, ay = sty * iy, az = stz * iz;
+      const float ddx = crh_u2f(q->w[0]) - o.x, ddy = crh_u2f(q->w[1]) - o.y, ddz = crh_u2f(q->w[2]) - o.z;
+      const float bx = ddx * ix, by = ddy * iy, bz = ddz * iz;
+      const float reach = CRH_FMA(crh_max(crh_max(stx, sty), stz), 256.0f, (crh_abs(ddx) + crh_abs(ddy)) + crh_abs(ddz));
+      const float ex = reach * gx, ey = reach * gy, ez = reach * gz;
       uint32_t key[4]; uint32_t rf[4]; int nh = 0;
       const int nch = (int)CRH_NODE_NCHILDREN(ew);
       for (int k = 0; k < nch; ++k) {
         uint32_t r = crh_node_child_ref(q->w, (uint32_t)k);
         const int sh = 8 * k;
-        float a0 = CRH_FMA((float)((q->w[4] >> sh) & 0xffu), ax, bx), a1 = CRH_FMA((float)((q->w[7] >> sh) & 0xffu), ax, bx);
-        float b0 = CRH_FMA((float)((q->w[5] >> sh) & 0xffu), ay, by), b1 = CRH_FMA((float)((q->w[8] >> sh) & 0xffu), ay, by);
-        float c0 = CRH_FMA((float)((q->w[6] >> sh) & 0xffu), az, bz), c1 = CRH_FMA((float)((q->w[9] >> sh) & 0xffu), az, bz);
-        float tmin = crh_max(crh_max(crh_max(crh_min(a0, a1), crh_min(b0, b1)), crh_min(c0, c1)), 0.f);
-        float tmx  = crh_min(crh_min(crh_min(crh_max(a0, a1), crh_max(b0, b1)), crh_max(c0, c1)), best);
+        /* along a negative direction the ray enters through the upper plane */
+        const float qix = (float)(((ix < 0.f ? q->w[7] : q->w[4]) >> sh) & 0xffu), qox = (float)(((ix < 0.f ? q->w[4] : q->w[7]) >> sh) & 0xffu);
+        const float qiy = (float)(((iy < 0.f ? q->w[8] : q->w[5]) >> sh) & 0xffu), qoy = (float)(((iy < 0.f ? q->w[5] : q->w[8]) >> sh) & 0xffu);
+        const float qiz = (float)(((iz < 0.f ? q->w[9] : q->w[6]) >> sh) & 0xffu), qoz = (float)(((iz < 0.f ? q->w[6] : q->w[9]) >> sh) & 0xffu);
+        float a0 = CRH_FMA(qix, ax, bx - ex), a1 = CRH_FMA(qox, ax, bx + ex);
+        float b0 = CRH_FMA(qiy, ay, by - ey), b1 = CRH_FMA(qoy, ay, by + ey);
+        float c0 = CRH_FMA(qiz, az, bz - ez), c1 = CRH_FMA(qoz, az, bz + ez);
+        float tmin = crh_max(crh_max(crh_max(a0, b0), c0), 0.f);
+        float tmx  = crh_min(crh_min(crh_min(a1, b1), c1), best);
         if (tmin <= tmx) {
           /* order key: entry distance with the slot index in the two low mantissa bits -> unique keys,
            * ascending unsigned order == near-to-far, ties by slot */
@@ -444,7 +461,7 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
     if (cur == CRH_REF_SENTINEL) {                /* back to world space */
       o = wo; d = wd;
       ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
-      nox = -(o.x * ix); noy = -(o.y * iy); noz = -(o.z * iz);
+      gx = crh_abs(ix) * SLAB_GUARD; gy = crh_abs(iy) * SLAB_GUARD; gz = crh_abs(iz) * SLAB_GUARD;
       if (sp == 0) break;
       cur = stack[--sp];
     }
@@ -653,6 +670,8 @@ static void apply_texture(const orc_ctx* c, const int32_t* ti, float w0, float u
   float ss = m->Kt[3] != 0.f ? m->Kt[3] : 1.0f, st = m->Le[3] != 0.f ? m->Le[3] : 1.0f;
   float us = CRH_FMA(t2[0], v, CRH_FMA(t1[0], u, t0[0] * w0)) * ss;
   float vs = CRH_FMA(t2[1], v, CRH_FMA(t1[1], u, t0[1] * w0)) * st;
+  if (!(crh_abs(us) < 4194304.0f)) us = 0.f;      /* beyond 2^22: no fraction left, (int) would overflow -> coordinate 0 */
+  if (!(crh_abs(vs) < 4194304.0f)) vs = 0.f;
   float uf = (float)(int)us; if (uf > us) uf -= 1.0f;
   float vf = (float)(int)vs; if (vf > vs) vf -= 1.0f;
   float x = CRH_FMA(us - uf, (float)W, -0.5f), y = CRH_FMA(1.0f - (vs - vf), (float)H, -0.5f);
@@ -930,15 +949,27 @@ static int render_tiles(orc_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t
   struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
   uint64_t rn = 0, ra = 0, nn = 0, tt = 0, na = 0, ta = 0, hh = 0, sm = 0;
   uint32_t total = tiles ? nt : tx * ty;
+  /* work item = one sub-block of a tile (the whole tile in the parity build; 8x8 pixels in the fast build, so that 256 host
+   * threads are not left waiting for the last of ~8 tiles each) -- pixels are independent, so the image does not depend on it */
+#ifdef ORC_FAST
+  const uint32_t sub = 8u;
+#else
+  const uint32_t sub = ts;
+#endif
+  const uint32_t spr = (ts + sub - 1) / sub, nsub = spr * spr;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rn, ra, nn, tt, na, ta, hh, sm)
-  for (uint32_t ti = 0; ti < total; ++ti) {
+  for (uint32_t wi = 0; wi < total * nsub; ++wi) {
+    const uint32_t ti = wi / nsub, sb = wi - ti * nsub;
     uint32_t t = tiles ? tiles[ti] : ti;
     if (t >= tx * ty) continue;
-    uint32_t x0 = (t % tx) * ts, y0 = (t / tx) * ts;
+    uint32_t x0 = (t % tx) * ts + (sb % spr) * sub, y0 = (t / tx) * ts + (sb / spr) * sub;
+    uint32_t x1 = x0 + sub, y1 = y0 + sub;
+    if (x1 > (t % tx) * ts + ts) x1 = (t % tx) * ts + ts;
+    if (y1 > (t / tx) * ts + ts) y1 = (t / tx) * ts + ts;
     crh_stats st; memset(&st, 0, sizeof st); trav_counters cn = {0, 0, 0, 0};
     for (uint32_t s = 0; s < ns; ++s)
-      for (uint32_t y = y0; y < y0 + ts && y < c->par.height; ++y)
-        for (uint32_t x = x0; x < x0 + ts && x < c->par.width; ++x) {
+      for (uint32_t y = y0; y < y1 && y < c->par.height; ++y)
+        for (uint32_t x = x0; x < x1 && x < c->par.width; ++x) {
           v3 r = path_trace(c, x, y, tile_seeds ? tile_seeds[ti] : seeds[s], &st, &cn);
           accumulate_px(c, &c->accum[4 * ((size_t)y * c->par.width + x)], r, c->adaptive ? &c->m2[(size_t)y * c->par.width + x] : NULL);
           st.samples++;

@@ -33,19 +33,58 @@ def lib():
 
 
 class Oracle(Backend):
-    def __init__(self, threads=0):
-        super().__init__(lib(), "orc_")
-        if threads:
-            lib().orc_set_threads(int(threads))
+    _libfn = staticmethod(lambda: lib())
 
-    @staticmethod
-    def set_threads(n):
-        return int(lib().orc_set_threads(int(n)))
+    def __init__(self, threads=0):
+        super().__init__(self._libfn(), "orc_")
+        if threads:
+            self._libfn().orc_set_threads(int(threads))
+
+    @classmethod
+    def set_threads(cls, n):
+        return int(cls._libfn().orc_set_threads(int(n)))
 
     def read_accum(self):
         out = np.empty((self.height, self.width, 4), np.float32)
         self._call("read_accum", out.ctypes.data_as(C.POINTER(C.c_float)))
         return out
+
+
+_FAST = None
+
+
+def fast_lib():
+    """libcrh_oracle_fast.so: bench.py's CPU-baseline build (-O3 -march=native, ORC_FAST).  -march=native ties the file to
+    the CPU it was built on, so it is rebuilt when the sidecar names another CPU model (the GPU box's host is not this one)."""
+    global _FAST
+    if _FAST is None:
+        so, tag = os.path.join(_HERE, "libcrh_oracle_fast.so"), os.path.join(_HERE, "libcrh_oracle_fast.cpu")
+        here = ""
+        try:
+            here = next(l for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except (OSError, StopIteration):
+            pass
+        src = os.path.join(_HERE, "crh_oracle.c")
+        stale = (not os.path.exists(so)) or (not os.path.exists(tag)) or open(tag).read() != here or os.path.getmtime(src) > os.path.getmtime(so)
+        if stale:
+            subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libcrh_oracle_fast.so"])
+        _FAST = C.CDLL(so)
+    return _FAST
+
+
+class FastOracle(Oracle):
+    """Same entry points on the fast build.  A baseline to time, never a checker (contraction changes the low bits)."""
+    _libfn = staticmethod(lambda: fast_lib())
+
+
+def oracle_class(kind="parity"):
+    if kind == "parity":
+        lib()
+        return Oracle
+    if kind == "fast":
+        fast_lib()
+        return FastOracle
+    raise ValueError(kind)
 
 
 # --- unit entry points ------------------------------------------------------------------------

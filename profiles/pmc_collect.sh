@@ -1,0 +1,23 @@
+#!/bin/bash
+# Memory-side counter passes for bench.py's roofline.traffic, one set per config (run through gpurun):
+#   ./profiles/pmc_collect.sh <tag> [configs...]        default configs: C3 C2 C5
+# Per config: one rocprofv3 --kernel-trace --stats pass and three separate --pmc passes (FETCH_SIZE | WRITE_SIZE |
+# TCC_HIT_sum TCC_MISS_sum; --pmc is only ever combined with --kernel-trace), all around the SAME command bench.py's
+# default run uses.  profiles/pmc_fold.py then writes profiles/pmc_traffic.json, keyed by the hash of the kernel sources, so
+# that bench.py can refuse figures that belong to another build.  Outputs under gpurun_out/pmc_<tag>/.
+TAG=${1:-x}; shift
+CFGS=${@:-C3 C2 C5}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for cfg in $CFGS; do
+  ARGS="--config $cfg --steps 2 --warmup 1 --no-cpu --no-interactive"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$cfg/trace -o t -- python3 $REPO/bench.py $ARGS > $OUT/$cfg.trace.log 2>&1
+  tail -1 $OUT/$cfg.trace.log > $OUT/$cfg.bench.json
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    name=$(echo $grp | tr ' ' '_')
+    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$cfg/pmc_$name -o p -- python3 $REPO/bench.py $ARGS > $OUT/$cfg.pmc_$name.log 2>&1
+  done
+done
+python3 $REPO/profiles/pmc_fold.py $OUT $CFGS

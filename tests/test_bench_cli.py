@@ -1,0 +1,108 @@
+"""bench.py's launcher and roofline bookkeeping (CPU), and the N > 1 flow on one GPU (gpu).
+
+`python bench.py --gpus N` outside a launcher must start N rank processes itself (the parent never touches the GPU) and
+rank 0 must report n_gpus == N; counter traffic that belongs to another build of the kernel must not be reported."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra, timeout=600):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        if k not in env_extra:
+            env.pop(k, None)
+    p = subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    p, out = _run(["--gpus", "3"], {"CRH_BENCH_RANK_PROBE": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out == {"probe": True, "n_gpus": 3, "rccl_ranks": 3, "sum": 3, "spawned": True}
+
+
+def test_gpus_flag_must_match_the_launcher():
+    p, out = _run(["--gpus", "3"], {"CRH_BENCH_RANK_PROBE": "1", "WORLD_SIZE": "2", "RANK": "0"})
+    assert p.returncode != 0 and out is None and "WORLD_SIZE=2" in p.stderr
+
+
+def test_parent_of_spawned_ranks_never_imports_torch():
+    code = ("import sys, bench\n"
+            "sys.argv = ['bench.py', '--gpus', '2']\n"
+            "import os; os.environ['CRH_BENCH_RANK_PROBE'] = '1'\n"
+            "try:\n    bench.main()\nexcept SystemExit as e:\n    assert not e.code, e.code\n"
+            "assert 'torch' not in sys.modules and 'cadrays_amd' not in sys.modules, 'parent touched the GPU stack'\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+
+
+def test_strong_and_weak_defaults():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(["--config", "C4"])
+    assert a.scaling == "strong" and a.steps == 1
+    a = bench.parse_args([])
+    assert a.scaling == "weak" and a.config == "C3" and a.gpus == 1
+
+
+def test_stale_counter_traffic_is_refused(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    f = tmp_path / "pmc.json"
+    ent = {"source_hash": "0" * 16, "spp_per_step": 128, "hbm_bytes_per_launch": 1.0e11, "tcc_hit_per_launch": 6.0, "tcc_miss_per_launch": 4.0}
+    f.write_text(json.dumps({"configs": {"C3": ent}}))
+    monkeypatch.setattr(bench, "PMC_FILE", str(f))
+    got, why = bench.pmc_entry("C3", 128, False)
+    assert got is None and why.startswith("stale")
+    r = bench.roofline_report("C3", 128, False, 1.2e11, 16.0, 81 << 20, {})
+    assert r["traffic"] is None and r["frac"] is None and r["bound"].startswith("l2-miss")          # cache-resident, no counters: no HBM fraction
+    r = bench.roofline_report("C5", 32, False, 1.5e11, 28.0, 1 << 30, {})
+    assert r["bound"] == "hbm" and r["traffic"] is None and 0 < r["frac"] < 1
+    # a matching entry is used, and a cache-resident scene can then never report more than what crossed the memory side
+    ent["source_hash"] = bench.kernel_source_hash()
+    f.write_text(json.dumps({"configs": {"C3": ent}}))
+    r = bench.roofline_report("C3", 128, False, 1.4e11, 16.0, 81 << 20, {})
+    assert r["traffic"] == 1.0e11 and r["l2_hit_rate"] == 0.6 and r["traffic_over_alg"] < 1
+    assert abs(r["achieved"] - 1.0e11 / 16e-3 / 1e9) < 1 and r["frac"] <= 1 and r["alg_frac_of_hbm_peak"] > 1
+    assert bench.pmc_entry("C3", 64, False)[0] is None and bench.pmc_entry("C3", 128, True)[0] is None
+
+
+def test_committed_counter_traffic_belongs_to_this_build():
+    """profiles/pmc_traffic.json must be re-collected (profiles/pmc_collect.sh) whenever the traversal kernel or the node format
+    changes: a stale file would silently report another kernel's traffic."""
+    sys.path.insert(0, ROOT)
+    import bench
+    data = json.load(open(bench.PMC_FILE))
+    want = bench.kernel_source_hash()
+    for cfg in ("C3", "C5", "C2"):
+        assert cfg in data["configs"], f"no counter passes for {cfg}"
+        assert data["configs"][cfg]["source_hash"] == want, f"{cfg}: counter passes are from kernel build {data['configs'][cfg]['source_hash']}, sources are {want}"
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_report_two(hip_lib):
+    """the whole N = 2 flow (spawn, tile shards, framebuffer reduce, rank-0 report) on the single GPU of the test box"""
+    p, out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu", "--config", "C1", "--spp", "4"],
+                  {"CRH_BENCH_SHARE_DEVICE": "1", "CRH_BENCH_BACKEND": "gloo"})
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["value"] > 0
+    assert out["config"]["tiles_per_rank"] * 2 >= 256 - 1            # 512 x 512 in 32 x 32 tiles, interleaved
+
+
+@pytest.mark.gpu
+def test_strong_scaling_step_is_the_fixed_job(hip_lib):
+    p1, o1 = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-interactive", "--config", "C1", "--spp", "8", "--scaling", "strong"], {})
+    p2, o2 = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu", "--config", "C1", "--spp", "8", "--scaling", "strong"],
+                  {"CRH_BENCH_SHARE_DEVICE": "1", "CRH_BENCH_BACKEND": "gloo"})
+    assert p1.returncode == 0 and p2.returncode == 0, (p1.stderr + p2.stderr)[-3000:]
+    assert o1["scaling"] == o2["scaling"] == "strong"
+    assert o1["config"]["rays_nearest"] == o2["config"]["rays_nearest"]         # same job, sharded: same rays in total

@@ -147,3 +147,27 @@ def test_alpha_room_gpu_bit_exact(hip_lib, oracle_lib):
     assert not np.array_equal(b, p.read_hdr())              # the alpha channel did change the light transport
     with pytest.raises(Exception):
         v.set_texture(0, np.ones((4, 4, 2), np.float32))
+
+
+# ---- texture coordinates far beyond the float -> int range (uv * scale >= 2^31 indexed texels out of bounds)
+def huge_uv_scene(scale):
+    sc = textured_quad(quadrant_texture(), scale=scale, res=16)
+    uv = sc.uv.copy(); uv[1:3, 0] = 3.0e9; uv[2:, 1] = -7.5e12          # finite, so the boundary accepts them
+    return dataclasses.replace(sc, uv=uv)
+
+
+@pytest.mark.parametrize("scale", [(1.0, 1.0), (1.0e30, 3.0e38), (1.0e-3, 65536.0)])
+def test_huge_texture_coordinates_stay_in_bounds_oracle(oracle_lib, scale):
+    o = oracle_lib.Oracle().load_scene(huge_uv_scene(scale)); o.render(2)
+    img = o.read_hdr()
+    assert np.isfinite(img).all() and img.max() <= 0.9 + 1e-6              # every sample is Kd x a texel of the image
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [(1.0, 1.0), (1.0e30, 3.0e38), (1.0e-3, 65536.0)])
+def test_huge_texture_coordinates_gpu_bit_exact(hip_lib, oracle_lib, scale):
+    from cadrays_amd.view import View
+    sc = huge_uv_scene(scale)
+    v = View(0).load_scene(sc); v.render(2)
+    o = oracle_lib.Oracle().load_scene(sc); o.render(2)
+    assert np.array_equal(v.read_hdr().view(np.uint32), o.read_hdr().view(np.uint32))
