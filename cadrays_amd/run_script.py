@@ -25,8 +25,8 @@ def write_png(path, rgb8):
 
 
 class ScriptHost:
-    def __init__(self, view_factory, outdir=".", size=None, max_vfps=None, lookahead=0):
-        self.view_factory, self.outdir, self.size, self.max_vfps, self.lookahead = view_factory, outdir, size, max_vfps, lookahead
+    def __init__(self, view_factory, outdir=".", size=None, max_vfps=None, lookahead=0, hdr=False):
+        self.view_factory, self.outdir, self.size, self.max_vfps, self.lookahead, self.hdr = view_factory, outdir, size, max_vfps, lookahead, hdr
         self.view = None
         self.frames = 0
         self.seconds = 0.0
@@ -87,6 +87,10 @@ class ScriptHost:
             self.render(n_frames)
             base = os.path.join(self.outdir, f"Output_{name}_{n_frames}")
             self.dump(base + ".png")
+            if self.hdr and hasattr(self.view, "read_hdr"):    # beside the reference's two files: the linear HDR accumulator (tools/compare_runs.py)
+                rgb = np.ascontiguousarray(self.view.read_hdr(), np.float32)
+                with open(base + ".pfm", "wb") as f:
+                    f.write(b"PF\n%d %d\n-1.0\n" % (rgb.shape[1], rgb.shape[0])); f.write(rgb[::-1].astype("<f4").tobytes())
             with open(base + ".txt", "w") as f:
                 f.write("%g" % (self.frames / max(self.seconds, 1e-9)))
         return {"script": name, "frames": self.frames, "seconds": round(self.seconds, 4),
@@ -101,12 +105,13 @@ def main(argv=None):
     ap.add_argument("--outdir", default=".")
     ap.add_argument("--max-vfps", type=int, default=0, help="cap the frames a single vfps renders")
     ap.add_argument("--size", default="", help="WxH render target (default: the script's vinit size, else 512x512)")
+    ap.add_argument("--hdr", action="store_true", help="also write Output_<name>_<n>.pfm (linear HDR) for tools/compare_runs.py")
     a = ap.parse_args(argv)
     import torch  # noqa: F401  (runtime ordering: torch's HIP runtime first)
     from .view import View
     os.makedirs(a.outdir, exist_ok=True)
     size = tuple(int(x) for x in a.size.lower().split("x")) if a.size else None
-    host = ScriptHost(lambda: View(a.device), a.outdir, size, a.max_vfps or None)
+    host = ScriptHost(lambda: View(a.device), a.outdir, size, a.max_vfps or None, hdr=a.hdr)
     print(json.dumps(host.run(a.script, a.frames)))
 
 
