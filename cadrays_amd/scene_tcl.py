@@ -299,8 +299,108 @@ def _finish_mesh(pos, faces, nrm=None, uv=None, smooth=False):
             None if uv is None else uv[flat])
 
 
+def read_mtl(path):
+    """Wavefront .mtl: {name: {"Kd": (r,g,b), "Ks": ..., "Ke": ..., "Ka": ..., "Ns": float, "map_Kd": path, "map_Ks": path}} -- only the
+    statements a file actually holds (the conversion applies a key when it is present, AisMesh.cxx:262-333)"""
+    mats, cur = {}, None
+    if not os.path.isfile(path):
+        return mats
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            k = t[0]
+            if k == "newmtl":
+                cur = mats.setdefault(" ".join(t[1:]), {})
+            elif cur is None:
+                continue
+            elif k in ("Kd", "Ks", "Ke", "Ka") and len(t) >= 2:
+                v = [float(x) for x in t[1:4]]
+                cur[k] = tuple((v * 3)[:3]) if len(v) == 1 else tuple(v[:3])
+            elif k == "Ns" and len(t) >= 2:
+                cur["Ns"] = float(t[1])
+            elif k in ("map_Kd", "map_Ks") and len(t) >= 2:
+                cur[k] = os.path.join(os.path.dirname(path), t[-1].replace("\\", "/"))       # options (-s, -o ...) precede the file name
+    return mats
+
+
+def mtl_to_bsdf(m):
+    """The reference's Phong -> BSDF rule for imported meshes (AisMesh.cxx:246-319): CreateDiffuse(0.8) unless the material says
+    otherwise; Kd / Ks / Le from the diffuse / specular / emissive colours; Ks.w = sqrt(2 / (shininess + 2)); then
+    Graphic3d_BSDF::Normalize().  Returns (bsdf, Kd texture path or None) -- the specular map is picked up by the reference but
+    never bound (AisMesh.cxx:327-330, 340-345), so it is ignored here too."""
+    b = BSDF.CreateDiffuse(0.8)
+    if m is None:
+        return b, None
+    if "Kd" in m:
+        b.Kd = np.array(m["Kd"], np.float32)
+    if "Ks" in m:
+        b.Ks[:3] = np.array(m["Ks"], np.float32)
+    if "Ke" in m:
+        b.Le = np.array(m["Ke"], np.float32)
+    if "Ns" in m:
+        from .materials import phong_to_roughness
+        b.Ks[3] = phong_to_roughness(m["Ns"])
+    b.Normalize()
+    tex = m.get("map_Kd")
+    return b, (tex if tex and os.path.isfile(tex) else None)
+
+
+def read_obj_meshes(path, smooth=False, group_by_material=False):
+    """Wavefront OBJ as the list of meshes assimp hands the reference (MeshImporter.cxx:73-91): one mesh per (object / group,
+    material) run of faces -- per material only with group_by_material (rtmeshread -group, Import_GroupByMaterial).  v / vn / vt / f
+    (polygons fan-triangulated, negative indices, v//vn and v/vt/vn forms), o / g, mtllib / usemtl.
+    Returns ([{"name", "material", "pos", "nrm", "faces", "uv"}], {material name: .mtl record})."""
+    v, vn, vt = [], [], []
+    parts, order = {}, []                       # key -> {"corners": {}, "faces": []}
+    group, material, mtl = "", None, {}
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "v":
+                v.append([float(x) for x in t[1:4]])
+            elif t[0] == "vn":
+                vn.append([float(x) for x in t[1:4]])
+            elif t[0] == "vt":
+                vt.append([float(x) for x in (t[1:3] + ["0"])[:2]])
+            elif t[0] in ("o", "g"):
+                group = " ".join(t[1:])
+            elif t[0] == "mtllib":
+                mtl.update(read_mtl(os.path.join(os.path.dirname(path), " ".join(t[1:]))))
+            elif t[0] == "usemtl":
+                material = " ".join(t[1:])
+            elif t[0] == "f":
+                key = (material,) if group_by_material else (group, material)
+                if key not in parts:
+                    parts[key] = {"corners": {}, "faces": [], "name": "" if group_by_material else group, "material": material}
+                    order.append(key)
+                pt = parts[key]
+                idx = []
+                for c in t[1:]:
+                    ps = (c.split("/") + ["", ""])[:3]
+                    ck = tuple((int(x) - 1 if int(x) > 0 else n + int(x)) if x else -1 for x, n in zip(ps, (len(v), len(vt), len(vn))))
+                    idx.append(pt["corners"].setdefault(ck, len(pt["corners"])))
+                for k in range(1, len(idx) - 1):
+                    pt["faces"].append((idx[0], idx[k], idx[k + 1]))
+    meshes = []
+    for key in order:
+        pt = parts[key]
+        keys = sorted(pt["corners"], key=pt["corners"].get)
+        pos = np.array([v[k[0]] for k in keys], np.float32).reshape(-1, 3)
+        has_n = bool(keys) and all(k[2] >= 0 for k in keys)
+        has_t = bool(keys) and all(k[1] >= 0 for k in keys)
+        nrm = np.array([vn[k[2]] for k in keys], np.float32) if has_n else None
+        uv = np.array([vt[k[1]] for k in keys], np.float32) if has_t else None
+        p, n, fc, u = _finish_mesh(pos, pt["faces"], nrm, uv, smooth)
+        meshes.append({"name": pt["name"], "material": pt["material"], "pos": p, "nrm": n, "faces": fc, "uv": u})
+    return meshes, mtl
+
+
 def read_obj(path, smooth=False):
-    """Wavefront OBJ: v / vn / vt / f (polygons fan-triangulated, negative indices, v//vn and v/vt/vn forms); one mesh"""
+    """Wavefront OBJ as ONE mesh (materials and groups ignored): pos, nrm, faces, uv"""
     v, vn, vt, corners, faces = [], [], [], {}, []
     with open(path, "r", errors="replace") as f:
         for line in f:
@@ -328,6 +428,25 @@ def read_obj(path, smooth=False):
     nrm = np.array([vn[k[2]] for k in keys], np.float32) if has_n else None
     uv = np.array([vt[k[1]] for k in keys], np.float32) if has_t else None
     return _finish_mesh(pos, faces, nrm, uv, smooth)
+
+
+def fix_infacing_normals(pos, nrm, faces):
+    """rtmeshread -fixnorms (Import_FixInfaceNormals = assimp's FixInfacingNormals step [assimp-ext]): when the bounding box of
+    the vertices pushed along their normals is SMALLER than the bounding box of the vertices, the normals point inwards: flip
+    them and the winding.  Left alone when the axes disagree (a flat mesh has no inside)."""
+    pos = np.asarray(pos, np.float64); nrm = np.asarray(nrm, np.float64)
+    if not len(pos):
+        return pos, nrm, faces, False
+    d0 = pos.max(0) - pos.min(0)
+    q = pos + nrm
+    d1 = q.max(0) - q.min(0)
+    if (d1[0] > d0[0]) != (d1[1] > d0[1]) or (d1[0] > d0[0]) != (d1[2] > d0[2]):
+        return pos, nrm, faces, False
+    if d0[0] < 0.05 * np.sqrt(d0[1] * d0[2]) or d0[1] < 0.05 * np.sqrt(d0[2] * d0[0]) or d0[2] < 0.05 * np.sqrt(d0[0] * d0[1]):
+        return pos, nrm, faces, False                                       # a (nearly) planar surface has no inside
+    if abs(d0[0] * d0[1] * d0[2]) < abs(d1[0] * d1[1] * d1[2]):
+        return pos, nrm, faces, False
+    return pos, -nrm, np.ascontiguousarray(np.asarray(faces)[:, ::-1]), True
 
 
 def read_stl(path, smooth=False):
@@ -418,6 +537,7 @@ class SceneBuilder:
     def __init__(self, root=".", sphere_res=(48, 24)):
         self.root, self.sphere_res = root, sphere_res
         self.objs, self.light_colors = {}, {}
+        self.groups = {}                         # parent node of a multi-mesh import -> its sub-nodes (commands on the parent reach them all)
         # a fresh V3d viewer owns a directional headlight (0) and an ambient light (1) [OCCT-ext]; the reference's start-up
         # script edits them in place (AppGui.cxx:956-957: `vlight del 1`, `vlight change 0 head 0 direction -0.25 -1 -1 ...`)
         self.lights = [dict(kind="directional", vec=(0.0, 0.0, -1.0), sm=0.0, int=1.0, head=1, color=(1.0, 1.0, 1.0)),
@@ -429,26 +549,82 @@ class SceneBuilder:
         self.commands = {k[4:]: getattr(self, k) for k in dir(self) if k.startswith("cmd_")}
 
     # ---- geometry sources
+    _RTMESHREAD_USAGE = ("usage: rtmeshread <file name> <node name> [-rename|-rn] [-group|-gr] [-pretrans|-pt] [-gensmooth|-gs] "
+                         "[-fixnorms|-fn] [-genuv|-uv] [-up X|Y|Z|-X|-Y|-Z]")
+
     def cmd_rtmeshread(self, a):
+        """rtmeshread (ImportExportPlugin.cxx:132-354): options parsed like the plugin does; the imported meshes get the
+        reference's Phong -> BSDF conversion (AisMesh.cxx:228-346) and their diffuse map."""
+        if len(a) < 2:
+            raise TclError(self._RTMESHREAD_USAGE)
         path, name = a[0], a[1]
-        flags = [x.lower() for x in a[2:]]
-        smooth = "-gensmooth" in flags or "-gs" in flags       # options as the plugin parses them (ImportExportPlugin.cxx:195-215)
-        up = a[2:][flags.index("-up") + 1].upper().lstrip("+") if "-up" in flags and flags.index("-up") + 1 < len(flags) else "Z"
-        if up not in _UP_FLIP:
-            raise TclError(f"rtmeshread: -up {up}: expected X|Y|Z|-X|-Y|-Z")
+        opt = dict(group=False, rename=False, pretrans=False, smooth=False, fixnorms=False, genuv=False)
+        alias = {"-group": "group", "-gr": "group", "-rename": "rename", "-rn": "rename", "-pretrans": "pretrans", "-pt": "pretrans",
+                 "-gensmooth": "smooth", "-gs": "smooth", "-fixnorms": "fixnorms", "-fn": "fixnorms", "-genuv": "genuv", "-uv": "genuv"}
+        up, i = "Z", 2
+        while i < len(a):
+            k = a[i].lower()
+            if k in alias:
+                opt[alias[k]] = True
+            elif k == "-up":
+                i += 1
+                if i >= len(a):
+                    raise TclError(self._RTMESHREAD_USAGE)
+                up = a[i].upper().lstrip("+")
+                if up not in _UP_FLIP:
+                    raise TclError(f"rtmeshread: -up {a[i]}: expected X|Y|Z|-X|-Y|-Z")
+            else:
+                raise TclError(self._RTMESHREAD_USAGE)              # the plugin rejects unknown words (ImportExportPlugin.cxx:242-245)
+            i += 1
+        if not name or not name[0].isalpha():
+            raise TclError(self._RTMESHREAD_USAGE)
+        if name in self.objs or name in self.groups:
+            if not opt["rename"]:
+                raise TclError(f"Error: Mesh with the name '{name}' already exists")
+            for k in range(1, 1024):
+                if f"{a[1]}_{k}" not in self.objs and f"{a[1]}_{k}" not in self.groups:
+                    name = f"{a[1]}_{k}"
+                    break
+            else:
+                raise TclError(f"Error: Mesh with the name '{name}' already exists")
         ext = os.path.splitext(path)[1].lower()
+        mtl = {}
         if ext == ".obj":
-            pos, nrm, faces, uv = read_obj(path, smooth)
+            meshes, mtl = read_obj_meshes(path, opt["smooth"], opt["group"])
         elif ext == ".stl":
-            pos, nrm, faces, uv = read_stl(path, smooth)
+            pos, nrm, faces, uv = read_stl(path, opt["smooth"])
+            meshes = [{"name": "", "material": None, "pos": pos, "nrm": nrm, "faces": faces, "uv": uv}]
         elif ext == ".ply":
             pos, nrm, faces, uv = read_ply(path)
+            meshes = [{"name": "", "material": None, "pos": pos, "nrm": nrm, "faces": faces, "uv": uv}]
         else:
             raise TclError(f"rtmeshread: {ext or path} files are not supported (ply, obj, stl are)")
-        pos, nrm = _UP_FLIP[up](np.asarray(pos, np.float64)), _UP_FLIP[up](np.asarray(nrm, np.float64))
-        self.objs[name] = _Obj(pos, nrm, faces)
-        self.objs[name].uv = uv
-        self.objs[name].displayed = True                     # rtmeshread displays what it loads (ImportExportPlugin.cxx:132-354)
+        if not meshes:
+            raise TclError(f"Error: ASSIMP failed to import mesh from file: {path}")
+        # -pretrans bakes the file's node transforms and -genuv generates coordinates for non-UV mappings a material asks for:
+        # ply / obj / stl have neither a node hierarchy nor such mappings, so both leave these meshes as they are
+        made = []
+        for k, m in enumerate(meshes):
+            pos, nrm, faces = np.asarray(m["pos"], np.float64), np.asarray(m["nrm"], np.float64), m["faces"]
+            if opt["fixnorms"]:
+                pos, nrm, faces, _ = fix_infacing_normals(pos, nrm, faces)
+            o = _Obj(_UP_FLIP[up](pos), _UP_FLIP[up](nrm), faces)
+            o.uv = m["uv"]
+            o.bsdf, tex = mtl_to_bsdf(mtl.get(m["material"]) if m["material"] is not None else None)
+            if tex is not None and o.uv is not None:              # SetTextureMap + SetTextureMapOn (AisMesh.cxx:340-345)
+                o.texture, o.tex_on = tex, True
+            o.displayed = True                                    # rtmeshread displays what it loads
+            if len(meshes) == 1:
+                sub = name                                        # a single mesh takes the node name itself (ImportExportPlugin.cxx:341-344)
+            else:                                                 # several: a parent node with one sub-node per mesh (:320-339); an
+                sub = m["name"] if m["name"] else name + "_"      # unnamed mesh takes the parent's name + "_", made unique
+                base, c = sub, 1
+                while sub in self.objs or sub in self.groups or sub == name or sub in made:
+                    sub = f"{base}{c}" if base.endswith("_") else f"{base}_{c}"; c += 1
+            self.objs[sub] = o
+            made.append(sub)
+        if len(meshes) > 1:
+            self.groups[name] = made
 
     def cmd_restore(self, a):
         self.unsupported.append("restore " + " ".join(a))    # B-Rep: needs OCCT's mesher
@@ -498,7 +674,21 @@ class SceneBuilder:
 
     # ---- display state
     def _names(self, a):
-        return [x for x in a if not x.startswith("-") and x in self.objs]
+        out = []
+        for x in a:
+            if x.startswith("-"):
+                continue
+            out += self.groups.get(x, [x] if x in self.objs else [])
+        return out
+
+    def _fan_out(self, fn, a, pos=0):
+        """a command addressed to the parent node of a multi-mesh import applies to every sub-node; returns True when it did"""
+        words = [i for i, x in enumerate(a) if not x.startswith("-") or _NUM.fullmatch(x)]
+        if len(words) > pos and a[words[pos]] in self.groups and a[words[pos]] not in self.objs:
+            for m in self.groups[a[words[pos]]]:
+                fn(a[:words[pos]] + [m] + a[words[pos] + 1:])
+            return True
+        return False
 
     def cmd_vdisplay(self, a):
         for n in self._names(a):
@@ -513,10 +703,14 @@ class SceneBuilder:
             o.displayed = False
 
     def cmd_vsetmaterial(self, a):
+        if self._fan_out(self.cmd_vsetmaterial, a):
+            return
         args = [x for x in a if not x.startswith("-")]
         self.objs[args[0]].bsdf = _stock(args[1])
 
     def cmd_vlocation(self, a):
+        if self._fan_out(self.cmd_vlocation, a):
+            return
         args = [x for x in a if x != "-noupdate"]
         o, i = self.objs[args[0]], 1
         while i < len(args):
@@ -537,6 +731,8 @@ class SceneBuilder:
                 raise TclError(f"vlocation: unknown option {args[i]}")
 
     def cmd_vbsdf(self, a):
+        if self._fan_out(self.cmd_vbsdf, a):
+            return
         args = [x for x in a if x != "-noupdate"]
         b, i = self.objs[args[0]].bsdf, 1
 
@@ -660,6 +856,8 @@ class SceneBuilder:
         """rttexture <node> [<image file>] [-scale S T] [-on|-off]   (ImportExportPlugin.cxx:608-752)"""
         if not 2 <= len(a) <= 5:
             raise TclError("usage: rttexture <node> [file] [-scale S T] [-on|-off]")
+        if self._fan_out(self.cmd_rttexture, a):
+            return
         if a[0] not in self.objs:
             raise TclError(f"rttexture: no object {a[0]}")
         o, i = self.objs[a[0]], 1
@@ -690,6 +888,8 @@ class SceneBuilder:
             self.view_size = (int(kv["w"]), int(kv["h"]))
 
     def cmd_vsetlocation(self, a):                            # vsetlocation [-noupdate] name x y z  (preview.tcl:22)
+        if self._fan_out(self.cmd_vsetlocation, a):
+            return
         args = [x for x in a if x != "-noupdate"]
         self.objs[args[0]].t = np.array([float(x) for x in args[1:4]])
 

@@ -291,3 +291,105 @@ def test_rtmeshread_obj_stl_and_up_axis(tmp_path):
     assert np.allclose(b.objs["C"].nrm, [1, 0, 0])                                                      # (x, y, z) -> (z, y, -x)
     with pytest.raises(TclError):
         t.eval(f"rtmeshread {tmp_path}/q.fbx D")
+
+
+# ---- rtmeshread: materials of the imported mesh (AisMesh.cxx:228-346) and the plugin's options (ImportExportPlugin.cxx:132-354)
+def _write_obj_with_mtl(d):
+    """two quads and a box side with three materials, one with a diffuse map"""
+    from PIL import Image
+    tex = (np.arange(16 * 16 * 3).reshape(16, 16, 3) % 251).astype(np.uint8)
+    Image.fromarray(tex, "RGB").save(d / "checker.png")
+    (d / "room.mtl").write_text(
+        "# materials\nnewmtl red_paint\nKa 0.1 0.1 0.1\nKd 0.9 0.2 0.1\nKs 0.5 0.5 0.5\nNs 98\n\n"
+        "newmtl lamp\nKd 0.0 0.0 0.0\nKe 4 3 2\n\n"
+        "newmtl tiles\nKd 1 1 1\nmap_Kd -s 1 1 1 checker.png\nmap_Ks spec.png\n")
+    (d / "room.obj").write_text(
+        "mtllib room.mtl\n"
+        "v 0 0 0\nv 2 0 0\nv 2 2 0\nv 0 2 0\nv 0 0 1\nv 2 0 1\nv 2 2 1\nv 0 2 1\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "o floor\nusemtl tiles\nf 1/1 2/2 3/3 4/4\n"
+        "o ceiling\nusemtl lamp\nf 8/4 7/3 6/2 5/1\n"
+        "o wall\nusemtl red_paint\nf 1/1 5/4 6/3 2/2\nusemtl tiles\nf 2/1 6/4 7/3 3/2\n"
+        "o back\nf 4/1 3/2 7/3 8/4\n")
+    return d / "room.obj"
+
+
+def test_rtmeshread_imports_mtl_materials_like_aismesh(tmp_path):
+    from cadrays_amd.materials import BSDF
+    from cadrays_amd.scene_tcl import MiniTcl, SceneBuilder, mtl_to_bsdf, read_mtl, read_obj_meshes
+    obj = _write_obj_with_mtl(tmp_path)
+    mtl = read_mtl(str(tmp_path / "room.mtl"))
+    assert set(mtl) == {"red_paint", "lamp", "tiles"} and mtl["tiles"]["map_Kd"].endswith("checker.png") and mtl["red_paint"]["Ns"] == 98
+    # the conversion rule: Kd / Ks / Le copied, Ks.w = sqrt(2 / (Ns + 2)), then Normalize()
+    b, tex = mtl_to_bsdf(mtl["red_paint"])
+    s = np.float32(1.0) / np.float32(1.4)                                   # max channel of Kd + Ks = 0.9 + 0.5
+    np.testing.assert_allclose(b.Kd[:3], np.float32([0.9, 0.2, 0.1]) * s, rtol=1e-6)
+    np.testing.assert_allclose(b.Ks[:3], np.float32([0.5, 0.5, 0.5]) * s, rtol=1e-6)
+    assert abs(b.Ks[3] - np.sqrt(2.0 / 100.0)) < 1e-7 and tex is None
+    assert float(np.max(b.Kd[:3] + b.Ks[:3] + b.Kt[:3])) <= 1.0 + 1e-6
+    b, tex = mtl_to_bsdf(mtl["lamp"])
+    assert np.allclose(b.Le[:3], [4, 3, 2]) and np.allclose(b.Kd[:3], 0)
+    b, tex = mtl_to_bsdf(mtl["tiles"])
+    assert tex == str(tmp_path / "checker.png") and np.allclose(b.Kd[:3], 1)
+    d, _ = mtl_to_bsdf(None)
+    assert np.allclose(d.Kd[:3], BSDF.CreateDiffuse(0.8).Kd[:3])             # a mesh without a material: CreateDiffuse(0.8), AisMesh.cxx:246
+    # one mesh per (object, material) run; -group merges by material
+    meshes, _ = read_obj_meshes(str(obj))
+    assert [(m["name"], m["material"]) for m in meshes] == [("floor", "tiles"), ("ceiling", "lamp"), ("wall", "red_paint"), ("wall", "tiles"), ("back", "tiles")]
+    grouped, _ = read_obj_meshes(str(obj), group_by_material=True)
+    assert [m["material"] for m in grouped] == ["tiles", "lamp", "red_paint"] and len(grouped[0]["faces"]) == 6
+
+    b = SceneBuilder(str(tmp_path)); t = MiniTcl(b.commands, {})
+    t.eval(f"rtmeshread {obj} room")
+    assert b.groups["room"] == ["floor", "ceiling", "wall", "wall_1", "back"] and "room" not in b.objs
+    assert b.objs["floor"].texture == str(tmp_path / "checker.png") and b.objs["floor"].tex_on and b.objs["ceiling"].texture is None
+    assert np.allclose(b.objs["ceiling"].bsdf.Le[:3], [4, 3, 2]) and abs(b.objs["wall"].bsdf.Ks[3] - np.sqrt(0.02)) < 1e-7
+    # commands addressed to the parent reach every sub-node
+    t.eval("vlocation room -location 1 2 3\nverase room\nvdisplay room\nvbsdf wall_1 -kd 0.25")
+    assert all(np.allclose(b.objs[n].t, [1, 2, 3]) and b.objs[n].displayed for n in b.groups["room"])
+    sc = b.snapshot(32, 32)
+    assert len(sc.materials) == 5 and len(sc.textures) == 1 and sc.uv is not None
+    assert [m.texture for m in sc.materials] == [0, -1, -1, 0, 0] or [getattr(m, "texture", None) for m in sc.materials].count(0) == 3
+    # the plugin's error behaviour
+    with pytest.raises(TclError, match="already exists"):
+        t.eval(f"rtmeshread {obj} room")
+    t.eval(f"rtmeshread {obj} room -rename -group")
+    assert len(b.groups["room_1"]) == 3
+    with pytest.raises(TclError, match="usage"):
+        t.eval(f"rtmeshread {obj} other -nosuchflag")
+    with pytest.raises(TclError, match="usage"):
+        t.eval(f"rtmeshread {obj} 9lives")
+    t.eval(f"rtmeshread {obj} third -pretrans -genuv -pt -uv")             # accepted: no node hierarchy / no non-UV mapping in an OBJ
+
+
+def test_rtmeshread_fixnorms_flips_inward_normals(tmp_path):
+    from cadrays_amd.scene_tcl import MiniTcl, SceneBuilder, fix_infacing_normals
+    m = scenes._Mesh(); m.box((1, 2, 3), 0, (0, 0, 0))
+    pos, nrm, tri = m.arrays()
+    p, n, f, flipped = fix_infacing_normals(pos, nrm, tri[:, :3])
+    assert not flipped and np.array_equal(n, nrm)
+    p, n, f, flipped = fix_infacing_normals(pos, -nrm, tri[:, :3])
+    assert flipped and np.allclose(n, nrm) and np.array_equal(f, tri[:, :3][:, ::-1])
+    quad = np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])           # flat: no inside, left alone
+    p, n, f, flipped = fix_infacing_normals(quad, np.tile(np.float32([0, 0, -1]), (4, 1)), np.int32([[0, 1, 2], [0, 2, 3]]))
+    assert not flipped
+    lines = ["v %g %g %g" % tuple(x) for x in pos] + ["vn %g %g %g" % tuple(-x) for x in nrm]
+    lines += ["f %d//%d %d//%d %d//%d" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1) for a, b, c in tri[:, :3]]
+    (tmp_path / "inward.obj").write_text("\n".join(lines) + "\n")
+    b = SceneBuilder(str(tmp_path)); t = MiniTcl(b.commands, {})
+    t.eval(f"rtmeshread {tmp_path}/inward.obj A\nrtmeshread {tmp_path}/inward.obj B -fixnorms")
+    assert np.allclose(b.objs["A"].nrm, -nrm) and np.allclose(b.objs["B"].nrm, nrm)
+
+
+@pytest.mark.gpu
+def test_obj_with_mtl_renders_bit_exact_on_gpu(hip_lib, oracle_lib, tmp_path):
+    from cadrays_amd.scene_tcl import MiniTcl, SceneBuilder
+    from cadrays_amd.view import View
+    obj = _write_obj_with_mtl(tmp_path)
+    b = SceneBuilder(str(tmp_path)); t = MiniTcl(b.commands, {})
+    t.eval(f"rtmeshread {obj} room\nvcamera -persp\nvviewparams -eye 1 -3 0.5 -at 1 1 0.5 -up 0 0 1\nvrenderparams -ray -gi -rayDepth 5\nvlight del 0\nvlight del 1")
+    sc = b.snapshot(64, 48)
+    v = View(0).load_scene(sc); v.render(4)
+    o = oracle_lib.Oracle().load_scene(sc); o.render(4)
+    a, r = v.read_hdr(), o.read_hdr()
+    assert np.array_equal(a.view(np.uint32), r.view(np.uint32)) and a.max() > 0.1          # lit by the emissive ceiling of the .mtl
