@@ -170,6 +170,10 @@ void fill_scene(const crh_ctx* c, DScene& S)
   std::memset(&S, 0, sizeof S);
   S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = c->d_env;
   S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * c->inst.size() : nullptr; S.root = c->root; S.two_level = c->two_level ? 1 : 0;
+  {
+    const float* lo = c->bvh.bbmin; const float* hi = c->bvh.bbmax;      // bounds of the tree the walk starts in (the world box of a two-level scene)
+    S.guard_box = make_float4((lo[0] + hi[0]) * 0.5f, (lo[1] + hi[1]) * 0.5f, (lo[2] + hi[2]) * 0.5f, (((hi[0] - lo[0]) + (hi[1] - lo[1])) + (hi[2] - lo[2])) * 0.5f);
+  }
   S.uvs = c->d_uvs; S.texels = c->d_texels; S.tex_desc = c->d_tex_desc; S.n_tex = c->d_tex_desc ? (uint32_t)c->textures.size() : 0u;
   S.n_mats = (uint32_t)c->mats.size(); S.n_lights = (uint32_t)c->lights.size(); S.env_w = c->envW; S.env_h = c->envH;
   for (int k = 0; k < 3; ++k) S.bg[k] = c->par.background[k];
@@ -225,6 +229,9 @@ int build_tlas(crh_ctx* c)
     const uint32_t pure_translation = (iv[0] == 1.f && iv[5] == 1.f && iv[10] == 1.f && iv[1] == 0.f && iv[2] == 0.f && iv[4] == 0.f &&
                                        iv[6] == 0.f && iv[8] == 0.f && iv[9] == 0.f) ? 1u : 0u;
     std::memcpy(&table[32 * (size_t)i + 26], &pure_translation, 4);
+    // the object's own box {centre, L1 half-extent}: the guard band of the slab test inside the object
+    for (int a = 0; a < 3; ++a) table[32 * (size_t)i + 28 + a] = (in.bmin[a] + in.bmax[a]) * 0.5f;
+    table[32 * (size_t)i + 31] = (((in.bmax[0] - in.bmin[0]) + (in.bmax[1] - in.bmin[1])) + (in.bmax[2] - in.bmin[2])) * 0.5f;
   }
   std::vector<uint32_t> order;
   c->root = build_tree(boxes.data(), n, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, 1);

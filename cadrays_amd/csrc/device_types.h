@@ -38,8 +38,9 @@ struct DScene {
   const float4* texels;   // all diffuse textures back to back
   const uint4*  tex_desc; // per slot: {first texel, width, height, 0}; width 0 = empty slot
   uint32_t n_tex;
-  const float4* inst;     // two-level: 8 x float4 per instance: inverse rows (3), forward rows (3), {root, object, -, -}, pad
+  const float4* inst;     // two-level: 8 x float4 per instance: inverse rows (3), forward rows (3), {root, object, translation-only, -}, {object box centre.xyz, L1 half-extent}
   const float4* inst_leaf;  // the same records in top-level leaf order (a top-level leaf reference is a position in this list)
+  float4 guard_box;       // {centre.xyz, L1 half-extent} of the tree traversal starts in: scales the slab test's guard band (kSlabGuard)
   uint32_t root;          // node index traversal starts at (0 for a single-level scene, the top-level root otherwise)
   int two_level;
   uint32_t n_mats, n_lights, env_w, env_h;

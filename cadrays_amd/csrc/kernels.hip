@@ -123,7 +123,7 @@ __device__ __forceinline__ float inv_dir(float d)
 // space (direction not renormalised, so t keeps its meaning), a sentinel on the stack restores the world ray.
 template <bool ANY, bool COUNT, bool TWO, class Load, class Store>
 __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                             const float4* __restrict__ inst, uint32_t root,
+                                             const float4* __restrict__ inst, uint32_t root, float4 gbox,
                                              uint32_t* __restrict__ cursor, uint32_t n, uint32_t* lds,
                                              Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris)
 {
@@ -137,7 +137,14 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   v3 o = crh_mk3(0.f, 0.f, 0.f), d = o;
   v3 wo = o, wd = o;     // world-space ray while inside an object (TWO only) ...
   float wix = 0.f, wiy = 0.f, wiz = 0.f;   // ... and its reciprocal direction (restored, not recomputed, on leaving)
-  float ix = 0.f, iy = 0.f, iz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, best = 0.f;   // g = |1/d| * 2^-21: the slab test's guard band per unit of distance
+  float ix = 0.f, iy = 0.f, iz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, best = 0.f;   // g: the slab test's guard band along each axis, in t
+  // guard band: entry / exit planes move apart by g = 2^-21 * |1/d| * R, R = |o - c|_1 + 3 h >= |origin - o| +
+  // 256 * step of every node of the tree whose box has centre c and L1 half-extent h -- twice the worst rounding error of the
+  // plane evaluation below, so a child box the exact ray touches is never culled
+  auto set_guard = [&](float4 gb) {
+    const float R = CRH_FMA(gb.w, 3.0f, (crh_abs(o.x - gb.x) + crh_abs(o.y - gb.y)) + crh_abs(o.z - gb.z)) * kSlabGuard;
+    gx = crh_abs(ix) * R; gy = crh_abs(iy) * R; gz = crh_abs(iz) * R;
+  };
   float4 hit = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   bool found = false;
   // wave-uniform pool state.  Chunk per atomic: kPoolChunk for long queues (one cursor word sustains ~88 atomics/us); short
@@ -168,7 +175,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           float tmax;
           load(pool_next + rank, o, d, tmax, tag);
           ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
-          gx = crh_abs(ix) * kSlabGuard; gy = crh_abs(iy) * kSlabGuard; gz = crh_abs(iz) * kSlabGuard;
+          set_guard(gbox);
           if (TWO) { wo = o; wd = d; wix = ix; wiy = iy; wiz = iz; }
           best = tmax; found = false; sp = 0; cur = root; have = true;
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
@@ -189,7 +196,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       read_top();
       if (TWO && cur == CRH_REF_SENTINEL) {          // leaving an object: back to the world-space ray
         o = wo; d = wd; ix = wix; iy = wiy; iz = wiz;                                            // the saved reciprocals are the bits inv_dir(wd) would recompute
-        gx = crh_abs(ix) * kSlabGuard; gy = crh_abs(iy) * kSlabGuard; gz = crh_abs(iz) * kSlabGuard;
+        set_guard(gbox);
         if (sp == 0) cur = kDone; else read_top();
       }
     };
@@ -198,18 +205,13 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;
       const float4 n0 = np[0], n1 = np[1], n2 = np[2];
       if (COUNT) ++n_nodes;
-      // per-node grid: face t = fma(q, step * inv_d, (origin - o) * inv_d -+ guard) -- the difference is taken BEFORE the
-      // multiplication (fma(origin, inv_d, -o * inv_d) cancels catastrophically when |o * inv_d| >> t: a ray grazing a box
-      // corner was culled by 2e-5 of t), and the entry / exit planes move apart by guard = 2^-21 * |inv_d| * L with
-      // L = |D|_1 + 256 * largest step >= the distance to anything in the node: twice the worst rounding error of this
-      // evaluation, so a child box the exact ray touches is never culled
+      // per-node grid: face t = fma(q, step * inv_d, fma(origin - o, inv_d, -+ guard)).  The difference is taken BEFORE the
+      // multiplication: fma(origin, inv_d, -o * inv_d) cancels catastrophically when |o * inv_d| >> t (a ray grazing a box
+      // corner was culled by 2e-5 of t); the guard is the per-ray constant above.
       const uint32_t ew = __float_as_uint(n0.w);
-      const float stx = __uint_as_float((ew & 0xffu) << 23), sty = __uint_as_float(((ew >> 8) & 0xffu) << 23), stz = __uint_as_float(((ew >> 16) & 0xffu) << 23);
-      const float ax = stx * ix, ay = sty * iy, az = stz * iz;
+      const float ax = __uint_as_float((ew & 0xffu) << 23) * ix, ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * iy,
+                  az = __uint_as_float(((ew >> 16) & 0xffu) << 23) * iz;
       const float ddx = n0.x - o.x, ddy = n0.y - o.y, ddz = n0.z - o.z;
-      const float bx = ddx * ix, by = ddy * iy, bz = ddz * iz;
-      const float reach = CRH_FMA(fmaxf(fmaxf(stx, sty), stz), 256.0f, (crh_abs(ddx) + crh_abs(ddy)) + crh_abs(ddz));
-      const float ex = reach * gx, ey = reach * gy, ez = reach * gz;
       // child references are implicit: slots < ni are the consecutive inner nodes from child_base, the others the leaves
       // with consecutive references from leaf_base (crh_bvh_format.h): ref(slot) = (slot < ni ? child_base : leaf_base - ni) + slot
       const uint32_t ni = (ew >> 24) & 7u, nch = ew >> 28;
@@ -219,7 +221,10 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const bool sx = ix < 0.f, sy = iy < 0.f, sz = iz < 0.f;
       const uint32_t lx = __float_as_uint(sx ? n1.w : n1.x), ly = __float_as_uint(sy ? n2.x : n1.y), lz = __float_as_uint(sz ? n2.y : n1.z);
       const uint32_t hx = __float_as_uint(sx ? n1.x : n1.w), hy = __float_as_uint(sy ? n1.y : n2.x), hz = __float_as_uint(sz ? n1.z : n2.y);
-      const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx - ex, bx + ex}, by2 = {by - ey, by + ey}, bz2 = {bz - ez, bz + ez};
+      const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+      const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ddx, ddx}, (f32x2){ix, ix}, (f32x2){-gx, gx});      // {entry, exit} offsets
+      const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (f32x2){-gy, gy});
+      const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ddz, ddz}, (f32x2){iz, iz}, (f32x2){-gz, gz});
       uint32_t key[4];
 #define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))      /* v_cvt_f32_ubyteK */
 #define CRH_CHILD(K)                                                                                         \
@@ -299,10 +304,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       o = crh_xform_point(m, wo); d = crh_xform_vector(m, wd);
       // an instance that is only translated (inverse 3x3 == identity exactly, flagged by the host) leaves |d| and its signs
       // unchanged, so the reciprocals are the world ray's: three IEEE divisions saved on the common "placed, not rotated" part
-      if (__float_as_uint(meta.z) == 0u) {
-        ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
-        gx = crh_abs(ix) * kSlabGuard; gy = crh_abs(iy) * kSlabGuard; gz = crh_abs(iz) * kSlabGuard;
-      }
+      if (__float_as_uint(meta.z) == 0u) { ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z); }
+      set_guard(ip[7]);                                          // the object's own box: {centre, L1 half-extent}
       const uint32_t mark = CRH_REF_SENTINEL;
       if (sp < kLdsStack) lds[sp * kBlock] = mark; else ovf[sp - kLdsStack] = mark;
       ++sp;
@@ -331,7 +334,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, int cur, co
   }
   uint32_t nn = 0, nt = 0;
   const float4* __restrict__ ray_o = P.ray_o[cur]; const float4* __restrict__ ray_d = P.ray_d[cur];
-  trace_engine<false, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, cursors + 0, n, &stk[threadIdx.x],
+  trace_engine<false, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursors + 0, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = ld_stream(&ray_o[tag]), d4 = ld_stream(&ray_d[tag]);      // .w lanes carry the path's rng state / slot + flags, not ray data
@@ -352,7 +355,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
   const uint32_t n = *count;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
   uint32_t nn = 0, nt = 0;
-  trace_engine<true, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, cursors + 2, n, &stk[threadIdx.x],
+  trace_engine<true, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursors + 2, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
@@ -380,7 +383,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   uint32_t nn = 0, nt = 0;
-  trace_engine<ANY, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, cursor, n, &stk[threadIdx.x],
+  trace_engine<ANY, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursor, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = idx;
       const float4 o4 = rays[2u * idx], d4 = rays[2u * idx + 1u];

@@ -391,7 +391,15 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
 {
   uint32_t stack[STACK_MAX]; int sp = 0;
   float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
-  float gx = crh_abs(ix) * SLAB_GUARD, gy = crh_abs(iy) * SLAB_GUARD, gz = crh_abs(iz) * SLAB_GUARD;
+  /* guard band of the slab test along each axis, in t: 2^-21 * |1/d| * (|o - c|_1 + 3 h) for the tree with box centre c and L1
+   * half-extent h the walk is in (the scene; inside an instance: the object) */
+  float gx, gy, gz;
+#define SET_GUARD(LO, HI) do { \
+    const float cx_ = ((LO)[0] + (HI)[0]) * 0.5f, cy_ = ((LO)[1] + (HI)[1]) * 0.5f, cz_ = ((LO)[2] + (HI)[2]) * 0.5f; \
+    const float h_ = ((((HI)[0] - (LO)[0]) + ((HI)[1] - (LO)[1])) + ((HI)[2] - (LO)[2])) * 0.5f; \
+    const float R_ = CRH_FMA(h_, 3.0f, (crh_abs(o.x - cx_) + crh_abs(o.y - cy_)) + crh_abs(o.z - cz_)) * SLAB_GUARD; \
+    gx = crh_abs(ix) * R_; gy = crh_abs(iy) * R_; gz = crh_abs(iz) * R_; } while (0)
+  SET_GUARD(c->bbmin, c->bbmax);
   float best = tmax; int found = 0;
   h->t = tmax; h->u = 0.f; h->v = 0.f; h->prim = -1;
   const v3 wo = o, wd = d;                       /* the world-space ray (restored when an object is left) */
@@ -403,7 +411,7 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
       const orc_instance* in = &c->inst[c->tlas_order[cur & 0x0FFFFFFFu]];
       o = crh_xform_point(in->inv, wo); d = crh_xform_vector(in->inv, wd);
       ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
-      gx = crh_abs(ix) * SLAB_GUARD; gy = crh_abs(iy) * SLAB_GUARD; gz = crh_abs(iz) * SLAB_GUARD;
+      SET_GUARD(in->bmin, in->bmax);
       stack[sp++] = CRH_REF_SENTINEL;
       cur = in->root;
       continue;
@@ -417,15 +425,13 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
       }
     } else {
       const qnode* q = &c->nodes[cur]; ORC_COUNT(any_hit ? cn->nodes_any++ : cn->nodes++);
-      /* decode the per-node grid: face t = fma(q, step * inv, (origin - o) * inv -+ guard), where the
-       * entry / exit planes are moved apart by guard = 2^-21 * |inv| * reach, reach = |origin - o|_1 + 256 * largest step */
+      /* decode the per-node grid: face t = fma(q, step * inv, fma(origin - o, inv, -+ guard)) */
       const uint32_t ew = q->w[3];
-      const float stx = crh_quant_step(ew & 0xffu), sty = crh_quant_step((ew >> 8) & 0xffu), stz = crh_quant_step((ew >> 16) & 0xffu);
-      const float ax = stx * ix, ay = sty * iy, az = stz * iz;
+      const float ax = crh_quant_step(ew & 0xffu) * ix, ay = crh_quant_step((ew >> 8) & 0xffu) * iy, az = crh_quant_step((ew >> 16) & 0xffu) * iz;
       const float ddx = crh_u2f(q->w[0]) - o.x, ddy = crh_u2f(q->w[1]) - o.y, ddz = crh_u2f(q->w[2]) - o.z;
-      const float bx = ddx * ix, by = ddy * iy, bz = ddz * iz;
-      const float reach = CRH_FMA(crh_max(crh_max(stx, sty), stz), 256.0f, (crh_abs(ddx) + crh_abs(ddy)) + crh_abs(ddz));
-      const float ex = reach * gx, ey = reach * gy, ez = reach * gz;
+      const float bix = CRH_FMA(ddx, ix, -gx), box = CRH_FMA(ddx, ix, gx);
+      const float biy = CRH_FMA(ddy, iy, -gy), boy = CRH_FMA(ddy, iy, gy);
+      const float biz = CRH_FMA(ddz, iz, -gz), boz = CRH_FMA(ddz, iz, gz);
       uint32_t key[4]; uint32_t rf[4]; int nh = 0;
       const int nch = (int)CRH_NODE_NCHILDREN(ew);
       for (int k = 0; k < nch; ++k) {
@@ -435,9 +441,9 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
         const float qix = (float)(((ix < 0.f ? q->w[7] : q->w[4]) >> sh) & 0xffu), qox = (float)(((ix < 0.f ? q->w[4] : q->w[7]) >> sh) & 0xffu);
         const float qiy = (float)(((iy < 0.f ? q->w[8] : q->w[5]) >> sh) & 0xffu), qoy = (float)(((iy < 0.f ? q->w[5] : q->w[8]) >> sh) & 0xffu);
         const float qiz = (float)(((iz < 0.f ? q->w[9] : q->w[6]) >> sh) & 0xffu), qoz = (float)(((iz < 0.f ? q->w[6] : q->w[9]) >> sh) & 0xffu);
-        float a0 = CRH_FMA(qix, ax, bx - ex), a1 = CRH_FMA(qox, ax, bx + ex);
-        float b0 = CRH_FMA(qiy, ay, by - ey), b1 = CRH_FMA(qoy, ay, by + ey);
-        float c0 = CRH_FMA(qiz, az, bz - ez), c1 = CRH_FMA(qoz, az, bz + ez);
+        float a0 = CRH_FMA(qix, ax, bix), a1 = CRH_FMA(qox, ax, box);
+        float b0 = CRH_FMA(qiy, ay, biy), b1 = CRH_FMA(qoy, ay, boy);
+        float c0 = CRH_FMA(qiz, az, biz), c1 = CRH_FMA(qoz, az, boz);
         float tmin = crh_max(crh_max(crh_max(a0, b0), c0), 0.f);
         float tmx  = crh_min(crh_min(crh_min(a1, b1), c1), best);
         if (tmin <= tmx) {
@@ -461,7 +467,7 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
     if (cur == CRH_REF_SENTINEL) {                /* back to world space */
       o = wo; d = wd;
       ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
-      gx = crh_abs(ix) * SLAB_GUARD; gy = crh_abs(iy) * SLAB_GUARD; gz = crh_abs(iz) * SLAB_GUARD;
+      SET_GUARD(c->bbmin, c->bbmax);
       if (sp == 0) break;
       cur = stack[--sp];
     }

@@ -28,7 +28,8 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        # CRH_ORACLE_LIB: another build of the same file (tools/run_sanitizers.sh loads the ASan / UBSan builds this way)
+        _LIB = C.CDLL(os.environ.get("CRH_ORACLE_LIB") or build())
     return _LIB
 
 

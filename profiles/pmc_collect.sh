@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 for cfg in $CFGS; do
   ARGS="--config $cfg --steps 2 --warmup 1 --no-cpu --no-interactive"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$cfg/trace -o t -- python3 $REPO/bench.py $ARGS > $OUT/$cfg.trace.log 2>&1
-  tail -1 $OUT/$cfg.trace.log > $OUT/$cfg.bench.json
+  grep '^{"metric"' $OUT/$cfg.trace.log | tail -1 > $OUT/$cfg.bench.json
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     name=$(echo $grp | tr ' ' '_')
     rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$cfg/pmc_$name -o p -- python3 $REPO/bench.py $ARGS > $OUT/$cfg.pmc_$name.log 2>&1

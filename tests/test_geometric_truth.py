@@ -115,8 +115,8 @@ def _inside_distance(tri_pos, rays, rows, prims):
         inpl /= np.maximum(np.linalg.norm(inpl, axis=1, keepdims=True), 1e-300)
         dist = np.minimum(dist, np.einsum("ij,ij->i", P - a, inpl))
     size = np.max(np.linalg.norm(tp - np.roll(tp, 1, axis=1), axis=2), axis=1)
-    cosi = np.abs(np.einsum("ij,ij->i", d, nrm)) / nl                   # grazing incidence stretches the band along the plane
-    return dist, (2e-5 * size + 2e-6 * scene) / np.maximum(cosi, 1e-3)
+    cosi = np.abs(np.einsum("ij,ij->i", d, nrm)) / nl                   # grazing incidence stretches the band along the plane:
+    return dist, (2e-5 * size + 2e-6 * scene + 1e-6 * np.abs(t)) / np.maximum(cosi, 1e-5)      # a ray nearly IN the plane is ill-conditioned for any float test
 
 
 def check_against_truth(hits, tri_pos, rays, aimed, exact_f32):

@@ -1,0 +1,28 @@
+#!/bin/bash
+# CPU-side sanitizer pass: the oracle (C, OpenMP) and the product's host-side BVH builder (C++ threads,
+# atomics, futures) under AddressSanitizer, UndefinedBehaviorSanitizer and ThreadSanitizer.  Never on the GPU.
+#   tools/run_sanitizers.sh [asan ubsan tsan]      -> sanitizers/<kind>.log, exit status 1 on any report
+cd "$(dirname "$0")/.."
+KINDS=${@:-asan ubsan tsan}
+OUT=sanitizers; mkdir -p $OUT
+rc=0
+for k in $KINDS; do
+  make -s -C oracle $k || { echo "$k: build failed"; rc=1; continue; }
+  log=$OUT/$k.log; : > $log
+  # 1. the multi-threaded builder
+  case $k in
+    tsan) env="TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0" ;;
+    asan) env="ASAN_OPTIONS=detect_leaks=1" ;;
+    *)    env="UBSAN_OPTIONS=print_stacktrace=1" ;;
+  esac
+  env $env oracle/san/$k/sanitize_host 30000 >> $log 2>&1 || { echo "$k: sanitize_host failed"; rc=1; }
+  # 2. the oracle through the CPU test-suite's own oracle tests (the sanitized library is preloaded in place of the -O2 one)
+  if [ $k != tsan ]; then       # libgomp is not TSan-instrumented: its barriers read as races; the oracle's OpenMP loops only touch disjoint pixels
+    pre=$(gcc -print-file-name=lib${k}.so)
+    env $env LD_PRELOAD=$pre CRH_ORACLE_LIB=$PWD/oracle/san/$k/libcrh_oracle.so ASAN_OPTIONS=detect_leaks=0 \
+      python -m pytest tests/test_oracle_kat.py tests/test_golden.py tests/test_node_quantiser.py tests/test_geometric_truth.py -x -q -m "not gpu" -k "not product_builder" >> $log 2>&1 \
+      || { echo "$k: oracle tests failed"; rc=1; }
+  fi
+  if grep -E "ERROR: (Address|Thread|Leak)Sanitizer|runtime error:|WARNING: ThreadSanitizer" $log > /dev/null; then echo "$k: sanitizer reports in $log"; rc=1; else echo "$k: clean"; fi
+done
+exit $rc
