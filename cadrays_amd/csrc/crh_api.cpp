@@ -69,6 +69,12 @@ struct crh_ctx {
   DCounters* d_counters = nullptr;
   uint32_t* d_api_cursor = nullptr;   // work cursor of the API-level trace kernels
   void* d_scratch = nullptr; size_t scratch_bytes = 0;
+  // setters called every GUI frame (material-editor drags MaterialEditor.cxx:331-337, manipulator moves ImRaytraceControls.cxx:58-89)
+  // reuse their device allocations (capacities below) and copy through a small ring of pinned staging buffers on the context's
+  // stream: no hipFree / hipMalloc, no device-wide synchronisation, kernels still in flight keep reading the old bytes
+  size_t cap_nodes = 0, cap_inst = 0, cap_mats = 0, cap_lights = 0, cap_env = 0;
+  struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } stage[4];
+  uint32_t stage_next = 0;
   bool counters_on = false, timing_on = false;
   uint32_t frames_done = 0;       // whole-frame iterations since reset (crh_render continues from here)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> render_ev, trace_ev;
@@ -98,12 +104,55 @@ bool all_finite(const float* v, size_t n, float limit = 3.0e38f)
   return true;
 }
 
+// Every copy and memset goes through the context's own stream: it is created non-blocking, so work on the null stream (plain
+// hipMemset / hipMemcpy) is NOT ordered with it -- a hipMemset of the queue counters on the null stream used to land in the middle
+// of the first batch of a fresh context when other contexts kept the device busy (lost and doubled paths).
 template <class T> int dev_upload(crh_ctx* c, T*& dptr, const void* src, size_t bytes)
 {
+  CRH_HIP(hipStreamSynchronize(c->stream));
   if (dptr) { CRH_HIP(hipFree(dptr)); dptr = nullptr; }
   if (!bytes) return CRH_OK;
   CRH_HIP(hipMalloc((void**)&dptr, bytes));
-  CRH_HIP(hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+  CRH_HIP(hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));            // `src` may be a temporary of the caller
+  return CRH_OK;
+}
+
+// Stream-ordered copy of a small host block: staged through one of four pinned buffers, so the call returns at once and `src`
+// can be reused; a slot is waited for only when the copy issued four uploads earlier has not finished yet.
+int stage_copy(crh_ctx* c, void* dst, const void* src, size_t bytes)
+{
+  if (!bytes) return CRH_OK;
+  crh_ctx::Stage& st = c->stage[c->stage_next++ & 3u];
+  if (st.used) CRH_HIP(hipEventSynchronize(st.ev));
+  if (st.cap < bytes) {
+    if (st.p) { CRH_HIP(hipHostFree(st.p)); st.p = nullptr; st.cap = 0; }
+    const size_t want = bytes + bytes / 2 + 4096;
+    CRH_HIP(hipHostMalloc(&st.p, want, hipHostMallocDefault));
+    st.cap = want;
+  }
+  if (!st.ev) CRH_HIP(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+  std::memcpy(st.p, src, bytes);
+  CRH_HIP(hipMemcpyAsync(dst, st.p, bytes, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipEventRecord(st.ev, c->stream));
+  st.used = true;
+  return CRH_OK;
+}
+
+// Refresh a device array in place: the allocation is kept (and grown with head-room only when it is too small), the bytes travel
+// stream-ordered.  Large blocks (environment maps, whole node arrays) are copied straight from the caller's memory and waited for.
+template <class T> int dev_put(crh_ctx* c, T*& dptr, size_t& cap, const void* src, size_t bytes, size_t headroom = 0)
+{
+  if (bytes > cap || !dptr) {
+    CRH_HIP(hipStreamSynchronize(c->stream));          // kernels in flight may still read the old allocation
+    if (dptr) { CRH_HIP(hipFree(dptr)); dptr = nullptr; cap = 0; }
+    const size_t want = std::max<size_t>(bytes + headroom, 256);
+    CRH_HIP(hipMalloc((void**)&dptr, want));
+    cap = want;
+  }
+  if (bytes <= (4u << 20)) return stage_copy(c, dptr, src, bytes);
+  CRH_HIP(hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
   return CRH_OK;
 }
 
@@ -130,6 +179,14 @@ int trim_events(crh_ctx* c)
   return CRH_OK;
 }
 
+// A restart does not need the old epoch's times: hand the events back without waiting for them (no stream synchronisation).
+void discard_events(crh_ctx* c)
+{
+  for (auto& p : c->render_ev) { c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second); }
+  for (auto& p : c->trace_ev) { c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second); }
+  c->render_ev.clear(); c->trace_ev.clear();
+}
+
 uint32_t frame_seed(uint32_t seed, uint32_t n)   // Bullard generator, SURVEY.md a14
 {
   uint32_t hi = seed, lo = seed ^ 0x49616E42u, r = 0;
@@ -151,7 +208,7 @@ int ensure_paths(crh_ctx* c, uint32_t need)
     if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
     CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
   }
-  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, 8 * sizeof(uint32_t))); CRH_HIP(hipMemset(c->queues.counts, 0, 8 * sizeof(uint32_t))); }
+  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, 8 * sizeof(uint32_t))); CRH_HIP(hipMemsetAsync(c->queues.counts, 0, 8 * sizeof(uint32_t), c->stream)); }
   c->path_cap = need;
   return CRH_OK;
 }
@@ -168,7 +225,7 @@ int ensure_scratch(crh_ctx* c, size_t bytes)
 void fill_scene(const crh_ctx* c, DScene& S)
 {
   std::memset(&S, 0, sizeof S);
-  S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = c->d_env;
+  S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = (c->envW && c->envH) ? c->d_env : nullptr;
   S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * c->inst.size() : nullptr; S.root = c->root; S.two_level = c->two_level ? 1 : 0;
   {
     const float* lo = c->bvh.bbmin; const float* hi = c->bvh.bbmax;      // bounds of the tree the walk starts in (the world box of a two-level scene)
@@ -206,7 +263,7 @@ int upload_lights(crh_ctx* c)
     }
     o[4] = s.emission[0]; o[5] = s.emission[1]; o[6] = s.emission[2];
   }
-  return dev_upload(c, c->d_lights, l.data(), l.size() * sizeof(float));
+  return dev_put(c, c->d_lights, c->cap_lights, l.data(), l.size() * sizeof(float), 8 * 32);
 }
 
 // (Re)build the top-level tree over the instances' world boxes behind the object trees [0, n_blas_nodes) and refresh the
@@ -234,9 +291,9 @@ int build_tlas(crh_ctx* c)
     table[32 * (size_t)i + 31] = (((in.bmax[0] - in.bmin[0]) + (in.bmax[1] - in.bmin[1])) + (in.bmax[2] - in.bmin[2])) * 0.5f;
   }
   std::vector<uint32_t> order;
-  c->root = build_tree(boxes.data(), n, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, 1);
+  c->root = build_tree(boxes.data(), n, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, n >= 8192 ? 0 : 1);   // small trees: one thread beats the hand-off
   for (uint32_t p = 0; p < n; ++p) std::memcpy(&table[32 * (size_t)(n + p)], &table[32 * (size_t)order[p]], 128);
-  return dev_upload(c, c->d_inst, table.data(), table.size() * sizeof(float));
+  return dev_put(c, c->d_inst, c->cap_inst, table.data(), table.size() * sizeof(float));
 }
 
 int upload_textures(crh_ctx* c)
@@ -269,15 +326,14 @@ int alloc_accum(crh_ctx* c)
 
 int do_reset(crh_ctx* c)
 {
+  // stream-ordered: kernels still in flight finish into the old accumulator contents first, nothing is waited for
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
   int rc = alloc_accum(c); if (rc) return rc;
   CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, c->stream));
   CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, c->stream));
   c->adaptive_picks = 0; c->pending_n = 0; c->last_picked.clear(); c->assembled_valid = false;
   CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
-  drain_events(c);
+  discard_events(c);
   c->seconds_acc = c->trace_ms_acc = c->all_ms_acc = 0.0; c->trace_launches = 0; c->frames_done = 0;
   return CRH_OK;
 }
@@ -550,7 +606,8 @@ crh_ctx* crh_create(int device_ordinal)
   crh_ctx* c = new crh_ctx();
   c->device = device_ordinal;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&c->d_counters, sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemset(c->d_counters, 0, sizeof(DCounters)) != hipSuccess) {
+      hipMalloc((void**)&c->d_counters, sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) {
     fprintf(stderr, "crh_create: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
     delete c; return nullptr;
   }
@@ -580,6 +637,7 @@ void crh_destroy(crh_ctx* c)
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->d_assembled) hipFree(c->d_assembled);
   if (c->d_peer_stage) hipFree(c->d_peer_stage);
+  for (crh_ctx::Stage& st : c->stage) { if (st.p) hipHostFree(st.p); if (st.ev) hipEventDestroy(st.ev); }
   release_comms(c);
   hipStreamDestroy(c->stream);
   delete c;
@@ -623,11 +681,16 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
   if (!c->two_level || nO != c->nO) return fail(c, CRH_E_INVALID, "crh_set_transforms needs a two-level scene with the same object count");
   if (!all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return fail(c, CRH_E_INVALID, "transform holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
   c->xf.assign(xf, xf + 12 * (size_t)nO);
   if (c->built) {
+    // the manipulator calls this every frame (ImRaytraceControls.cxx:58-89): rebuild the top-level tree on the host and send only
+    // its nodes (the tail of the node array, behind the untouched object trees) and the instance table, stream-ordered into
+    // the allocations crh_build left head-room in
     int rc = build_tlas(c); if (rc) return rc;
-    if ((rc = dev_upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode)))) return rc;
+    const size_t tail = c->bvh.nodes.size() - c->n_blas_nodes;
+    if (c->bvh.nodes.size() * sizeof(QNode) > c->cap_nodes) {          // cannot happen for an unchanged instance count; kept for safety
+      if ((rc = dev_put(c, c->d_nodes, c->cap_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode), (size_t)(c->inst.size() + 64) * sizeof(QNode)))) return rc;
+    } else if ((rc = stage_copy(c, (char*)c->d_nodes + (size_t)c->n_blas_nodes * sizeof(QNode), c->bvh.nodes.data() + c->n_blas_nodes, tail * sizeof(QNode)))) return rc;
   }
   return do_reset(c);
 }
@@ -645,9 +708,8 @@ int crh_set_materials(crh_ctx* c, const crh_bsdf* m, uint32_t n)
   if (!c || (n && !m)) return fail(c, CRH_E_INVALID, "null materials");
   if (!all_finite((const float*)m, 32 * (size_t)n)) return fail(c, CRH_E_INVALID, "material holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
   c->mats.assign(m, m + n); c->pending_n = 0;
-  return dev_upload(c, c->d_mats, c->mats.data(), sizeof(crh_bsdf) * n);
+  return dev_put(c, c->d_mats, c->cap_mats, c->mats.data(), sizeof(crh_bsdf) * n, 16 * sizeof(crh_bsdf));
 }
 
 int crh_set_lights(crh_ctx* c, const crh_light* l, uint32_t n)
@@ -655,7 +717,6 @@ int crh_set_lights(crh_ctx* c, const crh_light* l, uint32_t n)
   if (!c || (n && !l)) return fail(c, CRH_E_INVALID, "null lights");
   if (!all_finite((const float*)l, 8 * (size_t)n, 1.0e30f)) return fail(c, CRH_E_INVALID, "light holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
   c->lights.assign(l, l + n); c->pending_n = 0;
   return upload_lights(c);
 }
@@ -665,16 +726,14 @@ int crh_set_envmap(crh_ctx* c, const float* rgb, uint32_t w, uint32_t h)
   if (!c) return CRH_E_INVALID;
   if (rgb && w && h && !all_finite(rgb, 3 * (size_t)w * h)) return fail(c, CRH_E_INVALID, "environment map holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
   c->envW = c->envH = 0; c->pending_n = 0;
-  if (c->d_env) { CRH_HIP(hipFree(c->d_env)); c->d_env = nullptr; }
   if (rgb && w && h) {
     std::vector<float> t(4 * (size_t)w * h);
     for (size_t i = 0; i < (size_t)w * h; ++i) { t[4 * i] = rgb[3 * i]; t[4 * i + 1] = rgb[3 * i + 1]; t[4 * i + 2] = rgb[3 * i + 2]; t[4 * i + 3] = 0.f; }
-    int rc = dev_upload(c, c->d_env, t.data(), t.size() * sizeof(float)); if (rc) return rc;
+    int rc = dev_put(c, c->d_env, c->cap_env, t.data(), t.size() * sizeof(float)); if (rc) return rc;
     c->envW = w; c->envH = h;
   }
-  return CRH_OK;
+  return CRH_OK;      // without a map the kernels take the background colour (fill_scene hands them a null pointer); the allocation is kept
 }
 
 int crh_set_texture(crh_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uint32_t h, uint32_t channels)
@@ -775,7 +834,8 @@ int crh_build(crh_ctx* c)
     std::memcpy(&sh[12 * (size_t)i + 7], &tri_inst[t], 4);       // n1.w = instance index (two-level shading fetches its transform)
   }
   int rc;
-  if ((rc = dev_upload(c, c->d_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode)))) return rc;
+  // head-room behind the node array: crh_set_transforms rebuilds the top-level tree into it (<= one node per instance + alignment holes)
+  if ((rc = dev_put(c, c->d_nodes, c->cap_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode), (size_t)(2 * c->inst.size() + 64) * sizeof(QNode)))) return rc;
   if (kTriStride == 3) { if ((rc = dev_upload(c, c->d_tris, c->h_tris.data(), c->h_tris.size() * sizeof(float)))) return rc; }
   else {
     std::vector<float> padded(4 * (size_t)kTriStride * std::max(nT, 1u), 0.f);
@@ -792,7 +852,9 @@ int crh_build(crh_ctx* c)
     if ((rc = dev_upload(c, c->d_uvs, uvr.data(), uvr.size() * sizeof(float)))) return rc;
   } else if (c->d_uvs) { CRH_HIP(hipFree(c->d_uvs)); c->d_uvs = nullptr; }
   c->built = true;
-  return do_reset(c);
+  rc = do_reset(c); if (rc) return rc;
+  CRH_HIP(hipStreamSynchronize(c->stream));
+  return CRH_OK;
 }
 
 int crh_reset(crh_ctx* c) { if (!c) return CRH_E_INVALID; return do_reset(c); }
@@ -931,7 +993,8 @@ int crh_save_accum(crh_ctx* c, float* out, uint32_t* frames_done)
   if (!c || !out || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null output");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
-  CRH_HIP(hipMemcpy(out, c->assembled_valid ? c->d_assembled : c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyDeviceToHost));
+  CRH_HIP(hipMemcpyAsync(out, c->assembled_valid ? c->d_assembled : c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
   if (frames_done) *frames_done = c->frames_done;
   return CRH_OK;
 }
@@ -942,7 +1005,8 @@ int crh_load_accum(crh_ctx* c, const float* in, uint32_t frames_done)
   if (c->adaptive) return fail(c, CRH_E_INVALID, "checkpoints do not carry the adaptive sampler's second moments");
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(c->stream));
-  CRH_HIP(hipMemcpy(c->d_accum, in, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyHostToDevice));
+  CRH_HIP(hipMemcpyAsync(c->d_accum, in, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
   c->frames_done = frames_done; c->pending_n = 0; c->assembled_valid = false;
   return CRH_OK;
 }
@@ -969,7 +1033,8 @@ int crh_get_stats(crh_ctx* c, crh_stats* out)
   CRH_HIP(hipStreamSynchronize(c->stream));
   drain_events(c);
   DCounters h;
-  CRH_HIP(hipMemcpy(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+  CRH_HIP(hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  CRH_HIP(hipStreamSynchronize(c->stream));
   out->rays_nearest = h.rays_nearest; out->rays_any = h.rays_any; out->nodes_nearest = h.nodes_nearest; out->tris_nearest = h.tris_nearest;
   out->nodes_any = h.nodes_any; out->tris_any = h.tris_any; out->shaded_hits = h.shaded_hits; out->samples = h.samples;
   out->seconds = c->seconds_acc;

@@ -387,7 +387,7 @@ def test_obj_with_mtl_renders_bit_exact_on_gpu(hip_lib, oracle_lib, tmp_path):
     from cadrays_amd.view import View
     obj = _write_obj_with_mtl(tmp_path)
     b = SceneBuilder(str(tmp_path)); t = MiniTcl(b.commands, {})
-    t.eval(f"rtmeshread {obj} room\nvcamera -persp\nvviewparams -eye 1 -3 0.5 -at 1 1 0.5 -up 0 0 1\nvrenderparams -ray -gi -rayDepth 5\nvlight del 0\nvlight del 1")
+    t.eval(f"rtmeshread {obj} room\nvcamera -persp\nvviewparams -eye 0.25 0.3 0.45 -at 2 1.8 0.6 -up 0 0 1\nvrenderparams -ray -gi -rayDepth 5\nvlight del 0\nvlight del 1")
     sc = b.snapshot(64, 48)
     v = View(0).load_scene(sc); v.render(4)
     o = oracle_lib.Oracle().load_scene(sc); o.render(4)
