@@ -49,6 +49,7 @@ struct Builder {
   std::atomic<uint32_t> next{0};
   std::atomic<int> spare_threads{0};
   uint32_t leaf_max = kLeafSize;       // one primitive per leaf (triangle trees and the top-level tree over instances alike)
+  uint32_t task_min = 32768;           // a left half larger than this may be handed to another thread (smaller for small trees: build_tree)
 
   uint32_t alloc() { return next.fetch_add(1, std::memory_order_relaxed); }
 
@@ -85,7 +86,63 @@ struct Builder {
     auto c_lo = [&](int c) { return lo + (uint32_t)((uint64_t)n * c / chunks); };
     const int need = ceil_log2((n + leaf_max - 1) / leaf_max);
     const bool force_median = depth + need >= kMaxDepth;
-    if (!force_median) {
+    if (!force_median && chunks == 1) {
+      // One thread, typically a small node (most nodes of a tree hold a handful of primitives): bins are cleared on first touch
+      // and the sweep visits only OCCUPIED bins.  Same result as the full sweep below: a split after an empty bin s has the
+      // same two sides -- hence bit-identical cost -- as the split after the previous bin, and only a strictly lower cost
+      // replaces the best one, so an empty bin never wins.  (1 000 boxes: 0.92 -> 0.3 ms; this is crh_set_transforms' per-frame cost.)
+      float ext[3]; bool ok[3];
+      for (int a = 0; a < 3; ++a) { ext[a] = cmx[a] - cmn[a]; ok[a] = ext[a] > 0.f; }
+      uint32_t cnt[3][kBins]; Box bb[3][kBins]; uint32_t occ[3] = {0u, 0u, 0u};
+      static_assert(kBins == 32, "occupancy masks are one 32-bit word per axis");
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t p = idx[i];
+        const Box pb = prim_box(p);
+        for (int a = 0; a < 3; ++a) {
+          if (!ok[a]) continue;
+          int b = (int)(((cen[a][p] - cmn[a]) / ext[a]) * (float)kBins);
+          if (b > kBins - 1) b = kBins - 1;
+          if (!(occ[a] >> b & 1u)) { occ[a] |= 1u << b; cnt[a][b] = 0; bb[a][b].clear(); }
+          cnt[a][b]++; bb[a][b].grow(pb);
+        }
+      }
+      float best = 3.0e38f; int baxis = -1, bsplit = -1;
+      for (int a = 0; a < 3; ++a) {
+        if (!ok[a]) continue;
+        // suffix (area, count) at every occupied bin, highest first
+        float rarea[kBins]; uint32_t rcnt[kBins]; int next_occ[kBins];
+        Box acc; acc.clear(); uint32_t c = 0; int above = -1;
+        for (uint32_t m = occ[a]; m;) {
+          const int b = 31 - __builtin_clz(m); m &= ~(1u << b);
+          next_occ[b] = above;
+          acc.grow(bb[a][b]); c += cnt[a][b]; rcnt[b] = c; rarea[b] = acc.half_area();
+          above = b;
+        }
+        acc.clear(); c = 0;
+        for (uint32_t m = occ[a]; m;) {
+          const int sbin = __builtin_ctz(m); m &= m - 1u;
+          acc.grow(bb[a][sbin]); c += cnt[a][sbin];
+          const int nb = next_occ[sbin];
+          if (nb < 0 || sbin >= kBins - 1) continue;            // nothing on the right of this split
+          const float cost = fma_(acc.half_area(), (float)c, rarea[nb] * (float)rcnt[nb]);
+          if (cost < best) { best = cost; baxis = a; bsplit = sbin; }
+        }
+      }
+      if (baxis >= 0) {
+        const std::vector<float>& cc = cen[baxis];
+        const float c0 = cmn[baxis], e = ext[baxis];
+        uint32_t nl = 0, nr = 0;
+        uint32_t* right = tmp.data() + lo;          // this subtree's private scratch range
+        for (uint32_t i = lo; i < hi; ++i) {
+          const uint32_t p = idx[i];
+          int b = (int)(((cc[p] - c0) / e) * (float)kBins);
+          if (b > kBins - 1) b = kBins - 1;
+          if (b <= bsplit) idx[lo + nl++] = p; else right[nr++] = p;
+        }
+        std::memcpy(&idx[lo + nl], right, sizeof(uint32_t) * nr);
+        return lo + nl;
+      }
+    } else if (!force_median) {
       float ext[3], inv_ok[3];
       for (int a = 0; a < 3; ++a) { ext[a] = cmx[a] - cmn[a]; inv_ok[a] = ext[a] > 0.f ? 1.f : 0.f; }
       struct Bins { uint32_t cnt[3][kBins]; Box bb[3][kBins]; };
@@ -175,24 +232,37 @@ struct Builder {
       const int extra = grab_threads(hi - lo);         // > 0: this node is processed in extra+1 chunks
       const int chunks = extra + 1;
       struct Bounds { Box box; float cmn[3], cmx[3]; };
-      std::vector<Bounds> bp(chunks);
-      run_chunks(chunks, [&](int c) {
-        Bounds& b = bp[c]; b.box.clear();
-        for (int a = 0; a < 3; ++a) { b.cmn[a] = 3.0e38f; b.cmx[a] = -3.0e38f; }
-        const uint32_t n_ = hi - lo;
-        for (uint32_t i = lo + (uint32_t)((uint64_t)n_ * c / chunks), e = lo + (uint32_t)((uint64_t)n_ * (c + 1) / chunks); i < e; ++i) {
+      Box box; float cmn[3], cmx[3];
+      if (chunks == 1) {                               // the common case: no heap traffic per node
+        box.clear();
+        for (int a = 0; a < 3; ++a) { cmn[a] = 3.0e38f; cmx[a] = -3.0e38f; }
+        for (uint32_t i = lo; i < hi; ++i) {
           const uint32_t p = idx[i];
           for (int a = 0; a < 3; ++a) {
-            b.box.mn[a] = std::min(b.box.mn[a], pmn[a][p]); b.box.mx[a] = std::max(b.box.mx[a], pmx[a][p]);
-            b.cmn[a] = std::min(b.cmn[a], cen[a][p]); b.cmx[a] = std::max(b.cmx[a], cen[a][p]);
+            box.mn[a] = std::min(box.mn[a], pmn[a][p]); box.mx[a] = std::max(box.mx[a], pmx[a][p]);
+            cmn[a] = std::min(cmn[a], cen[a][p]); cmx[a] = std::max(cmx[a], cen[a][p]);
           }
         }
-      });
-      Box box = bp[0].box;
-      float cmn[3] = {bp[0].cmn[0], bp[0].cmn[1], bp[0].cmn[2]}, cmx[3] = {bp[0].cmx[0], bp[0].cmx[1], bp[0].cmx[2]};
-      for (int c = 1; c < chunks; ++c) {
-        box.grow(bp[c].box);
-        for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], bp[c].cmn[a]); cmx[a] = std::max(cmx[a], bp[c].cmx[a]); }
+      } else {
+        std::vector<Bounds> bp(chunks);
+        run_chunks(chunks, [&](int c) {
+          Bounds& b = bp[c]; b.box.clear();
+          for (int a = 0; a < 3; ++a) { b.cmn[a] = 3.0e38f; b.cmx[a] = -3.0e38f; }
+          const uint32_t n_ = hi - lo;
+          for (uint32_t i = lo + (uint32_t)((uint64_t)n_ * c / chunks), e = lo + (uint32_t)((uint64_t)n_ * (c + 1) / chunks); i < e; ++i) {
+            const uint32_t p = idx[i];
+            for (int a = 0; a < 3; ++a) {
+              b.box.mn[a] = std::min(b.box.mn[a], pmn[a][p]); b.box.mx[a] = std::max(b.box.mx[a], pmx[a][p]);
+              b.cmn[a] = std::min(b.cmn[a], cen[a][p]); b.cmx[a] = std::max(b.cmx[a], cen[a][p]);
+            }
+          }
+        });
+        box = bp[0].box;
+        for (int a = 0; a < 3; ++a) { cmn[a] = bp[0].cmn[a]; cmx[a] = bp[0].cmx[a]; }
+        for (int c = 1; c < chunks; ++c) {
+          box.grow(bp[c].box);
+          for (int a = 0; a < 3; ++a) { cmn[a] = std::min(cmn[a], bp[c].cmn[a]); cmx[a] = std::max(cmx[a], bp[c].cmx[a]); }
+        }
       }
       nd.box = box;
       if (hi - lo <= leaf_max) { spare_threads.fetch_add(extra); return; }
@@ -201,13 +271,13 @@ struct Builder {
       const uint32_t l = alloc(), r = alloc();
       nodes[me].left = (int32_t)l; nodes[me].right = (int32_t)r;
       // hand the left half to another thread when it is big enough and one is free
-      if (mid - lo > 32768u && spare_threads.fetch_sub(1) > 0) {
+      if (mid - lo > task_min && spare_threads.fetch_sub(1) > 0) {
         auto fut = std::async(std::launch::async, [this, l, lo, mid, depth] { build(l, lo, mid, depth + 1); spare_threads.fetch_add(1); });
         build(r, mid, hi, depth + 1);
         fut.get();
         return;
       }
-      else if (mid - lo > 32768u) spare_threads.fetch_add(1);
+      else if (mid - lo > task_min) spare_threads.fetch_add(1);
       build(l, lo, mid, depth + 1);
       me = r; lo = mid; ++depth;   // tail-iterate on the right half
     }
@@ -299,6 +369,7 @@ uint32_t build_tree(const float* boxes, uint32_t n, bool instance_leaves, uint32
                     std::vector<QNode>& nodes, std::vector<uint32_t>& order, float bmin[3], float bmax[3], int threads) {
   Builder B;
   B.leaf_max = 1;                      // the node format holds one primitive per leaf
+  if (n < 524288u) B.task_min = std::max(1024u, n / 16u);       // small trees (a top-level tree over instances is rebuilt every frame) still split across threads
   const uint32_t cap = n ? n : 1;
   for (int a = 0; a < 3; ++a) { B.pmn[a].resize(cap); B.pmx[a].resize(cap); B.cen[a].resize(cap); }
   B.idx.resize(cap); B.tmp.resize(cap);

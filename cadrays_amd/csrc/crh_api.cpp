@@ -75,6 +75,13 @@ struct crh_ctx {
   size_t cap_nodes = 0, cap_inst = 0, cap_mats = 0, cap_lights = 0, cap_env = 0;
   struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } stage[4];
   uint32_t stage_next = 0;
+  // Small batches (one Redraw() = +1 spp of one frame, AppViewer.cxx:1045-1047) are launch- and drain-bound: every traversal
+  // launch ends with the longest rays of a few wavefronts while the rest of the chip idles.  Such a batch is cut into `n_lanes`
+  // tile ranges that run the same wavefront schedule on their own streams and their own slice of the path state, so one
+  // range's drain phases overlap the others' busy phases.  Pixels, seeds and the per-pixel accumulation order do not change.
+  uint32_t n_lanes = 4, lane_max_paths = 12u << 20; int lane_grid = 0, lane_grid_trace = 0;
+  hipStream_t lane_stream[8] = {}; hipEvent_t lane_fork = nullptr, lane_join[8] = {}; uint32_t* d_lane_counts = nullptr;
+  std::vector<uint32_t> h_tile_ids;      // what d_tile_ids holds (an unchanged tile list is not uploaded again)
   bool counters_on = false, timing_on = false;
   uint32_t frames_done = 0;       // whole-frame iterations since reset (crh_render continues from here)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> render_ev, trace_ev;
@@ -291,7 +298,7 @@ int build_tlas(crh_ctx* c)
     table[32 * (size_t)i + 31] = (((in.bmax[0] - in.bmin[0]) + (in.bmax[1] - in.bmin[1])) + (in.bmax[2] - in.bmin[2])) * 0.5f;
   }
   std::vector<uint32_t> order;
-  c->root = build_tree(boxes.data(), n, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, n >= 8192 ? 0 : 1);   // small trees: one thread beats the hand-off
+  c->root = build_tree(boxes.data(), n, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, n >= 4096 ? 0 : 1);   // small trees: one thread beats the hand-off
   for (uint32_t p = 0; p < n; ++p) std::memcpy(&table[32 * (size_t)(n + p)], &table[32 * (size_t)order[p]], 128);
   return dev_put(c, c->d_inst, c->cap_inst, table.data(), table.size() * sizeof(float));
 }
@@ -339,28 +346,77 @@ int do_reset(crh_ctx* c)
 }
 
 // One batch: `ns` samples of `nt` tiles whose ids sit at d_tiles; seeds at d_seeds.
+// One wavefront schedule: `ns` samples of `nt` tiles (ids at d_tiles, seeds at d_seeds) on one stream and one slice of the path state.
+struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; };
+
+int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile,
+             bool accumulate)
+{
+  Launch L{ln.stream, ln.grid, c->counters_on};
+  Launch LT{ln.stream, ln.grid_trace, c->counters_on};
+  launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile);
+  int qin = 0;
+  for (uint32_t b = 0; b < S.max_depth; ++b) {
+    if (ln.timed && c->timing_on) {
+      hipEvent_t e0 = get_event(c), e1 = get_event(c);
+      hipEventRecord(e0, ln.stream);
+      launch_trace_nearest(LT, S, ln.P, ln.Q, qin, c->d_counters);
+      hipEventRecord(e1, ln.stream);
+      c->trace_ev.emplace_back(e0, e1);
+    } else launch_trace_nearest(LT, S, ln.P, ln.Q, qin, c->d_counters);
+    launch_shade(L, S, ln.P, ln.Q, qin, b, c->d_counters);
+    if (S.n_lights > 0) launch_trace_any(LT, S, ln.P, ln.Q, c->d_counters);
+    qin = 1 - qin;
+  }
+  if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, c->d_counters);
+  CRH_HIP(hipGetLastError());
+  return CRH_OK;
+}
+
+int ensure_lanes(crh_ctx* c)
+{
+  if (c->d_lane_counts) return CRH_OK;
+  for (uint32_t k = 0; k < c->n_lanes; ++k) {
+    CRH_HIP(hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+    CRH_HIP(hipEventCreateWithFlags(&c->lane_join[k], hipEventDisableTiming));
+  }
+  CRH_HIP(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
+  CRH_HIP(hipMalloc((void**)&c->d_lane_counts, 8 * sizeof(uint32_t) * 8));
+  CRH_HIP(hipMemsetAsync(c->d_lane_counts, 0, 8 * sizeof(uint32_t) * 8, c->stream));
+  return CRH_OK;
+}
+
+// One batch: `ns` samples of `nt` tiles whose ids sit at d_tiles; seeds at d_seeds.
 int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile = 0,
               bool accumulate = true)
 {
   c->pending_n = 0;                                  // the path buffer is about to be overwritten
-  Launch L{c->stream, c->grid, c->counters_on};
-  Launch LT{c->stream, c->grid_trace, c->counters_on};
-  launch_raygen(L, S, c->paths, c->queues, 0, d_tiles, nt, d_seeds, ns, seed_per_tile);
-  int qin = 0;
-  for (uint32_t b = 0; b < S.max_depth; ++b) {
-    if (c->timing_on) {
-      hipEvent_t e0 = get_event(c), e1 = get_event(c);
-      hipEventRecord(e0, c->stream);
-      launch_trace_nearest(LT, S, c->paths, c->queues, qin, c->d_counters);
-      hipEventRecord(e1, c->stream);
-      c->trace_ev.emplace_back(e0, e1);
-    } else launch_trace_nearest(LT, S, c->paths, c->queues, qin, c->d_counters);
-    launch_shade(L, S, c->paths, c->queues, qin, b, c->d_counters);
-    if (S.n_lights > 0) launch_trace_any(LT, S, c->paths, c->queues, c->d_counters);
-    qin = 1 - qin;
+  const uint32_t tpp = S.tile_size * S.tile_size;
+  const uint64_t total = (uint64_t)nt * tpp * ns;
+  const uint32_t K = std::min<uint32_t>(c->n_lanes, nt / 4u);           // a lane wants at least a few tiles
+  if (K < 2 || total > c->lane_max_paths || !accumulate || c->counters_on)
+    return run_lane(c, Lane{c->stream, c->paths, c->queues, c->grid, c->grid_trace, true}, S, d_tiles, nt, d_seeds, ns, seed_per_tile, accumulate);
+  // small batch: K tile ranges on K streams, each with its own slice [base, base + n_k * tpp * ns) of every path-state array
+  // (queue entries are positions relative to the slice) and its own counter block; fork from / join into the context's stream
+  int rc = ensure_lanes(c); if (rc) return rc;
+  CRH_HIP(hipEventRecord(c->lane_fork, c->stream));
+  size_t base = 0;
+  for (uint32_t k = 0; k < K; ++k) {
+    const uint32_t t0 = (uint32_t)((uint64_t)nt * k / K), t1 = (uint32_t)((uint64_t)nt * (k + 1) / K);
+    Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false;
+    ln.grid = c->lane_grid > 0 ? c->lane_grid : std::max(256, c->grid / (int)K);
+    ln.grid_trace = c->lane_grid_trace > 0 ? c->lane_grid_trace : std::max(256, c->grid_trace / (int)K);
+    const DPaths& P = c->paths; const DQueues& Q = c->queues;
+    ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
+    ln.P.thr[0] = P.thr[0] + base; ln.P.thr[1] = P.thr[1] + base; ln.P.hit = P.hit + base; ln.P.rad = P.rad + base;
+    ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base;
+    ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.counts = c->d_lane_counts + 8 * k;
+    CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
+    rc = run_lane(c, ln, S, d_tiles + t0, t1 - t0, seed_per_tile ? d_seeds + t0 : d_seeds, ns, seed_per_tile, true); if (rc) return rc;
+    CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
+    CRH_HIP(hipStreamWaitEvent(c->stream, c->lane_join[k], 0));
+    base += (size_t)(t1 - t0) * tpp * ns;
   }
-  if (accumulate) launch_accumulate(L, S, c->paths, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, c->d_counters);
-  CRH_HIP(hipGetLastError());
   return CRH_OK;
 }
 
@@ -380,18 +436,21 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
       seen[tiles[i]] = 1;
     }
   }
-  // tile ids + frame seeds to the device (stream-ordered behind any kernels still reading the old ones)
-  if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; }
+  // tile ids + frame seeds to the device, stream-ordered behind any kernels still reading the old ones, through pinned staging:
+  // a Redraw() does not wait for the previous one (an unchanged tile list is not sent again)
+  if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; c->h_tile_ids.clear(); }
   if (ns > c->seed_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * ns)); c->seed_cap = ns; }
-  CRH_HIP(hipMemcpyAsync(c->d_tile_ids, tiles, sizeof(uint32_t) * nt, hipMemcpyHostToDevice, c->stream));
-  std::vector<uint32_t> seeds(ns);
+  if (c->h_tile_ids.size() != nt || std::memcmp(c->h_tile_ids.data(), tiles, sizeof(uint32_t) * nt) != 0) {
+    int rc_u = stage_copy(c, c->d_tile_ids, tiles, sizeof(uint32_t) * nt); if (rc_u) return rc_u;
+    c->h_tile_ids.assign(tiles, tiles + nt);
+  }
   {
     // frame seeds: Bullard generator restarted at par.seed, frame n uses next() >> 2
+    std::vector<uint32_t> seeds(ns);
     uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;
     for (uint32_t i = 0; i < first + ns; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; if (i >= first) seeds[i - first] = hi >> 2; }
+    int rc_u = stage_copy(c, c->d_seeds, seeds.data(), sizeof(uint32_t) * ns); if (rc_u) return rc_u;
   }
-  CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * ns, hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));   // host staging buffers may go out of scope
 
   const uint32_t cap_tiles = std::max<uint32_t>(1u, c->max_paths / tpp);
   const uint32_t group = std::min(nt, cap_tiles);
@@ -466,6 +525,7 @@ int adaptive_iteration(crh_ctx* c)
   const uint32_t n = (uint32_t)tiles.size(), tpp = c->par.tile_size * c->par.tile_size;
   if (n > c->tile_cap) { if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * n)); c->tile_cap = n; }
   if (n > c->seed_cap) { if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * n)); c->seed_cap = n; }
+  c->h_tile_ids.clear();
   CRH_HIP(hipMemcpyAsync(c->d_tile_ids, tiles.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
   CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
   CRH_HIP(hipStreamSynchronize(c->stream));
@@ -616,6 +676,10 @@ crh_ctx* crh_create(int device_ordinal)
   if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)std::min<long>(v, 1l << 30); }   // a path slot travels in 31 bits
   if (const char* e = getenv("CRH_GRID")) { int v = atoi(e); if (v > 0) c->grid = v; }
   if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }
+  if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }
+  if (const char* e = getenv("CRH_LANE_MAX_PATHS")) { long v = atol(e); if (v >= 0) c->lane_max_paths = (uint32_t)std::min<long>(v, 1l << 30); }
+  if (const char* e = getenv("CRH_LANE_GRID")) { int v = atoi(e); if (v > 0) c->lane_grid = v; }
+  if (const char* e = getenv("CRH_LANE_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->lane_grid_trace = v; }
   // reference defaults: GI on, depth as vrenderparams default, two-sided (SettingsWidget.cxx:65-90)
   c->par.width = 64; c->par.height = 64; c->par.max_depth = 5; c->par.two_sided = 1; c->par.seed = 1; c->par.tile_size = 32;
   c->par.white_point = 1.0f; c->par.russian_roulette = 1; c->par.env_as_background = 1;
@@ -638,6 +702,9 @@ void crh_destroy(crh_ctx* c)
   if (c->d_assembled) hipFree(c->d_assembled);
   if (c->d_peer_stage) hipFree(c->d_peer_stage);
   for (crh_ctx::Stage& st : c->stage) { if (st.p) hipHostFree(st.p); if (st.ev) hipEventDestroy(st.ev); }
+  for (int k = 0; k < 8; ++k) { if (c->lane_stream[k]) { hipStreamSynchronize(c->lane_stream[k]); hipStreamDestroy(c->lane_stream[k]); } if (c->lane_join[k]) hipEventDestroy(c->lane_join[k]); }
+  if (c->lane_fork) hipEventDestroy(c->lane_fork);
+  if (c->d_lane_counts) hipFree(c->d_lane_counts);
   release_comms(c);
   hipStreamDestroy(c->stream);
   delete c;
@@ -886,6 +953,7 @@ int crh_render(crh_ctx* c, uint32_t n)
         std::vector<uint32_t> seeds(k);
         { uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;
           for (uint32_t i = 0; i < c->frames_done + k; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; if (i >= c->frames_done) seeds[i - c->frames_done] = hi >> 2; } }
+        c->h_tile_ids.clear();
         CRH_HIP(hipMemcpyAsync(c->d_tile_ids, all.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice, c->stream));
         CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * k, hipMemcpyHostToDevice, c->stream));
         CRH_HIP(hipStreamSynchronize(c->stream));

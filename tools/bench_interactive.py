@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""The reference's interactive regime: one Redraw() = +1 sample per pixel per GUI frame (AppViewer.cxx:1045-1047), on a BASELINE
+config at its full resolution.  Prints Redraw/s without look-ahead (crh_set_lookahead(1)) -- free-running, with an LDR read-back
+after every frame (what a GUI that shows every frame does), and with speculative look-ahead 16 for comparison.
+
+  python tools/bench_interactive.py [--config C3] [--frames 64]        (CRH_LANES=1 disables the multi-stream small-batch path)"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401
+from cadrays_amd import scenes
+from cadrays_amd.view import View
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="C3")
+ap.add_argument("--frames", type=int, default=64)
+a = ap.parse_args()
+sc = scenes.baseline_config(a.config)
+v = View(0).load_scene(sc)
+out = {"config": a.config, "lanes": os.environ.get("CRH_LANES", "default"), "lane_grid_trace": os.environ.get("CRH_LANE_GRID_TRACE", "default")}
+for name, k, readback in (("free_running", 1, False), ("with_ldr_readback", 1, True), ("lookahead16_free_running", 16, False)):
+    v.set_lookahead(k); v.reset()
+    for _ in range(8 if k == 1 else 2 * k):
+        v.Redraw()
+    v.sync()
+    n = a.frames if k == 1 else max(a.frames, 4 * k)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        v.Redraw()
+        if readback:
+            v.read_ldr()
+    v.sync()
+    dt = time.perf_counter() - t0
+    st = v.stats()
+    out[name + "_redraw_per_s"] = round(n / dt, 1)
+print(json.dumps(out), flush=True)
