@@ -79,7 +79,9 @@ struct crh_ctx {
   // launch ends with the longest rays of a few wavefronts while the rest of the chip idles.  Such a batch is cut into `n_lanes`
   // tile ranges that run the same wavefront schedule on their own streams and their own slice of the path state, so one
   // range's drain phases overlap the others' busy phases.  Pixels, seeds and the per-pixel accumulation order do not change.
-  uint32_t n_lanes = 4, lane_max_paths = 12u << 20; int lane_grid = 0, lane_grid_trace = 0;
+  // Measured on C3 at 1080p, 1 spp per call (tools/bench_interactive.py): 1 / 2 / 4 / 8 ranges -> 162 / 175 / 114 / 84 Redraw/s: two
+  // concurrent schedules overlap, more of them only add launches that each end in their own ~0.4 ms drain.
+  uint32_t n_lanes = 2, lane_max_paths = 12u << 20; int lane_grid = 0, lane_grid_trace = 0;
   hipStream_t lane_stream[8] = {}; hipEvent_t lane_fork = nullptr, lane_join[8] = {}; uint32_t* d_lane_counts = nullptr;
   std::vector<uint32_t> h_tile_ids;      // what d_tile_ids holds (an unchanged tile list is not uploaded again)
   bool counters_on = false, timing_on = false;

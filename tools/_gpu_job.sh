@@ -1,5 +1,7 @@
-mkdir -p gpurun_out/r2c
-timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r2c/pytest_gpu.log 2>&1; grep -E "^FAILED|passed|failed" gpurun_out/r2c/pytest_gpu.log | cut -c1-200
-timeout 1500 python -m pytest tests -m gpu -q -p no:randomly > gpurun_out/r2c/pytest_gpu2.log 2>&1; grep -E "^FAILED|passed|failed" gpurun_out/r2c/pytest_gpu2.log | cut -c1-200
-python tools/bench_transforms.py 10 30 2>&1 | tee gpurun_out/r2c/bench_transforms.txt
-python bench.py --no-cpu 2>/dev/null | tail -1 > gpurun_out/r2c/bench_C3.json; cut -c1-200 gpurun_out/r2c/bench_C3.json; grep -o '"interactive": {[^}]*}' gpurun_out/r2c/bench_C3.json
+for lib in cadrays_amd/libcadrays_hip.so cadrays_amd/variants/pf16.so cadrays_amd/variants/pf64.so; do
+  echo "== $lib"
+  CRH_LIB_PATH=$PWD/$lib CRH_LANES=1 python tools/bench_interactive.py 2>/dev/null | tail -1
+  CRH_LIB_PATH=$PWD/$lib CRH_LANES=2 python tools/bench_interactive.py 2>/dev/null | tail -1
+  CRH_LIB_PATH=$PWD/$lib python bench.py --no-cpu --no-interactive --steps 3 2>/dev/null | tail -1 | cut -c1-120
+done
+timeout 600 env CRH_LIB_PATH=$PWD/cadrays_amd/variants/pf64.so python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_two_level.py -m gpu -q 2>&1 | tail -2
