@@ -58,7 +58,8 @@ struct crh_ctx {
   float4* d_assembled = nullptr; float4* d_peer_stage = nullptr; uint32_t assembledW = 0, assembledH = 0; bool assembled_valid = false;
   std::vector<ncclComm_t> comms; std::vector<crh_ctx*> comm_ctxs;      // RCCL communicators of the last multi-device group (kept on the root)
   float* d_tile_err = nullptr; uint32_t* d_tile_cnt = nullptr; uint32_t tile_stat_cap = 0;
-  bool show_tiles = false; std::vector<uint8_t> last_picked;                            // ShowSamplingTiles: tiles of the last adaptive iteration
+  bool show_tiles = false; bool picked_valid = false;                                   // ShowSamplingTiles: d_picked marks the tiles of the last adaptive iteration
+  float* d_tile_cdf = nullptr; uint8_t* d_picked = nullptr; uint32_t* d_adapt_n = nullptr;   // adaptive sampler state in HBM (running sum, drawn-tile mask, tile count)
   bool adaptive = false; uint32_t adaptive_tiles = 128; uint32_t adaptive_picks = 0;   // NbRayTracingTiles, Halton index
   // speculative look-ahead for the +1-spp-per-Redraw boundary: frames [pending_first, pending_first + pending_n) are traced
   // and wait in the path buffer (batch sample index pending_off ...) to be folded in by the next crh_render calls
@@ -340,7 +341,7 @@ int do_reset(crh_ctx* c)
   int rc = alloc_accum(c); if (rc) return rc;
   CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, c->stream));
   CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, c->stream));
-  c->adaptive_picks = 0; c->pending_n = 0; c->last_picked.clear(); c->assembled_valid = false;
+  c->adaptive_picks = 0; c->pending_n = 0; c->picked_valid = false; c->assembled_valid = false;
   CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream));
   discard_events(c);
   c->seconds_acc = c->trace_ms_acc = c->all_ms_acc = 0.0; c->trace_launches = 0; c->frames_done = 0;
@@ -349,14 +350,14 @@ int do_reset(crh_ctx* c)
 
 // One batch: `ns` samples of `nt` tiles whose ids sit at d_tiles; seeds at d_seeds.
 // One wavefront schedule: `ns` samples of `nt` tiles (ids at d_tiles, seeds at d_seeds) on one stream and one slice of the path state.
-struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; };
+struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; };
 
 int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile,
              bool accumulate)
 {
   Launch L{ln.stream, ln.grid, c->counters_on};
   Launch LT{ln.stream, ln.grid_trace, c->counters_on};
-  launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile);
+  launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev);
   int qin = 0;
   for (uint32_t b = 0; b < S.max_depth; ++b) {
     if (ln.timed && c->timing_on) {
@@ -370,7 +371,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     if (S.n_lights > 0) launch_trace_any(LT, S, ln.P, ln.Q, c->d_counters);
     qin = 1 - qin;
   }
-  if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, c->d_counters);
+  if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, c->d_counters, ln.n_tiles_dev);
   CRH_HIP(hipGetLastError());
   return CRH_OK;
 }
@@ -482,6 +483,8 @@ int tile_stats(crh_ctx* c, std::vector<float>& err, std::vector<uint32_t>& cnt)
     CRH_HIP(hipStreamSynchronize(c->stream));
     if (c->d_tile_err) CRH_HIP(hipFree(c->d_tile_err));
     if (c->d_tile_cnt) CRH_HIP(hipFree(c->d_tile_cnt));
+    for (void* q : {(void*)c->d_tile_cdf, (void*)c->d_picked, (void*)c->d_adapt_n}) if (q) CRH_HIP(hipFree(q));
+    c->d_tile_cdf = nullptr; c->d_picked = nullptr; c->d_adapt_n = nullptr; c->picked_valid = false;      // the sampler allocates them again at this size
     CRH_HIP(hipMalloc((void**)&c->d_tile_err, sizeof(float) * nt)); CRH_HIP(hipMalloc((void**)&c->d_tile_cnt, sizeof(uint32_t) * nt));
     c->tile_stat_cap = nt;
   }
@@ -495,47 +498,41 @@ int tile_stats(crh_ctx* c, std::vector<float>& err, std::vector<uint32_t>& cnt)
   return CRH_OK;
 }
 
-// One adaptive iteration: pick `adaptive_tiles` tiles with probability proportional to their error estimate (inverse CDF
-// driven by the base-2 radical inverse of a running pick counter), render +1 sample on the distinct tiles picked.
+// One adaptive iteration: draw `adaptive_tiles` tiles with probability proportional to their error estimate (inverse CDF
+// driven by the base-2 radical inverse of a running pick counter), render +1 sample on the distinct tiles drawn.  Everything --
+// error estimate, running sum, draws, tile list, per-tile seeds -- happens in HBM, stream-ordered: the host only advances the
+// pick counter, so a GUI loop of crh_render(1) calls never waits for the device (the reference offers this mode as its
+// responsiveness feature, SettingsWidget.cxx:427-477).
 int adaptive_iteration(crh_ctx* c)
 {
-  std::vector<float> err; std::vector<uint32_t> cnt;
   int rc = upload_textures(c); if (rc) return rc;
-  rc = tile_stats(c, err, cnt); if (rc) return rc;
-  const uint32_t nt = (uint32_t)err.size();
-  std::vector<float> cdf(nt);
-  float acc = 0.f;
-  for (uint32_t i = 0; i < nt; ++i) { acc += err[i] > 0.f ? err[i] : 0.f; cdf[i] = acc; }
-  std::vector<uint8_t> picked(nt, 0);
-  for (uint32_t k = 0; k < c->adaptive_tiles; ++k) {
-    uint32_t v = c->adaptive_picks++;
-    v = (v << 16) | (v >> 16); v = ((v & 0x00ff00ffu) << 8) | ((v & 0xff00ff00u) >> 8); v = ((v & 0x0f0f0f0fu) << 4) | ((v & 0xf0f0f0f0u) >> 4);
-    v = ((v & 0x33333333u) << 2) | ((v & 0xccccccccu) >> 2); v = ((v & 0x55555555u) << 1) | ((v & 0xaaaaaaaau) >> 1);
-    const float u = (float)(v >> 8) * 5.9604644775390625e-8f;
-    uint32_t t;
-    if (!(acc > 0.f)) t = (uint32_t)(u * (float)nt);                       // no estimate yet: uniform
-    else { const float x = u * acc; t = (uint32_t)(std::upper_bound(cdf.begin(), cdf.end(), x) - cdf.begin()); }
-    if (t >= nt) t = nt - 1;
-    picked[t] = 1;
+  const uint32_t ts = c->par.tile_size, tpp = ts * ts;
+  const uint32_t nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
+  const uint32_t most = std::min(c->adaptive_tiles, nt);                // distinct tiles one iteration can draw
+  if (nt > c->tile_stat_cap || !c->d_tile_cdf) {
+    CRH_HIP(hipStreamSynchronize(c->stream));
+    for (void* q : {(void*)c->d_tile_err, (void*)c->d_tile_cnt, (void*)c->d_tile_cdf, (void*)c->d_picked, (void*)c->d_adapt_n}) if (q) CRH_HIP(hipFree(q));
+    c->d_tile_err = nullptr; c->d_tile_cnt = nullptr; c->d_tile_cdf = nullptr; c->d_picked = nullptr; c->d_adapt_n = nullptr; c->tile_stat_cap = 0;
+    CRH_HIP(hipMalloc((void**)&c->d_tile_err, sizeof(float) * nt)); CRH_HIP(hipMalloc((void**)&c->d_tile_cnt, sizeof(uint32_t) * nt));
+    CRH_HIP(hipMalloc((void**)&c->d_tile_cdf, sizeof(float) * nt)); CRH_HIP(hipMalloc((void**)&c->d_picked, nt)); CRH_HIP(hipMalloc((void**)&c->d_adapt_n, 64));
+    c->tile_stat_cap = std::max(nt, c->tile_stat_cap);
   }
-  c->last_picked = picked;
-  std::vector<uint32_t> tiles, seeds; uint32_t maxc = 0;
-  for (uint32_t i = 0; i < nt; ++i) if (picked[i]) { tiles.push_back(i); maxc = std::max(maxc, cnt[i]); }
-  std::vector<uint32_t> table(maxc + 1);
-  { uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u; for (uint32_t i = 0; i <= maxc; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; table[i] = hi >> 2; } }
-  for (uint32_t t : tiles) seeds.push_back(table[cnt[t]]);
-  const uint32_t n = (uint32_t)tiles.size(), tpp = c->par.tile_size * c->par.tile_size;
-  if (n > c->tile_cap) { if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * n)); c->tile_cap = n; }
-  if (n > c->seed_cap) { if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * n)); c->seed_cap = n; }
-  c->h_tile_ids.clear();
-  CRH_HIP(hipMemcpyAsync(c->d_tile_ids, tiles.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
-  rc = ensure_paths(c, n * tpp); if (rc) return rc;
+  if (most > c->tile_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * most)); c->tile_cap = most; }
+  if (most > c->seed_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * most)); c->seed_cap = most; }
+  c->h_tile_ids.clear();                                                // the device is about to write its own list there
+  rc = ensure_paths(c, most * tpp); if (rc) return rc;
   DScene S; fill_scene(c, S);
   hipEvent_t e0 = get_event(c), e1 = get_event(c);
   hipEventRecord(e0, c->stream);
-  rc = run_batch(c, S, c->d_tile_ids, n, c->d_seeds, 1, 1); if (rc) return rc;
+  Launch L{c->stream, c->grid, false};
+  launch_tile_error(L, S, c->d_accum, c->d_m2, c->d_tile_err, c->d_tile_cnt, nt);
+  launch_adaptive_pick(L, c->d_tile_err, c->d_tile_cnt, nt, c->adaptive_picks, c->adaptive_tiles, c->par.seed, c->d_tile_cdf, c->d_picked,
+                       c->d_tile_ids, c->d_seeds, c->d_adapt_n);
+  c->adaptive_picks += c->adaptive_tiles; c->picked_valid = true;
+  c->pending_n = 0;
+  Lane ln{c->stream, c->paths, c->queues, c->grid, c->grid_trace, true};
+  ln.n_tiles_dev = c->d_adapt_n;
+  rc = run_lane(c, ln, S, c->d_tile_ids, most, c->d_seeds, 1, 1, true); if (rc) return rc;
   hipEventRecord(e1, c->stream);
   c->render_ev.emplace_back(e0, e1);
   return trim_events(c);
@@ -707,6 +704,7 @@ void crh_destroy(crh_ctx* c)
   for (int k = 0; k < 8; ++k) { if (c->lane_stream[k]) { hipStreamSynchronize(c->lane_stream[k]); hipStreamDestroy(c->lane_stream[k]); } if (c->lane_join[k]) hipEventDestroy(c->lane_join[k]); }
   if (c->lane_fork) hipEventDestroy(c->lane_fork);
   if (c->d_lane_counts) hipFree(c->d_lane_counts);
+  for (void* q : {(void*)c->d_tile_cdf, (void*)c->d_picked, (void*)c->d_adapt_n}) if (q) hipFree(q);
   release_comms(c);
   hipStreamDestroy(c->stream);
   delete c;
@@ -1044,13 +1042,9 @@ int crh_read_ldr(crh_ctx* c, uint8_t* out)
   CRH_HIP(hipSetDevice(c->device));
   const uint32_t n = c->par.width * c->par.height;
   const uint32_t ts = c->par.tile_size, n_tiles = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
-  const bool overlay = c->show_tiles && c->adaptive && c->last_picked.size() == n_tiles;
-  int rc = ensure_scratch(c, 3 * (size_t)n + (overlay ? n_tiles : 0)); if (rc) return rc;
-  uint8_t* d_mask = nullptr;
-  if (overlay) {
-    d_mask = (uint8_t*)c->d_scratch + 3 * (size_t)n;
-    CRH_HIP(hipMemcpyAsync(d_mask, c->last_picked.data(), n_tiles, hipMemcpyHostToDevice, c->stream));
-  }
+  const bool overlay = c->show_tiles && c->adaptive && c->picked_valid && c->d_picked && c->tile_stat_cap >= n_tiles;
+  int rc = ensure_scratch(c, 3 * (size_t)n); if (rc) return rc;
+  const uint8_t* d_mask = overlay ? c->d_picked : nullptr;            // written by the device-side tile draw of the last iteration
   Launch L{c->stream, c->grid, false};
   launch_tonemap(L, c->assembled_valid ? c->d_assembled : c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, d_mask, c->par.width, ts);
   CRH_HIP(hipMemcpyAsync(out, c->d_scratch, 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));

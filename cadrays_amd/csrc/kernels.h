@@ -13,7 +13,7 @@ struct Launch {
 // camera rays for n_samples x n_tiles x tile^2 path slots; fills queue `qsel` and its count
 void launch_raygen(const Launch&, const DScene&, const DPaths&, const DQueues&, int qsel,
                    const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_frame_seeds, uint32_t n_samples,
-                   int seed_per_tile = 0);
+                   int seed_per_tile = 0, const uint32_t* d_n_tiles = nullptr /* tile count in HBM (device-drawn tile list) */);
 // nearest-hit traversal of queue `qin`; also zeroes the other queue's count and the shadow count
 void launch_trace_nearest(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, DCounters*);
 // emission, NEE, BSDF sampling, Russian roulette; survivors -> queue 1-qin, shadow rays -> q_sh
@@ -23,7 +23,12 @@ void launch_trace_any(const Launch&, const DScene&, const DPaths&, const DQueues
 // clamp + running mean of the finished paths of batch samples [first_sample, first_sample + n_samples) into the float4
 // accumulator, sample by sample
 void launch_accumulate(const Launch&, const DScene&, const DPaths&, float4* accum, float* m2 /* or nullptr */,
-                       const uint32_t* d_tile_ids, uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, DCounters*);
+                       const uint32_t* d_tile_ids, uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, DCounters*,
+                       const uint32_t* d_n_tiles = nullptr);
+// adaptive tile sampler, device side: running sum of the tile errors, n_picks inverse-CDF draws (radical inverse of pick0 + k),
+// the distinct tiles in ascending order with their per-tile frame seeds and their number -- all left in HBM
+void launch_adaptive_pick(const Launch&, const float* tile_err, const uint32_t* tile_cnt, uint32_t n_tiles_total, uint32_t pick0, uint32_t n_picks,
+                          uint32_t seed, float* cdf, uint8_t* picked, uint32_t* tiles_out, uint32_t* seeds_out, uint32_t* n_out);
 // adaptive tile sampler: per-tile mean standard error and minimum per-pixel sample count (one workgroup per tile)
 void launch_tile_error(const Launch&, const DScene&, const float4* accum, const float* m2, float* tile_err,
                        uint32_t* tile_min_count, uint32_t n_tiles_total);

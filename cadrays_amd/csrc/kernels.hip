@@ -720,8 +720,10 @@ __device__ __forceinline__ bool slot_pixel(const DScene& S, const uint32_t* __re
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t* __restrict__ q, uint32_t* __restrict__ count,
                                                     uint32_t* __restrict__ cursors,
                                                     const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
-                                                    const uint32_t* __restrict__ seeds, uint32_t n_samples, int seed_per_tile)
+                                                    const uint32_t* __restrict__ seeds, uint32_t n_samples, int seed_per_tile,
+                                                    const uint32_t* __restrict__ n_tiles_dev)
 {
+  if (n_tiles_dev) n_tiles = *n_tiles_dev;          // the tile list was drawn on the device (adaptive sampling): its length lives there too
   // Queue space is reserved ONCE per chunk of kGenIters x 256 slots: pass 1 counts the slots that map to a pixel
   // inside the image (edge tiles are partial), one atomic reserves the range, pass 2 generates the rays and writes
   // their ids at exclusive-scan offsets.  (Per-workgroup appends were atomic-rate bound: 261 K atomics per 67 M paths.)
@@ -983,8 +985,10 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
 // ================================================================== accumulate / display
 __global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float4* __restrict__ accum, float* __restrict__ m2,
                                                         const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
-                                                        uint32_t first_sample, uint32_t n_samples, DCounters* C)
+                                                        uint32_t first_sample, uint32_t n_samples, DCounters* C,
+                                                        const uint32_t* __restrict__ n_tiles_dev)
 {
+  if (n_tiles_dev) n_tiles = *n_tiles_dev;
   // samples [first_sample, first_sample + n_samples) of the batch in the path buffer are folded in, in order
   const uint32_t per_sample = n_tiles * S.tile_size * S.tile_size;
   uint32_t done = 0;
@@ -1058,6 +1062,72 @@ __global__ __launch_bounds__(kBlock) void k_tile_error(DScene S, const float4* _
     tile_err[tile] = s_n[0] > 0.f ? s_e[0] / s_n[0] : 0.f;
     tile_min_count[tile] = s_n[0] > 0.f ? (uint32_t)s_c[0] : 0u;
   }
+}
+
+// Adaptive tile selection on the device (reference: AdaptiveScreenSampling / NbRayTracingTiles, SettingsWidget.cxx:427-477; the
+// rule itself is DESIGN.md section 7 and the CPU oracle's adaptive_iteration): inverse-CDF draws driven by the base-2 radical
+// inverse of a running pick counter, +1 sample on every distinct tile drawn, each at its own sample index.  ONE workgroup; the
+// running sum of the errors is taken by one lane in tile order (the oracle's float summation order decides ties), through LDS
+// in chunks; draws and the ordered compaction are parallel.  Nothing goes through the host: the tile list, its length and the
+// per-tile frame seeds stay in HBM for k_raygen / k_accumulate.
+constexpr uint32_t kPickChunk = 4096;
+__global__ __launch_bounds__(kBlock) void k_adaptive_pick(const float* __restrict__ tile_err, const uint32_t* __restrict__ tile_cnt, uint32_t nt,
+                                                           uint32_t pick0, uint32_t n_picks, uint32_t seed, float* __restrict__ cdf,
+                                                           uint8_t* __restrict__ picked, uint32_t* __restrict__ tiles_out,
+                                                           uint32_t* __restrict__ seeds_out, uint32_t* __restrict__ n_out)
+{
+  __shared__ float s_v[kPickChunk];
+  __shared__ uint32_t s_part[kBlock];
+  __shared__ float s_acc;
+  if (threadIdx.x == 0) s_acc = 0.f;
+  for (uint32_t i = threadIdx.x; i < nt; i += kBlock) picked[i] = 0;
+  for (uint32_t c0 = 0; c0 < nt; c0 += kPickChunk) {
+    const uint32_t m = min(kPickChunk, nt - c0);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += kBlock) { const float e = tile_err[c0 + i]; s_v[i] = e > 0.f ? e : 0.f; }
+    __syncthreads();
+    if (threadIdx.x == 0) { float a = s_acc; for (uint32_t i = 0; i < m; ++i) { a += s_v[i]; s_v[i] = a; } s_acc = a; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += kBlock) cdf[c0 + i] = s_v[i];
+  }
+  __threadfence_block();
+  __syncthreads();
+  const float acc = s_acc;
+  for (uint32_t k = threadIdx.x; k < n_picks; k += kBlock) {
+    const uint32_t v = __brev(pick0 + k);
+    const float u = (float)(v >> 8) * 5.9604644775390625e-8f;
+    uint32_t t;
+    if (!(acc > 0.f)) t = (uint32_t)(u * (float)nt);                    // no estimate yet: uniform
+    else {                                                              // first tile whose running sum exceeds x
+      const float x = u * acc;
+      uint32_t lo = 0, hi = nt;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cdf[mid] > x) hi = mid; else lo = mid + 1; }
+      t = lo;
+    }
+    if (t >= nt) t = nt - 1u;
+    picked[t] = 1;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ordered compaction: thread j owns tiles [j * per, (j + 1) * per)
+  const uint32_t per = (nt + kBlock - 1) / kBlock, b0 = min(nt, threadIdx.x * per), b1 = min(nt, b0 + per);
+  uint32_t mine = 0;
+  for (uint32_t i = b0; i < b1; ++i) mine += picked[i];
+  s_part[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t a = 0; for (int j = 0; j < kBlock; ++j) { const uint32_t v = s_part[j]; s_part[j] = a; a += v; } *n_out = a; }
+  __syncthreads();
+  uint32_t w = s_part[threadIdx.x];
+  for (uint32_t i = b0; i < b1; ++i)
+    if (picked[i]) {
+      tiles_out[w] = i;
+      // the tile's own sample index selects its frame seed: Bullard generator restarted at `seed`, frame n uses next() >> 2
+      uint32_t hi = seed, lo = seed ^ 0x49616E42u, r = 0;
+      const uint32_t n = tile_cnt[i];
+      for (uint32_t j = 0; j <= n; ++j) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; r = hi; }
+      seeds_out[w] = r >> 2;
+      ++w;
+    }
 }
 
 __device__ __forceinline__ float hable(float x)
@@ -1173,10 +1243,11 @@ __global__ void k_debug_bsdf(int fn, const float4* __restrict__ m, const float* 
 
 // ================================================================== launch wrappers
 void launch_raygen(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qsel,
-                   const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds, uint32_t n_samples, int seed_per_tile)
+                   const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds, uint32_t n_samples, int seed_per_tile,
+                   const uint32_t* d_n_tiles)
 {
   hipMemsetAsync(Q.counts + qsel, 0, sizeof(uint32_t), L.stream);
-  hipLaunchKernelGGL(k_raygen, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile);
+  hipLaunchKernelGGL(k_raygen, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile, d_n_tiles);
 }
 void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, DCounters* C)
 {
@@ -1199,14 +1270,19 @@ void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const D
 #undef CRH_LAUNCH_TA
 }
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,
-                       uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, DCounters* C)
+                       uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, DCounters* C, const uint32_t* d_n_tiles)
 {
-  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, m2, d_tile_ids, n_tiles, first_sample, n_samples, C);
+  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, m2, d_tile_ids, n_tiles, first_sample, n_samples, C, d_n_tiles);
 }
 void launch_tile_error(const Launch& L, const DScene& S, const float4* accum, const float* m2, float* tile_err, uint32_t* tile_min_count,
                        uint32_t n_tiles_total)
 {
   hipLaunchKernelGGL(k_tile_error, dim3(n_tiles_total), dim3(kBlock), 0, L.stream, S, accum, m2, tile_err, tile_min_count);
+}
+void launch_adaptive_pick(const Launch& L, const float* tile_err, const uint32_t* tile_cnt, uint32_t n_tiles_total, uint32_t pick0, uint32_t n_picks,
+                          uint32_t seed, float* cdf, uint8_t* picked, uint32_t* tiles_out, uint32_t* seeds_out, uint32_t* n_out)
+{
+  hipLaunchKernelGGL(k_adaptive_pick, dim3(1), dim3(kBlock), 0, L.stream, tile_err, tile_cnt, n_tiles_total, pick0, n_picks, seed, cdf, picked, tiles_out, seeds_out, n_out);
 }
 void launch_tonemap(const Launch& L, const float4* accum, uint8_t* out, uint32_t n, int mode, float exposure, float wp,
                     const uint8_t* tile_mask, uint32_t width, uint32_t tile_size)

@@ -32,4 +32,27 @@ for name, k, readback in (("free_running", 1, False), ("with_ldr_readback", 1, T
     dt = time.perf_counter() - t0
     st = v.stats()
     out[name + "_redraw_per_s"] = round(n / dt, 1)
+# adaptive screen sampling (SettingsWidget.cxx:427-477): NbRayTracingTiles tiles per iteration, drawn on the device; beside it a
+# plain render of as many fixed tiles per call (equal paths per iteration)
+import numpy as np
+for ntiles in (128, 512):
+    v.set_lookahead(1); v.set_adaptive(True, ntiles)
+    for _ in range(16):
+        v.Redraw()
+    v.sync()
+    t0 = time.perf_counter()
+    for _ in range(4 * a.frames):
+        v.Redraw()
+    v.sync()
+    out[f"adaptive_{ntiles}_tiles_redraw_per_s"] = round(4 * a.frames / (time.perf_counter() - t0), 1)
+    v.set_adaptive(False, ntiles)
+    tiles = np.random.default_rng(1).permutation(v.n_tiles())[:ntiles].astype(np.uint32)
+    for i in range(16):
+        v.render_tiles(tiles, i, 1)
+    v.sync()
+    t0 = time.perf_counter()
+    for i in range(4 * a.frames):
+        v.render_tiles(tiles, 16 + i, 1)
+    v.sync()
+    out[f"fixed_{ntiles}_tiles_calls_per_s"] = round(4 * a.frames / (time.perf_counter() - t0), 1)
 print(json.dumps(out), flush=True)
