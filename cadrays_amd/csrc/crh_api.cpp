@@ -25,6 +25,7 @@ using namespace crh;
 struct crh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  int cus = 0;            // compute units (0: unknown)
   int grid = 2048;        // streaming / shading kernels: 8 workgroups per CU
   int grid_trace = 1536;  // traversal kernels: 6 workgroups (= 6 waves/SIMD) per CU -- measured: 4 / 5 / 6 / 7 / 8 per CU -> 3300 / 3424 /
                           // 3448 / 3448 / 3443 Mrays/s on C3 (more rays in flight enlarge the working set the 4 MB-per-XCD L2s hold)
@@ -76,6 +77,7 @@ struct crh_ctx {
   size_t cap_nodes = 0, cap_inst = 0, cap_mats = 0, cap_lights = 0, cap_env = 0;
   struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } stage[4];
   uint32_t stage_next = 0;
+  bool clamp_grid = true;   // CRH_CLAMP_GRID=0: A/B switch for the occupancy clamp of the traversal grids
   // Small batches (one Redraw() = +1 spp of one frame, AppViewer.cxx:1045-1047) are launch- and drain-bound: every traversal
   // launch ends with the longest rays of a few wavefronts while the rest of the chip idles.  Such a batch is cut into `n_lanes`
   // tile ranges that run the same wavefront schedule on their own streams and their own slice of the path state, so one
@@ -356,7 +358,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
              bool accumulate)
 {
   Launch L{ln.stream, ln.grid, c->counters_on};
-  Launch LT{ln.stream, ln.grid_trace, c->counters_on};
+  Launch LT{ln.stream, ln.grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0};
   launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev);
   int qin = 0;
   for (uint32_t b = 0; b < S.max_depth; ++b) {
@@ -671,10 +673,11 @@ crh_ctx* crh_create(int device_ordinal)
     delete c; return nullptr;
   }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->grid = prop.multiProcessorCount * 8; c->grid_trace = prop.multiProcessorCount * 6; }
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->cus = prop.multiProcessorCount; c->grid = prop.multiProcessorCount * 8; c->grid_trace = prop.multiProcessorCount * 6; }
   if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)std::min<long>(v, 1l << 30); }   // a path slot travels in 31 bits
   if (const char* e = getenv("CRH_GRID")) { int v = atoi(e); if (v > 0) c->grid = v; }
   if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }
+  if (const char* e = getenv("CRH_CLAMP_GRID")) c->clamp_grid = atoi(e) != 0;
   if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }
   if (const char* e = getenv("CRH_LANE_MAX_PATHS")) { long v = atol(e); if (v >= 0) c->lane_max_paths = (uint32_t)std::min<long>(v, 1l << 30); }
   if (const char* e = getenv("CRH_LANE_GRID")) { int v = atoi(e); if (v > 0) c->lane_grid = v; }
@@ -1116,7 +1119,7 @@ static int trace_api(crh_ctx* c, const float* rays, uint32_t n, int any_hit, flo
   char* base = (char*)c->d_scratch;
   CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
   DScene S; fill_scene(c, S);
-  Launch L{c->stream, c->grid_trace, c->counters_on};
+  Launch L{c->stream, c->grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0};
   launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
   CRH_HIP(hipGetLastError());
   CRH_HIP(hipMemcpyAsync(any_hit ? (void*)out_vis : (void*)out_hit, base + in_b, out_b, hipMemcpyDeviceToHost, c->stream));
@@ -1161,7 +1164,7 @@ int crh_bench_trace(crh_ctx* c, const float* rays, uint32_t n, int any_hit, uint
   char* base = (char*)c->d_scratch;
   CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
   DScene S; fill_scene(c, S);
-  Launch L{c->stream, c->grid_trace, false};
+  Launch L{c->stream, c->grid_trace, false, c->clamp_grid ? c->cus : 0};
   launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
   hipEvent_t e0 = get_event(c), e1 = get_event(c);
   CRH_HIP(hipEventRecord(e0, c->stream));

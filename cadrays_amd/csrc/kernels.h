@@ -8,6 +8,7 @@ struct Launch {
   hipStream_t stream;
   int grid;          // workgroups for the grid-stride kernels
   bool counters;     // collect node / triangle counters (slower)
+  int cus = 0;       // compute units of the device: persistent traversal grids are clamped to what is resident at once (0: as given)
 };
 
 // camera rays for n_samples x n_tiles x tile^2 path slots; fills queue `qsel` and its count

@@ -1249,9 +1249,19 @@ void launch_raygen(const Launch& L, const DScene& S, const DPaths& P, const DQue
   hipMemsetAsync(Q.counts + qsel, 0, sizeof(uint32_t), L.stream);
   hipLaunchKernelGGL(k_raygen, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile, d_n_tiles);
 }
+// A persistent traversal grid larger than what the register budget keeps resident leaves workgroups queued behind the first
+// wave of them, i.e. a second, nearly empty round at the end of every launch: clamp the grid to occupancy x compute units.
+template <auto Kernel> static int resident_grid(const Launch& L)
+{
+  if (L.cus <= 0) return L.grid;
+  static int per_cu = 0;                      // one instance per kernel (the kernel is a template argument, not just its type)
+  if (per_cu == 0) { int n = 0; per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, Kernel, kBlock, 0) == hipSuccess && n > 0) ? n : -1; }
+  return per_cu > 0 ? min(L.grid, per_cu * L.cus) : L.grid;
+}
+
 void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, DCounters* C)
 {
-#define CRH_LAUNCH_TN(CNT, TWO) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, qin, Q.q[qin], \
+#define CRH_LAUNCH_TN(CNT, TWO) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO>), dim3(resident_grid<k_trace_nearest<CNT, TWO>>(L)), dim3(kBlock), 0, L.stream, S, P, qin, Q.q[qin], \
                                                    Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, C)
   if (S.two_level) { if (L.counters) CRH_LAUNCH_TN(true, true); else CRH_LAUNCH_TN(false, true); }
   else             { if (L.counters) CRH_LAUNCH_TN(true, false); else CRH_LAUNCH_TN(false, false); }
@@ -1264,7 +1274,7 @@ void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueu
 }
 void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, DCounters* C)
 {
-#define CRH_LAUNCH_TA(CNT, TWO) hipLaunchKernelGGL((k_trace_any<CNT, TWO>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C)
+#define CRH_LAUNCH_TA(CNT, TWO) hipLaunchKernelGGL((k_trace_any<CNT, TWO>), dim3(resident_grid<k_trace_any<CNT, TWO>>(L)), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C)
   if (S.two_level) { if (L.counters) CRH_LAUNCH_TA(true, true); else CRH_LAUNCH_TA(false, true); }
   else             { if (L.counters) CRH_LAUNCH_TA(true, false); else CRH_LAUNCH_TA(false, false); }
 #undef CRH_LAUNCH_TA
@@ -1301,7 +1311,7 @@ void launch_trace_rays(const Launch& L, const DScene& S, const float4* rays, uin
                        uint32_t* out_vis, uint32_t* cursor, DCounters* C)
 {
   hipMemsetAsync(cursor, 0, sizeof(uint32_t), L.stream);
-#define CRH_LAUNCH_TR(ANY, CNT, TWO) hipLaunchKernelGGL((k_trace_rays<ANY, CNT, TWO>), dim3(L.grid), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C)
+#define CRH_LAUNCH_TR(ANY, CNT, TWO) hipLaunchKernelGGL((k_trace_rays<ANY, CNT, TWO>), dim3(resident_grid<k_trace_rays<ANY, CNT, TWO>>(L)), dim3(kBlock), 0, L.stream, S, rays, n, cursor, out_hit, out_vis, C)
 #define CRH_LAUNCH_TR2(ANY, CNT) { if (S.two_level) CRH_LAUNCH_TR(ANY, CNT, true); else CRH_LAUNCH_TR(ANY, CNT, false); }
   if (any_hit) { if (L.counters) CRH_LAUNCH_TR2(true, true) else CRH_LAUNCH_TR2(true, false) }
   else         { if (L.counters) CRH_LAUNCH_TR2(false, true) else CRH_LAUNCH_TR2(false, false) }
