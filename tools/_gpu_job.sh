@@ -1,5 +1,3 @@
-for cl in 0 1; do
-  echo "== CRH_CLAMP_GRID=$cl"
-  for cfg in C2 C3; do CRH_CLAMP_GRID=$cl python bench.py --config $cfg --no-cpu --no-interactive --steps 3 2>/dev/null | tail -1 | cut -c1-110; done
-  CRH_CLAMP_GRID=$cl python tools/bench_two_level.py 10 32 2>/dev/null | tail -1
-done
+mkdir -p gpurun_out/r2g
+python bench.py 2> gpurun_out/r2g/bench_C3.err | tail -1 > gpurun_out/r2g/bench_C3.json; cat gpurun_out/r2g/bench_C3.json
+bash profiles/pmc_collect.sh r2g C3 C2 C5 > gpurun_out/r2g/pmc.log 2>&1; tail -3 gpurun_out/r2g/pmc.log | cut -c1-300
