@@ -6,11 +6,13 @@
 //   loop: View->Redraw() once per frame, count frames      src/Launcher/AppViewer.cxx:1045-1071
 //   BufferDump(Graphic3d_BT_RGB) after the last frame      src/Launcher/AppViewer.cxx:1255-1264
 //   write Output_<name>_<n>.png and Output_<name>_<n>.txt (average frame rate)   main.cxx:193-228
-// Here: cadrays_headless <scene.crhscene> <nFrames> [device] [lookahead] [gpus] writes Output_<name>_<n>.ppm (LDR),
+// Here: cadrays_headless <scene.crhscene | model.tcl> <nFrames> [device] [lookahead] [gpus] [WxH] writes Output_<name>_<n>.ppm (LDR),
 // Output_<name>_<n>.pfm (linear HDR, the parity buffer of AppGui.cxx:345-349) and Output_<name>_<n>.txt.
 // gpus > 1: one context per GPU (devices device .. device+gpus-1; CRH_HEADLESS_SHARE_DEVICE=1 keeps them all on `device`),
 // screen tiles interleaved across the contexts, one host thread per context, crh_reduce (RCCL over xGMI) assembles the
 // frame on context 0 -- bit-identical to the one-GPU image.
+// A path ending in .tcl is the reference's own saved-scene format (model.tcl + meshes/ + textures/, what File > Export writes and
+// ImportSettingsEditor.cxx:378-380 sources back in): read by host/model_tcl.hpp at WxH (default 512x512).
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -21,6 +23,7 @@
 #include <vector>
 
 #include "../../include/cadrays_hip.h"
+#include "model_tcl.hpp"
 
 namespace {
 
@@ -34,7 +37,7 @@ template <class T> bool read_vec(FILE* f, std::vector<T>& v, size_t n)
 
 int main(int argc, char** argv)
 {
-  if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene> <nFrames> [device] [lookahead] [gpus]\n", argv[0]); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene | model.tcl> <nFrames> [device] [lookahead] [gpus] [WxH]\n", argv[0]); return 2; }
   const std::string path = argv[1];
   const int n_frames = atoi(argv[2]);
   const int device = argc > 3 ? atoi(argv[3]) : 0;
@@ -42,18 +45,31 @@ int main(int argc, char** argv)
   const int n_gpus = argc > 5 ? atoi(argv[5]) : 1;
   if (n_frames <= 0 || n_gpus <= 0) { fprintf(stderr, "nFrames and gpus must be > 0\n"); return 2; }
 
+  crh_camera cam; crh_params par;
+  std::vector<float> pos, nrm, env; std::vector<int32_t> tri; std::vector<crh_bsdf> mats; std::vector<crh_light> lights;
+  struct Tex { uint32_t w = 0, h = 0, ch = 0; std::vector<float> texels; };
+  std::vector<float> uv, xform; std::vector<int32_t> tri_obj; std::vector<Tex> textures; uint32_t nO = 0;
+  uint32_t nV = 0, nT = 0, nM = 0, nL = 0, eW = 0, eH = 0;
+  if (path.size() > 4 && path.substr(path.size() - 4) == ".tcl") {
+    uint32_t w = 512, h = 512;
+    if (argc > 6 && sscanf(argv[6], "%ux%u", &w, &h) != 2) { fprintf(stderr, "bad size %s (WxH)\n", argv[6]); return 2; }
+    crh_host::TclScene sc; std::string err;
+    if (!crh_host::read_model_tcl(path, w, h, sc, err)) { fprintf(stderr, "cadrays_headless: %s\n", err.c_str()); return 1; }
+    for (const std::string& u : sc.unsupported) fprintf(stderr, "cadrays_headless: not honoured: %s\n", u.c_str());
+    cam = sc.cam; par = sc.par; pos.swap(sc.pos); nrm.swap(sc.nrm); uv.swap(sc.uv); tri.swap(sc.tri); mats.swap(sc.mats); lights.swap(sc.lights);
+    env.swap(sc.env); eW = sc.envW; eH = sc.envH;
+    textures.resize(sc.textures.size());
+    for (size_t i = 0; i < textures.size(); ++i) { textures[i].w = sc.textures[i].w; textures[i].h = sc.textures[i].h; textures[i].ch = sc.textures[i].ch; textures[i].texels.swap(sc.textures[i].texels); }
+    nV = (uint32_t)(pos.size() / 3); nT = (uint32_t)(tri.size() / 4); nM = (uint32_t)mats.size(); nL = (uint32_t)lights.size();
+  } else {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { perror(path.c_str()); return 1; }
   char magic[4]; uint32_t hdr[7];
   if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "CRHS", 4) != 0 || fread(hdr, 4, 7, f) != 7 || (hdr[0] != 1 && hdr[0] != 2)) { fprintf(stderr, "not a .crhscene v1/v2 file\n"); return 1; }
-  const uint32_t nV = hdr[1], nT = hdr[2], nM = hdr[3], nL = hdr[4], eW = hdr[5], eH = hdr[6];
-  crh_camera cam; crh_params par;
-  std::vector<float> pos, nrm, env; std::vector<int32_t> tri; std::vector<crh_bsdf> mats; std::vector<crh_light> lights;
+  nV = hdr[1]; nT = hdr[2]; nM = hdr[3]; nL = hdr[4]; eW = hdr[5]; eH = hdr[6];
   bool ok = fread(&cam, sizeof cam, 1, f) == 1 && fread(&par, sizeof par, 1, f) == 1 && read_vec(f, pos, 3 * (size_t)nV) && read_vec(f, nrm, 3 * (size_t)nV) &&
             read_vec(f, tri, 4 * (size_t)nT) && read_vec(f, mats, nM) && read_vec(f, lights, nL) && read_vec(f, env, 3 * (size_t)eW * eH);
   // version 2: texture coordinates, the two-level (per-object transform) description and the Kd textures
-  struct Tex { uint32_t w = 0, h = 0, ch = 0; std::vector<float> texels; };
-  std::vector<float> uv, xform; std::vector<int32_t> tri_obj; std::vector<Tex> textures; uint32_t nO = 0;
   if (ok && hdr[0] >= 2) {
     uint32_t ext[3];
     ok = fread(ext, 4, 3, f) == 3;
@@ -68,6 +84,7 @@ int main(int argc, char** argv)
   }
   fclose(f);
   if (!ok) { fprintf(stderr, "truncated scene file\n"); return 1; }
+  }
 
   // one context per GPU (== driver + viewer + view + FBO, AppViewer.cxx:601-638), each holding the whole scene
   const bool share = getenv("CRH_HEADLESS_SHARE_DEVICE") != nullptr;

@@ -1,10 +1,13 @@
 """Scene wire format: the restricted Tcl evaluator, the reader of CADRays'
 exported model.tcl + binary PLY, the writer that emits the exporter's layout, and -- when the reference tree is
 mounted -- the reference's own demo scripts parsed into the same BSDF vectors the hand-restated fixtures hold."""
+import dataclasses
 import os
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from cadrays_amd import scenes
 from cadrays_amd.scene_tcl import MiniTcl, TclError, read_ply, read_scene, write_ply, write_scene
@@ -393,3 +396,67 @@ def test_obj_with_mtl_renders_bit_exact_on_gpu(hip_lib, oracle_lib, tmp_path):
     o = oracle_lib.Oracle().load_scene(sc); o.render(4)
     a, r = v.read_hdr(), o.read_hdr()
     assert np.array_equal(a.view(np.uint32), r.view(np.uint32)) and a.max() > 0.1          # lit by the emissive ceiling of the .mtl
+
+
+# ---- the C++ reader of the saved-scene format (host/model_tcl.hpp; the reference host is C++ and re-imports by sourcing model.tcl,
+# ImportSettingsEditor.cxx:378-380) must understand a model.tcl exactly like the Python reader does
+def _cpp_dump(model, out, size="80x60"):
+    import subprocess
+    host = os.path.join(ROOT, "cadrays_amd", "host")
+    exe = os.path.join(host, "model_tcl_dump")
+    if not os.path.exists(exe) or os.path.getmtime(os.path.join(host, "model_tcl.hpp")) > os.path.getmtime(exe):
+        subprocess.check_call(["make", "-s", "-C", host, "model_tcl_dump"])
+    p = subprocess.run([exe, str(model), str(out), size], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return p.stderr
+
+
+def _exported_scene(tmp_path):
+    sc = scenes.materials_scene(80, 60, 16, 8)
+    r = np.random.default_rng(5)
+    uv = (r.random((len(sc.pos), 2)) * 3).astype(np.float32)
+    tex = (r.random((8, 8, 3)) * 0.9 + 0.05).astype(np.float32)
+    atex = np.concatenate([(r.random((4, 4, 3))).astype(np.float32), (r.random((4, 4, 1)) > 0.5).astype(np.float32)], 2)
+    mats = [dataclasses.replace(m) for m in sc.materials]
+    mats[0] = dataclasses.replace(mats[0], texture=0); mats[2] = dataclasses.replace(mats[2], texture=1)
+    env = (r.random((16, 32, 3)) * 0.8).astype(np.float32)
+    lights = list(sc.lights) + [scenes.Light.positional((0.5, -2.0, 3.0), smoothness=0.25, intensity=40.0, color=(1.0, 0.5, 0.25))]
+    sc = dataclasses.replace(sc, uv=uv, textures=[tex, atex], materials=mats, env=env, lights=lights)
+    from cadrays_amd.scene_tcl import write_scene
+    return sc, write_scene(sc, str(tmp_path / "export"))
+
+
+def test_cpp_reader_understands_model_tcl_like_the_python_reader(tmp_path):
+    from cadrays_amd import scene_io
+    from cadrays_amd.scene_tcl import read_scene
+    sc, model = _exported_scene(tmp_path)
+    with open(model, "a") as f:                                   # what the exporter adds for moved objects (ImportExport.cxx:276-305)
+        f.write("vlocation Mesh1 -scale 1.5\nvlocation Mesh1 -location 0.25 -0.5 0.125\nvlocation Mesh3 -location 0 0 0.0625\n")
+    py, b = read_scene(model, 80, 60)
+    a_path, b_path = tmp_path / "py.crhscene", tmp_path / "cpp.crhscene"
+    scene_io.save_scene(py, str(a_path))
+    warn = _cpp_dump(model, b_path)
+    assert "not honoured" not in warn and not b.unsupported
+    A, B = a_path.read_bytes(), b_path.read_bytes()
+    assert len(A) == len(B) and A == B, "the C++ reader and the Python reader disagree about model.tcl"
+    # the straight-line subset is all the exporter writes; anything else is reported, not guessed
+    loop = os.path.join(os.path.dirname(model), "loop.tcl")
+    open(loop, "w").write(open(model).read() + "\nfor {set i 0} {$i < 3} {incr i} { vdisplay Mesh0 }\n")
+    assert "not honoured: for" in _cpp_dump(loop, tmp_path / "x.crhscene")
+
+
+@pytest.mark.gpu
+def test_cpp_driver_renders_model_tcl_like_the_oracle(hip_lib, oracle_lib, tmp_path):
+    import subprocess
+    from cadrays_amd.scene_tcl import read_scene
+    sc, model = _exported_scene(tmp_path)
+    exe = os.path.join(ROOT, "cadrays_amd", "host", "cadrays_headless")
+    p = subprocess.run([exe, model, "3", "0", "1", "1", "80x60"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    out = os.path.join(os.path.dirname(model), "Output_model_3.pfm")
+    with open(out, "rb") as f:
+        assert f.readline().strip() == b"PF"; w, h = (int(x) for x in f.readline().split()); f.readline()
+        img = np.frombuffer(f.read(), "<f4").reshape(h, w, 3)[::-1]
+    py, _ = read_scene(model, 80, 60)
+    o = oracle_lib.Oracle().load_scene(py); o.render(3)
+    assert np.array_equal(img.view(np.uint32), o.read_hdr().view(np.uint32))
