@@ -1012,6 +1012,22 @@ int crh_set_lookahead(crh_ctx* c, uint32_t frames)
   return CRH_OK;
 }
 
+int crh_set_path_budget(crh_ctx* c, uint64_t max_paths)
+{
+  if (!c || max_paths < 1024u || max_paths > (1ull << 30)) return fail(c, CRH_E_INVALID, "path budget must be in 1024 .. 2^30 slots");
+  CRH_HIP(hipSetDevice(c->device));
+  c->max_paths = (uint32_t)max_paths; c->pending_n = 0;
+  if (c->path_cap > c->max_paths) {                      // give the memory back now; the next render allocates what it needs
+    CRH_HIP(hipStreamSynchronize(c->stream));
+    void** ptrs[] = {(void**)&c->paths.ray_o[0], (void**)&c->paths.ray_d[0], (void**)&c->paths.hit, (void**)&c->paths.thr[0], (void**)&c->paths.rad,
+                     (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c, (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh,
+                     (void**)&c->paths.ray_o[1], (void**)&c->paths.ray_d[1], (void**)&c->paths.thr[1]};
+    for (void** q : ptrs) if (*q) { CRH_HIP(hipFree(*q)); *q = nullptr; }
+    c->path_cap = 0;
+  }
+  return CRH_OK;
+}
+
 int crh_get_tile_stats(crh_ctx* c, float* err, uint32_t* counts, uint32_t* n_tiles)
 {
   if (!c || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator");

@@ -57,6 +57,10 @@ class View(Backend):
         """trace `frames` Redraw()s ahead in one wide batch; images after every Redraw stay bit-identical"""
         self._call("set_lookahead", C.c_uint32(int(frames)))
 
+    def set_path_budget(self, max_paths):
+        """crh_set_path_budget: at most this many path slots (188 B each) in flight per batch; images do not depend on it"""
+        self._call("set_path_budget", C.c_uint64(int(max_paths)))
+
     def enable_counters(self, on=True):
         self._call("enable_counters", C.c_int(int(on)))
 

@@ -181,6 +181,13 @@ CRH_API int crh_set_show_tiles(crh_ctx* ctx, int on);
  * change of scene / camera / parameters, crh_reset, crh_render_tiles or adaptive mode discards what is pending.  Ray
  * counters include the speculative samples.  frames = 1 (default) disables it. */
 CRH_API int crh_set_lookahead(crh_ctx* ctx, uint32_t frames);
+/* Device-memory budget of the wavefront path state: at most `max_paths` path slots (188 B each) are in flight per batch; a render
+ * that needs more is cut into tile groups / sample batches (same image, bit for bit).  Default 2^28 slots = 50 GB of the
+ * 288 GB, allocated on demand (a 1080p Redraw() takes 0.4 GB): every launch of the schedule ends in a drain phase of fixed
+ * length, so wide batches are faster -- 32 M / 64 M / 128 M / 256 M slots reach 80 / 86 / 91 / 93 % of the 512 M-slot rate on
+ * the 1 M-triangle benchmark.  A host that shares the GPU with other consumers lowers it here (the environment variable
+ * CRH_MAX_PATHS sets the initial value).  1024 <= max_paths <= 2^30; buffers already larger are released. */
+CRH_API int crh_set_path_budget(crh_ctx* ctx, uint64_t max_paths);
 /* Per-tile error estimate (mean standard error of the pixel luminance) and per-tile sample count; pass NULL
  * arrays to query n_tiles.  Needs adaptive mode for a meaningful error. */
 CRH_API int crh_get_tile_stats(crh_ctx* ctx, float* err, uint32_t* counts, uint32_t* n_tiles);

@@ -432,3 +432,21 @@ def test_small_path_budget_splits_batches_identically(view_cls, monkeypatch, max
     a, b = v.stats(), ref.stats()
     for k in ("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "shaded_hits", "samples"):
         assert a[k] == b[k], k
+
+
+def test_path_budget_through_the_abi(view_cls):
+    """crh_set_path_budget: the same knob as CRH_MAX_PATHS, as an entry point (a host embedding the module next to other GPU
+    consumers sets it); the image does not depend on it, buffers above the budget are released, bad values are refused."""
+    from cadrays_amd.binding import BackendError
+    sc = scenes.cornell_box(True, 100, 76)
+    ref = view_cls(0).load_scene(sc); ref.render(4)
+    v = view_cls(0).load_scene(sc)
+    v.render(1)                                   # allocates a frame's worth of path state
+    v.set_path_budget(3000)                       # below one tile row: released and re-allocated small
+    v.render(3)
+    assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr()))
+    v.set_path_budget(1 << 28); v.render(2); ref.render(2)
+    assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr()))
+    for bad in (0, 1023, (1 << 30) + 1):
+        with pytest.raises(BackendError):
+            v.set_path_budget(bad)
