@@ -408,7 +408,7 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
   auto small_grid = [&](uint64_t paths, int full, int per) { return (int)std::min<uint64_t>((uint64_t)full, std::max<uint64_t>(512u, paths / (uint64_t)per)); };
   if (K < 2 || total > c->lane_max_paths || !accumulate || c->counters_on) {
     const bool small = total <= c->lane_max_paths && !c->counters_on;
-    return run_lane(c, Lane{c->stream, c->paths, c->queues, small ? small_grid(total, c->grid, 1024) : c->grid, small ? small_grid(total, c->grid_trace, 2048) : c->grid_trace, true},
+    return run_lane(c, Lane{c->stream, c->paths, c->queues, small ? small_grid(total, c->grid, 2048) : c->grid, small ? small_grid(total, c->grid_trace, 2048) : c->grid_trace, true},
                     S, d_tiles, nt, d_seeds, ns, seed_per_tile, accumulate);
   }
   // small batch: K tile ranges on K streams, each with its own slice [base, base + n_k * tpp * ns) of every path-state array
@@ -419,7 +419,7 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
   for (uint32_t k = 0; k < K; ++k) {
     const uint32_t t0 = (uint32_t)((uint64_t)nt * k / K), t1 = (uint32_t)((uint64_t)nt * (k + 1) / K);
     Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false;
-    ln.grid = c->lane_grid > 0 ? c->lane_grid : small_grid(total / K, c->grid, 1024);
+    ln.grid = c->lane_grid > 0 ? c->lane_grid : small_grid(total / K, c->grid, 2048);
     ln.grid_trace = c->lane_grid_trace > 0 ? c->lane_grid_trace : small_grid(total / K, c->grid_trace, 2048);
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
