@@ -78,6 +78,8 @@ struct crh_ctx {
   struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } stage[4];
   uint32_t stage_next = 0;
   bool clamp_grid = true;   // CRH_CLAMP_GRID=0: A/B switch for the occupancy clamp of the traversal grids
+  bool donate = true;       // small batches use the work-donating traversal kernels (kernels.hip, DON); CRH_DONATE=0 switches them off
+                            // (measured with plain kernels + wider grids for the first 1-4 bounces: 232 -> 232 / 226 / 222 / 218 Redraw/s: donate from bounce 0)
   // Small batches (one Redraw() = +1 spp of one frame, AppViewer.cxx:1045-1047) are launch- and drain-bound: every traversal
   // launch ends with the longest rays of a few wavefronts while the rest of the chip idles.  Such a batch is cut into `n_lanes`
   // tile ranges that run the same wavefront schedule on their own streams and their own slice of the path state, so one
@@ -352,25 +354,27 @@ int do_reset(crh_ctx* c)
 
 // One batch: `ns` samples of `nt` tiles whose ids sit at d_tiles; seeds at d_seeds.
 // One wavefront schedule: `ns` samples of `nt` tiles (ids at d_tiles, seeds at d_seeds) on one stream and one slice of the path state.
-struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; };
+struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; bool donate = false; };
 
 int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile,
              bool accumulate)
 {
   Launch L{ln.stream, ln.grid, c->counters_on};
-  Launch LT{ln.stream, ln.grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0};
+  Launch LT{ln.stream, ln.grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0, ln.donate && !c->counters_on};
+
   launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev);
   int qin = 0;
   for (uint32_t b = 0; b < S.max_depth; ++b) {
+    const Launch& T = LT;
     if (ln.timed && c->timing_on) {
       hipEvent_t e0 = get_event(c), e1 = get_event(c);
       hipEventRecord(e0, ln.stream);
-      launch_trace_nearest(LT, S, ln.P, ln.Q, qin, c->d_counters);
+      launch_trace_nearest(T, S, ln.P, ln.Q, qin, c->d_counters);
       hipEventRecord(e1, ln.stream);
       c->trace_ev.emplace_back(e0, e1);
-    } else launch_trace_nearest(LT, S, ln.P, ln.Q, qin, c->d_counters);
+    } else launch_trace_nearest(T, S, ln.P, ln.Q, qin, c->d_counters);
     launch_shade(L, S, ln.P, ln.Q, qin, b, c->d_counters);
-    if (S.n_lights > 0) launch_trace_any(LT, S, ln.P, ln.Q, c->d_counters);
+    if (S.n_lights > 0) launch_trace_any(T, S, ln.P, ln.Q, c->d_counters);
     qin = 1 - qin;
   }
   if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, c->d_counters, ln.n_tiles_dev);
@@ -408,8 +412,9 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
   auto small_grid = [&](uint64_t paths, int full, int per) { return (int)std::min<uint64_t>((uint64_t)full, std::max<uint64_t>(512u, paths / (uint64_t)per)); };
   if (K < 2 || total > c->lane_max_paths || !accumulate || c->counters_on) {
     const bool small = total <= c->lane_max_paths && !c->counters_on;
-    return run_lane(c, Lane{c->stream, c->paths, c->queues, small ? small_grid(total, c->grid, 2048) : c->grid, small ? small_grid(total, c->grid_trace, 2048) : c->grid_trace, true},
-                    S, d_tiles, nt, d_seeds, ns, seed_per_tile, accumulate);
+    Lane one{c->stream, c->paths, c->queues, small ? small_grid(total, c->grid, 2048) : c->grid, small ? small_grid(total, c->grid_trace, 2048) : c->grid_trace, true};
+    one.donate = small && c->donate;
+    return run_lane(c, one, S, d_tiles, nt, d_seeds, ns, seed_per_tile, accumulate);
   }
   // small batch: K tile ranges on K streams, each with its own slice [base, base + n_k * tpp * ns) of every path-state array
   // (queue entries are positions relative to the slice) and its own counter block; fork from / join into the context's stream
@@ -418,7 +423,7 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
   size_t base = 0;
   for (uint32_t k = 0; k < K; ++k) {
     const uint32_t t0 = (uint32_t)((uint64_t)nt * k / K), t1 = (uint32_t)((uint64_t)nt * (k + 1) / K);
-    Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false;
+    Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false; ln.donate = c->donate;
     ln.grid = c->lane_grid > 0 ? c->lane_grid : small_grid(total / K, c->grid, 2048);
     ln.grid_trace = c->lane_grid_trace > 0 ? c->lane_grid_trace : small_grid(total / K, c->grid_trace, 2048);
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
@@ -544,7 +549,7 @@ int adaptive_iteration(crh_ctx* c)
   c->pending_n = 0;
   Lane ln{c->stream, c->paths, c->queues, (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>(512u, (uint64_t)most * tpp / 1024u)),
           (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(512u, (uint64_t)most * tpp / 2048u)), true};      // grids follow the batch (run_batch)
-  ln.n_tiles_dev = c->d_adapt_n;
+  ln.n_tiles_dev = c->d_adapt_n; ln.donate = c->donate;
   rc = run_lane(c, ln, S, c->d_tile_ids, most, c->d_seeds, 1, 1, true); if (rc) return rc;
   hipEventRecord(e1, c->stream);
   c->render_ev.emplace_back(e0, e1);
@@ -689,6 +694,7 @@ crh_ctx* crh_create(int device_ordinal)
   if (const char* e = getenv("CRH_GRID")) { int v = atoi(e); if (v > 0) c->grid = v; }
   if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }
   if (const char* e = getenv("CRH_CLAMP_GRID")) c->clamp_grid = atoi(e) != 0;
+  if (const char* e = getenv("CRH_DONATE")) c->donate = atoi(e) != 0;
   if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }
   if (const char* e = getenv("CRH_LANE_MAX_PATHS")) { long v = atol(e); if (v >= 0) c->lane_max_paths = (uint32_t)std::min<long>(v, 1l << 30); }
   if (const char* e = getenv("CRH_LANE_GRID")) { int v = atoi(e); if (v > 0) c->lane_grid = v; }

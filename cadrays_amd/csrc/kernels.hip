@@ -121,12 +121,44 @@ __device__ __forceinline__ float inv_dir(float d)
 // spill to scratch (never touched on ordinary scenes).
 // TWO: two-level scene -- traversal starts at the top-level root; an instance leaf re-expresses the ray in the object's
 // space (direction not renormalised, so t keeps its meaning), a sentinel on the stack restores the world ray.
-template <bool ANY, bool COUNT, bool TWO, class Load, class Store>
+// position of the k-th (0-based) set bit of a wave mask
+__device__ __forceinline__ uint32_t kth_bit(unsigned long long m, uint32_t k)
+{
+  uint32_t pos = 0, w32 = (uint32_t)m;
+  const uint32_t c = (uint32_t)__popc(w32);
+  if (k >= c) { k -= c; pos = 32u; w32 = (uint32_t)(m >> 32); }
+#pragma unroll
+  for (uint32_t w = 16u; w >= 1u; w >>= 1) {
+    const uint32_t part = w32 & ((1u << w) - 1u), c2 = (uint32_t)__popc(part);
+    if (k >= c2) { k -= c2; w32 >>= w; pos += w; } else w32 = part;
+  }
+  return pos;
+}
+
+constexpr uint32_t kNoLane = 64u;
+
+// DON (work donation, small batches only).  A launch cannot end before its longest ray does -- ~400 node visits at ~1 us each on
+// the benchmark scene, whatever the launch's size -- and a 1-spp frame is twenty such launches.  Once a
+// wavefront's queue is exhausted, every lane that still walks hands the BOTTOM entry of its stack (the subtree it would visit
+// last) to an idle lane of the wavefront, which walks it with a copy of the ray; helpers donate in turn, and a lane donates again
+// as soon as another lane is idle, so a long ray fans out over the wavefront.
+//   The lanes working on one ray form a list in traversal order: a helper is inserted right after its donor (everything the
+// donor still has, and will push, comes before the donated subtree; everything donated earlier comes after it).  The sequential
+// result is the earliest hit with the smallest t, i.e. a left-biased minimum over that list -- an associative fold.  A lane
+// whose own part is walked and which has no successor left is finished; its predecessor absorbs its total in FRONT of what it
+// has absorbed before (`chit`), and the head of the list stores fold(own, chit).  Hits are bit-identical to the sequential walk;
+// only pruning differs (the parts do not see each other's `best`), i.e. the number of visits -- which is why the counting kernels
+// never donate.
+template <bool ANY, bool COUNT, bool TWO, bool DON, class Load, class Store>
 __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                              const float4* __restrict__ inst, uint32_t root, float4 gbox,
                                              uint32_t* __restrict__ cursor, uint32_t n, uint32_t* lds,
-                                             Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris)
+                                             Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris, uint32_t* bound = nullptr)
 {
+  // bound (DON): one word per lane of this wavefront in LDS -- the smallest hit distance any part of the ray that STARTED in that
+  // lane has found so far (float bits; distances are >= 0, so unsigned order = float order).  Every part prunes BOXES with it
+  // (a box entered later than the bound holds nothing that can win the fold; equality is kept, ties are decided by order);
+  // triangles are still accepted against the part's own `best`, which only knows what came earlier in traversal order.
   uint32_t ovf[kOvfStack];
   const uint32_t lane = lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -147,18 +179,28 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   };
   float4 hit = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   bool found = false;
+  // donation state (DON): stack entries live in [sbase, sp); is_child: this lane walks a donated subtree, its total is absorbed by
+  // its predecessor instead of stored; next: the lane that holds what comes right after this lane's part in traversal order;
+  // chit / cfound: the folded totals of the successors absorbed so far (they come after everything this lane still walks)
+  int sbase = 0; bool is_child = false, cfound = false; uint32_t next = kNoLane, head = 0;
+  float4 chit = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   // wave-uniform pool state.  Chunk per atomic: kPoolChunk for long queues (one cursor word sustains ~88 atomics/us); short
   // queues are cut finer so that every wavefront gets work -- a 75 K-ray launch in 256-ray chunks would keep 292 of the 5120
   // wavefronts busy with four 64-ray generations each (0.5 ms) instead of 1170 with one (CRH_POOL_DIV chunks per wavefront).
-  const uint32_t chunk = min(kPoolChunk, max(64u, ((n / (gridDim.x * (uint32_t)(kBlock / 64) * (uint32_t)CRH_POOL_DIV)) + 63u) & ~63u));
+  const uint32_t per_wave = n / (gridDim.x * (uint32_t)(kBlock / 64) * (uint32_t)CRH_POOL_DIV);
+  // DON, thin mode: a queue too short to give every wavefront 32 rays is dealt out in chunks of 8 ... 32 rays (about one per wavefront); a wavefront
+  // takes ONE chunk at a time and all of its 64 lanes work on it (donation from the start), so the launch ends after ~the
+  // average ray instead of after the longest one
+  const bool thin = DON && per_wave < 17u;                                   // at most half of the lanes get a ray of their own
+  const uint32_t chunk = thin ? max(8u, (2u * per_wave + 7u) & ~7u) : min(kPoolChunk, max(64u, (per_wave + 63u) & ~63u));
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
 
   for (;;) {
     // ------------------------------------------------------------------ refill idle lanes
     unsigned long long idle = __ballot(!have);
-    if (!exhausted && (uint32_t)__popcll(idle) >= (uint32_t)CRH_REFILL_IDLE) {
-      for (int round = 0; round < 2 && idle != 0ull; ++round) {
+    if (!exhausted && (thin ? idle == ~0ull : (uint32_t)__popcll(idle) >= (uint32_t)CRH_REFILL_IDLE)) {
+      for (int round = 0; round < (thin ? 1 : 2) && idle != 0ull; ++round) {
         if (pool_next == pool_end) {
           uint32_t base = 0;
           if (lane == 0) base = atomicAdd(cursor, chunk);
@@ -179,6 +221,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           if (TWO) { wo = o; wd = d; wix = ix; wiy = iy; wiz = iz; }
           best = tmax; found = false; sp = 0; cur = root; have = true;
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
+          if (DON) { sbase = 0; is_child = false; cfound = false; next = kNoLane; head = lane; bound[lane] = __float_as_uint(tmax); }
         }
         pool_next += take;
         idle &= ~__ballot(mine);
@@ -186,18 +229,64 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     }
     if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
 
+    if (DON && (exhausted || thin)) {
+      // ---------------------------------------------------------------- donation: bottom stack entries -> idle lanes
+      const unsigned long long idle_m = __ballot(!have);
+      if (idle_m != 0ull) {
+        // a donor gives the FAR half of its stack (the entries below the middle, all of them in the LDS part); the helper
+        // copies them into its own column and starts with the nearest of them
+        bool can = have && cur != kDone && sp > sbase && sp <= kLdsStack && !(ANY && found);
+        if (TWO && can && lds[sbase * kBlock] == CRH_REF_SENTINEL) can = false;
+        const int give_n = (sp - sbase + 1) >> 1;
+        if (TWO && can)      // only world-level entries travel (the helper starts with the world ray): stop below an object sentinel
+          for (int e = 0; e < give_n; ++e) if (lds[(sbase + e) * kBlock] == CRH_REF_SENTINEL) { can = false; break; }
+        // lanes with a deep stack (much left to walk) are served first; within a class, by lane order
+        const bool deep = can && sp - sbase >= 3;
+        const unsigned long long deep_m = __ballot(deep), shal_m = __ballot(can && !deep);
+        const uint32_t n_deep = (uint32_t)__popcll(deep_m);
+        const uint32_t npair = min((uint32_t)__popcll(idle_m), n_deep + (uint32_t)__popcll(shal_m));
+        if (npair != 0u) {
+          const uint32_t rank_d = deep ? (uint32_t)__popcll(deep_m & lt_mask) : n_deep + (uint32_t)__popcll(shal_m & lt_mask);
+          const uint32_t rank_i = (uint32_t)__popcll(idle_m & lt_mask);
+          const bool gives = can && rank_d < npair, takes = !have && rank_i < npair;
+          const uint32_t src = !takes ? lane : (rank_i < n_deep ? kth_bit(deep_m, rank_i) : kth_bit(shal_m, rank_i - n_deep));
+          const int rcnt = __shfl(give_n, src), rsb = __shfl(sbase, src);
+          if (takes) {
+            const uint32_t* from = lds + ((int)src - (int)lane);                    // the donor's column of the same wavefront's stack
+            for (int e = 0; e < rcnt; ++e) lds[e * kBlock] = from[(rsb + e) * kBlock];
+          }
+          // the helper walks in WORLD space (a donated entry sits below any object sentinel), with the donor's current bound
+          const v3 so = TWO ? wo : o, sd = TWO ? wd : d;
+          const float rox = __shfl(so.x, src), roy = __shfl(so.y, src), roz = __shfl(so.z, src);
+          const float rdx = __shfl(sd.x, src), rdy = __shfl(sd.y, src), rdz = __shfl(sd.z, src);
+          const float rbest = __shfl(best, src);
+          const uint32_t rnext = __shfl(next, src), rhead = __shfl(head, src);
+          if (gives) { next = kth_bit(idle_m, rank_d); sbase += give_n; }          // the helper comes right after the donor ...
+          if (takes) {
+            o = crh_mk3(rox, roy, roz); d = crh_mk3(rdx, rdy, rdz);
+            ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
+            set_guard(gbox);
+            if (TWO) { wo = o; wd = d; wix = ix; wiy = iy; wiz = iz; }
+            best = rbest; found = false; sbase = 0; sp = rcnt - 1; cur = lds[sp * kBlock]; have = true;      // the nearest of the entries received
+            hit = make_float4(rbest, 0.f, 0.f, __int_as_float(-1));
+            is_child = true; cfound = false; next = rnext; head = rhead;            // ... and before what the donor gave away earlier
+          }
+        }
+      }
+    }
+
     auto read_top = [&]() {
       --sp;
       if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
       else { cur = ovf[sp - kLdsStack]; asm volatile("" : "+v"(cur)); }
     };
     auto pop = [&]() {
-      if ((ANY && found) || sp == 0) { cur = kDone; return; }
+      if ((ANY && found) || sp == (DON ? sbase : 0)) { cur = kDone; return; }
       read_top();
       if (TWO && cur == CRH_REF_SENTINEL) {          // leaving an object: back to the world-space ray
         o = wo; d = wd; ix = wix; iy = wiy; iz = wiz;                                            // the saved reciprocals are the bits inv_dir(wd) would recompute
         set_guard(gbox);
-        if (sp == 0) cur = kDone; else read_top();
+        if (sp == (DON ? sbase : 0)) cur = kDone; else read_top();
       }
     };
     // one inner-node step of this lane: fetch the 48-B node (3 x dwordx4), slab-test and order its children, push / descend / pop
@@ -221,6 +310,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const bool sx = ix < 0.f, sy = iy < 0.f, sz = iz < 0.f;
       const uint32_t lx = __float_as_uint(sx ? n1.w : n1.x), ly = __float_as_uint(sy ? n2.x : n1.y), lz = __float_as_uint(sz ? n2.y : n1.z);
       const uint32_t hx = __float_as_uint(sx ? n1.x : n1.w), hy = __float_as_uint(sy ? n1.y : n2.x), hz = __float_as_uint(sz ? n1.z : n2.y);
+      const float prune = DON ? fminf(best, __uint_as_float(bound[head])) : best;
       const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
       const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ddx, ddx}, (f32x2){ix, ix}, (f32x2){-gx, gx});      // {entry, exit} offsets
       const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (f32x2){-gy, gy});
@@ -233,7 +323,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         const f32x2 ty = __builtin_elementwise_fma((f32x2){CRH_QB(ly, K), CRH_QB(hy, K)}, ay2, by2);      \
         const f32x2 tz = __builtin_elementwise_fma((f32x2){CRH_QB(lz, K), CRH_QB(hz, K)}, az2, bz2);      \
         const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
-        const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), best);                                    \
+        const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), prune);                                   \
         const int bits = max(__float_as_int(tmin), 0);                                                     \
         key[K] = ((uint32_t)K < nch && tmin <= tmx) ? (((uint32_t)bits & ~3u) | (uint32_t)K) : 0xFFFFFFFFu;   \
       }
@@ -285,6 +375,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float vv = crh_dot3(vc, e0) * inv;
       if (tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f && tt < best) {
         best = tt; found = true;
+        if (DON) atomicMin(&bound[head], ANY ? 0u : __float_as_uint(tt));      // any-hit: one occluder ends every part's walk
         hit = make_float4(tt, uu, vv, __int_as_float((int)ti));
       }
     };
@@ -316,16 +407,39 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     }
 
     // ------------------------------------------------------------------ (C) retire finished rays
-    if (have && cur == kDone) { store(tag, hit, found); have = false; }
+    if (DON) {
+      // own part walked and no successor left: fold what was absorbed behind the own hit (left-biased minimum: a later part
+      // wins only with a strictly smaller t); helpers then wait to be absorbed by their predecessor, the head stores
+      const bool finished = have && cur == kDone && next == kNoLane;
+      if (finished && cfound) { if (ANY || !found || chit.x < hit.x) { hit = chit; found = true; } cfound = false; }
+      const unsigned long long fin_children = __ballot(finished && is_child);
+      if (fin_children != 0ull) {
+        const bool takes = have && next != kNoLane && ((fin_children >> next) & 1ull);
+        const uint32_t from = takes ? next : lane;
+        const float hx = __shfl(hit.x, from), hy = __shfl(hit.y, from), hz = __shfl(hit.z, from), hw = __shfl(hit.w, from);
+        const int hf = __shfl((int)found, from);
+        if (takes) {
+          // the successor's total goes IN FRONT of what this lane absorbed before (it was donated later = it comes earlier)
+          if (hf && (ANY || !cfound || !(chit.x < hx))) { chit = make_float4(hx, hy, hz, hw); cfound = true; }
+          next = kNoLane;
+        }
+        if ((fin_children >> lane) & 1ull) { have = false; is_child = false; }           // absorbed: the lane is free again
+      }
+      if (have && !is_child && cur == kDone && next == kNoLane) {
+        if (cfound) { if (ANY || !found || chit.x < hit.x) { hit = chit; found = true; } cfound = false; }
+        store(tag, hit, found); have = false;
+      }
+    } else if (have && cur == kDone) { store(tag, hit, found); have = false; }
   }
 }
 
-template <bool COUNT, bool TWO>
+template <bool COUNT, bool TWO, bool DON>
 __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, int cur, const uint32_t* __restrict__ q,
                                                   const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors,
                                                   uint32_t* zero_a, uint32_t* zero_b, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
+  __shared__ uint32_t s_bound[DON ? kBlock : 1];
   const uint32_t n = *count;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *zero_a = 0u; *zero_b = 0u;
@@ -334,28 +448,29 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, int cur, co
   }
   uint32_t nn = 0, nt = 0;
   const float4* __restrict__ ray_o = P.ray_o[cur]; const float4* __restrict__ ray_d = P.ray_d[cur];
-  trace_engine<false, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursors + 0, n, &stk[threadIdx.x],
+  trace_engine<false, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursors + 0, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = ld_stream(&ray_o[tag]), d4 = ld_stream(&ray_d[tag]);      // .w lanes carry the path's rng state / slot + flags, not ray data
       o = xyz(o4); d = xyz(d4); tmax = CRH_MAXFLOAT;
     },
-    [&](uint32_t tag, float4 h, bool) { st_stream(&P.hit[tag], h); }, nn, nt);
+    [&](uint32_t tag, float4 h, bool) { st_stream(&P.hit[tag], h); }, nn, nt, DON ? &s_bound[threadIdx.x & ~63u] : nullptr);
   if (COUNT) {
     nn = wave_sum(nn); nt = wave_sum(nt);
     if (lane_id() == 0) { atomicAdd(&C->nodes_nearest, (unsigned long long)nn); atomicAdd(&C->tris_nearest, (unsigned long long)nt); }
   }
 }
 
-template <bool COUNT, bool TWO>
+template <bool COUNT, bool TWO, bool DON>
 __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t* __restrict__ q,
                                               const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
+  __shared__ uint32_t s_bound[DON ? kBlock : 1];
   const uint32_t n = *count;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
   uint32_t nn = 0, nt = 0;
-  trace_engine<true, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursors + 2, n, &stk[threadIdx.x],
+  trace_engine<true, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursors + 2, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
@@ -369,7 +484,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
         r.x += c.x; r.y += c.y; r.z += c.z;
         P.rad[slot] = r;
       }
-    }, nn, nt);
+    }, nn, nt, DON ? &s_bound[threadIdx.x & ~63u] : nullptr);
   if (COUNT) {
     nn = wave_sum(nn); nt = wave_sum(nt);
     if (lane_id() == 0) { atomicAdd(&C->nodes_any, (unsigned long long)nn); atomicAdd(&C->tris_any, (unsigned long long)nt); }
@@ -383,7 +498,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   uint32_t nn = 0, nt = 0;
-  trace_engine<ANY, COUNT, TWO>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursor, n, &stk[threadIdx.x],
+  trace_engine<ANY, COUNT, TWO, false>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursor, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = idx;
       const float4 o4 = rays[2u * idx], d4 = rays[2u * idx + 1u];
@@ -1261,10 +1376,10 @@ template <auto Kernel> static int resident_grid(const Launch& L)
 
 void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, DCounters* C)
 {
-#define CRH_LAUNCH_TN(CNT, TWO) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO>), dim3(resident_grid<k_trace_nearest<CNT, TWO>>(L)), dim3(kBlock), 0, L.stream, S, P, qin, Q.q[qin], \
+#define CRH_LAUNCH_TN(CNT, TWO, DON) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO, DON>), dim3(resident_grid<k_trace_nearest<CNT, TWO, DON>>(L)), dim3(kBlock), 0, L.stream, S, P, qin, Q.q[qin], \
                                                    Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, C)
-  if (S.two_level) { if (L.counters) CRH_LAUNCH_TN(true, true); else CRH_LAUNCH_TN(false, true); }
-  else             { if (L.counters) CRH_LAUNCH_TN(true, false); else CRH_LAUNCH_TN(false, false); }
+  if (S.two_level) { if (L.counters) CRH_LAUNCH_TN(true, true, false); else if (L.donate) CRH_LAUNCH_TN(false, true, true); else CRH_LAUNCH_TN(false, true, false); }
+  else             { if (L.counters) CRH_LAUNCH_TN(true, false, false); else if (L.donate) CRH_LAUNCH_TN(false, false, true); else CRH_LAUNCH_TN(false, false, false); }
 #undef CRH_LAUNCH_TN
 }
 void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, uint32_t bounce, DCounters* C)
@@ -1274,9 +1389,9 @@ void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueu
 }
 void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, DCounters* C)
 {
-#define CRH_LAUNCH_TA(CNT, TWO) hipLaunchKernelGGL((k_trace_any<CNT, TWO>), dim3(resident_grid<k_trace_any<CNT, TWO>>(L)), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C)
-  if (S.two_level) { if (L.counters) CRH_LAUNCH_TA(true, true); else CRH_LAUNCH_TA(false, true); }
-  else             { if (L.counters) CRH_LAUNCH_TA(true, false); else CRH_LAUNCH_TA(false, false); }
+#define CRH_LAUNCH_TA(CNT, TWO, DON) hipLaunchKernelGGL((k_trace_any<CNT, TWO, DON>), dim3(resident_grid<k_trace_any<CNT, TWO, DON>>(L)), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C)
+  if (S.two_level) { if (L.counters) CRH_LAUNCH_TA(true, true, false); else if (L.donate) CRH_LAUNCH_TA(false, true, true); else CRH_LAUNCH_TA(false, true, false); }
+  else             { if (L.counters) CRH_LAUNCH_TA(true, false, false); else if (L.donate) CRH_LAUNCH_TA(false, false, true); else CRH_LAUNCH_TA(false, false, false); }
 #undef CRH_LAUNCH_TA
 }
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,
