@@ -24,7 +24,7 @@ using namespace crh;
 
 struct crh_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream_ = nullptr;   // use cstream(c): it first joins frames still in flight on the pipeline streams
   int cus = 0;            // compute units (0: unknown)
   int grid = 2048;        // streaming / shading kernels: 8 workgroups per CU
   int grid_trace = 1536;  // traversal kernels: 6 workgroups (= 6 waves/SIMD) per CU -- measured: 4 / 5 / 6 / 7 / 8 per CU -> 3300 / 3424 /
@@ -89,6 +89,11 @@ struct crh_ctx {
   uint32_t n_lanes = 2, lane_max_paths = 12u << 20; int lane_grid = 0, lane_grid_trace = 0;
   hipStream_t lane_stream[8] = {}; hipEvent_t lane_fork = nullptr, lane_join[8] = {}; uint32_t* d_lane_counts = nullptr;
   std::vector<uint32_t> h_tile_ids;      // what d_tile_ids holds (an unchanged tile list is not uploaded again)
+  // frame pipelining: consecutive small whole batches (one Redraw() each) run on alternating streams and path-state halves, so
+  // the drain-bound late bounces of frame n overlap the throughput-bound first bounces of frame n + 1; accumulation stays in
+  // frame order (an event between the two accumulate launches)
+  bool pipeline = true; bool pipe_pending[2] = {false, false}; uint32_t pipe_seq = 0; uint32_t* d_pipe_seeds = nullptr; int pipe_div = 4096;
+  bool read_since_render = true;   // a host that looks at every frame (read-back / sync between Redraws) gets the two-range schedule instead
   bool counters_on = false, timing_on = false;
   uint32_t frames_done = 0;       // whole-frame iterations since reset (crh_render continues from here)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> render_ev, trace_ev;
@@ -100,6 +105,15 @@ struct crh_ctx {
   // 3205 / 3243 Mrays/s on C3
   uint32_t max_paths = 256u << 20;
 };
+
+// The context's stream.  Small whole-frame batches alternate between two pipeline streams (render_impl) and are joined lazily:
+// whoever wants to enqueue on, or wait for, the context's stream first makes it wait for the frames still in flight.
+static inline hipStream_t cstream(crh_ctx* c)
+{
+  for (int k = 0; k < 2; ++k)
+    if (c->pipe_pending[k]) { hipStreamWaitEvent(c->stream_, c->lane_join[k], 0); c->pipe_pending[k] = false; }
+  return c->stream_;
+}
 
 namespace {
 
@@ -123,20 +137,21 @@ bool all_finite(const float* v, size_t n, float limit = 3.0e38f)
 // of the first batch of a fresh context when other contexts kept the device busy (lost and doubled paths).
 template <class T> int dev_upload(crh_ctx* c, T*& dptr, const void* src, size_t bytes)
 {
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   if (dptr) { CRH_HIP(hipFree(dptr)); dptr = nullptr; }
   if (!bytes) return CRH_OK;
   CRH_HIP(hipMalloc((void**)&dptr, bytes));
-  CRH_HIP(hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));            // `src` may be a temporary of the caller
+  CRH_HIP(hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));            // `src` may be a temporary of the caller
   return CRH_OK;
 }
 
 // Stream-ordered copy of a small host block: staged through one of four pinned buffers, so the call returns at once and `src`
 // can be reused; a slot is waited for only when the copy issued four uploads earlier has not finished yet.
-int stage_copy(crh_ctx* c, void* dst, const void* src, size_t bytes)
+int stage_copy(crh_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t on = nullptr)
 {
   if (!bytes) return CRH_OK;
+  const hipStream_t stream = on ? on : cstream(c);
   crh_ctx::Stage& st = c->stage[c->stage_next++ & 3u];
   if (st.used) CRH_HIP(hipEventSynchronize(st.ev));
   if (st.cap < bytes) {
@@ -147,8 +162,8 @@ int stage_copy(crh_ctx* c, void* dst, const void* src, size_t bytes)
   }
   if (!st.ev) CRH_HIP(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
   std::memcpy(st.p, src, bytes);
-  CRH_HIP(hipMemcpyAsync(dst, st.p, bytes, hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipEventRecord(st.ev, c->stream));
+  CRH_HIP(hipMemcpyAsync(dst, st.p, bytes, hipMemcpyHostToDevice, stream));
+  CRH_HIP(hipEventRecord(st.ev, stream));
   st.used = true;
   return CRH_OK;
 }
@@ -158,15 +173,15 @@ int stage_copy(crh_ctx* c, void* dst, const void* src, size_t bytes)
 template <class T> int dev_put(crh_ctx* c, T*& dptr, size_t& cap, const void* src, size_t bytes, size_t headroom = 0)
 {
   if (bytes > cap || !dptr) {
-    CRH_HIP(hipStreamSynchronize(c->stream));          // kernels in flight may still read the old allocation
+    CRH_HIP(hipStreamSynchronize(cstream(c)));          // kernels in flight may still read the old allocation
     if (dptr) { CRH_HIP(hipFree(dptr)); dptr = nullptr; cap = 0; }
     const size_t want = std::max<size_t>(bytes + headroom, 256);
     CRH_HIP(hipMalloc((void**)&dptr, want));
     cap = want;
   }
   if (bytes <= (4u << 20)) return stage_copy(c, dptr, src, bytes);
-  CRH_HIP(hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;
 }
 
@@ -189,7 +204,7 @@ void drain_events(crh_ctx* c)
 // per GUI frame, adaptive or look-ahead) must not grow the lists without bound: fold them in every 4096 pairs.
 int trim_events(crh_ctx* c)
 {
-  if (c->render_ev.size() + c->trace_ev.size() > 4096) { CRH_HIP(hipStreamSynchronize(c->stream)); drain_events(c); }
+  if (c->render_ev.size() + c->trace_ev.size() > 4096) { CRH_HIP(hipStreamSynchronize(cstream(c))); drain_events(c); }
   return CRH_OK;
 }
 
@@ -211,7 +226,7 @@ uint32_t frame_seed(uint32_t seed, uint32_t n)   // Bullard generator, SURVEY.md
 int ensure_paths(crh_ctx* c, uint32_t need)
 {
   if (need <= c->path_cap) return CRH_OK;
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   void** ptrs[] = {(void**)&c->paths.ray_o[0], (void**)&c->paths.ray_d[0], (void**)&c->paths.hit, (void**)&c->paths.thr[0], (void**)&c->paths.rad,
                    (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c,
                    (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh,
@@ -222,7 +237,7 @@ int ensure_paths(crh_ctx* c, uint32_t need)
     if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
     CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
   }
-  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, 8 * sizeof(uint32_t))); CRH_HIP(hipMemsetAsync(c->queues.counts, 0, 8 * sizeof(uint32_t), c->stream)); }
+  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, 8 * sizeof(uint32_t))); CRH_HIP(hipMemsetAsync(c->queues.counts, 0, 8 * sizeof(uint32_t), cstream(c))); }
   c->path_cap = need;
   return CRH_OK;
 }
@@ -329,7 +344,7 @@ int upload_textures(crh_ctx* c)
 int alloc_accum(crh_ctx* c)
 {
   if (c->d_accum && c->accumW == c->par.width && c->accumH == c->par.height) return CRH_OK;
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   if (c->d_accum) { CRH_HIP(hipFree(c->d_accum)); c->d_accum = nullptr; }
   CRH_HIP(hipMalloc((void**)&c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height));
   if (c->d_m2) { CRH_HIP(hipFree(c->d_m2)); c->d_m2 = nullptr; }
@@ -343,10 +358,10 @@ int do_reset(crh_ctx* c)
   // stream-ordered: kernels still in flight finish into the old accumulator contents first, nothing is waited for
   CRH_HIP(hipSetDevice(c->device));
   int rc = alloc_accum(c); if (rc) return rc;
-  CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, c->stream));
-  CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, c->stream));
+  CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, cstream(c)));
+  CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, cstream(c)));
   c->adaptive_picks = 0; c->pending_n = 0; c->picked_valid = false; c->assembled_valid = false;
-  CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream));
+  CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), cstream(c)));
   discard_events(c);
   c->seconds_acc = c->trace_ms_acc = c->all_ms_acc = 0.0; c->trace_launches = 0; c->frames_done = 0;
   return CRH_OK;
@@ -357,7 +372,7 @@ int do_reset(crh_ctx* c)
 struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; bool donate = false; };
 
 int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile,
-             bool accumulate)
+             bool accumulate, hipEvent_t before_accumulate = nullptr)
 {
   Launch L{ln.stream, ln.grid, c->counters_on};
   Launch LT{ln.stream, ln.grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0, ln.donate && !c->counters_on};
@@ -377,6 +392,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     if (S.n_lights > 0) launch_trace_any(T, S, ln.P, ln.Q, c->d_counters);
     qin = 1 - qin;
   }
+  if (accumulate && before_accumulate) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate, 0));      // samples are folded in in frame order
   if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, c->d_counters, ln.n_tiles_dev);
   CRH_HIP(hipGetLastError());
   return CRH_OK;
@@ -390,8 +406,9 @@ int ensure_lanes(crh_ctx* c)
     CRH_HIP(hipEventCreateWithFlags(&c->lane_join[k], hipEventDisableTiming));
   }
   CRH_HIP(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
+  CRH_HIP(hipMalloc((void**)&c->d_pipe_seeds, 2 * 16 * sizeof(uint32_t)));
   CRH_HIP(hipMalloc((void**)&c->d_lane_counts, 8 * sizeof(uint32_t) * 8));
-  CRH_HIP(hipMemsetAsync(c->d_lane_counts, 0, 8 * sizeof(uint32_t) * 8, c->stream));
+  CRH_HIP(hipMemsetAsync(c->d_lane_counts, 0, 8 * sizeof(uint32_t) * 8, cstream(c)));
   return CRH_OK;
 }
 
@@ -412,14 +429,14 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
   auto small_grid = [&](uint64_t paths, int full, int per) { return (int)std::min<uint64_t>((uint64_t)full, std::max<uint64_t>(512u, paths / (uint64_t)per)); };
   if (K < 2 || total > c->lane_max_paths || !accumulate || c->counters_on) {
     const bool small = total <= c->lane_max_paths && !c->counters_on;
-    Lane one{c->stream, c->paths, c->queues, small ? small_grid(total, c->grid, 2048) : c->grid, small ? small_grid(total, c->grid_trace, 2048) : c->grid_trace, true};
+    Lane one{cstream(c), c->paths, c->queues, small ? small_grid(total, c->grid, 2048) : c->grid, small ? small_grid(total, c->grid_trace, 2048) : c->grid_trace, true};
     one.donate = small && c->donate;
     return run_lane(c, one, S, d_tiles, nt, d_seeds, ns, seed_per_tile, accumulate);
   }
   // small batch: K tile ranges on K streams, each with its own slice [base, base + n_k * tpp * ns) of every path-state array
   // (queue entries are positions relative to the slice) and its own counter block; fork from / join into the context's stream
   int rc = ensure_lanes(c); if (rc) return rc;
-  CRH_HIP(hipEventRecord(c->lane_fork, c->stream));
+  CRH_HIP(hipEventRecord(c->lane_fork, cstream(c)));
   size_t base = 0;
   for (uint32_t k = 0; k < K; ++k) {
     const uint32_t t0 = (uint32_t)((uint64_t)nt * k / K), t1 = (uint32_t)((uint64_t)nt * (k + 1) / K);
@@ -434,7 +451,7 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
     CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
     rc = run_lane(c, ln, S, d_tiles + t0, t1 - t0, seed_per_tile ? d_seeds + t0 : d_seeds, ns, seed_per_tile, true); if (rc) return rc;
     CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
-    CRH_HIP(hipStreamWaitEvent(c->stream, c->lane_join[k], 0));
+    CRH_HIP(hipStreamWaitEvent(cstream(c), c->lane_join[k], 0));
     base += (size_t)(t1 - t0) * tpp * ns;
   }
   return CRH_OK;
@@ -458,12 +475,56 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   }
   // tile ids + frame seeds to the device, stream-ordered behind any kernels still reading the old ones, through pinned staging:
   // a Redraw() does not wait for the previous one (an unchanged tile list is not sent again)
-  if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; c->h_tile_ids.clear(); }
-  if (ns > c->seed_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * ns)); c->seed_cap = ns; }
+  if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; c->h_tile_ids.clear(); }
   if (c->h_tile_ids.size() != nt || std::memcmp(c->h_tile_ids.data(), tiles, sizeof(uint32_t) * nt) != 0) {
     int rc_u = stage_copy(c, c->d_tile_ids, tiles, sizeof(uint32_t) * nt); if (rc_u) return rc_u;
     c->h_tile_ids.assign(tiles, tiles + nt);
   }
+  const uint32_t cap_tiles = std::max<uint32_t>(1u, c->max_paths / tpp);
+  const uint32_t group = std::min(nt, cap_tiles);
+  const uint32_t spb = std::max<uint32_t>(1u, std::min(ns, c->max_paths / (group * tpp)));
+  const uint64_t total = (uint64_t)nt * tpp * ns;
+  // Measured on C3 at 1080p, 1 spp per call: free-running 232 -> 326 Redraw/s (C2: 323 -> 442); a host that reads every frame back
+  // would get 187 instead of 225 (one schedule per frame is slower than two tile ranges when nothing overlaps it), so a
+  // read-back / synchronisation since the last render selects the two-range schedule for this frame.
+  const bool host_runs_ahead = !c->read_since_render;
+  c->read_since_render = false;
+  if (c->pipeline && host_runs_ahead && !c->counters_on && !c->timing_on && !c->adaptive && group == nt && spb == ns && ns <= 16u && total >= (1u << 20) &&
+      total <= c->lane_max_paths && 2u * total <= c->max_paths) {
+    // ---- frame pipelining: this batch (one Redraw() worth) goes to pipeline stream k with its own half of the path state; it
+    // starts as soon as the previous frame ON THAT STREAM is done and overlaps the frame on the other stream; its samples are
+    // folded in after that frame's.  Nothing is joined into the context's stream here -- cstream() does that on demand.
+    int rc = ensure_paths(c, (uint32_t)(2u * total)); if (rc) return rc;
+    rc = ensure_lanes(c); if (rc) return rc;
+    const uint32_t k = c->pipe_seq++ & 1u;
+    const hipStream_t cs = c->stream_;                 // raw: no join
+    if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(cs, c->lane_join[k], 0));      // this stream's seed slot is free once its last frame is done
+    uint32_t* d_seeds_k = c->d_pipe_seeds + 16u * k;
+    {
+      std::vector<uint32_t> seeds(ns);
+      uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;
+      for (uint32_t i = 0; i < first + ns; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; if (i >= first) seeds[i - first] = hi >> 2; }
+      rc = stage_copy(c, d_seeds_k, seeds.data(), sizeof(uint32_t) * ns, cs); if (rc) return rc;
+    }
+    DScene S; fill_scene(c, S);
+    CRH_HIP(hipEventRecord(c->lane_fork, cs));
+    Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false; ln.donate = c->donate;
+    ln.grid = (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>(512u, total / 2048u));
+    ln.grid_trace = (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(512u, total / (uint64_t)c->pipe_div));
+    const size_t base = (size_t)k * total;
+    const DPaths& P = c->paths; const DQueues& Q = c->queues;
+    ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
+    ln.P.thr[0] = P.thr[0] + base; ln.P.thr[1] = P.thr[1] + base; ln.P.hit = P.hit + base; ln.P.rad = P.rad + base;
+    ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base;
+    ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.counts = c->d_lane_counts + 8 * k;
+    CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
+    c->pending_n = 0;
+    rc = run_lane(c, ln, S, c->d_tile_ids, nt, d_seeds_k, ns, 0, true, c->pipe_pending[1u - k] ? c->lane_join[1u - k] : nullptr); if (rc) return rc;
+    CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
+    c->pipe_pending[k] = true;
+    return CRH_OK;
+  }
+  if (ns > c->seed_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * ns)); c->seed_cap = ns; }
   {
     // frame seeds: Bullard generator restarted at par.seed, frame n uses next() >> 2
     std::vector<uint32_t> seeds(ns);
@@ -472,13 +533,10 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     int rc_u = stage_copy(c, c->d_seeds, seeds.data(), sizeof(uint32_t) * ns); if (rc_u) return rc_u;
   }
 
-  const uint32_t cap_tiles = std::max<uint32_t>(1u, c->max_paths / tpp);
-  const uint32_t group = std::min(nt, cap_tiles);
-  const uint32_t spb = std::max<uint32_t>(1u, std::min(ns, c->max_paths / (group * tpp)));
   int rc = ensure_paths(c, group * tpp * spb); if (rc) return rc;
   DScene S; fill_scene(c, S);
   hipEvent_t e0 = get_event(c), e1 = get_event(c);
-  hipEventRecord(e0, c->stream);
+  hipEventRecord(e0, cstream(c));
   for (uint32_t t0 = 0; t0 < nt; t0 += group) {
     const uint32_t g = std::min(group, nt - t0);
     for (uint32_t s0 = 0; s0 < ns; s0 += spb) {
@@ -486,7 +544,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
       if (rc) return rc;
     }
   }
-  hipEventRecord(e1, c->stream);
+  hipEventRecord(e1, cstream(c));
   c->render_ev.emplace_back(e0, e1);
   return trim_events(c);
 }
@@ -497,7 +555,7 @@ int tile_stats(crh_ctx* c, std::vector<float>& err, std::vector<uint32_t>& cnt)
   const uint32_t ts = c->par.tile_size;
   const uint32_t nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
   if (nt > c->tile_stat_cap) {
-    CRH_HIP(hipStreamSynchronize(c->stream));
+    CRH_HIP(hipStreamSynchronize(cstream(c)));
     if (c->d_tile_err) CRH_HIP(hipFree(c->d_tile_err));
     if (c->d_tile_cnt) CRH_HIP(hipFree(c->d_tile_cnt));
     for (void* q : {(void*)c->d_tile_cdf, (void*)c->d_picked, (void*)c->d_adapt_n}) if (q) CRH_HIP(hipFree(q));
@@ -506,12 +564,12 @@ int tile_stats(crh_ctx* c, std::vector<float>& err, std::vector<uint32_t>& cnt)
     c->tile_stat_cap = nt;
   }
   DScene S; fill_scene(c, S);
-  Launch L{c->stream, c->grid, false};
+  Launch L{cstream(c), c->grid, false};
   launch_tile_error(L, S, c->d_accum, c->d_m2, c->d_tile_err, c->d_tile_cnt, nt);
   err.resize(nt); cnt.resize(nt);
-  CRH_HIP(hipMemcpyAsync(err.data(), c->d_tile_err, sizeof(float) * nt, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipMemcpyAsync(cnt.data(), c->d_tile_cnt, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpyAsync(err.data(), c->d_tile_err, sizeof(float) * nt, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipMemcpyAsync(cnt.data(), c->d_tile_cnt, sizeof(uint32_t) * nt, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;
 }
 
@@ -527,31 +585,31 @@ int adaptive_iteration(crh_ctx* c)
   const uint32_t nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
   const uint32_t most = std::min(c->adaptive_tiles, nt);                // distinct tiles one iteration can draw
   if (nt > c->tile_stat_cap || !c->d_tile_cdf) {
-    CRH_HIP(hipStreamSynchronize(c->stream));
+    CRH_HIP(hipStreamSynchronize(cstream(c)));
     for (void* q : {(void*)c->d_tile_err, (void*)c->d_tile_cnt, (void*)c->d_tile_cdf, (void*)c->d_picked, (void*)c->d_adapt_n}) if (q) CRH_HIP(hipFree(q));
     c->d_tile_err = nullptr; c->d_tile_cnt = nullptr; c->d_tile_cdf = nullptr; c->d_picked = nullptr; c->d_adapt_n = nullptr; c->tile_stat_cap = 0;
     CRH_HIP(hipMalloc((void**)&c->d_tile_err, sizeof(float) * nt)); CRH_HIP(hipMalloc((void**)&c->d_tile_cnt, sizeof(uint32_t) * nt));
     CRH_HIP(hipMalloc((void**)&c->d_tile_cdf, sizeof(float) * nt)); CRH_HIP(hipMalloc((void**)&c->d_picked, nt)); CRH_HIP(hipMalloc((void**)&c->d_adapt_n, 64));
     c->tile_stat_cap = std::max(nt, c->tile_stat_cap);
   }
-  if (most > c->tile_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * most)); c->tile_cap = most; }
-  if (most > c->seed_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * most)); c->seed_cap = most; }
+  if (most > c->tile_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * most)); c->tile_cap = most; }
+  if (most > c->seed_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * most)); c->seed_cap = most; }
   c->h_tile_ids.clear();                                                // the device is about to write its own list there
   rc = ensure_paths(c, most * tpp); if (rc) return rc;
   DScene S; fill_scene(c, S);
   hipEvent_t e0 = get_event(c), e1 = get_event(c);
-  hipEventRecord(e0, c->stream);
-  Launch L{c->stream, c->grid, false};
+  hipEventRecord(e0, cstream(c));
+  Launch L{cstream(c), c->grid, false};
   launch_tile_error(L, S, c->d_accum, c->d_m2, c->d_tile_err, c->d_tile_cnt, nt);
   launch_adaptive_pick(L, c->d_tile_err, c->d_tile_cnt, nt, c->adaptive_picks, c->adaptive_tiles, c->par.seed, c->d_tile_cdf, c->d_picked,
                        c->d_tile_ids, c->d_seeds, c->d_adapt_n);
   c->adaptive_picks += c->adaptive_tiles; c->picked_valid = true;
   c->pending_n = 0;
-  Lane ln{c->stream, c->paths, c->queues, (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>(512u, (uint64_t)most * tpp / 1024u)),
+  Lane ln{cstream(c), c->paths, c->queues, (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>(512u, (uint64_t)most * tpp / 1024u)),
           (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(512u, (uint64_t)most * tpp / 2048u)), true};      // grids follow the batch (run_batch)
   ln.n_tiles_dev = c->d_adapt_n; ln.donate = c->donate;
   rc = run_lane(c, ln, S, c->d_tile_ids, most, c->d_seeds, 1, 1, true); if (rc) return rc;
-  hipEventRecord(e1, c->stream);
+  hipEventRecord(e1, cstream(c));
   c->render_ev.emplace_back(e0, e1);
   return trim_events(c);
 }
@@ -622,7 +680,7 @@ int reduce_impl(crh_ctx* const* ctxs, uint32_t n, uint32_t root)
     c->assembledW = W; c->assembledH = H;
   }
   // every shard's queued rendering must have landed before its accumulator is read by another stream / device
-  for (uint32_t i = 0; i < n; ++i) { CRH_HIP(hipSetDevice(ctxs[i]->device)); CRH_HIP(hipStreamSynchronize(ctxs[i]->stream)); }
+  for (uint32_t i = 0; i < n; ++i) { CRH_HIP(hipSetDevice(ctxs[i]->device)); CRH_HIP(hipStreamSynchronize(cstream(ctxs[i]))); }
 
   // CRH_REDUCE_RCCL_SINGLE=1 sends even a one-context group through RCCL (exercises the library binding on a 1-GPU box)
   RcclApi* R = (distinct && (n > 1 || getenv("CRH_REDUCE_RCCL_SINGLE"))) ? rccl() : nullptr;
@@ -639,30 +697,30 @@ int reduce_impl(crh_ctx* const* ctxs, uint32_t n, uint32_t root)
     for (uint32_t i = 0; i < n; ++i) {
       hipSetDevice(ctxs[i]->device);
       ncclResult_t r = R->Reduce(ctxs[i]->d_accum, i == root ? (void*)c->d_assembled : (void*)ctxs[i]->d_accum, 4 * n4, ncclFloat, ncclSum, (int)root,
-                                 c->comms[i], ctxs[i]->stream);
+                                 c->comms[i], cstream(ctxs[i]));
       if (r != ncclSuccess) { R->GroupEnd(); c->err = "ncclReduce failed"; return CRH_E_DEVICE; }
     }
     CRH_NCCL(R->GroupEnd());
-    for (uint32_t i = 0; i < n; ++i) { CRH_HIP(hipSetDevice(ctxs[i]->device)); CRH_HIP(hipStreamSynchronize(ctxs[i]->stream)); }
+    for (uint32_t i = 0; i < n; ++i) { CRH_HIP(hipSetDevice(ctxs[i]->device)); CRH_HIP(hipStreamSynchronize(cstream(ctxs[i]))); }
     CRH_HIP(hipSetDevice(c->device));
   } else {
     // contexts that share a device (rehearsal of the sharded flow on one GPU) or no RCCL in the process: the root pulls
     // every shard (peer copy when it lives on another device) and adds it in context order -- same sums, since every pixel
     // is non-zero in exactly one shard
-    CRH_HIP(hipMemcpyAsync(c->d_assembled, c->d_accum, sizeof(float4) * n4, hipMemcpyDeviceToDevice, c->stream));
-    Launch L{c->stream, c->grid, false};
+    CRH_HIP(hipMemcpyAsync(c->d_assembled, c->d_accum, sizeof(float4) * n4, hipMemcpyDeviceToDevice, cstream(c)));
+    Launch L{cstream(c), c->grid, false};
     for (uint32_t i = 0; i < n; ++i) {
       if (i == root) continue;
       const float4* src = ctxs[i]->d_accum;
       if (ctxs[i]->device != c->device) {
         if (!c->d_peer_stage) CRH_HIP(hipMalloc((void**)&c->d_peer_stage, sizeof(float4) * n4));
-        CRH_HIP(hipMemcpyPeerAsync(c->d_peer_stage, c->device, ctxs[i]->d_accum, ctxs[i]->device, sizeof(float4) * n4, c->stream));
+        CRH_HIP(hipMemcpyPeerAsync(c->d_peer_stage, c->device, ctxs[i]->d_accum, ctxs[i]->device, sizeof(float4) * n4, cstream(c)));
         src = c->d_peer_stage;
       }
       launch_add4(L, c->d_assembled, src, (uint32_t)n4);
     }
     CRH_HIP(hipGetLastError());
-    CRH_HIP(hipStreamSynchronize(c->stream));
+    CRH_HIP(hipStreamSynchronize(cstream(c)));
   }
   c->assembled_valid = true;
   return CRH_OK;
@@ -682,9 +740,9 @@ crh_ctx* crh_create(int device_ordinal)
   }
   crh_ctx* c = new crh_ctx();
   c->device = device_ordinal;
-  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&c->d_counters, sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), c->stream) != hipSuccess ||
-      hipStreamSynchronize(c->stream) != hipSuccess) {
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&c->d_counters, sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), cstream(c)) != hipSuccess ||
+      hipStreamSynchronize(cstream(c)) != hipSuccess) {
     fprintf(stderr, "crh_create: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
     delete c; return nullptr;
   }
@@ -695,6 +753,8 @@ crh_ctx* crh_create(int device_ordinal)
   if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }
   if (const char* e = getenv("CRH_CLAMP_GRID")) c->clamp_grid = atoi(e) != 0;
   if (const char* e = getenv("CRH_DONATE")) c->donate = atoi(e) != 0;
+  if (const char* e = getenv("CRH_PIPELINE")) c->pipeline = atoi(e) != 0;
+  if (const char* e = getenv("CRH_PIPE_DIV")) { int v = atoi(e); if (v > 0) c->pipe_div = v; }
   if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }
   if (const char* e = getenv("CRH_LANE_MAX_PATHS")) { long v = atol(e); if (v >= 0) c->lane_max_paths = (uint32_t)std::min<long>(v, 1l << 30); }
   if (const char* e = getenv("CRH_LANE_GRID")) { int v = atoi(e); if (v > 0) c->lane_grid = v; }
@@ -710,7 +770,7 @@ void crh_destroy(crh_ctx* c)
 {
   if (!c) return;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  hipStreamSynchronize(cstream(c));
   drain_events(c);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o[0], c->paths.ray_d[0], c->paths.ray_o[1], c->paths.ray_d[1], c->paths.thr[1],
@@ -724,9 +784,10 @@ void crh_destroy(crh_ctx* c)
   for (int k = 0; k < 8; ++k) { if (c->lane_stream[k]) { hipStreamSynchronize(c->lane_stream[k]); hipStreamDestroy(c->lane_stream[k]); } if (c->lane_join[k]) hipEventDestroy(c->lane_join[k]); }
   if (c->lane_fork) hipEventDestroy(c->lane_fork);
   if (c->d_lane_counts) hipFree(c->d_lane_counts);
+  if (c->d_pipe_seeds) hipFree(c->d_pipe_seeds);
   for (void* q : {(void*)c->d_tile_cdf, (void*)c->d_picked, (void*)c->d_adapt_n}) if (q) hipFree(q);
   release_comms(c);
-  hipStreamDestroy(c->stream);
+  hipStreamDestroy(c->stream_);
   delete c;
 }
 
@@ -829,7 +890,7 @@ int crh_set_texture(crh_ctx* c, uint32_t slot, const float* rgb, uint32_t w, uin
   if (rgb && channels != 3u && channels != 4u) return fail(c, CRH_E_INVALID, "texture channels must be 3 or 4");
   if (rgb && w && h && !all_finite(rgb, (size_t)channels * w * h)) return fail(c, CRH_E_INVALID, "texture holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   if (c->textures.size() <= slot) c->textures.resize(slot + 1);
   crh_ctx::HostTex& t = c->textures[slot];
   t.rgba.clear(); t.w = t.h = 0;
@@ -873,7 +934,7 @@ int crh_build(crh_ctx* c)
   const uint32_t nT = (uint32_t)(c->tri.size() / 4);
   if (nT && c->mats.empty()) return fail(c, CRH_E_INVALID, "no materials");
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   int threads = 0; if (const char* e = getenv("CRH_BUILD_THREADS")) threads = atoi(e);
   std::vector<int32_t> tri_inst(nT ? nT : 1, -1);   // triangle -> instance (two-level only)
   c->inst.clear(); c->root = 0;
@@ -940,7 +1001,7 @@ int crh_build(crh_ctx* c)
   } else if (c->d_uvs) { CRH_HIP(hipFree(c->d_uvs)); c->d_uvs = nullptr; }
   c->built = true;
   rc = do_reset(c); if (rc) return rc;
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;
 }
 
@@ -968,28 +1029,28 @@ int crh_render(crh_ctx* c, uint32_t n)
       if (c->pending_n == 0 || c->pending_first != c->frames_done || c->pending_tiles != nt) {
         int rc_t = upload_textures(c); if (rc_t) return rc_t;
         const uint32_t k = c->lookahead;
-        if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; }
-        if (k > c->seed_cap) { CRH_HIP(hipStreamSynchronize(c->stream)); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * k)); c->seed_cap = k; }
+        if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; }
+        if (k > c->seed_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * k)); c->seed_cap = k; }
         std::vector<uint32_t> seeds(k);
         { uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;
           for (uint32_t i = 0; i < c->frames_done + k; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; if (i >= c->frames_done) seeds[i - c->frames_done] = hi >> 2; } }
         c->h_tile_ids.clear();
-        CRH_HIP(hipMemcpyAsync(c->d_tile_ids, all.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice, c->stream));
-        CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * k, hipMemcpyHostToDevice, c->stream));
-        CRH_HIP(hipStreamSynchronize(c->stream));
+        CRH_HIP(hipMemcpyAsync(c->d_tile_ids, all.data(), sizeof(uint32_t) * nt, hipMemcpyHostToDevice, cstream(c)));
+        CRH_HIP(hipMemcpyAsync(c->d_seeds, seeds.data(), sizeof(uint32_t) * k, hipMemcpyHostToDevice, cstream(c)));
+        CRH_HIP(hipStreamSynchronize(cstream(c)));
         int rc_p = ensure_paths(c, nt * ts * ts * k); if (rc_p) return rc_p;
         DScene S; fill_scene(c, S);
         hipEvent_t e0 = get_event(c), e1 = get_event(c);
-        hipEventRecord(e0, c->stream);
+        hipEventRecord(e0, cstream(c));
         int rc_b = run_batch(c, S, c->d_tile_ids, nt, c->d_seeds, k, 0, false); if (rc_b) return rc_b;
-        hipEventRecord(e1, c->stream);
+        hipEventRecord(e1, cstream(c));
         c->render_ev.emplace_back(e0, e1);
         { int rc_e = trim_events(c); if (rc_e) return rc_e; }
         c->pending_first = c->frames_done; c->pending_n = k; c->pending_off = 0; c->pending_tiles = nt;
       }
       const uint32_t m = std::min(n, c->pending_n);
       DScene S; fill_scene(c, S);
-      Launch L{c->stream, c->grid, false};
+      Launch L{cstream(c), c->grid, false};
       launch_accumulate(L, S, c->paths, c->d_accum, nullptr, c->d_tile_ids, nt, c->pending_off, m, c->d_counters);
       CRH_HIP(hipGetLastError());
       c->pending_off += m; c->pending_n -= m; c->pending_first += m; c->frames_done += m; n -= m;
@@ -1035,7 +1096,7 @@ int crh_set_path_budget(crh_ctx* c, uint64_t max_paths)
   CRH_HIP(hipSetDevice(c->device));
   c->max_paths = (uint32_t)max_paths; c->pending_n = 0;
   if (c->path_cap > c->max_paths) {                      // give the memory back now; the next render allocates what it needs
-    CRH_HIP(hipStreamSynchronize(c->stream));
+    CRH_HIP(hipStreamSynchronize(cstream(c)));
     void** ptrs[] = {(void**)&c->paths.ray_o[0], (void**)&c->paths.ray_d[0], (void**)&c->paths.hit, (void**)&c->paths.thr[0], (void**)&c->paths.rad,
                      (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c, (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh,
                      (void**)&c->paths.ray_o[1], (void**)&c->paths.ray_d[1], (void**)&c->paths.thr[1]};
@@ -1057,23 +1118,25 @@ int crh_get_tile_stats(crh_ctx* c, float* err, uint32_t* counts, uint32_t* n_til
   return CRH_OK;
 }
 
-int crh_sync(crh_ctx* c) { if (!c) return CRH_E_INVALID; CRH_HIP(hipSetDevice(c->device)); CRH_HIP(hipStreamSynchronize(c->stream)); return CRH_OK; }
+int crh_sync(crh_ctx* c) { if (!c) return CRH_E_INVALID; c->read_since_render = true; CRH_HIP(hipSetDevice(c->device)); CRH_HIP(hipStreamSynchronize(cstream(c))); return CRH_OK; }
 
 int crh_read_hdr(crh_ctx* c, float* out)
 {
+  if (c) c->read_since_render = true;
   if (!c || !out || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null output");
   CRH_HIP(hipSetDevice(c->device));
   const uint32_t n = c->par.width * c->par.height;
   int rc = ensure_scratch(c, sizeof(float) * 3 * (size_t)n); if (rc) return rc;
-  Launch L{c->stream, c->grid, false};
+  Launch L{cstream(c), c->grid, false};
   launch_hdr(L, c->assembled_valid ? c->d_assembled : c->d_accum, (float*)c->d_scratch, n);
-  CRH_HIP(hipMemcpyAsync(out, c->d_scratch, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpyAsync(out, c->d_scratch, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;
 }
 
 int crh_read_ldr(crh_ctx* c, uint8_t* out)
 {
+  if (c) c->read_since_render = true;
   if (!c || !out || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null output");
   CRH_HIP(hipSetDevice(c->device));
   const uint32_t n = c->par.width * c->par.height;
@@ -1081,20 +1144,21 @@ int crh_read_ldr(crh_ctx* c, uint8_t* out)
   const bool overlay = c->show_tiles && c->adaptive && c->picked_valid && c->d_picked && c->tile_stat_cap >= n_tiles;
   int rc = ensure_scratch(c, 3 * (size_t)n); if (rc) return rc;
   const uint8_t* d_mask = overlay ? c->d_picked : nullptr;            // written by the device-side tile draw of the last iteration
-  Launch L{c->stream, c->grid, false};
+  Launch L{cstream(c), c->grid, false};
   launch_tonemap(L, c->assembled_valid ? c->d_assembled : c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, d_mask, c->par.width, ts);
-  CRH_HIP(hipMemcpyAsync(out, c->d_scratch, 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpyAsync(out, c->d_scratch, 3 * (size_t)n, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;
 }
 
 int crh_save_accum(crh_ctx* c, float* out, uint32_t* frames_done)
 {
+  if (c) c->read_since_render = true;
   if (!c || !out || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null output");
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
-  CRH_HIP(hipMemcpyAsync(out, c->assembled_valid ? c->d_assembled : c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
+  CRH_HIP(hipMemcpyAsync(out, c->assembled_valid ? c->d_assembled : c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   if (frames_done) *frames_done = c->frames_done;
   return CRH_OK;
 }
@@ -1104,9 +1168,9 @@ int crh_load_accum(crh_ctx* c, const float* in, uint32_t frames_done)
   if (!c || !in || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator / null input");
   if (c->adaptive) return fail(c, CRH_E_INVALID, "checkpoints do not carry the adaptive sampler's second moments");
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
-  CRH_HIP(hipMemcpyAsync(c->d_accum, in, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
+  CRH_HIP(hipMemcpyAsync(c->d_accum, in, sizeof(float4) * (size_t)c->par.width * c->par.height, hipMemcpyHostToDevice, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   c->frames_done = frames_done; c->pending_n = 0; c->assembled_valid = false;
   return CRH_OK;
 }
@@ -1128,13 +1192,14 @@ int crh_enable_counters(crh_ctx* c, int on) { if (!c) return CRH_E_INVALID; c->c
 
 int crh_get_stats(crh_ctx* c, crh_stats* out)
 {
+  if (c) c->read_since_render = true;
   if (!c || !out) return fail(c, CRH_E_INVALID, "null stats");
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   drain_events(c);
   DCounters h;
-  CRH_HIP(hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   out->rays_nearest = h.rays_nearest; out->rays_any = h.rays_any; out->nodes_nearest = h.nodes_nearest; out->tris_nearest = h.tris_nearest;
   out->nodes_any = h.nodes_any; out->tris_any = h.tris_any; out->shaded_hits = h.shaded_hits; out->samples = h.samples;
   out->seconds = c->seconds_acc;
@@ -1150,13 +1215,13 @@ static int trace_api(crh_ctx* c, const float* rays, uint32_t n, int any_hit, flo
   const size_t in_b = 32 * (size_t)n, out_b = (any_hit ? 4 : 16) * (size_t)n;
   int rc = ensure_scratch(c, in_b + out_b); if (rc) return rc;
   char* base = (char*)c->d_scratch;
-  CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, cstream(c)));
   DScene S; fill_scene(c, S);
-  Launch L{c->stream, c->grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0};
+  Launch L{cstream(c), c->grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0};
   launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
   CRH_HIP(hipGetLastError());
-  CRH_HIP(hipMemcpyAsync(any_hit ? (void*)out_vis : (void*)out_hit, base + in_b, out_b, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpyAsync(any_hit ? (void*)out_vis : (void*)out_hit, base + in_b, out_b, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;
 }
 int crh_trace_nearest(crh_ctx* c, const float* rays, uint32_t n, float* out_hit) { return trace_api(c, rays, n, 0, out_hit, nullptr); }
@@ -1195,16 +1260,16 @@ int crh_bench_trace(crh_ctx* c, const float* rays, uint32_t n, int any_hit, uint
   const size_t in_b = 32 * (size_t)n, out_b = 16 * (size_t)n;
   int rc = ensure_scratch(c, in_b + out_b); if (rc) return rc;
   char* base = (char*)c->d_scratch;
-  CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, c->stream));
+  CRH_HIP(hipMemcpyAsync(base, rays, in_b, hipMemcpyHostToDevice, cstream(c)));
   DScene S; fill_scene(c, S);
-  Launch L{c->stream, c->grid_trace, false, c->clamp_grid ? c->cus : 0};
+  Launch L{cstream(c), c->grid_trace, false, c->clamp_grid ? c->cus : 0};
   launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
   hipEvent_t e0 = get_event(c), e1 = get_event(c);
-  CRH_HIP(hipEventRecord(e0, c->stream));
+  CRH_HIP(hipEventRecord(e0, cstream(c)));
   for (uint32_t r = 0; r < repeat; ++r)
     launch_trace_rays(L, S, (const float4*)base, n, any_hit, (float4*)(base + in_b), (uint32_t*)(base + in_b), c->d_api_cursor, c->d_counters);
-  CRH_HIP(hipEventRecord(e1, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipEventRecord(e1, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   float ms = 0.f; CRH_HIP(hipEventElapsedTime(&ms, e0, e1));
   c->ev_pool.push_back(e0); c->ev_pool.push_back(e1);
   *avg_ms = ms / (float)repeat;
@@ -1218,15 +1283,15 @@ int crh_debug_math(crh_ctx* c, int fn, const float* a, const float* b, float* ou
   const size_t bytes = sizeof(float) * (size_t)n;
   int rc = ensure_scratch(c, 4 * bytes); if (rc) return rc;
   float* d = (float*)c->d_scratch;
-  CRH_HIP(hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipMemcpyAsync(d + n, b, bytes, hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipMemsetAsync(d + 2 * (size_t)n, 0, 2 * bytes, c->stream));
-  Launch L{c->stream, c->grid, false};
+  CRH_HIP(hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, cstream(c)));
+  CRH_HIP(hipMemcpyAsync(d + n, b, bytes, hipMemcpyHostToDevice, cstream(c)));
+  CRH_HIP(hipMemsetAsync(d + 2 * (size_t)n, 0, 2 * bytes, cstream(c)));
+  Launch L{cstream(c), c->grid, false};
   launch_debug_math(L, fn, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, n);
   CRH_HIP(hipGetLastError());
-  CRH_HIP(hipMemcpyAsync(out, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipMemcpyAsync(out2, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpyAsync(out, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipMemcpyAsync(out2, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;
 }
 
@@ -1239,14 +1304,14 @@ int crh_debug_bsdf(crh_ctx* c, int fn, const crh_bsdf* m, const float* a, const 
   int rc = ensure_scratch(c, 256 + 2 * in_b + out_b); if (rc) return rc;
   char* base = (char*)c->d_scratch;
   float* d_a = (float*)(base + 256); float* d_b = (float*)(base + 256 + in_b); float* d_o = (float*)(base + 256 + 2 * in_b);
-  CRH_HIP(hipMemcpyAsync(base, m, sizeof(crh_bsdf), hipMemcpyHostToDevice, c->stream));
-  CRH_HIP(hipMemcpyAsync(d_a, a, in_b, hipMemcpyHostToDevice, c->stream));
-  if (b) CRH_HIP(hipMemcpyAsync(d_b, b, in_b, hipMemcpyHostToDevice, c->stream));
-  Launch L{c->stream, c->grid, false};
+  CRH_HIP(hipMemcpyAsync(base, m, sizeof(crh_bsdf), hipMemcpyHostToDevice, cstream(c)));
+  CRH_HIP(hipMemcpyAsync(d_a, a, in_b, hipMemcpyHostToDevice, cstream(c)));
+  if (b) CRH_HIP(hipMemcpyAsync(d_b, b, in_b, hipMemcpyHostToDevice, cstream(c)));
+  Launch L{cstream(c), c->grid, false};
   launch_debug_bsdf(L, fn, (const float4*)base, d_a, d_b, d_o, n, two_sided);
   CRH_HIP(hipGetLastError());
-  CRH_HIP(hipMemcpyAsync(out, d_o, out_b, hipMemcpyDeviceToHost, c->stream));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipMemcpyAsync(out, d_o, out_b, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;
 }
 
@@ -1256,7 +1321,7 @@ int crh_get_kernel_timing(crh_ctx* c, double* trace_ms_total, uint64_t* trace_la
 {
   if (!c) return CRH_E_INVALID;
   CRH_HIP(hipSetDevice(c->device));
-  CRH_HIP(hipStreamSynchronize(c->stream));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
   drain_events(c);
   if (trace_ms_total) *trace_ms_total = c->trace_ms_acc;
   if (trace_launches) *trace_launches = c->trace_launches;
