@@ -112,6 +112,7 @@ static inline hipStream_t cstream(crh_ctx* c)
 {
   for (int k = 0; k < 2; ++k)
     if (c->pipe_pending[k]) { hipStreamWaitEvent(c->stream_, c->lane_join[k], 0); c->pipe_pending[k] = false; }
+  c->read_since_render = true;      // something other than the next frame used the stream (render_impl clears this when it is done)
   return c->stream_;
 }
 
@@ -488,7 +489,6 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   // would get 187 instead of 225 (one schedule per frame is slower than two tile ranges when nothing overlaps it), so a
   // read-back / synchronisation since the last render selects the two-range schedule for this frame.
   const bool host_runs_ahead = !c->read_since_render;
-  c->read_since_render = false;
   if (c->pipeline && host_runs_ahead && !c->counters_on && !c->timing_on && !c->adaptive && group == nt && spb == ns && ns <= 16u && total >= (1u << 20) &&
       total <= c->lane_max_paths && 2u * total <= c->max_paths) {
     // ---- frame pipelining: this batch (one Redraw() worth) goes to pipeline stream k with its own half of the path state; it
@@ -522,6 +522,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     rc = run_lane(c, ln, S, c->d_tile_ids, nt, d_seeds_k, ns, 0, true, c->pipe_pending[1u - k] ? c->lane_join[1u - k] : nullptr); if (rc) return rc;
     CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
     c->pipe_pending[k] = true;
+    c->read_since_render = false;
     return CRH_OK;
   }
   if (ns > c->seed_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * ns)); c->seed_cap = ns; }
@@ -546,7 +547,9 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   }
   hipEventRecord(e1, cstream(c));
   c->render_ev.emplace_back(e0, e1);
-  return trim_events(c);
+  rc = trim_events(c);
+  c->read_since_render = false;      // from here on, only a call other than the next render sets it again
+  return rc;
 }
 
 // ---- adaptive screen sampling (reference: AdaptiveScreenSampling / NbRayTracingTiles, SettingsWidget.cxx:427-477) ----------
@@ -913,6 +916,7 @@ int crh_set_camera(crh_ctx* c, const crh_camera* cam)
                      cam->fovy_deg, cam->aspect, cam->ortho_scale, cam->aperture_radius, cam->focal_dist};
   if (!all_finite(f, sizeof f / sizeof f[0], 1.0e30f)) return fail(c, CRH_E_INVALID, "camera holds a NaN / Inf");
   c->cam = *cam; c->pending_n = 0;                      // samples traced ahead with the old camera are dropped
+  c->read_since_render = true;
   return CRH_OK;
 }
 
