@@ -519,11 +519,16 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.counts = c->d_lane_counts + 8 * k;
     CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
     c->pending_n = 0;
+    hipEvent_t e0 = get_event(c), e1 = get_event(c);          // crh_stats.seconds: device time of this frame (frames in flight overlap)
+    hipEventRecord(e0, ln.stream);
     rc = run_lane(c, ln, S, c->d_tile_ids, nt, d_seeds_k, ns, 0, true, c->pipe_pending[1u - k] ? c->lane_join[1u - k] : nullptr); if (rc) return rc;
+    hipEventRecord(e1, ln.stream);
+    c->render_ev.emplace_back(e0, e1);
     CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
     c->pipe_pending[k] = true;
+    rc = trim_events(c);                                        // every 4096 frames: waits for the device once
     c->read_since_render = false;
-    return CRH_OK;
+    return rc;
   }
   if (ns > c->seed_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * ns)); c->seed_cap = ns; }
   {
