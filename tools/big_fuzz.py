@@ -17,4 +17,4 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[
     ok = ok and np.array_equal(fz.bits(w.read_hdr()), fz.bits(o.read_hdr()))
     if not ok: bad.append(seed)
     v.close(); w.close(); o.close()
-print("400 scenes, mismatches:", bad)
+print("scenes checked, mismatches:", bad)

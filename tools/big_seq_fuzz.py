@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""One-off hunt beside tools/big_fuzz.py: the random CALL-SEQUENCE tests of tests/test_gpu_fuzz.py with many more seeds (renders,
+Redraws under look-ahead, tile subsets, resets, camera / material / light / environment / parameter changes, object moves,
+adaptive on / off, checkpoints), GPU vs oracle after every step.  python tools/big_seq_fuzz.py [first] [last]"""
+import sys, importlib.util
+sys.path.insert(0, '.')
+import torch  # noqa: F401
+spec = importlib.util.spec_from_file_location("fz", "tests/test_gpu_fuzz.py"); fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+from cadrays_amd.view import View
+from oracle.pyoracle import Oracle
+a, b = (int(sys.argv[1]) if len(sys.argv) > 1 else 1000), (int(sys.argv[2]) if len(sys.argv) > 2 else 1200)
+bad = []
+for seed in range(a, b):
+    for fn in (fz.test_random_call_sequences_keep_both_sides_in_step, fz.test_random_sequences_two_level_adaptive_checkpoint):
+        try:
+            fn.__wrapped__(View, Oracle, seed) if hasattr(fn, "__wrapped__") else fn(View, Oracle, seed)
+        except AssertionError as e:
+            bad.append((fn.__name__, seed, str(e)[:80]))
+print(f"{b - a} seeds x 2 sequence kinds, mismatches:", bad)
