@@ -92,7 +92,8 @@ struct crh_ctx {
   // frame pipelining: consecutive small whole batches (one Redraw() each) run on alternating streams and path-state halves, so
   // the drain-bound late bounces of frame n overlap the throughput-bound first bounces of frame n + 1; accumulation stays in
   // frame order (an event between the two accumulate launches)
-  bool pipeline = true; bool pipe_pending[2] = {false, false}; uint32_t pipe_seq = 0; uint32_t* d_pipe_seeds = nullptr; int pipe_div = 4096;
+  bool pipeline = true; bool pipe_pending[4] = {false, false, false, false}; uint32_t pipe_seq = 0; uint32_t* d_pipe_seeds = nullptr; int pipe_div = 4096;
+  uint32_t pipe_depth = 3;         // frames in flight: 2 / 3 / 4 -> 323 / 391 / 312 Redraw/s on C3, 448 / 558 / 453 on C2
   bool read_since_render = true;   // a host that looks at every frame (read-back / sync between Redraws) gets the two-range schedule instead
   bool counters_on = false, timing_on = false;
   uint32_t frames_done = 0;       // whole-frame iterations since reset (crh_render continues from here)
@@ -110,7 +111,7 @@ struct crh_ctx {
 // whoever wants to enqueue on, or wait for, the context's stream first makes it wait for the frames still in flight.
 static inline hipStream_t cstream(crh_ctx* c)
 {
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 4; ++k)
     if (c->pipe_pending[k]) { hipStreamWaitEvent(c->stream_, c->lane_join[k], 0); c->pipe_pending[k] = false; }
   c->read_since_render = true;      // something other than the next frame used the stream (render_impl clears this when it is done)
   return c->stream_;
@@ -402,12 +403,12 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
 int ensure_lanes(crh_ctx* c)
 {
   if (c->d_lane_counts) return CRH_OK;
-  for (uint32_t k = 0; k < c->n_lanes; ++k) {
+  for (uint32_t k = 0; k < std::max(c->n_lanes, 4u); ++k) {      // tile ranges of one batch, or frames in flight (pipe_depth <= 4)
     CRH_HIP(hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
     CRH_HIP(hipEventCreateWithFlags(&c->lane_join[k], hipEventDisableTiming));
   }
   CRH_HIP(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
-  CRH_HIP(hipMalloc((void**)&c->d_pipe_seeds, 2 * 16 * sizeof(uint32_t)));
+  CRH_HIP(hipMalloc((void**)&c->d_pipe_seeds, 4 * 16 * sizeof(uint32_t)));
   CRH_HIP(hipMalloc((void**)&c->d_lane_counts, 8 * sizeof(uint32_t) * 8));
   CRH_HIP(hipMemsetAsync(c->d_lane_counts, 0, 8 * sizeof(uint32_t) * 8, cstream(c)));
   return CRH_OK;
@@ -490,13 +491,14 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   // read-back / synchronisation since the last render selects the two-range schedule for this frame.
   const bool host_runs_ahead = !c->read_since_render;
   if (c->pipeline && host_runs_ahead && !c->counters_on && !c->timing_on && !c->adaptive && group == nt && spb == ns && ns <= 16u && total >= (1u << 20) &&
-      total <= c->lane_max_paths && 2u * total <= c->max_paths) {
+      total <= c->lane_max_paths && (uint64_t)c->pipe_depth * total <= c->max_paths) {
     // ---- frame pipelining: this batch (one Redraw() worth) goes to pipeline stream k with its own half of the path state; it
     // starts as soon as the previous frame ON THAT STREAM is done and overlaps the frame on the other stream; its samples are
     // folded in after that frame's.  Nothing is joined into the context's stream here -- cstream() does that on demand.
-    int rc = ensure_paths(c, (uint32_t)(2u * total)); if (rc) return rc;
+    int rc = ensure_paths(c, (uint32_t)(c->pipe_depth * total)); if (rc) return rc;
     rc = ensure_lanes(c); if (rc) return rc;
-    const uint32_t k = c->pipe_seq++ & 1u;
+    const uint32_t k = c->pipe_seq % c->pipe_depth, prev = (c->pipe_seq + c->pipe_depth - 1u) % c->pipe_depth;      // this frame's stream, the previous frame's
+    ++c->pipe_seq;
     const hipStream_t cs = c->stream_;                 // raw: no join
     if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(cs, c->lane_join[k], 0));      // this stream's seed slot is free once its last frame is done
     uint32_t* d_seeds_k = c->d_pipe_seeds + 16u * k;
@@ -521,7 +523,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     c->pending_n = 0;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);          // crh_stats.seconds: device time of this frame (frames in flight overlap)
     hipEventRecord(e0, ln.stream);
-    rc = run_lane(c, ln, S, c->d_tile_ids, nt, d_seeds_k, ns, 0, true, c->pipe_pending[1u - k] ? c->lane_join[1u - k] : nullptr); if (rc) return rc;
+    rc = run_lane(c, ln, S, c->d_tile_ids, nt, d_seeds_k, ns, 0, true, c->pipe_pending[prev] ? c->lane_join[prev] : nullptr); if (rc) return rc;
     hipEventRecord(e1, ln.stream);
     c->render_ev.emplace_back(e0, e1);
     CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
@@ -762,6 +764,7 @@ crh_ctx* crh_create(int device_ordinal)
   if (const char* e = getenv("CRH_CLAMP_GRID")) c->clamp_grid = atoi(e) != 0;
   if (const char* e = getenv("CRH_DONATE")) c->donate = atoi(e) != 0;
   if (const char* e = getenv("CRH_PIPELINE")) c->pipeline = atoi(e) != 0;
+  if (const char* e = getenv("CRH_PIPE_DEPTH")) { int v = atoi(e); if (v >= 2 && v <= 4) c->pipe_depth = (uint32_t)v; }
   if (const char* e = getenv("CRH_PIPE_DIV")) { int v = atoi(e); if (v > 0) c->pipe_div = v; }
   if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }
   if (const char* e = getenv("CRH_LANE_MAX_PATHS")) { long v = atol(e); if (v >= 0) c->lane_max_paths = (uint32_t)std::min<long>(v, 1l << 30); }
