@@ -479,3 +479,53 @@ def test_pipelined_frames_equal_unpipelined(view_cls, monkeypatch):
     got = calls(view_cls(0).load_scene(sc))
     assert np.array_equal(bits(got[0]), bits(ref[0])) and np.array_equal(bits(got[1]), bits(ref[1])) and got[2] == ref[2]
     assert got[0][..., 0].max() > 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_call_sequences_with_frames_in_flight(view_cls, monkeypatch, seed):
+    """Random API sequences on a frame large enough to be pipelined (>= 1 M paths): bursts of Redraw()s with setters, resets,
+    tile subsets, look-ahead and adaptive switches and read-outs in between.  Every read-out must be bit-identical to the same
+    sequence with CRH_PIPELINE=0 / CRH_DONATE=0 / one stream (the schedule the other tests tie to the oracle)."""
+    import dataclasses
+    sc = scenes.cornell_box(True, 1216, 896)                       # 1064 tiles = 1.09 M paths per frame
+    r0 = np.random.default_rng(seed)
+    ops = []
+    for _ in range(14):
+        k = r0.integers(0, 9)
+        ops.append((int(k), int(r0.integers(1, 6)), float(r0.random())))
+
+    def run(v):
+        outs = []
+        for k, n, x in ops:
+            if k <= 2:
+                for _ in range(n):
+                    v.Redraw()
+            elif k == 3:
+                v.set_camera(dataclasses.replace(sc.camera, eye=(0.3 + 0.3 * x, -1.5, 0.5))); v.reset()
+            elif k == 4:
+                mats = [dataclasses.replace(m) for m in sc.materials]
+                mats[0] = dataclasses.replace(mats[0], Kd=np.float32([x, 0.5, 0.3]))
+                v.set_materials(mats)                                # no reset: like a material-editor drag between frames
+            elif k == 5:
+                outs.append(v.read_hdr().copy())
+            elif k == 6:
+                v.render_tiles(np.arange(0, v.n_tiles(), 3, dtype=np.uint32), 40 + n, n)
+            elif k == 7:
+                v.set_lookahead(1 + (n % 3) * 3)
+            else:
+                v.set_adaptive(n % 2 == 0, 64 + 16 * n)
+                for _ in range(2):
+                    v.Redraw()
+                v.set_adaptive(False, 64)
+        for _ in range(3):
+            v.Redraw()
+        outs.append(v.read_hdr().copy())
+        return outs
+
+    monkeypatch.setenv("CRH_PIPELINE", "0"); monkeypatch.setenv("CRH_DONATE", "0"); monkeypatch.setenv("CRH_LANES", "1")
+    ref = run(view_cls(0).load_scene(sc))
+    monkeypatch.delenv("CRH_PIPELINE"); monkeypatch.delenv("CRH_DONATE"); monkeypatch.delenv("CRH_LANES")
+    got = run(view_cls(0).load_scene(sc))
+    assert len(got) == len(ref)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(bits(a), bits(b)), (seed, i)
