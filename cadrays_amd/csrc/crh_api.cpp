@@ -981,17 +981,24 @@ int crh_build(crh_ctx* c)
   }
   // leaf-ordered triangle and shading records
   c->h_tris.assign(12 * (size_t)std::max(nT, 1u), 0.f);
-  std::vector<float> sh(12 * (size_t)std::max(nT, 1u), 0.f);
+  std::vector<float> sh(16 * (size_t)std::max(nT, 1u), 0.f);      // 64-B shading records: three vertex normals (+ material, instance) and the geometric normal
   for (uint32_t i = 0; i < nT; ++i) {
     const uint32_t t = c->bvh.prim_order[i];
     for (int k = 0; k < 3; ++k) {
       const int32_t vi = c->tri[4 * t + k];
-      for (int a = 0; a < 3; ++a) { c->h_tris[12 * (size_t)i + 4 * k + a] = c->pos[3 * vi + a]; sh[12 * (size_t)i + 4 * k + a] = c->nrm[3 * vi + a]; }
+      for (int a = 0; a < 3; ++a) { c->h_tris[12 * (size_t)i + 4 * k + a] = c->pos[3 * vi + a]; sh[16 * (size_t)i + 4 * k + a] = c->nrm[3 * vi + a]; }
+    }
+    {
+      // the kernel's former expression on the three vertices, evaluated once here with the same inline arithmetic (same bits)
+      const float* q = &c->h_tris[12 * (size_t)i];
+      const crh_v3 p0 = crh_mk3(q[0], q[1], q[2]), p1 = crh_mk3(q[4], q[5], q[6]), p2 = crh_mk3(q[8], q[9], q[10]);
+      const crh_v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
+      sh[16 * (size_t)i + 12] = ng.x; sh[16 * (size_t)i + 13] = ng.y; sh[16 * (size_t)i + 14] = ng.z;
     }
     std::memcpy(&c->h_tris[12 * (size_t)i + 3], &t, 4);
     const int32_t mat = c->tri[4 * t + 3];
-    std::memcpy(&sh[12 * (size_t)i + 3], &mat, 4);
-    std::memcpy(&sh[12 * (size_t)i + 7], &tri_inst[t], 4);       // n1.w = instance index (two-level shading fetches its transform)
+    std::memcpy(&sh[16 * (size_t)i + 3], &mat, 4);
+    std::memcpy(&sh[16 * (size_t)i + 7], &tri_inst[t], 4);       // n1.w = instance index (two-level shading fetches its transform)
   }
   int rc;
   // head-room behind the node array: crh_set_transforms rebuilds the top-level tree into it (<= one node per instance + alignment holes)

@@ -30,7 +30,7 @@ constexpr int kOvfStack   = 112;   // spill entries per lane (scratch, rarely to
 struct DScene {
   const float4* nodes;    // 3 x float4 used per node (64-B stride): {origin.xyz, exps | child counts}, {qlo xyz, qhi x}, {qhi yz, child base, leaf base}  (crh_bvh_format.h)
   const float4* tris;     // 3 x float4 per triangle in leaf order (kTriStride apart): v0|prim, v1, v2
-  const float4* shade;    // 3 x float4 per triangle in leaf order: n0|material, n1, n2
+  const float4* shade;    // 4 x float4 (one 64-B sector) per triangle in leaf order: n0|material, n1|instance, n2, geometric normal (single-level scenes)
   const float4* mats;     // 8 x float4 per material (crh_bsdf)
   const float4* lights;   // 2 x float4 per light: {vec.xyz (unit to-light dir | position), is_point}, {emission.rgb, cosmax | radius}
   const float4* env;      // W*H float4 texels, row 0 = zenith; nullptr -> constant background

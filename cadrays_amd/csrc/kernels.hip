@@ -974,19 +974,24 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
         P.rad[pid] = mk4(crh_add3(xyz(r4), crh_scale3(crh_mul3(W, le), mis)), 0.f);
       } else {
         ++n_shaded;
-        const float4* tp = S.tris + kTriStride * (uint32_t)hk;
-        const float4* sp = S.shade + 3u * (uint32_t)hk;      // (a 64-B stride for these records was measured: +0.1 %, not kept)
-        const float4 a = tp[0], b4 = tp[1], c4 = tp[2], s0 = sp[0], s1 = sp[1], s2 = sp[2];
-        v3 p0 = xyz(a), p1 = xyz(b4), p2 = xyz(c4);
+        // shading record: one 64-B sector {n0 | material, n1 | instance, n2, geometric normal}.  The geometric normal of a
+        // single-level scene is precomputed on the host with the same inline arithmetic (crh_math.h) the kernel used to apply to
+        // the three vertices -- same bits -- so shading no longer gathers the 48-B triangle record (a second 128-B line per hit);
+        // a two-level scene still needs the vertices: the normal is taken from the TRANSFORMED corners
+        const float4* sp = S.shade + 4u * (uint32_t)hk;
+        const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
         float M[12];
+        v3 ng;
         if (S.two_level) {                                   // object -> world through the instance's forward transform
+          const float4* tp = S.tris + kTriStride * (uint32_t)hk;
+          const float4 a = tp[0], b4 = tp[1], c4 = tp[2];
           const float4* ip = S.inst + 8u * (uint32_t)__float_as_int(s1.w);
           const float4 f0 = ip[3], f1 = ip[4], f2 = ip[5];
           M[0] = f0.x; M[1] = f0.y; M[2] = f0.z; M[3] = f0.w; M[4] = f1.x; M[5] = f1.y; M[6] = f1.z; M[7] = f1.w;
           M[8] = f2.x; M[9] = f2.y; M[10] = f2.z; M[11] = f2.w;
-          p0 = crh_xform_point(M, p0); p1 = crh_xform_point(M, p1); p2 = crh_xform_point(M, p2);
-        }
-        const v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
+          const v3 p0 = crh_xform_point(M, xyz(a)), p1 = crh_xform_point(M, xyz(b4)), p2 = crh_xform_point(M, xyz(c4));
+          ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
+        } else ng = xyz(sp[3]);
         const float w0 = (1.0f - h.y) - h.z;
         v3 ns = crh_norm3(crh_mk3(CRH_FMA(s2.x, h.z, CRH_FMA(s1.x, h.y, s0.x * w0)),
                                   CRH_FMA(s2.y, h.z, CRH_FMA(s1.y, h.y, s0.y * w0)),

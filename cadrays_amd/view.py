@@ -85,10 +85,10 @@ class View(Backend):
         self._call("load_accum", rgba.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(int(frames_done)))
 
     def scene_bytes(self):
-        """HBM residency of the built scene: 64-B-stride nodes, 64-B-stride triangle records, 48-B shading records"""
+        """HBM residency of the built scene: 64-B-stride nodes, 64-B-stride triangle records, 64-B shading records"""
         nn, nt = C.c_uint32(0), C.c_uint32(0)
         self._call("get_bvh", None, C.byref(nn), None, C.byref(nt))
-        return {"nodes": 4 * abi.NODE_DWORDS * nn.value, "triangles": 64 * nt.value, "shading": 48 * nt.value,
+        return {"nodes": 4 * abi.NODE_DWORDS * nn.value, "triangles": 64 * nt.value, "shading": 64 * nt.value,
                 "n_nodes": nn.value, "n_triangles": nt.value}
 
     def accum_device_ptr(self):
