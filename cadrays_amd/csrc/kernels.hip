@@ -914,8 +914,10 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
 // ================================================================== shade
 constexpr int kLdsMats = 64;   // materials staged in LDS (8 KB); larger tables are read from HBM/L2
 
+// workgroups per CU the register allocation must allow: 4 => <= 128 VGPRs (143 unconstrained, 3 waves/SIMD).  Measured, Mrays/s at
+// 0 / 4 / 5: C3 3457 / 3474 / 3200, C2 4803 / 4856 / 4569, C5 2416 / 2423, C1 13390 / 13765 (5 = 96 VGPRs spills the BSDF code)
 #ifndef CRH_SHADE_MINWAVES
-#define CRH_SHADE_MINWAVES 0
+#define CRH_SHADE_MINWAVES 4
 #endif
 #if CRH_SHADE_MINWAVES > 0
 #define CRH_SHADE_BOUNDS __launch_bounds__(kBlock, CRH_SHADE_MINWAVES)

@@ -154,6 +154,58 @@ def test_trace_edge_cases(view_cls, Oracle):
         assert np.array_equal(v.trace_any(rays), o.trace_any(rays))
 
 
+def _model_stack_depth(nodes):
+    """Deepest stack of a ray that enters EVERY child box of every node (walk in slot order sorted by the lower z bound):
+    what the engine's stack holds for the rays of test_deep_stack_spills_to_scratch."""
+    w = nodes.view(np.uint32)
+    best, stack, cur = 0, [], 0
+    while True:
+        if cur & 0x80000000:
+            if not stack: return best
+            cur = stack.pop()
+            continue
+        ew = int(w[cur, 3]); ni, nch = (ew >> 24) & 7, (ew >> 28) & 7
+        order = sorted(range(nch), key=lambda k: (int(w[cur, 6]) >> (8 * k)) & 255)
+        refs = [int(w[cur, 10]) + k if k < ni else int(w[cur, 11]) + (k - ni) for k in order]
+        stack.extend(reversed(refs[1:])); best = max(best, len(stack)); cur = refs[0]
+
+
+def test_deep_stack_spills_to_scratch(view_cls, Oracle):
+    """16 384 parallel corner triangles stacked along z, their boxes all [-1,1]^2 in xy: a ray along z through the free half of
+    the square enters every box and hits nothing, so nothing is ever pruned and the per-lane stack grows by three entries per
+    level -- past the 16 LDS entries into the scratch spill (kernels.hip: CRH_PUSH / read_top slow paths), which ordinary
+    scenes never reach.  Hits, any-hit flags and visit counters must still equal the oracle's."""
+    n = 16384
+    z = np.linspace(-1, 1, n, dtype=np.float32)
+    pos = np.zeros((n, 3, 3), np.float32)
+    pos[:, 0] = np.stack([-np.ones(n), -np.ones(n), z], 1); pos[:, 1] = np.stack([np.ones(n), -np.ones(n), z], 1); pos[:, 2] = np.stack([-np.ones(n), np.ones(n), z], 1)
+    pos = pos.reshape(-1, 3)
+    tri = np.concatenate([np.arange(3 * n, dtype=np.int32).reshape(n, 3), np.zeros((n, 1), np.int32)], 1)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (3 * n, 1))
+    sc = scenes.Scene(pos, nrm, tri, [BSDF.CreateDiffuse(0.5)])
+    v = view_cls(0).load_scene(sc); o = Oracle().load_scene(sc)
+    gn, _ = v.get_bvh()
+    assert _model_stack_depth(gn) > 16 + 2                         # really beyond the LDS part, not just at its edge
+    r = np.random.default_rng(5)
+    m = 4096
+    rays = np.zeros((m, 8), np.float32)
+    xy = r.random((m, 2)).astype(np.float32) * 0.9 + 0.05        # x + y > 0: beside every triangle
+    rays[:, 0:2] = xy; rays[:, 2] = -2; rays[:, 3] = 1e15; rays[:, 6] = 1
+    rays[m // 2:, 2] = 2; rays[m // 2:, 6] = -1                      # half of them the other way
+    rays[::7, 0:2] *= -1                                          # some hit the nearest sheet straight away
+    rays[::5, 4] = 0.05; rays[::5, 6] *= 0.99874921777                  # some oblique (unit length: 0.05^2 + 0.99874921777^2 = 1)
+    v.reset(); o.reset(); v.enable_counters(True)
+    g, c = v.trace_nearest(rays), o.trace_nearest(rays)
+    assert np.array_equal(bits(g), bits(c))
+    assert np.array_equal(v.trace_any(rays), o.trace_any(rays))
+    gs, cs = v.stats(), o.stats()
+    for k in ("nodes_nearest", "tris_nearest", "nodes_any", "tris_any"):
+        assert gs[k] == cs[k], k
+    assert gs["nodes_nearest"] > 0.3 * m * len(gn)                 # the free rays did walk the whole tree
+    v.enable_counters(False)                                      # the plain (non-counting) instantiation takes the same path
+    assert np.array_equal(bits(v.trace_nearest(rays)), bits(c))
+
+
 # ----------------------------------------------------------------------------------------------
 def render_both(view_cls, Oracle, sc, spp):
     v = view_cls(0).load_scene(sc); v.enable_counters(True); v.reset()

@@ -395,6 +395,26 @@ __global__ __launch_bounds__(kBlock) void k_trace(const float4* __restrict__ nod
   if (COUNT) { atomicAdd(&counters[0], (unsigned long long)n_nodes); atomicAdd(&counters[1], (unsigned long long)n_tris); }
 }
 
+
+// bounds of (triangle ∩ box): Sutherland-Hodgman against the six planes (double precision; experiment only)
+static bool clip_bounds(const float* tri, const float* blo, const float* bhi, float* olo, float* ohi)
+{
+  double poly[16][3], tmp[16][3]; int np = 3;
+  for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) poly[k][a] = tri[3 * k + a];
+  for (int a = 0; a < 3; ++a) for (int side = 0; side < 2; ++side) {
+    const double pl = side ? bhi[a] : blo[a]; int nq = 0;
+    for (int k = 0; k < np; ++k) { const double* A = poly[k]; const double* Bq = poly[(k + 1) % np];
+      const bool ia = side ? A[a] <= pl : A[a] >= pl, ib = side ? Bq[a] <= pl : Bq[a] >= pl;
+      if (ia) { for (int c = 0; c < 3; ++c) tmp[nq][c] = A[c]; ++nq; }
+      if (ia != ib) { const double t = (pl - A[a]) / (Bq[a] - A[a]); for (int c = 0; c < 3; ++c) tmp[nq][c] = A[c] + t * (Bq[c] - A[c]); tmp[nq][a] = pl; ++nq; } }
+    np = nq; if (np == 0) return false;
+    for (int k = 0; k < np; ++k) for (int c = 0; c < 3; ++c) poly[k][c] = tmp[k][c];
+  }
+  for (int a = 0; a < 3; ++a) { double lo = 1e300, hi = -1e300; for (int k = 0; k < np; ++k) { lo = std::min(lo, poly[k][a]); hi = std::max(hi, poly[k][a]); }
+    olo[a] = std::max((float)blo[a], std::nextafterf((float)lo, -3e38f)); ohi[a] = std::min((float)bhi[a], std::nextafterf((float)hi, 3e38f)); }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ main
 template <int W, int MODE, int LDS_STACK>
 static void run(const char* name, const Wide& wd, const float4* d_tris, const float4* d_rays, uint32_t n_rays, float4 gbox, int waves, std::vector<float>& t_out)
@@ -434,7 +454,7 @@ int main(int argc, char** argv)
 {
   const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 1000000u;
   const uint32_t n_rays = argc > 2 ? (uint32_t)atoi(argv[2]) : (16u << 20);
-  const int waves4 = argc > 3 ? atoi(argv[3]) : 6, waves8 = argc > 4 ? atoi(argv[4]) : 6;
+  const int waves4 = argc > 3 ? atoi(argv[3]) : 6, waves8 = argc > 4 ? atoi(argv[4]) : 6, presplit = argc > 5 ? atoi(argv[5]) : 0;
   { // 0-1 principle check of the 19-comparator network
     for (uint32_t m = 0; m < 256; ++m) { uint32_t key[8]; for (int k = 0; k < 8; ++k) key[k] = (m >> k) & 1u;
 #define HCE(a, b) { uint32_t lo_ = std::min(a, b), hi_ = std::max(a, b); a = lo_; b = hi_; }
@@ -470,8 +490,10 @@ int main(int argc, char** argv)
   float4* d_rays; HIPCHECK(hipMalloc(&d_rays, rays.size() * 4)); HIPCHECK(hipMemcpy(d_rays, rays.data(), rays.size() * 4, hipMemcpyHostToDevice));
   float4 gbox = make_float4(0.5f * (B.bn[0].mn[0] + B.bn[0].mx[0]), 0.5f * (B.bn[0].mn[1] + B.bn[0].mx[1]), 0.5f * (B.bn[0].mn[2] + B.bn[0].mx[2]),
                             0.5f * ((B.bn[0].mx[0] - B.bn[0].mn[0]) + (B.bn[0].mx[1] - B.bn[0].mn[1]) + (B.bn[0].mx[2] - B.bn[0].mn[2])));
-  auto upload_tris = [&](const Wide& w) { std::vector<float> tr((size_t)16 * n, 0.f);
-    for (uint32_t k = 0; k < n; ++k) { const float* p = &pos[(size_t)9 * w.leaf_prims[k]]; float* o = &tr[(size_t)16 * k];
+  const std::vector<uint32_t>* piece_tri = nullptr;                  // pre-split run: leaf primitive = piece of a triangle
+  auto upload_tris = [&](const Wide& w) { const size_t nl = w.leaf_prims.size(); std::vector<float> tr((size_t)16 * nl, 0.f);
+    for (size_t k = 0; k < nl; ++k) { const uint32_t t_ = piece_tri ? (*piece_tri)[w.leaf_prims[k]] : w.leaf_prims[k];
+      const float* p = &pos[(size_t)9 * t_]; float* o = &tr[(size_t)16 * k];
       o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[4] = p[3]; o[5] = p[4]; o[6] = p[5]; o[8] = p[6]; o[9] = p[7]; o[10] = p[8]; }
     float4* d; HIPCHECK(hipMalloc(&d, tr.size() * 4)); HIPCHECK(hipMemcpy(d, tr.data(), tr.size() * 4, hipMemcpyHostToDevice)); return d; };
   printf("%u triangles, %u rays (origin on a random triangle, random direction)\n", n, n_rays);
@@ -479,6 +501,32 @@ int main(int argc, char** argv)
   float4* d_t = upload_tris(w4);  run<4, 0, 16>("4-wide 64-B node, sorted", w4, d_t, d_rays, n_rays, gbox, waves4, t4); HIPCHECK(hipFree(d_t));
   d_t = upload_tris(w8);          run<8, 0, 24>("8-wide 128-B node, sorted", w8, d_t, d_rays, n_rays, gbox, waves8, t8); HIPCHECK(hipFree(d_t));
   d_t = upload_tris(w8o);         run<8, 1, 24>("8-wide 128-B node, octant order", w8o, d_t, d_rays, n_rays, gbox, waves8, t8o); HIPCHECK(hipFree(d_t));
+  if (presplit > 0) {
+    // early split clipping: every triangle's box is cut `presplit` times at the middle of its longest axis; a piece keeps the
+    // bounds of the clipped triangle.  Leaves = pieces (the triangle record is duplicated); traversal unchanged.
+    std::vector<float> ppb, pcen; std::vector<uint32_t> ptri;
+    struct Piece { float lo[3], hi[3]; };
+    for (uint32_t t = 0; t < n; ++t) {
+      std::vector<Piece> cur(1), nxt; for (int a = 0; a < 3; ++a) { cur[0].lo[a] = pb[(size_t)6 * t + a]; cur[0].hi[a] = pb[(size_t)6 * t + 3 + a]; }
+      for (int lv = 0; lv < presplit; ++lv) { nxt.clear();
+        for (const Piece& pc : cur) { int ax = 0; for (int a = 1; a < 3; ++a) if (pc.hi[a] - pc.lo[a] > pc.hi[ax] - pc.lo[ax]) ax = a;
+          const float mid = 0.5f * (pc.lo[ax] + pc.hi[ax]);
+          Piece l = pc, r2 = pc; l.hi[ax] = mid; r2.lo[ax] = mid; Piece o;
+          if (clip_bounds(&pos[(size_t)9 * t], l.lo, l.hi, o.lo, o.hi)) nxt.push_back(o);
+          if (clip_bounds(&pos[(size_t)9 * t], r2.lo, r2.hi, o.lo, o.hi)) nxt.push_back(o); }
+        cur.swap(nxt); }
+      for (const Piece& pc : cur) { for (int a = 0; a < 3; ++a) ppb.push_back(pc.lo[a]); for (int a = 0; a < 3; ++a) ppb.push_back(pc.hi[a]);
+        for (int a = 0; a < 3; ++a) pcen.push_back(0.5f * (pc.lo[a] + pc.hi[a])); ptri.push_back(t); }
+    }
+    const uint32_t n2 = (uint32_t)ptri.size();
+    Build B2; B2.pb = ppb.data(); B2.cen = pcen.data(); B2.idx.resize(n2); for (uint32_t t = 0; t < n2; ++t) B2.idx[t] = t; B2.bn.reserve((size_t)2 * n2);
+    B2.rec(0, n2);
+    const Wide w4s = collapse(B2.bn, 4, false); std::vector<float> t4s; piece_tri = &ptri;
+    char nm[64]; snprintf(nm, sizeof nm, "4-wide, %d x pre-split (%.2f refs/tri)", presplit, (double)n2 / n);
+    d_t = upload_tris(w4s); run<4, 0, 16>(nm, w4s, d_t, d_rays, n_rays, gbox, waves4, t4s); HIPCHECK(hipFree(d_t)); piece_tri = nullptr;
+    uint64_t bad = 0; for (uint32_t i = 0; i < n_rays; ++i) bad += memcmp(&t4[i], &t4s[i], 4) != 0;
+    printf("hit distances differing from the 4-wide walk: pre-split %llu\n", (unsigned long long)bad);
+  }
   { std::vector<float> t4n; d_t = upload_tris(w4); run<4, 3, 16>("4-wide, deep nodes non-temporal", w4, d_t, d_rays, n_rays, gbox, waves4, t4n); HIPCHECK(hipFree(d_t)); }
   { const Wide w4p = collapse4_pairs(B.bn); std::vector<float> t4p;
     d_t = upload_tris(w4p); run<4, 2, 16>("4-wide, parent + favourite child / line", w4p, d_t, d_rays, n_rays, gbox, waves4, t4p); HIPCHECK(hipFree(d_t));
