@@ -10,10 +10,10 @@
 //   vsetmaterial <name> <stock>                              stand-ins for OCCT's stock materials (every field is overridden by vbsdf)
 //   vbsdf <name> -Kc|-Kd|-Ks|-Kt|-Le r g b | -baseRoughness|-coatRoughness x | -absorpColor r g b | -absorpCoeff x |
 //                -baseFresnel|-coatFresnel Schlick r g b | Constant f | Conductor n k | Dielectric n | -normalize
-//   rttexture <name> <image.png> | -scale S T | -on | -off   8-bit PNG; texels squared like the environment [OCCT-ext]
+//   rttexture <name> <image> | -scale S T | -on | -off       8-bit PNG or baseline JPEG (jpeg_baseline.hpp); texels squared like the environment [OCCT-ext]
 //   vlocation <name> -rotation x y z w | -scale s | -location x y z
 //   vcamera -orthographic | -perspective | -fovy a | -distance d      vviewparams -proj|-up|-at|-eye x y z | -size s
-//   vtextureenv on <image.png>    vlight clear | add directional direction x y z | add positional position x y z ... smoothness s
+//   vtextureenv on <image>        vlight clear | add directional direction x y z | add positional position x y z ... smoothness s
 //   intensity i [head 1]          rtlight <id> -color r g b           vrenderparams ... -rayDepth n
 //   rtmodel / rtdisplay / vupdate ...                        accepted, no effect on the path
 //
@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/cadrays_hip.h"
+#include "jpeg_baseline.hpp"
 
 namespace crh_host {
 
@@ -118,11 +119,20 @@ inline bool read_png(const std::string& path, uint32_t& w, uint32_t& h, uint32_t
   return true;
 }
 
+// 8-bit image file -> RGB(A) bytes; the format is recognised by content, not by extension
+inline bool read_image_u8(const std::string& path, uint32_t& w, uint32_t& h, uint32_t& ch, std::vector<uint8_t>& px, std::string& err)
+{
+  uint8_t sig[2] = {0, 0};
+  { std::ifstream f(path, std::ios::binary); if (f) f.read((char*)sig, 2); }
+  if (sig[0] == 0xFF && sig[1] == 0xD8) { ch = 3; return read_jpeg(path, w, h, px, err); }
+  return read_png(path, w, h, ch, px, err);
+}
+
 // 8-bit image -> linear float texels: rgb squared ("de-gamma for gamma = 2", like the environment map [OCCT-ext]), alpha kept
 inline bool load_texture(const std::string& path, Texture& t, std::string& err)
 {
   std::vector<uint8_t> px;
-  if (!read_png(path, t.w, t.h, t.ch, px, err)) return false;
+  if (!read_image_u8(path, t.w, t.h, t.ch, px, err)) return false;
   t.texels.resize(px.size());
   for (size_t i = 0; i < px.size(); ++i) {
     const float v = (float)px[i] / 255.0f;

@@ -1,12 +1,19 @@
 // model_tcl_dump.cpp -- host-only: read a model.tcl with host/model_tcl.hpp and write what it understood as a .crhscene v2 file
 // (cadrays_amd/scene_io.py layout), so that tests can compare the C++ reader with the Python reader byte for byte without a GPU.
 //   model_tcl_dump <model.tcl> <out.crhscene> [WxH]
+//   model_tcl_dump --image <file.png|jpg> <out.raw>      decoded image as three uint32 (w, h, channels) + bytes
 #include <cstdio>
 
 #include "model_tcl.hpp"
 
 int main(int argc, char** argv)
 {
+  if (argc == 4 && std::string(argv[1]) == "--image") {
+    uint32_t d[3]; std::vector<uint8_t> px; std::string e;
+    if (!crh_host::detail::read_image_u8(argv[2], d[0], d[1], d[2], px, e)) { fprintf(stderr, "%s\n", e.c_str()); return 1; }
+    FILE* f = fopen(argv[3], "wb"); if (!f) { perror(argv[3]); return 1; }
+    fwrite(d, 4, 3, f); fwrite(px.data(), 1, px.size(), f); fclose(f); return 0;
+  }
   if (argc < 3) { fprintf(stderr, "usage: %s <model.tcl> <out.crhscene> [WxH]\n", argv[0]); return 2; }
   uint32_t w = 512, h = 512;
   if (argc > 3 && sscanf(argv[3], "%ux%u", &w, &h) != 2) { fprintf(stderr, "bad size\n"); return 2; }

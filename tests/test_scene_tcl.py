@@ -404,7 +404,7 @@ def _cpp_dump(model, out, size="80x60"):
     import subprocess
     host = os.path.join(ROOT, "cadrays_amd", "host")
     exe = os.path.join(host, "model_tcl_dump")
-    if not os.path.exists(exe) or os.path.getmtime(os.path.join(host, "model_tcl.hpp")) > os.path.getmtime(exe):
+    if not os.path.exists(exe) or max(os.path.getmtime(os.path.join(host, f)) for f in ("model_tcl.hpp", "jpeg_baseline.hpp", "model_tcl_dump.cpp")) > os.path.getmtime(exe):
         subprocess.check_call(["make", "-s", "-C", host, "model_tcl_dump"])
     p = subprocess.run([exe, str(model), str(out), size], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
@@ -443,6 +443,68 @@ def test_cpp_reader_understands_model_tcl_like_the_python_reader(tmp_path):
     loop = os.path.join(os.path.dirname(model), "loop.tcl")
     open(loop, "w").write(open(model).read() + "\nfor {set i 0} {$i < 3} {incr i} { vdisplay Mesh0 }\n")
     assert "not honoured: for" in _cpp_dump(loop, tmp_path / "x.crhscene")
+
+
+def _cpp_image(path, tmp_path):
+    import struct, subprocess
+    host = os.path.join(ROOT, "cadrays_amd", "host"); exe = os.path.join(host, "model_tcl_dump")
+    if not os.path.exists(exe) or max(os.path.getmtime(os.path.join(host, f)) for f in ("model_tcl.hpp", "jpeg_baseline.hpp", "model_tcl_dump.cpp")) > os.path.getmtime(exe):
+        subprocess.check_call(["make", "-s", "-C", host, "model_tcl_dump"])
+    out = str(tmp_path / "img.raw")
+    p = subprocess.run([exe, "--image", str(path), out], capture_output=True, text=True)
+    if p.returncode: return p.stderr.strip()
+    d = open(out, "rb").read(); w, h, ch = struct.unpack("<3I", d[:12])
+    return np.frombuffer(d[12:], np.uint8).reshape(h, w, ch)
+
+
+def test_cpp_jpeg_reader_matches_pillow(tmp_path):
+    """The environment map CADRays ships and loads by default is a baseline JPEG (data/maps/default.jpg, AppGui.cxx:963), so exported
+    scenes reference one; host/jpeg_baseline.hpp must decode to the very bytes Pillow gives the Python reader: 4:4:4 / 4:2:2 /
+    4:2:0, sizes that are not MCU multiples, grey, restart intervals, optimised tables, three quality levels."""
+    from PIL import Image
+    r = np.random.default_rng(1)
+    cases = 0
+    for (w, h) in [(64, 48), (67, 53), (17, 9), (1, 1), (8, 8), (33, 16), (200, 131)]:
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 120 * np.sin(x / 7.0 + y / 11.0), 127 + 120 * np.cos(x / 5.0), (x * 3 + y * 5) % 256], -1) + r.normal(0, 12, (h, w, 3))
+        img = np.clip(img, 0, 255).astype(np.uint8)
+        variants = [dict(quality=q, subsampling=sub) for sub in (0, 1, 2) for q in (30, 75, 95)]
+        variants += [dict(quality=80, subsampling=2, restart_marker_blocks=3), dict(quality=80, optimize=True), dict(quality=80, grey=True)]
+        for kw in variants:
+            src = img[..., 0] if kw.pop("grey", False) else img
+            path = tmp_path / "t.jpg"; Image.fromarray(src).save(path, **kw)
+            got = _cpp_image(path, tmp_path); want = np.asarray(Image.open(path).convert("RGB"))
+            assert not isinstance(got, str), got
+            assert got.shape == want.shape and np.array_equal(got, want), (w, h, kw)
+            cases += 1
+    assert cases == 84
+    path = tmp_path / "p.jpg"; Image.fromarray(img).save(path, progressive=True)
+    assert "baseline only" in _cpp_image(path, tmp_path)              # refused with a message, not mis-decoded
+    ref = "/root/reference/data/maps/default.jpg"
+    if os.path.exists(ref):
+        assert np.array_equal(_cpp_image(ref, tmp_path), np.asarray(Image.open(ref).convert("RGB")))
+
+
+def test_cpp_reader_loads_a_jpeg_environment_like_the_python_reader(tmp_path):
+    from PIL import Image
+    from cadrays_amd import scene_io
+    from cadrays_amd.scene_tcl import read_scene
+    sc, model = _exported_scene(tmp_path)
+    r = np.random.default_rng(9)
+    y, x = np.mgrid[0:32, 0:64]
+    env = np.clip(np.stack([128 + 100 * np.sin(x / 9.0), 128 + 100 * np.cos(y / 5.0), 60 + 2 * x], -1) + r.normal(0, 6, (32, 64, 3)), 0, 255).astype(np.uint8)
+    d = os.path.dirname(model)
+    Image.fromarray(env).save(os.path.join(d, "textures", "sky.jpg"), quality=90, subsampling=2)
+    txt = open(model).read()
+    import re
+    txt2, n = re.subn(r"vtextureenv on \S+", "vtextureenv on $Root/textures/sky.jpg", txt)
+    assert n == 1
+    open(model, "w").write(txt2)
+    py, b = read_scene(model, 80, 60)
+    assert py.env.shape == (32, 64, 3) and not b.unsupported
+    a_path, b_path = tmp_path / "py.crhscene", tmp_path / "cpp.crhscene"
+    scene_io.save_scene(py, str(a_path)); _cpp_dump(model, b_path)
+    assert a_path.read_bytes() == b_path.read_bytes()
 
 
 @pytest.mark.gpu
