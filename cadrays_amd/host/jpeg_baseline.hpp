@@ -1,12 +1,13 @@
-// jpeg_baseline.hpp -- baseline (sequential Huffman, 8-bit) JPEG reader for the C++ scene reader.
+// jpeg_baseline.hpp -- 8-bit Huffman JPEG reader (baseline and progressive) for the C++ scene reader.
 // Why it exists: the environment map the reference ships and loads by default is a JPEG (data/maps/default.jpg, loaded at
 // reference src/Launcher/AppGui.cxx:963; the GUI's file filters are png/jpg, LightSourcesEditor.cxx:348,388), so a scene exported
 // by CADRays normally references one.  The Python reader decodes it with Pillow (libjpeg-turbo); this decoder restates the same
 // arithmetic -- the "islow" integer inverse DCT (13-bit constants, two passes), fancy (triangle) chroma upsampling for 2x1 / 2x2
 // subsampling and the 16-bit fixed-point YCbCr -> RGB tables of the IJG specification -- so that both hosts hand identical
 // texels to the boundary (tests/test_scene_tcl.py::test_cpp_jpeg_reader_matches_pillow).
-// Read: SOF0 / SOF1 with 1 or 3 components, sampling factors 1 or 2 (chroma 1x1), one interleaved scan, restart intervals,
-// Adobe APP14 transform flag.  Refused with a message: progressive, arithmetic coding, 12-bit, CMYK, multi-scan files.
+// Read: sequential (SOF0 / SOF1) and progressive (SOF2: spectral selection + successive approximation) Huffman JPEG with 1 or 3
+// components, sampling factors 1 or 2 (chroma 1x1), interleaved and per-component scans, restart intervals, Adobe APP14 transform
+// flag.  Refused with a message: arithmetic coding, lossless / hierarchical, 12-bit, CMYK.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -123,15 +124,16 @@ inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::ve
   static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
   uint16_t qt[4][64] = {{0}}; JpegHuff hdc[4], hac[4];
-  struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; int bw = 0, bh = 0; std::vector<uint8_t> plane; };
-  Comp comp[3]; int nc = 0, restart = 0, adobe_transform = -1; bool have_sof = false; W = H = 0;
+  struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; int bw = 0, bh = 0, rw = 0, rh = 0; std::vector<int16_t> coef; std::vector<uint8_t> plane; };
+  Comp comp[3]; int nc = 0, restart = 0, adobe_transform = -1, hmax = 1, vmax = 1, mcux = 0, mcuy = 0; bool have_sof = false, progressive = false, seen_scan = false; W = H = 0;
   size_t o = 2;
   auto be16 = [&](size_t p) { return (int)((d[p] << 8) | d[p + 1]); };
   for (;;) {
-    if (o + 4 > d.size()) { err = path + ": truncated JPEG"; return false; }
+    if (o + 4 > d.size()) { if (seen_scan) break; err = path + ": truncated JPEG"; return false; }
     if (d[o] != 0xFF) { err = path + ": bad JPEG marker"; return false; }
     const int m = d[o + 1];
     if (m == 0xFF) { ++o; continue; }
+    if (m == 0xD9) { if (seen_scan) break; err = path + ": no image data"; return false; }
     const int L = be16(o + 2);
     if (o + 2 + (size_t)L > d.size()) { err = path + ": truncated JPEG segment"; return false; }
     const uint8_t* p = &d[o + 4]; const int n = L - 2;
@@ -141,66 +143,117 @@ inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::ve
         JpegHuff& h = tc ? hac[th] : hdc[th]; int cnt = 0; for (int l = 1; l <= 16; ++l) { h.bits[l] = p[k + l - 1]; cnt += h.bits[l]; } k += 16;
         if (cnt > 256 || k + cnt > n) { err = path + ": bad Huffman table"; return false; }
         memcpy(h.vals, p + k, (size_t)cnt); k += cnt; jpeg_build_huff(h); } }
-    else if (m == 0xC0 || m == 0xC1) {
+    else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+      if (have_sof) { err = path + ": second frame header"; return false; }
       if (p[0] != 8) { err = path + ": only 8-bit JPEG images are read"; return false; }
+      progressive = m == 0xC2;
       H = (uint32_t)be16(o + 5); W = (uint32_t)be16(o + 7); nc = p[5];
       if ((nc != 1 && nc != 3) || !W || !H) { err = path + ": only grey and 3-component JPEG images are read"; return false; }
       for (int c = 0; c < nc; ++c) { comp[c].id = p[6 + 3 * c]; comp[c].h = p[7 + 3 * c] >> 4; comp[c].v = p[7 + 3 * c] & 15; comp[c].tq = p[8 + 3 * c] & 3; }
+      if (nc == 1) comp[0].h = comp[0].v = 1;                                    // a single-component frame is never interleaved
+      for (int c = 0; c < nc; ++c) { hmax = std::max(hmax, comp[c].h); vmax = std::max(vmax, comp[c].v); }
+      for (int c = 0; c < nc; ++c)
+        if (comp[c].h < 1 || comp[c].v < 1 || comp[c].h > 2 || comp[c].v > 2 || (c > 0 && (comp[c].h != 1 || comp[c].v != 1)) || (c == 0 && (comp[c].h != hmax || comp[c].v != vmax)))
+          { err = path + ": unsupported JPEG sampling factors"; return false; }
+      if (hmax == 1 && vmax == 2) { err = path + ": unsupported JPEG sampling factors (1x2)"; return false; }
+      mcux = (int)((W + 8 * hmax - 1) / (8 * hmax)); mcuy = (int)((H + 8 * vmax - 1) / (8 * vmax));
+      for (int c = 0; c < nc; ++c) { Comp& C = comp[c]; C.bw = mcux * C.h; C.bh = mcuy * C.v;
+        const int cw = (int)((W * C.h + hmax - 1) / hmax), chh = (int)((H * C.v + vmax - 1) / vmax); C.rw = (cw + 7) / 8; C.rh = (chh + 7) / 8;   // blocks a non-interleaved scan covers
+        C.coef.assign((size_t)C.bw * C.bh * 64, 0); }
       have_sof = true;
     }
-    else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) { err = path + ": progressive / lossless / arithmetic JPEG is not read (baseline only)"; return false; }
+    else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) { err = path + ": lossless / hierarchical / arithmetic-coded JPEG is not read"; return false; }
     else if (m == 0xDD) restart = be16(o + 4);
     else if (m == 0xEE && n >= 12 && memcmp(p, "Adobe", 5) == 0) adobe_transform = p[11];
     else if (m == 0xDA) {
       if (!have_sof) { err = path + ": scan before frame header"; return false; }
-      if (p[0] != nc) { err = path + ": multi-scan JPEG files are not read"; return false; }
-      for (int c = 0; c < nc; ++c) { if (p[1 + 2 * c] != comp[c].id) { err = path + ": unexpected component order"; return false; } comp[c].td = p[2 + 2 * c] >> 4; comp[c].ta = p[2 + 2 * c] & 15;
-        if (comp[c].td > 3 || comp[c].ta > 3 || !hdc[comp[c].td].set || !hac[comp[c].ta].set) { err = path + ": missing Huffman table"; return false; } }
-      o += 2 + (size_t)L; break;
+      const int ns = p[0]; if (ns < 1 || ns > nc || n < 4 + 2 * ns) { err = path + ": bad scan header"; return false; }
+      int sc[3];
+      for (int k = 0; k < ns; ++k) { int c = 0; while (c < nc && comp[c].id != p[1 + 2 * k]) ++c; if (c == nc) { err = path + ": scan of an unknown component"; return false; }
+        sc[k] = c; comp[c].td = p[2 + 2 * k] >> 4; comp[c].ta = p[2 + 2 * k] & 15; if (comp[c].td > 3 || comp[c].ta > 3) { err = path + ": bad table selector"; return false; } }
+      const int Ss = p[1 + 2 * ns], Se = p[2 + 2 * ns], Ah = p[3 + 2 * ns] >> 4, Al = p[3 + 2 * ns] & 15;
+      if (!progressive && (Ss != 0 || Se != 63 || Ah != 0 || Al != 0)) { err = path + ": bad sequential scan parameters"; return false; }
+      if (progressive && (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13)) { err = path + ": bad progressive scan parameters"; return false; }
+      for (int k = 0; k < ns; ++k) { const Comp& C = comp[sc[k]];
+        if ((Ss == 0 && Ah == 0 && !hdc[C.td].set) || (Se > 0 && !hac[C.ta].set)) { err = path + ": missing Huffman table"; return false; } }
+      o += 2 + (size_t)L; seen_scan = true;
+      JpegBits br{&d[o], d.data() + d.size()};
+      for (int c = 0; c < nc; ++c) comp[c].pred = 0;
+      int eobrun = 0, todo = restart, rst = 0;
+      const bool inter = ns > 1;
+      const int ux = inter ? mcux : comp[sc[0]].rw, uy = inter ? mcuy : comp[sc[0]].rh;       // scan units: MCUs, or the component's own blocks
+      bool bad = false;
+      // one block of this scan
+      auto decode_block = [&](Comp& C, int16_t* blk) {
+        if (!progressive) {
+          const int s = jpeg_decode_sym(br, hdc[C.td]); if (s < 0 || s > 11) { bad = true; return; }
+          C.pred += jpeg_extend(br.receive(s), s); blk[0] = (int16_t)C.pred;
+          for (int k = 1; k < 64;) { const int rs = jpeg_decode_sym(br, hac[C.ta]); if (rs < 0) { bad = true; return; }
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+            k += r; if (k > 63) { bad = true; return; }
+            blk[zz[k]] = (int16_t)jpeg_extend(br.receive(sz), sz); ++k; }
+          return;
+        }
+        if (Ss == 0) {
+          if (Ah == 0) { const int s = jpeg_decode_sym(br, hdc[C.td]); if (s < 0 || s > 11) { bad = true; return; }
+            C.pred += jpeg_extend(br.receive(s), s); blk[0] = (int16_t)(C.pred * (1 << Al)); }
+          else if (br.bit()) blk[0] |= (int16_t)(1 << Al);
+          return;
+        }
+        if (Ah == 0) {
+          if (eobrun > 0) { --eobrun; return; }
+          for (int k = Ss; k <= Se; ++k) { const int rs = jpeg_decode_sym(br, hac[C.ta]); if (rs < 0) { bad = true; return; }
+            const int r = rs >> 4, sz = rs & 15;
+            if (sz) { k += r; if (k > 63) { bad = true; return; } blk[zz[k]] = (int16_t)(jpeg_extend(br.receive(sz), sz) * (1 << Al)); }
+            else if (r == 15) k += 15;
+            else { eobrun = (1 << r); if (r) eobrun += br.receive(r); --eobrun; break; } }
+          return;
+        }
+        const int p1 = 1 << Al, m1 = -(1 << Al);
+        auto refine = [&](int16_t& cf) { if (br.bit() && (cf & p1) == 0) cf = (int16_t)(cf >= 0 ? cf + p1 : cf + m1); };
+        int k = Ss;
+        if (eobrun == 0) {
+          for (; k <= Se; ++k) { const int rs = jpeg_decode_sym(br, hac[C.ta]); if (rs < 0) { bad = true; return; }
+            int r = rs >> 4, sv = rs & 15;
+            if (sv) sv = br.bit() ? p1 : m1;
+            else if (r != 15) { eobrun = 1 << r; if (r) eobrun += br.receive(r); break; }
+            for (; k <= Se; ++k) { int16_t& cf = blk[zz[k]];
+              if (cf != 0) refine(cf); else if (--r < 0) break; }
+            if (sv && k <= Se) blk[zz[k]] = (int16_t)sv; }
+        }
+        if (eobrun > 0) { for (; k <= Se; ++k) { int16_t& cf = blk[zz[k]]; if (cf != 0) refine(cf); } --eobrun; }
+      };
+      for (int my = 0; my < uy && !bad; ++my) for (int mx = 0; mx < ux && !bad; ++mx) {
+        if (restart && todo == 0) {
+          br.reset();
+          while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
+          if (br.p + 1 >= br.end || br.p[1] != 0xD0 + (rst & 7)) { err = path + ": restart marker missing"; return false; }
+          br.p += 2; ++rst; todo = restart; eobrun = 0;
+          for (int c = 0; c < nc; ++c) comp[c].pred = 0;
+        }
+        if (inter) { for (int k = 0; k < ns && !bad; ++k) { Comp& C = comp[sc[k]];
+            for (int by = 0; by < C.v; ++by) for (int bx = 0; bx < C.h; ++bx) decode_block(C, &C.coef[((size_t)(my * C.v + by) * C.bw + (size_t)(mx * C.h + bx)) * 64]); } }
+        else { Comp& C = comp[sc[0]]; decode_block(C, &C.coef[((size_t)my * C.bw + (size_t)mx) * 64]); }
+        if (restart) --todo;
+      }
+      if (bad) { err = path + ": corrupt JPEG data"; return false; }
+      // continue after the entropy-coded segment: the next marker that is not a restart marker or a stuffed byte
+      const uint8_t* q = br.p;
+      while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0 && !(q[1] >= 0xD0 && q[1] <= 0xD7) && q[1] != 0xFF)) ++q;
+      o = (size_t)(q - d.data());
+      continue;
     }
-    else if (m == 0xD9) { err = path + ": no image data"; return false; }
     o += 2 + (size_t)L;
   }
-  int hmax = 1, vmax = 1;
-  for (int c = 0; c < nc; ++c) { hmax = std::max(hmax, comp[c].h); vmax = std::max(vmax, comp[c].v); }
-  if (nc == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }                  // a single-component scan is never interleaved
-  for (int c = 0; c < nc; ++c) {
-    if (comp[c].h < 1 || comp[c].v < 1 || comp[c].h > 2 || comp[c].v > 2 || (c > 0 && (comp[c].h != 1 || comp[c].v != 1)) || (c == 0 && (comp[c].h != hmax || comp[c].v != vmax)))
-      { err = path + ": unsupported JPEG sampling factors"; return false; }
-  }
-  if (hmax == 1 && vmax == 2) { err = path + ": unsupported JPEG sampling factors (1x2)"; return false; }
-  const int mcux = (int)((W + 8 * hmax - 1) / (8 * hmax)), mcuy = (int)((H + 8 * vmax - 1) / (8 * vmax));
-  for (int c = 0; c < nc; ++c) { comp[c].bw = mcux * comp[c].h; comp[c].bh = mcuy * comp[c].v; comp[c].plane.assign((size_t)comp[c].bw * 8 * comp[c].bh * 8, 0); }
-  JpegBits br{&d[o], d.data() + d.size()};
-  int coef[64], todo = restart, rst = 0;
-  for (int my = 0; my < mcuy; ++my) for (int mx = 0; mx < mcux; ++mx) {
-    if (restart && todo == 0) {
-      // byte-align, expect RSTn
-      br.reset();
-      while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
-      if (br.p + 1 >= br.end || br.p[1] != 0xD0 + (rst & 7)) { err = path + ": restart marker missing"; return false; }
-      br.p += 2; ++rst; todo = restart;
-      for (int c = 0; c < nc; ++c) comp[c].pred = 0;
-    }
-    for (int c = 0; c < nc; ++c) for (int by = 0; by < comp[c].v; ++by) for (int bx = 0; bx < comp[c].h; ++bx) {
-      memset(coef, 0, sizeof coef);
-      const int s = jpeg_decode_sym(br, hdc[comp[c].td]);
-      if (s < 0 || s > 11) { err = path + ": corrupt JPEG data"; return false; }
-      comp[c].pred += jpeg_extend(br.receive(s), s);
-      coef[0] = comp[c].pred * qt[comp[c].tq][0];
-      for (int k = 1; k < 64;) {
-        const int rs = jpeg_decode_sym(br, hac[comp[c].ta]);
-        if (rs < 0) { err = path + ": corrupt JPEG data"; return false; }
-        const int r = rs >> 4, sz = rs & 15;
-        if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
-        k += r; if (k > 63) { err = path + ": corrupt JPEG data"; return false; }
-        coef[zz[k]] = jpeg_extend(br.receive(sz), sz) * qt[comp[c].tq][zz[k]]; ++k;
-      }
-      const int stride = comp[c].bw * 8;
-      jpeg_idct_islow(coef, &comp[c].plane[(size_t)((my * comp[c].v + by) * 8) * stride + (size_t)(mx * comp[c].h + bx) * 8], stride);
-    }
-    if (restart) --todo;
-  }
+  if (!have_sof || !seen_scan) { err = path + ": no image data"; return false; }
+  // dequantise + inverse DCT
+  { int coef[64];
+    for (int c = 0; c < nc; ++c) { Comp& C = comp[c]; const int stride = C.bw * 8; C.plane.assign((size_t)stride * C.bh * 8, 0);
+      for (int by = 0; by < C.bh; ++by) for (int bx = 0; bx < C.bw; ++bx) { const int16_t* blk = &C.coef[((size_t)by * C.bw + bx) * 64];
+        for (int i = 0; i < 64; ++i) coef[i] = blk[i] * qt[C.tq][i];
+        jpeg_idct_islow(coef, &C.plane[(size_t)by * 8 * stride + (size_t)bx * 8], stride); }
+      std::vector<int16_t>().swap(C.coef); } }
   // chroma -> full resolution (fancy upsampling), over the real (not MCU-padded) extent
   auto sample_at = [](const Comp& c, int x, int y) { return (int)c.plane[(size_t)y * c.bw * 8 + x]; };
   std::vector<uint8_t> full[3];

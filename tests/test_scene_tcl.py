@@ -459,8 +459,8 @@ def _cpp_image(path, tmp_path):
 
 def test_cpp_jpeg_reader_matches_pillow(tmp_path):
     """The environment map CADRays ships and loads by default is a baseline JPEG (data/maps/default.jpg, AppGui.cxx:963), so exported
-    scenes reference one; host/jpeg_baseline.hpp must decode to the very bytes Pillow gives the Python reader: 4:4:4 / 4:2:2 /
-    4:2:0, sizes that are not MCU multiples, grey, restart intervals, optimised tables, three quality levels."""
+    scenes reference one; host/jpeg_baseline.hpp must decode to the very bytes Pillow gives the Python reader: sequential and
+    progressive, 4:4:4 / 4:2:2 / 4:2:0, sizes that are not MCU multiples, grey, restart intervals, optimised tables, three quality levels."""
     from PIL import Image
     r = np.random.default_rng(1)
     cases = 0
@@ -468,8 +468,10 @@ def test_cpp_jpeg_reader_matches_pillow(tmp_path):
         y, x = np.mgrid[0:h, 0:w]
         img = np.stack([127 + 120 * np.sin(x / 7.0 + y / 11.0), 127 + 120 * np.cos(x / 5.0), (x * 3 + y * 5) % 256], -1) + r.normal(0, 12, (h, w, 3))
         img = np.clip(img, 0, 255).astype(np.uint8)
-        variants = [dict(quality=q, subsampling=sub) for sub in (0, 1, 2) for q in (30, 75, 95)]
-        variants += [dict(quality=80, subsampling=2, restart_marker_blocks=3), dict(quality=80, optimize=True), dict(quality=80, grey=True)]
+        variants = [dict(quality=q, subsampling=sub, progressive=pr) for pr in (False, True) for sub in (0, 1, 2) for q in (30, 75, 95)]
+        for pr in (False, True):
+            variants += [dict(quality=80, subsampling=2, restart_marker_blocks=3, progressive=pr), dict(quality=80, optimize=True, progressive=pr),
+                         dict(quality=80, grey=True, progressive=pr)]
         for kw in variants:
             src = img[..., 0] if kw.pop("grey", False) else img
             path = tmp_path / "t.jpg"; Image.fromarray(src).save(path, **kw)
@@ -477,9 +479,9 @@ def test_cpp_jpeg_reader_matches_pillow(tmp_path):
             assert not isinstance(got, str), got
             assert got.shape == want.shape and np.array_equal(got, want), (w, h, kw)
             cases += 1
-    assert cases == 84
-    path = tmp_path / "p.jpg"; Image.fromarray(img).save(path, progressive=True)
-    assert "baseline only" in _cpp_image(path, tmp_path)              # refused with a message, not mis-decoded
+    assert cases == 168
+    path = tmp_path / "c.jpg"; Image.fromarray(img).convert("CMYK").save(path)
+    assert "3-component" in _cpp_image(path, tmp_path)                # refused with a message, not mis-decoded
     ref = "/root/reference/data/maps/default.jpg"
     if os.path.exists(ref):
         assert np.array_equal(_cpp_image(ref, tmp_path), np.asarray(Image.open(ref).convert("RGB")))
