@@ -6,7 +6,7 @@
 //   loop: View->Redraw() once per frame, count frames      src/Launcher/AppViewer.cxx:1045-1071
 //   BufferDump(Graphic3d_BT_RGB) after the last frame      src/Launcher/AppViewer.cxx:1255-1264
 //   write Output_<name>_<n>.png and Output_<name>_<n>.txt (average frame rate)   main.cxx:193-228
-// Here: cadrays_headless <scene.crhscene | model.tcl> <nFrames> [device] [lookahead] [gpus] [WxH] writes Output_<name>_<n>.ppm (LDR),
+// Here: cadrays_headless <scene.crhscene | model.tcl> <nFrames> [device] [lookahead] [gpus] [WxH] writes Output_<name>_<n>.png (+ .ppm: the same LDR pixels),
 // Output_<name>_<n>.pfm (linear HDR, the parity buffer of AppGui.cxx:345-349) and Output_<name>_<n>.txt.
 // gpus > 1: one context per GPU (devices device .. device+gpus-1; CRH_HEADLESS_SHARE_DEVICE=1 keeps them all on `device`),
 // screen tiles interleaved across the contexts, one host thread per context, crh_reduce (RCCL over xGMI) assembles the
@@ -150,6 +150,7 @@ int main(int argc, char** argv)
   std::string stem = path; const size_t sl = stem.find_last_of('/'); std::string dir = sl == std::string::npos ? "." : stem.substr(0, sl);
   std::string name = sl == std::string::npos ? stem : stem.substr(sl + 1); const size_t dot = name.find_last_of('.'); if (dot != std::string::npos) name = name.substr(0, dot);
   const std::string base = dir + "/Output_" + name + "_" + std::to_string(n_frames);
+  { std::string e; if (!crh_host::detail::write_png(base + ".png", ldr.data(), par.width, par.height, 3, e)) fprintf(stderr, "%s\n", e.c_str()); }   // the reference's dump format
   if (FILE* o = fopen((base + ".ppm").c_str(), "wb")) { fprintf(o, "P6\n%u %u\n255\n", par.width, par.height); fwrite(ldr.data(), 1, ldr.size(), o); fclose(o); }
   if (FILE* o = fopen((base + ".pfm").c_str(), "wb")) {
     fprintf(o, "PF\n%u %u\n-1.0\n", par.width, par.height);

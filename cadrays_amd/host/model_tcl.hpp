@@ -119,6 +119,34 @@ inline bool read_png(const std::string& path, uint32_t& w, uint32_t& h, uint32_t
   return true;
 }
 
+// RGB / RGBA bytes -> 8-bit PNG (filter 0, one zlib stream): the file format of the reference's image dump
+// (BufferDump -> Output_<name>_<n>.png, AppViewer.cxx:1259-1261, main.cxx:193-228), which the harness compares pixel by pixel
+inline bool write_png(const std::string& path, const uint8_t* px, uint32_t w, uint32_t h, uint32_t ch, std::string& err)
+{
+  if ((ch != 3 && ch != 4) || !w || !h) { err = path + ": only RGB / RGBA images are written"; return false; }
+  const size_t stride = (size_t)w * ch;
+  std::vector<uint8_t> raw((stride + 1) * h);
+  for (uint32_t y = 0; y < h; ++y) { raw[(stride + 1) * y] = 0; memcpy(&raw[(stride + 1) * y + 1], px + stride * y, stride); }
+  uLongf zlen = compressBound((uLong)raw.size()); std::vector<uint8_t> z(zlen);
+  if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { err = path + ": compression failed"; return false; }
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) { err = "cannot write " + path; return false; }
+  auto chunk = [&](const char* type, const uint8_t* data, uint32_t len) {
+    const uint8_t L[4] = {(uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len};
+    uLong crc = crc32(0L, (const Bytef*)type, 4); if (len) crc = crc32(crc, data, len);
+    const uint8_t Cc[4] = {(uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc};
+    fwrite(L, 1, 4, f); fwrite(type, 1, 4, f); if (len) fwrite(data, 1, len, f); fwrite(Cc, 1, 4, f);
+  };
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  fwrite(sig, 1, 8, f);
+  const uint8_t ihdr[13] = {(uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w, (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h,
+                            8, (uint8_t)(ch == 4 ? 6 : 2), 0, 0, 0};
+  chunk("IHDR", ihdr, 13); chunk("IDAT", z.data(), (uint32_t)zlen); chunk("IEND", nullptr, 0);
+  const bool ok = !ferror(f); fclose(f);
+  if (!ok) err = "cannot write " + path;
+  return ok;
+}
+
 // 8-bit image file -> RGB(A) bytes; the format is recognised by content, not by extension
 inline bool read_image_u8(const std::string& path, uint32_t& w, uint32_t& h, uint32_t& ch, std::vector<uint8_t>& px, std::string& err)
 {

@@ -2,6 +2,7 @@
 // (cadrays_amd/scene_io.py layout), so that tests can compare the C++ reader with the Python reader byte for byte without a GPU.
 //   model_tcl_dump <model.tcl> <out.crhscene> [WxH]
 //   model_tcl_dump --image <file.png|jpg> <out.raw>      decoded image as three uint32 (w, h, channels) + bytes
+//   model_tcl_dump --to-png <file.png|jpg> <out.png>     decoded image written back by the host's PNG writer
 #include <cstdio>
 
 #include "model_tcl.hpp"
@@ -13,6 +14,11 @@ int main(int argc, char** argv)
     if (!crh_host::detail::read_image_u8(argv[2], d[0], d[1], d[2], px, e)) { fprintf(stderr, "%s\n", e.c_str()); return 1; }
     FILE* f = fopen(argv[3], "wb"); if (!f) { perror(argv[3]); return 1; }
     fwrite(d, 4, 3, f); fwrite(px.data(), 1, px.size(), f); fclose(f); return 0;
+  }
+  if (argc == 4 && std::string(argv[1]) == "--to-png") {
+    uint32_t w, h, ch; std::vector<uint8_t> px; std::string e;
+    if (!crh_host::detail::read_image_u8(argv[2], w, h, ch, px, e) || !crh_host::detail::write_png(argv[3], px.data(), w, h, ch, e)) { fprintf(stderr, "%s\n", e.c_str()); return 1; }
+    return 0;
   }
   if (argc < 3) { fprintf(stderr, "usage: %s <model.tcl> <out.crhscene> [WxH]\n", argv[0]); return 2; }
   uint32_t w = 512, h = 512;

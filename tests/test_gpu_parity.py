@@ -323,7 +323,7 @@ def test_errors(view_cls):
 
 
 def test_headless_cpp_driver_matches_oracle(tmp_path, Oracle):
-    """the C++ host driver (script + frame count -> Output_*.ppm/.pfm/.txt, like main.cxx:164-228)."""
+    """the C++ host driver (script + frame count -> Output_*.png/.pfm/.txt, like main.cxx:164-228)."""
     import json, os, subprocess
     from cadrays_amd.scene_io import save_scene
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -341,6 +341,8 @@ def test_headless_cpp_driver_matches_oracle(tmp_path, Oracle):
     assert np.array_equal(bits(img), bits(o.read_hdr()))
     ppm = open(tmp_path / "Output_cornell_5.ppm", "rb").read()
     assert ppm.startswith(b"P6\n96 64\n255\n") and np.array_equal(np.frombuffer(ppm[len(b"P6\n96 64\n255\n"):], np.uint8).reshape(64, 96, 3), o.read_ldr())
+    from PIL import Image                                        # the reference's dump is a PNG (AppViewer.cxx:1259-1261); the harness compares its pixels
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "Output_cornell_5.png")), o.read_ldr())
     assert float(open(tmp_path / "Output_cornell_5.txt").read()) > 0
     # gpus = 3: one context per "GPU" (all on device 0 here), host thread per context, tiles interleaved, crh_reduce on context 0
     env = dict(os.environ, CRH_HEADLESS_SHARE_DEVICE="1")

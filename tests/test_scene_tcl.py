@@ -487,6 +487,22 @@ def test_cpp_jpeg_reader_matches_pillow(tmp_path):
         assert np.array_equal(_cpp_image(ref, tmp_path), np.asarray(Image.open(ref).convert("RGB")))
 
 
+def test_cpp_png_writer_round_trips(tmp_path):
+    """Output_<name>_<n>.png of the C++ host (the reference's dump format, main.cxx:193-228): what host/model_tcl.hpp writes must read
+    back -- through Pillow and through its own reader -- as the pixels it was given."""
+    import subprocess
+    from PIL import Image
+    _cpp_image(tmp_path / "missing.png", tmp_path)                  # builds the tool when needed
+    exe = os.path.join(ROOT, "cadrays_amd", "host", "model_tcl_dump")
+    r = np.random.default_rng(3)
+    for shape in [(5, 7, 3), (64, 33, 4), (1, 1, 3), (300, 200, 3)]:
+        a = (r.random(shape) * 255).astype(np.uint8)
+        Image.fromarray(a).save(tmp_path / "in.png")
+        subprocess.check_call([exe, "--to-png", str(tmp_path / "in.png"), str(tmp_path / "out.png")])
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "out.png")), a)
+        assert np.array_equal(_cpp_image(tmp_path / "out.png", tmp_path), a)
+
+
 def test_cpp_reader_loads_a_jpeg_environment_like_the_python_reader(tmp_path):
     from PIL import Image
     from cadrays_amd import scene_io
