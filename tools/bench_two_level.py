@@ -1,25 +1,58 @@
 #!/usr/bin/env python3
-"""C3's million-triangle scene rendered as a TWO-LEVEL scene: triangles grouped into G^3 spatial cells = objects with identity
-transforms (what a CAD assembly of many parts looks like to the backend).  Prints Mrays/s next to the single-level figure."""
-import dataclasses, os, sys, time
+"""Throughput of the TWO-LEVEL traversal kernels -- what a real CADRays scene uses: every displayed AIS object is an instance with its
+own location (ImRaytraceControls.cxx:85-89, DataNode.cxx:239-242) -- against the single-level kernels the BASELINE configs run.
+C3's million triangles grouped into G^3 objects (spatial cells; translated or rotated placements), same camera, 32 spp batches.
+
+  python tools/bench_two_level.py [G ...] [identity|translated|rotated ...]          default: 1 4 10 (1, 64, 1000 objects), all three placements
+"""
+import dataclasses, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401
 from cadrays_amd import scenes
 from cadrays_amd.view import View
 
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+KINDS = [k for k in sys.argv[1:] if not k.isdigit()] or ["identity", "translated", "rotated"]
+Gs = [int(x) for x in sys.argv[1:] if x.isdigit()] or [1, 4, 10]
+SPP = 32
 sc = scenes.baseline_config("C3")
-cen = sc.pos.reshape(-1, 3, 3).mean(1)                              # the generator emits 3 private vertices per triangle
-cell = np.clip(((cen + 1.0) * 0.5 * G).astype(np.int32), 0, G - 1)
-obj = (cell[:, 0] * G + cell[:, 1]) * G + cell[:, 2]
-ids, inv = np.unique(obj, return_inverse=True)
-xf = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(ids), 1))
-two = dataclasses.replace(sc, tri_object=inv.astype(np.int32), obj_xform=xf)
-for name, s in (("single-level", sc), (f"two-level, {len(ids)} objects", two)):
-    v = View(0).load_scene(s)
-    v.render(spp); v.sync(); v.reset()
-    t = time.perf_counter(); v.render(spp); v.sync(); dt = time.perf_counter() - t
-    st = v.stats()
-    print(f"{name:32s} {st['rays_nearest'] / dt / 1e6:8.1f} Mrays/s   {dt * 1e3:7.1f} ms for {spp} spp")
+cen = sc.pos.reshape(-1, 3, 3).mean(1)
+
+
+def rate(v):
+    v.render(SPP); v.sync(); v.reset()
+    s0 = v.stats(); t0 = time.perf_counter()
+    for _ in range(3):
+        v.render(SPP)
+    v.sync(); dt = time.perf_counter() - t0; s1 = v.stats()
+    rays = (s1["rays_nearest"] + s1["rays_any"]) - (s0["rays_nearest"] + s0["rays_any"])
+    return rays / dt * 1e-6
+
+
+v = View(0).load_scene(sc)
+print(json.dumps({"scene": "single level", "mrays_per_s": round(rate(v), 1)}), flush=True)
+v.close()
+for G in Gs:
+    cell = np.clip(((cen + 1.0) * 0.5 * G).astype(np.int32), 0, G - 1)
+    obj = (cell[:, 0] * G + cell[:, 1]) * G + cell[:, 2]
+    ids, inv = np.unique(obj, return_inverse=True)
+    for kind in KINDS:
+        xf = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(ids), 1))
+        pos = sc.pos.copy().reshape(-1, 3, 3); nrm = sc.nrm.copy().reshape(-1, 3, 3)
+        if kind != "identity":
+            r = np.random.default_rng(G)
+            t = (r.random((len(ids), 3)).astype(np.float32) - 0.5) * 0.5
+            if kind == "rotated":                                   # object space = world rotated about z by a per-object angle, then shifted
+                a = r.random(len(ids)) * 2 * np.pi; c, s = np.cos(a).astype(np.float32), np.sin(a).astype(np.float32)
+                R = np.zeros((len(ids), 3, 3), np.float32); R[:, 0, 0] = c; R[:, 0, 1] = -s; R[:, 1, 0] = s; R[:, 1, 1] = c; R[:, 2, 2] = 1
+            else:
+                R = np.tile(np.eye(3, dtype=np.float32), (len(ids), 1, 1))
+            # world = R p_obj + t  =>  p_obj = R^T (p_world - t)
+            Rt = np.transpose(R, (0, 2, 1))
+            pos = np.einsum("tij,tvj->tvi", Rt[inv], pos - t[inv][:, None, :]).astype(np.float32)
+            nrm = np.einsum("tij,tvj->tvi", Rt[inv], nrm).astype(np.float32)
+            xf = np.concatenate([R, t[:, :, None]], 2).reshape(len(ids), 12).astype(np.float32)
+        two = dataclasses.replace(sc, pos=pos.reshape(-1, 3), nrm=nrm.reshape(-1, 3), tri_object=inv.astype(np.int32), obj_xform=xf)
+        v = View(0).load_scene(two)
+        print(json.dumps({"scene": f"two-level, {len(ids)} objects, {kind}", "mrays_per_s": round(rate(v), 1)}), flush=True)
+        v.close()
