@@ -167,9 +167,15 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   uint32_t cur = kDone, tag = 0;
   int sp = 0;
   v3 o = crh_mk3(0.f, 0.f, 0.f), d = o;
-  v3 wo = o, wd = o;     // world-space ray while inside an object (TWO only) ...
-  float wix = 0.f, wiy = 0.f, wiz = 0.f;   // ... and its reciprocal direction (restored, not recomputed, on leaving)
+  // TWO: the world-space ray {origin, direction, reciprocal direction} of every lane waits in LDS while the lane walks inside an object
+  // (restored, not recomputed, on leaving; nine registers fewer = one more wavefront per SIMD); column = lane, row stride kBlock
+  __shared__ float s_world[TWO ? 9 * kBlock : 1];
+  float* const wray = &s_world[TWO ? threadIdx.x : 0u];
   float ix = 0.f, iy = 0.f, iz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, best = 0.f;   // g: the slab test's guard band along each axis, in t
+  auto save_world = [&]() {
+    wray[0 * kBlock] = o.x; wray[1 * kBlock] = o.y; wray[2 * kBlock] = o.z; wray[3 * kBlock] = d.x; wray[4 * kBlock] = d.y; wray[5 * kBlock] = d.z;
+    wray[6 * kBlock] = ix; wray[7 * kBlock] = iy; wray[8 * kBlock] = iz;
+  };
   // guard band: entry / exit planes move apart by g = 2^-21 * |1/d| * R, R = |o - c|_1 + 3 h >= |origin - o| +
   // 256 * step of every node of the tree whose box has centre c and L1 half-extent h -- twice the worst rounding error of the
   // plane evaluation below, so a child box the exact ray touches is never culled
@@ -218,7 +224,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           load(pool_next + rank, o, d, tmax, tag);
           ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
           set_guard(gbox);
-          if (TWO) { wo = o; wd = d; wix = ix; wiy = iy; wiz = iz; }
+          if (TWO) save_world();
           best = tmax; found = false; sp = 0; cur = root; have = true;
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
           if (DON) { sbase = 0; is_child = false; cfound = false; next = kNoLane; head = lane; bound[lane] = __float_as_uint(tmax); }
@@ -256,9 +262,13 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
             for (int e = 0; e < rcnt; ++e) lds[e * kBlock] = from[(rsb + e) * kBlock];
           }
           // the helper walks in WORLD space (a donated entry sits below any object sentinel), with the donor's current bound
-          const v3 so = TWO ? wo : o, sd = TWO ? wd : d;
-          const float rox = __shfl(so.x, src), roy = __shfl(so.y, src), roz = __shfl(so.z, src);
-          const float rdx = __shfl(sd.x, src), rdy = __shfl(sd.y, src), rdz = __shfl(sd.z, src);
+          float rox, roy, roz, rdx, rdy, rdz;
+          if (TWO) {                                                                 // the donor's world ray: its column of s_world
+            const float* from = wray + ((int)src - (int)lane);
+            rox = from[0 * kBlock]; roy = from[1 * kBlock]; roz = from[2 * kBlock]; rdx = from[3 * kBlock]; rdy = from[4 * kBlock]; rdz = from[5 * kBlock];
+          } else {
+            rox = __shfl(o.x, src); roy = __shfl(o.y, src); roz = __shfl(o.z, src); rdx = __shfl(d.x, src); rdy = __shfl(d.y, src); rdz = __shfl(d.z, src);
+          }
           const float rbest = __shfl(best, src);
           const uint32_t rnext = __shfl(next, src), rhead = __shfl(head, src);
           if (gives) { next = kth_bit(idle_m, rank_d); sbase += give_n; }          // the helper comes right after the donor ...
@@ -266,7 +276,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
             o = crh_mk3(rox, roy, roz); d = crh_mk3(rdx, rdy, rdz);
             ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
             set_guard(gbox);
-            if (TWO) { wo = o; wd = d; wix = ix; wiy = iy; wiz = iz; }
+            if (TWO) save_world();
             best = rbest; found = false; sbase = 0; sp = rcnt - 1; cur = lds[sp * kBlock]; have = true;      // the nearest of the entries received
             hit = make_float4(rbest, 0.f, 0.f, __int_as_float(-1));
             is_child = true; cfound = false; next = rnext; head = rhead;            // ... and before what the donor gave away earlier
@@ -284,7 +294,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       if ((ANY && found) || sp == (DON ? sbase : 0)) { cur = kDone; return; }
       read_top();
       if (TWO && cur == CRH_REF_SENTINEL) {          // leaving an object: back to the world-space ray
-        o = wo; d = wd; ix = wix; iy = wiy; iz = wiz;                                            // the saved reciprocals are the bits inv_dir(wd) would recompute
+        o = crh_mk3(wray[0 * kBlock], wray[1 * kBlock], wray[2 * kBlock]); d = crh_mk3(wray[3 * kBlock], wray[4 * kBlock], wray[5 * kBlock]);
+        ix = wray[6 * kBlock]; iy = wray[7 * kBlock]; iz = wray[8 * kBlock];                         // the saved reciprocals are the bits inv_dir(d) would recompute
         set_guard(gbox);
         if (sp == (DON ? sbase : 0)) cur = kDone; else read_top();
       }
@@ -392,7 +403,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float4* ip = inst + 8u * (cur & 0x0FFFFFFFu);
       const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2], meta = ip[6];
       const float m[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
-      o = crh_xform_point(m, wo); d = crh_xform_vector(m, wd);
+      // the lane holds the world ray here (instances do not nest), and s_world keeps it for the way out
+      o = crh_xform_point(m, o); d = crh_xform_vector(m, d);
       // an instance that is only translated (inverse 3x3 == identity exactly, flagged by the host) leaves |d| and its signs
       // unchanged, so the reciprocals are the world ray's: three IEEE divisions saved on the common "placed, not rotated" part
       if (__float_as_uint(meta.z) == 0u) { ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z); }
