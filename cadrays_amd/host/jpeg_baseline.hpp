@@ -265,24 +265,21 @@ inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::ve
     std::vector<int> colsum((size_t)dw);
     std::vector<uint8_t> row((size_t)dw * 2);
     for (uint32_t y = 0; y < H; ++y) {
-      if (vs == 1) {                                                   // h2v1: 3/4 nearer + 1/4 further, rounding alternates
+      if (dw <= 2) {                                                   // the IJG decoder filters only planes wider than two samples; narrower ones are replicated
+        const int sy = (int)(y / (uint32_t)vs);
+        for (int x = 0; x < dw; ++x) row[2 * x] = row[2 * x + 1] = (uint8_t)sample_at(comp[c], x, sy);
+      } else if (vs == 1) {                                            // h2v1: 3/4 nearer + 1/4 further, rounding alternates
         const int sy = (int)y;
-        if (dw == 1) { row[0] = row[1] = (uint8_t)sample_at(comp[c], 0, sy); }
-        else {
-          int v = sample_at(comp[c], 0, sy); row[0] = (uint8_t)v; row[1] = (uint8_t)((v * 3 + sample_at(comp[c], 1, sy) + 2) >> 2);
-          for (int x = 1; x < dw - 1; ++x) { v = sample_at(comp[c], x, sy) * 3; row[2 * x] = (uint8_t)((v + sample_at(comp[c], x - 1, sy) + 1) >> 2); row[2 * x + 1] = (uint8_t)((v + sample_at(comp[c], x + 1, sy) + 2) >> 2); }
-          v = sample_at(comp[c], dw - 1, sy); row[2 * dw - 2] = (uint8_t)((v * 3 + sample_at(comp[c], dw - 2, sy) + 1) >> 2); row[2 * dw - 1] = (uint8_t)v;
-        }
+        int v = sample_at(comp[c], 0, sy); row[0] = (uint8_t)v; row[1] = (uint8_t)((v * 3 + sample_at(comp[c], 1, sy) + 2) >> 2);
+        for (int x = 1; x < dw - 1; ++x) { v = sample_at(comp[c], x, sy) * 3; row[2 * x] = (uint8_t)((v + sample_at(comp[c], x - 1, sy) + 1) >> 2); row[2 * x + 1] = (uint8_t)((v + sample_at(comp[c], x + 1, sy) + 2) >> 2); }
+        v = sample_at(comp[c], dw - 1, sy); row[2 * dw - 2] = (uint8_t)((v * 3 + sample_at(comp[c], dw - 2, sy) + 1) >> 2); row[2 * dw - 1] = (uint8_t)v;
       } else {                                                         // h2v2: vertical 3:1 blend with the nearer neighbour row, then the same horizontally on 16ths
         const int sy = (int)(y >> 1); int oy = (y & 1) ? sy + 1 : sy - 1;
         oy = oy < 0 ? 0 : (oy > dh - 1 ? dh - 1 : oy);
         for (int x = 0; x < dw; ++x) colsum[x] = sample_at(comp[c], x, sy) * 3 + sample_at(comp[c], x, oy);
-        if (dw == 1) { row[0] = (uint8_t)((colsum[0] * 4 + 8) >> 4); row[1] = (uint8_t)((colsum[0] * 4 + 7) >> 4); }
-        else {
-          row[0] = (uint8_t)((colsum[0] * 4 + 8) >> 4); row[1] = (uint8_t)((colsum[0] * 3 + colsum[1] + 7) >> 4);
-          for (int x = 1; x < dw - 1; ++x) { row[2 * x] = (uint8_t)((colsum[x] * 3 + colsum[x - 1] + 8) >> 4); row[2 * x + 1] = (uint8_t)((colsum[x] * 3 + colsum[x + 1] + 7) >> 4); }
-          row[2 * dw - 2] = (uint8_t)((colsum[dw - 1] * 3 + colsum[dw - 2] + 8) >> 4); row[2 * dw - 1] = (uint8_t)((colsum[dw - 1] * 4 + 7) >> 4);
-        }
+        row[0] = (uint8_t)((colsum[0] * 4 + 8) >> 4); row[1] = (uint8_t)((colsum[0] * 3 + colsum[1] + 7) >> 4);
+        for (int x = 1; x < dw - 1; ++x) { row[2 * x] = (uint8_t)((colsum[x] * 3 + colsum[x - 1] + 8) >> 4); row[2 * x + 1] = (uint8_t)((colsum[x] * 3 + colsum[x + 1] + 7) >> 4); }
+        row[2 * dw - 2] = (uint8_t)((colsum[dw - 1] * 3 + colsum[dw - 2] + 8) >> 4); row[2 * dw - 1] = (uint8_t)((colsum[dw - 1] * 4 + 7) >> 4);
       }
       memcpy(&full[c][(size_t)y * W], row.data(), W);
     }

@@ -464,7 +464,7 @@ def test_cpp_jpeg_reader_matches_pillow(tmp_path):
     from PIL import Image
     r = np.random.default_rng(1)
     cases = 0
-    for (w, h) in [(64, 48), (67, 53), (17, 9), (1, 1), (8, 8), (33, 16), (200, 131)]:
+    for (w, h) in [(64, 48), (67, 53), (17, 9), (1, 1), (8, 8), (33, 16), (200, 131), (2, 37), (4, 16), (3, 3)]:      # the narrow ones: chroma planes of <= 2 samples are replicated, not filtered
         y, x = np.mgrid[0:h, 0:w]
         img = np.stack([127 + 120 * np.sin(x / 7.0 + y / 11.0), 127 + 120 * np.cos(x / 5.0), (x * 3 + y * 5) % 256], -1) + r.normal(0, 12, (h, w, 3))
         img = np.clip(img, 0, 255).astype(np.uint8)
@@ -479,7 +479,7 @@ def test_cpp_jpeg_reader_matches_pillow(tmp_path):
             assert not isinstance(got, str), got
             assert got.shape == want.shape and np.array_equal(got, want), (w, h, kw)
             cases += 1
-    assert cases == 168
+    assert cases == 240
     path = tmp_path / "c.jpg"; Image.fromarray(img).convert("CMYK").save(path)
     assert "3-component" in _cpp_image(path, tmp_path)                # refused with a message, not mis-decoded
     ref = "/root/reference/data/maps/default.jpg"
