@@ -98,3 +98,69 @@ def test_rendering_the_preview_script_twice_passes(hip_lib, tmp_path):
     cr.promote(tpl, runs[0])
     s = cr.compare(tpl, runs[1], max_diff=1e9)                           # timing of a 14-frame run is noise; the images are the point
     assert s["pass"] and s["scripts"][0]["ldr_status"] == "identical" and s["scripts"][0]["hdr_rel_l2"] == 0.0
+
+
+def test_whole_harness_protocol_with_a_stand_in_program(tmp_path):
+    """tools/cadrays_testing.py = testing/CADRays_Testing.py's command line and folder protocol (-i -c -f -d -o -m -u).  The program under
+    test is a stand-in that writes what CADRays' test mode writes (main.cxx:193-228), so the protocol itself is checked without a GPU."""
+    scripts, out, model = tmp_path / "scripts", tmp_path / "out", tmp_path / "model"
+    for d in (scripts, out, model): d.mkdir()
+    (scripts / "cornell.tcl").write_text("# a\n"); (scripts / "materials.TCL").write_text("# b\n"); (scripts / "notes.txt").write_text("x")
+    (scripts / "Output_stale_5.txt").write_text("1")                 # left over from an earlier run: must be cleared
+    prog = tmp_path / "fake_cadrays.py"
+    prog.write_text(f"""#!{sys.executable}
+import os, sys, zlib, struct
+sys.path.insert(0, {os.path.join(ROOT, "tools")!r})
+import numpy as np, compare_runs as cr
+script, n = sys.argv[1], int(sys.argv[2])
+name = os.path.splitext(os.path.basename(script))[0]
+fps = float(os.environ.get("FAKE_FPS", "100")) * (2 if name == "materials" else 1)
+img = np.full((8, 12, 3), len(name) * 9 % 256, np.uint8); img[2, 3, 0] = int(os.environ.get("FAKE_PIXEL", "7"))
+open(f"Output_{{name}}_{{n}}.txt", "w").write("%g" % fps)
+cr.write_png(f"Output_{{name}}_{{n}}.png", img)
+""")
+    os.chmod(prog, 0o755)
+    tool = [sys.executable, os.path.join(ROOT, "tools", "cadrays_testing.py")]
+    base = ["-i", str(scripts), "-c", str(prog), "-f", "5", "-o", str(out), "-m", str(model)]
+    p = subprocess.run(tool + base, capture_output=True, text=True)       # first run: no template yet -> reported, not failed
+    assert p.returncode == 0, p.stdout + p.stderr
+    s = json.loads(p.stdout.strip().splitlines()[-1])
+    assert [x["script"] for x in s["scripts"]] == ["cornell.tcl", "materials.tcl"] and all(x["fps_status"] == "no template" for x in s["scripts"])
+    runs = [d for d in os.listdir(out)]
+    assert len(runs) == 1 and not [f for f in os.listdir(scripts) if f.startswith("Output_")]            # outputs moved, stale ones cleared
+    assert sorted(os.listdir(out / runs[0])) == ["Output_cornell_5.png", "Output_materials_5.png", "Result.html", "compare.json"]
+    p = subprocess.run(tool + ["-u", "-o", str(out), "-m", str(model)], capture_output=True, text=True)   # accept it
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert cr.read_template_rates(str(model)) == {"cornell.tcl": 100.0, "materials.tcl": 200.0} and sorted(os.listdir(model)) == ["Result.html", "cornell.png", "materials.png"]
+    import time; time.sleep(1.1)                                      # the run folders are named by the second
+    p = subprocess.run(tool + base, capture_output=True, text=True, env=dict(os.environ, FAKE_FPS="101"))
+    s = json.loads(p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 0 and s["pass"] and all(x["fps_status"] == "same" and x["ldr_status"] == "identical" for x in s["scripts"])
+    time.sleep(1.1)
+    p = subprocess.run(tool + base + ["-d", "1"], capture_output=True, text=True, env=dict(os.environ, FAKE_FPS="97", FAKE_PIXEL="8"))
+    s = json.loads(p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 1 and not s["pass"] and all(x["fps_status"] == "slower" and x["ldr_diff_pixels"] == 1 for x in s["scripts"])
+    latest = sorted(os.listdir(out))[-1]
+    assert os.path.isfile(out / latest / "Diff_cornell.png") and "background-color:red" in (out / latest / "Result.html").read_text()
+    assert subprocess.run(tool + ["-i", str(tmp_path / "nope"), "-m", str(model)], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+def test_whole_harness_with_this_backend(hip_lib, tmp_path):
+    """the same command line with the default program = this backend's script host: run, accept (-u), run again -> identical images"""
+    import shutil
+    scripts, out, model = tmp_path / "scripts", tmp_path / "out", tmp_path / "model"
+    for d in (scripts, out, model): d.mkdir()
+    src = open(os.path.join(ROOT, "tools", "material_preview.tcl")).read().replace("set frames_per_material 8000", "set frames_per_material 3")
+    (scripts / "preview.tcl").write_text(src.replace("{brass bronze copper gold pewter plaster plastic silver steel stone shiny_plastic satin metalized neon_gnc chrome aluminium obsidian neon_phc jade charcoal water glass diamond transparent}", "{gold}"))
+    tool = [sys.executable, os.path.join(ROOT, "tools", "cadrays_testing.py"), "-i", str(scripts), "-o", str(out), "-m", str(model), "-f", "5", "-d", "1000000"]
+    p = subprocess.run(tool, capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    s = json.loads(p.stdout.strip().splitlines()[-1])
+    assert not s["did_not_run"] and s["scripts"][0]["script"] == "preview.tcl" and s["scripts"][0]["fps"] > 0
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cadrays_testing.py"), "-u", "-o", str(out), "-m", str(model)], capture_output=True).returncode == 0
+    assert sorted(os.listdir(model)) == ["Result.html", "preview.pfm", "preview.png"]
+    import time; time.sleep(1.1)
+    p = subprocess.run(tool, capture_output=True, text=True)
+    s = json.loads(p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 0 and s["pass"] and s["scripts"][0]["ldr_status"] == "identical" and s["scripts"][0]["hdr_rel_l2"] == 0.0
