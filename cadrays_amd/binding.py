@@ -192,6 +192,18 @@ class Backend:
         self._call("read_ldr", out.ctypes.data_as(_u8p))
         return out
 
+    def read_ldr_begin(self):
+        """queue tone map + read-back of the frame as submitted so far; returns at once (crh_read_ldr_begin)"""
+        self._call("read_ldr_begin")
+        self._rb_shapes = getattr(self, "_rb_shapes", []) + [(self.height, self.width, 3)]
+
+    def read_ldr_end(self):
+        """the oldest begun read-back (crh_read_ldr_end)"""
+        shape = self._rb_shapes.pop(0) if getattr(self, "_rb_shapes", None) else (self.height, self.width, 3)
+        out = np.empty(shape, np.uint8)
+        self._call("read_ldr_end", out.ctypes.data_as(_u8p))
+        return out
+
     def stats(self):
         s = abi.crh_stats()
         self._call("get_stats", C.byref(s))

@@ -94,6 +94,12 @@ struct crh_ctx {
   // frame order (an event between the two accumulate launches)
   bool pipeline = true; bool pipe_pending[4] = {false, false, false, false}; uint32_t pipe_seq = 0; uint32_t* d_pipe_seeds = nullptr; int pipe_div = 4096;
   uint32_t pipe_depth = 3;         // frames in flight: 2 / 3 / 4 -> 323 / 391 / 312 Redraw/s on C3, 448 / 558 / 453 on C2
+  // asynchronous LDR read-back (crh_read_ldr_begin / _end): tone map + device-to-host copy of the frame as submitted so far run on their
+  // own stream into one of two device / pinned-host buffer pairs while the next Redraw()s are already rendering; only the NEXT
+  // accumulate waits (for the tone map, which reads the accumulator), nothing else does
+  hipStream_t rb_stream = nullptr; hipEvent_t rb_fork = nullptr, rb_tm[2] = {nullptr, nullptr}, rb_done[2] = {nullptr, nullptr};
+  uint8_t* d_rb[2] = {nullptr, nullptr}; uint8_t* h_rb[2] = {nullptr, nullptr}; size_t rb_cap = 0, rb_bytes[2] = {0, 0};
+  uint32_t rb_head = 0, rb_outstanding = 0; bool rb_guard_pending = false; hipEvent_t rb_guard = nullptr;
   bool read_since_render = true;   // a host that looks at every frame (read-back / sync between Redraws) gets the two-range schedule instead
   bool counters_on = false, timing_on = false;
   uint32_t frames_done = 0;       // whole-frame iterations since reset (crh_render continues from here)
@@ -113,6 +119,7 @@ static inline hipStream_t cstream(crh_ctx* c)
 {
   for (int k = 0; k < 4; ++k)
     if (c->pipe_pending[k]) { hipStreamWaitEvent(c->stream_, c->lane_join[k], 0); c->pipe_pending[k] = false; }
+  if (c->rb_guard_pending) { hipStreamWaitEvent(c->stream_, c->rb_guard, 0); c->rb_guard_pending = false; }      // an asynchronous read-back still tone-maps the accumulator
   c->read_since_render = true;      // something other than the next frame used the stream (render_impl clears this when it is done)
   return c->stream_;
 }
@@ -374,7 +381,7 @@ int do_reset(crh_ctx* c)
 struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; bool donate = false; };
 
 int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile,
-             bool accumulate, hipEvent_t before_accumulate = nullptr)
+             bool accumulate, hipEvent_t before_accumulate = nullptr, hipEvent_t before_accumulate2 = nullptr)
 {
   Launch L{ln.stream, ln.grid, c->counters_on};
   Launch LT{ln.stream, ln.grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0, ln.donate && !c->counters_on};
@@ -395,6 +402,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     qin = 1 - qin;
   }
   if (accumulate && before_accumulate) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate, 0));      // samples are folded in in frame order
+  if (accumulate && before_accumulate2) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate2, 0));    // ... and not while a read-back tone-maps the accumulator
   if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, c->d_counters, ln.n_tiles_dev);
   CRH_HIP(hipGetLastError());
   return CRH_OK;
@@ -523,7 +531,8 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     c->pending_n = 0;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);          // crh_stats.seconds: device time of this frame (frames in flight overlap)
     hipEventRecord(e0, ln.stream);
-    rc = run_lane(c, ln, S, c->d_tile_ids, nt, d_seeds_k, ns, 0, true, c->pipe_pending[prev] ? c->lane_join[prev] : nullptr); if (rc) return rc;
+    const hipEvent_t guard = c->rb_guard_pending ? c->rb_guard : nullptr; c->rb_guard_pending = false;      // later frames are ordered behind this one's accumulate
+    rc = run_lane(c, ln, S, c->d_tile_ids, nt, d_seeds_k, ns, 0, true, c->pipe_pending[prev] ? c->lane_join[prev] : nullptr, guard); if (rc) return rc;
     hipEventRecord(e1, ln.stream);
     c->render_ev.emplace_back(e0, e1);
     CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
@@ -796,6 +805,9 @@ void crh_destroy(crh_ctx* c)
   if (c->lane_fork) hipEventDestroy(c->lane_fork);
   if (c->d_lane_counts) hipFree(c->d_lane_counts);
   if (c->d_pipe_seeds) hipFree(c->d_pipe_seeds);
+  if (c->rb_stream) { hipStreamSynchronize(c->rb_stream); hipStreamDestroy(c->rb_stream); }
+  for (int k = 0; k < 2; ++k) { if (c->d_rb[k]) hipFree(c->d_rb[k]); if (c->h_rb[k]) hipHostFree(c->h_rb[k]); if (c->rb_tm[k]) hipEventDestroy(c->rb_tm[k]); if (c->rb_done[k]) hipEventDestroy(c->rb_done[k]); }
+  if (c->rb_fork) hipEventDestroy(c->rb_fork);
   for (void* q : {(void*)c->d_tile_cdf, (void*)c->d_picked, (void*)c->d_adapt_n}) if (q) hipFree(q);
   release_comms(c);
   hipStreamDestroy(c->stream_);
@@ -1167,6 +1179,58 @@ int crh_read_ldr(crh_ctx* c, uint8_t* out)
   launch_tonemap(L, c->assembled_valid ? c->d_assembled : c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, d_mask, c->par.width, ts);
   CRH_HIP(hipMemcpyAsync(out, c->d_scratch, 3 * (size_t)n, hipMemcpyDeviceToHost, cstream(c)));
   CRH_HIP(hipStreamSynchronize(cstream(c)));
+  return CRH_OK;
+}
+
+int crh_read_ldr_begin(crh_ctx* c)
+{
+  if (!c || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator");
+  if (c->rb_outstanding >= 2) return fail(c, CRH_E_INVALID, "two read-backs are already in flight (crh_read_ldr_end first)");
+  CRH_HIP(hipSetDevice(c->device));
+  const uint32_t n = c->par.width * c->par.height;
+  const size_t bytes = 3 * (size_t)n;
+  if (!c->rb_stream) {
+    CRH_HIP(hipStreamCreateWithFlags(&c->rb_stream, hipStreamNonBlocking));
+    CRH_HIP(hipEventCreateWithFlags(&c->rb_fork, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) { CRH_HIP(hipEventCreateWithFlags(&c->rb_tm[k], hipEventDisableTiming)); CRH_HIP(hipEventCreateWithFlags(&c->rb_done[k], hipEventDisableTiming)); }
+  }
+  if (bytes > c->rb_cap) {
+    CRH_HIP(hipStreamSynchronize(c->rb_stream));
+    if (c->rb_outstanding) return fail(c, CRH_E_INVALID, "the image grew while a read-back was in flight (crh_read_ldr_end first)");
+    for (int k = 0; k < 2; ++k) { if (c->d_rb[k]) CRH_HIP(hipFree(c->d_rb[k])); if (c->h_rb[k]) CRH_HIP(hipHostFree(c->h_rb[k])); c->d_rb[k] = nullptr; c->h_rb[k] = nullptr; }
+    for (int k = 0; k < 2; ++k) { CRH_HIP(hipMalloc((void**)&c->d_rb[k], bytes)); CRH_HIP(hipHostMalloc((void**)&c->h_rb[k], bytes, hipHostMallocDefault)); }
+    c->rb_cap = bytes;
+  }
+  const uint32_t slot = c->rb_head & 1u;
+  // everything submitted so far comes first: the frames in flight on the pipeline streams (not joined, they stay in flight) and
+  // whatever sits on the context's stream
+  for (int k = 0; k < 4; ++k) if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(c->rb_stream, c->lane_join[k], 0));
+  CRH_HIP(hipEventRecord(c->rb_fork, c->stream_));
+  CRH_HIP(hipStreamWaitEvent(c->rb_stream, c->rb_fork, 0));
+  const uint32_t ts = c->par.tile_size, n_tiles = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
+  const bool overlay = c->show_tiles && c->adaptive && c->picked_valid && c->d_picked && c->tile_stat_cap >= n_tiles;
+  Launch L{c->rb_stream, c->grid, false};
+  launch_tonemap(L, c->assembled_valid ? c->d_assembled : c->d_accum, c->d_rb[slot], n, c->par.tonemap_mode, c->par.exposure, c->par.white_point,
+                 overlay ? c->d_picked : nullptr, c->par.width, ts);
+  CRH_HIP(hipGetLastError());
+  CRH_HIP(hipEventRecord(c->rb_tm[slot], c->rb_stream));
+  CRH_HIP(hipMemcpyAsync(c->h_rb[slot], c->d_rb[slot], bytes, hipMemcpyDeviceToHost, c->rb_stream));
+  CRH_HIP(hipEventRecord(c->rb_done[slot], c->rb_stream));
+  c->rb_bytes[slot] = bytes;
+  c->rb_guard = c->rb_tm[slot]; c->rb_guard_pending = true;
+  ++c->rb_head; ++c->rb_outstanding;
+  return CRH_OK;
+}
+
+int crh_read_ldr_end(crh_ctx* c, uint8_t* out)
+{
+  if (!c || !out) return fail(c, CRH_E_INVALID, "null output");
+  if (!c->rb_outstanding) return fail(c, CRH_E_INVALID, "no read-back in flight (crh_read_ldr_begin first)");
+  CRH_HIP(hipSetDevice(c->device));
+  const uint32_t slot = (c->rb_head - c->rb_outstanding) & 1u;          // the oldest one
+  CRH_HIP(hipEventSynchronize(c->rb_done[slot]));
+  std::memcpy(out, c->h_rb[slot], c->rb_bytes[slot]);
+  --c->rb_outstanding;
   return CRH_OK;
 }
 

@@ -199,6 +199,15 @@ CRH_API int crh_read_hdr(crh_ctx* ctx, float* rgb_out);
 /* == BufferDump(Graphic3d_BT_RGB) (AppViewer.cxx:1259-1261): W*H*3 uint8 after exposure,
  * tone map, gamma 2.2 */
 CRH_API int crh_read_ldr(crh_ctx* ctx, uint8_t* rgb_out);
+/* The same image without stalling the render loop.  The reference never reads pixels back to show them: ImGui draws the FBO's colour
+ * texture (AppViewer.cxx:1099) and the GL driver pipelines that behind the next Redraw().  A host of this boundary that displays
+ * every frame does the equivalent with two calls: crh_read_ldr_begin() queues tone map + device-to-host copy of the frame AS
+ * SUBMITTED SO FAR on a stream of its own (pinned staging, two buffers) and returns at once; rendering calls made afterwards run
+ * concurrently -- only their first accumulation waits until the tone map has read the accumulator; crh_read_ldr_end() waits for
+ * the OLDEST begun read-back and copies its W*H*3 bytes out.  At most two may be in flight.  The bytes are those crh_read_ldr
+ * would have returned at the moment of crh_read_ldr_begin(). */
+CRH_API int crh_read_ldr_begin(crh_ctx* ctx);
+CRH_API int crh_read_ldr_end(crh_ctx* ctx, uint8_t* rgb_out);
 /* Accumulator checkpoint / resume (SURVEY.md section 5 "checkpoint / resume", 8f rank 4; the reference only keeps the
  * image while paused, AppViewer.cxx:916-920,1045): copy out / restore the float4 accumulator (rgb running mean + per-pixel
  * sample count) together with the whole-frame iteration counter that selects the next frame seed. */

@@ -583,3 +583,30 @@ def test_random_call_sequences_with_frames_in_flight(view_cls, monkeypatch, seed
     assert len(got) == len(ref)
     for i, (a, b) in enumerate(zip(got, ref)):
         assert np.array_equal(bits(a), bits(b)), (seed, i)
+
+
+@pytest.mark.parametrize("mode", ["pipelined", "unpipelined", "lookahead"])
+def test_async_ldr_readback_returns_the_frame_of_its_begin(view_cls, Oracle, monkeypatch, mode):
+    """crh_read_ldr_begin / _end (the boundary's stand-in for the GL present of AppViewer.cxx:1099): the bytes are those crh_read_ldr would
+    have returned at the moment of begin, although more Redraw()s are submitted -- and, pipelined, already rendering -- in between."""
+    if mode == "unpipelined": monkeypatch.setenv("CRH_PIPELINE", "0")
+    sc = scenes.cornell_box(True, 1280, 960)                         # 1.2 M paths per frame: the pipelined schedule applies
+    v = view_cls(0).load_scene(sc); twin = view_cls(0).load_scene(sc)
+    if mode == "lookahead": v.set_lookahead(4); twin.set_lookahead(4)
+    v.reset(); twin.reset()
+    want, got = [], []
+    for i in range(7):
+        v.Redraw(); twin.Redraw()
+        want.append(twin.read_ldr())                                 # synchronous snapshot of frame i on the twin
+        if i >= 2: got.append(v.read_ldr_end())                      # two read-backs stay in flight while the next frames render
+        v.read_ldr_begin()
+    got.append(v.read_ldr_end()); got.append(v.read_ldr_end())
+    assert len(got) == 7 and all(np.array_equal(g, w) for g, w in zip(got, want))
+    assert any(not np.array_equal(want[i], want[i + 1]) for i in range(6))          # the frames do differ: a late read-back would show
+    with pytest.raises(Exception):
+        v.read_ldr_end()                                             # nothing in flight
+    v.read_ldr_begin(); v.read_ldr_begin()
+    with pytest.raises(Exception):
+        v.read_ldr_begin()                                           # at most two
+    v.read_ldr_end(); v.read_ldr_end()
+    assert np.array_equal(v.read_ldr(), want[-1]) and np.array_equal(bits(v.read_hdr()), bits(twin.read_hdr()))

@@ -17,17 +17,21 @@ a = ap.parse_args()
 sc = scenes.baseline_config(a.config)
 v = View(0).load_scene(sc)
 out = {"config": a.config, "lanes": os.environ.get("CRH_LANES", "default"), "lane_grid_trace": os.environ.get("CRH_LANE_GRID_TRACE", "default")}
-for name, k, readback in (("free_running", 1, False), ("with_ldr_readback", 1, True), ("lookahead16_free_running", 16, False)):
+for name, k, readback in (("free_running", 1, False), ("with_ldr_readback", 1, True), ("with_async_ldr_readback", 1, "async"), ("lookahead16_free_running", 16, False)):
     v.set_lookahead(k); v.reset()
     for _ in range(8 if k == 1 else 2 * k):
         v.Redraw()
     v.sync()
     n = a.frames if k == 1 else max(a.frames, 4 * k)
     t0 = time.perf_counter()
-    for _ in range(n):
+    for i in range(n):
         v.Redraw()
-        if readback:
+        if readback == "async":                                     # every frame is displayed, two frames later: the read-backs of frames i - 1 and i stay in flight
+            if i >= 2: v.read_ldr_end()
+            v.read_ldr_begin()
+        elif readback:
             v.read_ldr()
+    if readback == "async": v.read_ldr_end(); v.read_ldr_end()
     v.sync()
     dt = time.perf_counter() - t0
     st = v.stats()
