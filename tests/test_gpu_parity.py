@@ -610,3 +610,63 @@ def test_async_ldr_readback_returns_the_frame_of_its_begin(view_cls, Oracle, mon
         v.read_ldr_begin()                                           # at most two
     v.read_ldr_end(); v.read_ldr_end()
     assert np.array_equal(v.read_ldr(), want[-1]) and np.array_equal(bits(v.read_hdr()), bits(twin.read_hdr()))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_sequences_with_async_readbacks_in_flight(view_cls, monkeypatch, seed):
+    """crh_read_ldr_begin / _end under arbitrary call orders: read-backs begun between bursts of Redraw()s, setters without and with
+    reset, tile subsets, look-ahead and adaptive switches, collected later (FIFO, at most two in flight).  Each must equal the
+    synchronous crh_read_ldr taken at the same point of the same sequence on the plain schedule (no pipelining, one stream)."""
+    import dataclasses
+    sc = scenes.cornell_box(True, 1216, 896)                       # 1.09 M paths per frame: pipelined
+    r0 = np.random.default_rng(100 + seed)
+    ops = [(int(r0.integers(0, 10)), int(r0.integers(1, 5)), float(r0.random())) for _ in range(18)]
+
+    def run(v, use_async):
+        outs, fifo = [], []
+        def begin():
+            if len(fifo) == 2: end()
+            if use_async: v.read_ldr_begin(); fifo.append(None)
+            else: fifo.append(v.read_ldr().copy())
+        def end():
+            if fifo:
+                snap = fifo.pop(0); outs.append(v.read_ldr_end() if use_async else snap)
+        for k, n, x in ops:
+            if k <= 2:
+                for _ in range(n):
+                    v.Redraw()
+                begin()
+            elif k == 3:
+                v.set_camera(dataclasses.replace(sc.camera, eye=(0.3 + 0.3 * x, -1.5, 0.5))); v.reset()        # a restart while read-backs are in flight
+            elif k == 4:
+                mats = [dataclasses.replace(m) for m in sc.materials]
+                mats[0] = dataclasses.replace(mats[0], Kd=np.float32([x, 0.5, 0.3]))
+                v.set_materials(mats)
+            elif k == 5:
+                end()
+            elif k == 6:
+                v.render_tiles(np.arange(0, v.n_tiles(), 3, dtype=np.uint32), 40 + n, n); begin()
+            elif k == 7:
+                v.set_lookahead(1 + (n % 3) * 3)
+            elif k == 8:
+                v.set_adaptive(n % 2 == 0, 64 + 16 * n)
+                for _ in range(2):
+                    v.Redraw()
+                begin()
+                v.set_adaptive(False, 64)
+            else:
+                par = dataclasses.replace(sc.params, exposure=float(x - 0.5), tonemap_mode=n % 2)            # display parameters only: the accumulation continues
+                v.set_params(par)
+        for _ in range(2):
+            v.Redraw()
+        begin(); end(); end()
+        outs.append(v.read_ldr().copy())
+        return outs
+
+    monkeypatch.setenv("CRH_PIPELINE", "0"); monkeypatch.setenv("CRH_DONATE", "0"); monkeypatch.setenv("CRH_LANES", "1")
+    ref = run(view_cls(0).load_scene(sc), False)
+    monkeypatch.delenv("CRH_PIPELINE"); monkeypatch.delenv("CRH_DONATE"); monkeypatch.delenv("CRH_LANES")
+    got = run(view_cls(0).load_scene(sc), True)
+    assert len(got) == len(ref) and len(got) >= 3
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(a, b), (seed, i)
