@@ -272,11 +272,13 @@ def read_ply(path):
                             off += struct.calcsize(_PLY_T[p[0]])
     faces = np.array(faces, np.int32).reshape(-1, 3)
     if nrm is None:
-        nrm = np.zeros_like(pos)
-        fn = np.cross(pos[faces[:, 1]] - pos[faces[:, 0]], pos[faces[:, 2]] - pos[faces[:, 0]])
-        for k in range(3):
-            np.add.at(nrm, faces[:, k], fn)
-        nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+        # area-weighted vertex normals, in the arithmetic host/model_tcl.hpp uses (both readers must hand over the same bytes): float
+        # edge vectors, double cross products, accumulated face by face and corner by corner, normalised in double
+        nrm = np.zeros((len(pos), 3), np.float64)
+        if len(faces):
+            fn = np.cross((pos[faces[:, 1]] - pos[faces[:, 0]]).astype(np.float64), (pos[faces[:, 2]] - pos[faces[:, 0]]).astype(np.float64))
+            np.add.at(nrm, faces.reshape(-1), np.repeat(fn, 3, axis=0))
+        nrm /= np.maximum(np.sqrt((nrm[:, 0] * nrm[:, 0] + nrm[:, 1] * nrm[:, 1]) + nrm[:, 2] * nrm[:, 2]), 1e-30)[:, None]
     return pos, nrm.astype(np.float32), faces, uv
 
 
@@ -934,9 +936,9 @@ class SceneBuilder:
         if c["eye"] is not None and c["at"] is not None:
             eye, at = np.array(c["eye"], float), np.array(c["at"], float)
         else:                                                  # vfit: frame the bounding sphere
-            lo, hi = pos.min(0), pos.max(0)
+            lo, hi = pos.min(0).astype(np.float64), pos.max(0).astype(np.float64)        # double from here on, like host/model_tcl.hpp
             at = (lo + hi) / 2
-            r = np.linalg.norm(hi - lo) / 2
+            r = math.sqrt(float(((hi - lo) ** 2)[0] + ((hi - lo) ** 2)[1] + ((hi - lo) ** 2)[2])) / 2
             half = math.radians(c["fovy"]) / 2
             half = min(half, math.atan(math.tan(half) * width / height))
             eye = at + proj / np.linalg.norm(proj) * (r / math.sin(half))
