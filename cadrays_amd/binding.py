@@ -5,6 +5,7 @@ prefix 'orc_' on the CPU oracle with this same class, so the parity tests drive 
 the same calls with the same bytes.
 """
 import ctypes as C
+import os
 import numpy as np
 
 from . import abi
@@ -24,16 +25,34 @@ def _fp(a):
     return a.ctypes.data_as(_f32p) if a is not None else None
 
 
+_live = None      # weak set of open contexts: closed by an atexit hook, i.e. BEFORE the interpreter tears modules (and with them the HIP
+                  # runtime torch loaded) down in arbitrary order -- a context destroyed after that calls into a dead runtime
+
+
+def _close_all():
+    for b in list(_live or ()):
+        try:
+            b.close()
+        except Exception:
+            pass
+
+
 class Backend:
     """One rendering context ( == one V3d_View on one GPU )."""
 
     def __init__(self, lib, prefix, create_args=()):
+        global _live
         self._lib, self._p = lib, prefix
         f = self._fn("create")
         f.restype = C.c_void_p
         self._ctx = C.c_void_p(f(*create_args))
         if not self._ctx.value:
             raise BackendError(f"{prefix}create failed")
+        if _live is None:
+            import atexit, weakref
+            _live = weakref.WeakSet()
+            if not os.environ.get("CRH_NO_ATEXIT_CLOSE"): atexit.register(_close_all)      # the switch exists to measure what the hook prevents
+        _live.add(self)
         self.width = self.height = 0
         self._fn("last_error").restype = C.c_char_p
 

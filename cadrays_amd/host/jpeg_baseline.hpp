@@ -62,46 +62,48 @@ inline int jpeg_decode_sym(JpegBits& br, const JpegHuff& h)
 }
 inline int jpeg_extend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
-// islow inverse DCT of one dequantised block (natural order) -> 8x8 samples
-inline void jpeg_idct_islow(const int* in, uint8_t* out, int out_stride)
+// islow inverse DCT of one dequantised block (natural order) -> 8x8 samples.  64-bit intermediates: a valid stream never leaves the
+// 32-bit range the IJG code works in (same results), a corrupt one must not run into signed overflow
+inline void jpeg_idct_islow(const long long* in, uint8_t* out, int out_stride)
 {
+  typedef long long I;
   constexpr int CB = 13, P1 = 2;
-  constexpr int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633, F_1_501 = 12299,
+  constexpr I F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633, F_1_501 = 12299,
                 F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
-  int ws[64];
-  auto descale = [](int x, int n) { return (x + (1 << (n - 1))) >> n; };
+  I ws[64];
+  auto descale = [](I x, int n) { return (x + ((I)1 << (n - 1))) >> n; };
   for (int c = 0; c < 8; ++c) {
-    const int* i = in + c;
-    int z2 = i[16], z3 = i[48];
-    int z1 = (z2 + z3) * F_0_541;
-    int tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
+    const I* i = in + c;
+    I z2 = i[16], z3 = i[48];
+    I z1 = (z2 + z3) * F_0_541;
+    I tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
     z2 = i[0]; z3 = i[32];
-    int tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
-    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    I tmp0 = (z2 + z3) * ((I)1 << CB), tmp1 = (z2 - z3) * ((I)1 << CB);
+    const I tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = i[56]; tmp1 = i[40]; tmp2 = i[24]; tmp3 = i[8];
-    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int z4 = tmp1 + tmp3;
-    const int z5 = (z3 + z4) * F_1_175;
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; I z4 = tmp1 + tmp3;
+    const I z5 = (z3 + z4) * F_1_175;
     tmp0 *= F_0_298; tmp1 *= F_2_053; tmp2 *= F_3_072; tmp3 *= F_1_501;
     z1 *= -F_0_899; z2 *= -F_2_562; z3 *= -F_1_961; z4 *= -F_0_390;
     z3 += z5; z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-    int* w = ws + c;
+    I* w = ws + c;
     w[0] = descale(tmp10 + tmp3, CB - P1); w[56] = descale(tmp10 - tmp3, CB - P1);
     w[8] = descale(tmp11 + tmp2, CB - P1); w[48] = descale(tmp11 - tmp2, CB - P1);
     w[16] = descale(tmp12 + tmp1, CB - P1); w[40] = descale(tmp12 - tmp1, CB - P1);
     w[24] = descale(tmp13 + tmp0, CB - P1); w[32] = descale(tmp13 - tmp0, CB - P1);
   }
-  auto clamp8 = [](int v) { v += 128; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
+  auto clamp8 = [](I v) { v += 128; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
   for (int r = 0; r < 8; ++r) {
-    const int* w = ws + 8 * r;
-    int z2 = w[2], z3 = w[6];
-    int z1 = (z2 + z3) * F_0_541;
-    int tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
-    int tmp0 = (w[0] + w[4]) * (1 << CB), tmp1 = (w[0] - w[4]) * (1 << CB);
-    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    const I* w = ws + 8 * r;
+    I z2 = w[2], z3 = w[6];
+    I z1 = (z2 + z3) * F_0_541;
+    I tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
+    I tmp0 = (w[0] + w[4]) * ((I)1 << CB), tmp1 = (w[0] - w[4]) * ((I)1 << CB);
+    const I tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
-    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int z4 = tmp1 + tmp3;
-    const int z5 = (z3 + z4) * F_1_175;
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; I z4 = tmp1 + tmp3;
+    const I z5 = (z3 + z4) * F_1_175;
     tmp0 *= F_0_298; tmp1 *= F_2_053; tmp2 *= F_3_072; tmp3 *= F_1_501;
     z1 *= -F_0_899; z2 *= -F_2_562; z3 *= -F_1_961; z4 *= -F_0_390;
     z3 += z5; z4 += z5;
@@ -156,6 +158,7 @@ inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::ve
         if (comp[c].h < 1 || comp[c].v < 1 || comp[c].h > 2 || comp[c].v > 2 || (c > 0 && (comp[c].h != 1 || comp[c].v != 1)) || (c == 0 && (comp[c].h != hmax || comp[c].v != vmax)))
           { err = path + ": unsupported JPEG sampling factors"; return false; }
       if (hmax == 1 && vmax == 2) { err = path + ": unsupported JPEG sampling factors (1x2)"; return false; }
+      if ((double)W * H > 1073741824.0 || (double)W * H > 4096.0 * (double)d.size() + 65536.0) { err = path + ": image size does not fit its data"; return false; }      // untrusted input: no 65535 x 65535 canvas for a 300-byte file
       mcux = (int)((W + 8 * hmax - 1) / (8 * hmax)); mcuy = (int)((H + 8 * vmax - 1) / (8 * vmax));
       for (int c = 0; c < nc; ++c) { Comp& C = comp[c]; C.bw = mcux * C.h; C.bh = mcuy * C.v;
         const int cw = (int)((W * C.h + hmax - 1) / hmax), chh = (int)((H * C.v + vmax - 1) / vmax); C.rw = (cw + 7) / 8; C.rh = (chh + 7) / 8;   // blocks a non-interleaved scan covers
@@ -187,7 +190,7 @@ inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::ve
       auto decode_block = [&](Comp& C, int16_t* blk) {
         if (!progressive) {
           const int s = jpeg_decode_sym(br, hdc[C.td]); if (s < 0 || s > 11) { bad = true; return; }
-          C.pred += jpeg_extend(br.receive(s), s); blk[0] = (int16_t)C.pred;
+          C.pred = std::max(-(1 << 20), std::min(1 << 20, C.pred + jpeg_extend(br.receive(s), s))); blk[0] = (int16_t)C.pred;      // bounded: a corrupt stream must not overflow
           for (int k = 1; k < 64;) { const int rs = jpeg_decode_sym(br, hac[C.ta]); if (rs < 0) { bad = true; return; }
             const int r = rs >> 4, sz = rs & 15;
             if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
@@ -197,7 +200,7 @@ inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::ve
         }
         if (Ss == 0) {
           if (Ah == 0) { const int s = jpeg_decode_sym(br, hdc[C.td]); if (s < 0 || s > 11) { bad = true; return; }
-            C.pred += jpeg_extend(br.receive(s), s); blk[0] = (int16_t)(C.pred * (1 << Al)); }
+            C.pred = std::max(-(1 << 20), std::min(1 << 20, C.pred + jpeg_extend(br.receive(s), s))); blk[0] = (int16_t)((long long)C.pred * (1 << Al)); }
           else if (br.bit()) blk[0] |= (int16_t)(1 << Al);
           return;
         }
@@ -248,10 +251,10 @@ inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::ve
   }
   if (!have_sof || !seen_scan) { err = path + ": no image data"; return false; }
   // dequantise + inverse DCT
-  { int coef[64];
+  { long long coef[64];
     for (int c = 0; c < nc; ++c) { Comp& C = comp[c]; const int stride = C.bw * 8; C.plane.assign((size_t)stride * C.bh * 8, 0);
       for (int by = 0; by < C.bh; ++by) for (int bx = 0; bx < C.bw; ++bx) { const int16_t* blk = &C.coef[((size_t)by * C.bw + bx) * 64];
-        for (int i = 0; i < 64; ++i) coef[i] = blk[i] * qt[C.tq][i];
+        for (int i = 0; i < 64; ++i) coef[i] = (long long)blk[i] * qt[C.tq][i];
         jpeg_idct_islow(coef, &C.plane[(size_t)by * 8 * stride + (size_t)bx * 8], stride); }
       std::vector<int16_t>().swap(C.coef); } }
   // chroma -> full resolution (fancy upsampling), over the real (not MCU-padded) extent

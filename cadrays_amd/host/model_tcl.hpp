@@ -87,6 +87,8 @@ inline bool read_png(const std::string& path, uint32_t& w, uint32_t& h, uint32_t
   const uint32_t spp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if (!spp) { err = path + ": unknown PNG colour type"; return false; }
   const size_t stride = (size_t)w * spp;
+  // a file is untrusted input: the header's size must be one the compressed data can actually fill (deflate expands at most ~1032 : 1)
+  if (w > (1u << 16) || h > (1u << 16) || (double)(stride + 1) * h > 1032.0 * (double)idat.size() + 65536.0) { err = path + ": image size does not fit its data"; return false; }
   std::vector<uint8_t> raw((stride + 1) * h);
   uLongf rawlen = (uLongf)raw.size();
   if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) { err = path + ": corrupt image data"; return false; }
@@ -215,20 +217,28 @@ inline bool read_ply(const std::string& path, Mesh& m, std::string& err)
       if (n == "x") ix = (int)k; else if (n == "y") iy = (int)k; else if (n == "z") iz = (int)k; else if (n == "nx") inx = (int)k; else if (n == "ny") iny = (int)k;
       else if (n == "nz") inz = (int)k; else if (n == "s" || n == "u" || n == "texture_u") is = (int)k; else if (n == "t" || n == "v" || n == "texture_v") it = (int)k;
     }
+    // a file is untrusted input: a vertex needs all of x y z (normals all three, texture coordinates both), an element without
+    // properties has no data to walk over, a list cannot be longer than what is left of the file
+    const bool is_vertex = e.name == "vertex" && ix >= 0 && iy >= 0 && iz >= 0, with_n = inx >= 0 && iny >= 0 && inz >= 0, with_uv = is >= 0 && it >= 0;
+    if (e.name == "vertex" && !is_vertex) { err = path + ": vertex element without x, y, z"; return false; }
+    if (e.props.empty()) continue;
     for (size_t i = 0; i < e.count; ++i) {
       std::vector<double> vals(e.props.size(), 0.0);
       for (size_t k = 0; k < e.props.size(); ++k) {
         const Prop& p = e.props[k];
         if (!p.list) { if (!get(p.type, vals[k])) { err = path + ": truncated"; return false; } continue; }
         double cnt; if (!get(p.ltype, cnt)) { err = path + ": truncated"; return false; }
+        if (!(cnt >= 0.0) || cnt > (double)d.size()) { err = path + ": bad list length"; return false; }
         std::vector<int32_t> idx((size_t)cnt);
-        for (size_t j = 0; j < idx.size(); ++j) { double v; if (!get(p.itype, v)) { err = path + ": truncated"; return false; } idx[j] = (int32_t)v; }
+        for (size_t j = 0; j < idx.size(); ++j) { double v; if (!get(p.itype, v)) { err = path + ": truncated"; return false; }
+          if (!(v >= -2147483648.0 && v <= 2147483647.0)) { err = path + ": face index out of range"; return false; }
+          idx[j] = (int32_t)v; }
         if (e.name == "face") for (size_t j = 1; j + 1 < idx.size(); ++j) { m.faces.push_back(idx[0]); m.faces.push_back(idx[j]); m.faces.push_back(idx[j + 1]); }
       }
-      if (e.name == "vertex" && ix >= 0) {
+      if (is_vertex) {
         m.pos.push_back((float)vals[ix]); m.pos.push_back((float)vals[iy]); m.pos.push_back((float)vals[iz]);
-        if (inx >= 0) { has_n = true; m.nrm.push_back((float)vals[inx]); m.nrm.push_back((float)vals[iny]); m.nrm.push_back((float)vals[inz]); }
-        if (is >= 0 && it >= 0) { m.has_uv = true; m.uv.push_back((float)vals[is]); m.uv.push_back((float)vals[it]); }
+        if (with_n) { has_n = true; m.nrm.push_back((float)vals[inx]); m.nrm.push_back((float)vals[iny]); m.nrm.push_back((float)vals[inz]); }
+        if (with_uv) { m.has_uv = true; m.uv.push_back((float)vals[is]); m.uv.push_back((float)vals[it]); }
       }
     }
   }

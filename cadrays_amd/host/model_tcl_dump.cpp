@@ -31,8 +31,8 @@ int main(int argc, char** argv)
   const uint32_t hdr[7] = {2, (uint32_t)(sc.pos.size() / 3), (uint32_t)(sc.tri.size() / 4), (uint32_t)sc.mats.size(), (uint32_t)sc.lights.size(), sc.envW, sc.envH};
   fwrite("CRHS", 1, 4, f); fwrite(hdr, 4, 7, f); fwrite(&sc.cam, sizeof sc.cam, 1, f); fwrite(&sc.par, sizeof sc.par, 1, f);
   fwrite(sc.pos.data(), 4, sc.pos.size(), f); fwrite(sc.nrm.data(), 4, sc.nrm.size(), f); fwrite(sc.tri.data(), 4, sc.tri.size(), f);
-  fwrite(sc.mats.data(), sizeof(crh_bsdf), sc.mats.size(), f); fwrite(sc.lights.data(), sizeof(crh_light), sc.lights.size(), f);
-  fwrite(sc.env.data(), 4, sc.env.size(), f);
+  fwrite(sc.mats.data(), sizeof(crh_bsdf), sc.mats.size(), f); if (!sc.lights.empty()) fwrite(sc.lights.data(), sizeof(crh_light), sc.lights.size(), f);
+  if (!sc.env.empty()) fwrite(sc.env.data(), 4, sc.env.size(), f);
   const uint32_t ext[3] = {sc.uv.empty() ? 0u : 1u, 0u, (uint32_t)sc.textures.size()};
   fwrite(ext, 4, 3, f);
   if (!sc.uv.empty()) fwrite(sc.uv.data(), 4, sc.uv.size(), f);

@@ -248,10 +248,10 @@ def read_ply(path):
                 cols = {n: arr[n] for n in names}
             if name == "vertex":
                 pos = np.stack([cols["x"], cols["y"], cols["z"]], 1).astype(np.float32)
-                if "nx" in cols:
+                if "nx" in cols and "ny" in cols and "nz" in cols:
                     nrm = np.stack([cols["nx"], cols["ny"], cols["nz"]], 1).astype(np.float32)
                 for a, b in (("s", "t"), ("u", "v"), ("texture_u", "texture_v")):
-                    if a in cols:
+                    if a in cols and b in cols:
                         uv = np.stack([cols[a], cols[b]], 1).astype(np.float32)
         else:
             for _ in range(count):

@@ -2,7 +2,7 @@
 """One-off hunt beside tools/big_fuzz.py: the random CALL-SEQUENCE tests of tests/test_gpu_fuzz.py with many more seeds (renders,
 Redraws under look-ahead, tile subsets, resets, camera / material / light / environment / parameter changes, object moves,
 adaptive on / off, checkpoints), GPU vs oracle after every step.  python tools/big_seq_fuzz.py [first] [last]"""
-import sys, importlib.util
+import os, sys, importlib.util
 sys.path.insert(0, '.')
 import torch  # noqa: F401
 spec = importlib.util.spec_from_file_location("fz", "tests/test_gpu_fuzz.py"); fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
@@ -11,6 +11,7 @@ from oracle.pyoracle import Oracle
 a, b = (int(sys.argv[1]) if len(sys.argv) > 1 else 1000), (int(sys.argv[2]) if len(sys.argv) > 2 else 1200)
 bad = []
 for seed in range(a, b):
+    if os.environ.get('CRH_FUZZ_VERBOSE'): print('seed', seed, file=sys.stderr, flush=True)
     for fn in (fz.test_random_call_sequences_keep_both_sides_in_step, fz.test_random_sequences_two_level_adaptive_checkpoint):
         try:
             fn.__wrapped__(View, Oracle, seed) if hasattr(fn, "__wrapped__") else fn(View, Oracle, seed)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # CPU-side sanitizer pass: the oracle (C, OpenMP) and the product's host-side BVH builder (C++ threads,
 # atomics, futures) under AddressSanitizer, UndefinedBehaviorSanitizer and ThreadSanitizer.  Never on the GPU.
-#   tools/run_sanitizers.sh [asan ubsan tsan]      -> sanitizers/<kind>.log, exit status 1 on any report
+#   tools/run_sanitizers.sh [asan ubsan tsan]      -> sanitizers/<kind>.log (+ readers_malformed.log), exit status 1 on any report
 cd "$(dirname "$0")/.."
 KINDS=${@:-asan ubsan tsan}
 OUT=sanitizers; mkdir -p $OUT
@@ -25,4 +25,9 @@ for k in $KINDS; do
   fi
   if grep -E "ERROR: (Address|Thread|Leak)Sanitizer|runtime error:|WARNING: ThreadSanitizer" $log > /dev/null; then echo "$k: sanitizer reports in $log"; rc=1; else echo "$k: clean"; fi
 done
+# 3. the C++ file readers (model.tcl, PLY, PNG, JPEG: they parse files a user hands them): ASan + UBSan build, truncated / bit-flipped /
+#    spliced inputs (tools/fuzz_readers_malformed.py); anything but a clean exit or an error message is a finding
+if g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -o /tmp/model_tcl_dump_asan cadrays_amd/host/model_tcl_dump.cpp -lz; then
+  python3 tools/fuzz_readers_malformed.py /tmp/model_tcl_dump_asan 300 1 > $OUT/readers_malformed.log 2>&1 && echo "readers: clean" || { echo "readers: findings in $OUT/readers_malformed.log"; rc=1; }
+else echo "readers: build failed"; rc=1; fi
 exit $rc
