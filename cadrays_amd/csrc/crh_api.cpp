@@ -403,7 +403,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
   }
   if (accumulate && before_accumulate) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate, 0));      // samples are folded in in frame order
   if (accumulate && before_accumulate2) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate2, 0));    // ... and not while a read-back tone-maps the accumulator
-  if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, c->d_counters, ln.n_tiles_dev);
+  if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, ns, c->d_counters, ln.n_tiles_dev);
   CRH_HIP(hipGetLastError());
   return CRH_OK;
 }
@@ -1082,7 +1082,7 @@ int crh_render(crh_ctx* c, uint32_t n)
       const uint32_t m = std::min(n, c->pending_n);
       DScene S; fill_scene(c, S);
       Launch L{cstream(c), c->grid, false};
-      launch_accumulate(L, S, c->paths, c->d_accum, nullptr, c->d_tile_ids, nt, c->pending_off, m, c->d_counters);
+      launch_accumulate(L, S, c->paths, c->d_accum, nullptr, c->d_tile_ids, nt, c->pending_off, m, c->pending_off + c->pending_n, c->d_counters);      // the batch held pending_off + pending_n samples
       CRH_HIP(hipGetLastError());
       c->pending_off += m; c->pending_n -= m; c->pending_first += m; c->frames_done += m; n -= m;
     }

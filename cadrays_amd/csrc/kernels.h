@@ -23,9 +23,9 @@ void launch_shade(const Launch&, const DScene&, const DPaths&, const DQueues&, i
 // any-hit traversal of the shadow queue; unoccluded contributions are added to the path radiance
 void launch_trace_any(const Launch&, const DScene&, const DPaths&, const DQueues&, DCounters*);
 // clamp + running mean of the finished paths of batch samples [first_sample, first_sample + n_samples) into the float4
-// accumulator, sample by sample
+// accumulator, sample by sample; batch_samples = the sample count the batch was generated with (it fixes the slot layout)
 void launch_accumulate(const Launch&, const DScene&, const DPaths&, float4* accum, float* m2 /* or nullptr */,
-                       const uint32_t* d_tile_ids, uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, DCounters*,
+                       const uint32_t* d_tile_ids, uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, uint32_t batch_samples, DCounters*,
                        const uint32_t* d_n_tiles = nullptr);
 // adaptive tile sampler, device side: running sum of the tile errors, n_picks inverse-CDF draws (radical inverse of pick0 + k),
 // the distinct tiles in ascending order with their per-tile frame seeds and their number -- all left in HBM

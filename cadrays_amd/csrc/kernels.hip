@@ -844,6 +844,35 @@ __device__ __forceinline__ bool slot_pixel(const DScene& S, const uint32_t* __re
   return tile < tx * ty && px < S.width && py < S.height;
 }
 
+// Path slot <-> (pixel slot, sample) inside one batch of `ns` samples.  An 8x8 pixel block owns 64 * ns consecutive slots = ns
+// wavefronts.  With G = the largest power of two that divides ns (at most 64), a wavefront holds 64 / G pixels x G consecutive samples:
+// ns = 1 (one Redraw): the 8x8 block, as ever; ns = 128 (the batch bench.py times): ONE pixel x 64 samples -- camera rays that differ
+// only by their sub-pixel jitter walk the tree in lockstep and shade the same triangle (lane utilisation of the first launches), and
+// the wavefronts in flight cover a few thousand pixels instead of a fifth of the image.  Only the ORDER of the slots changes: every
+// path still owns (pixel, sample), seeds and per-pixel accumulation order are untouched, results are bit-identical.
+#ifndef CRH_SAMPLE_GROUP_MAX
+#define CRH_SAMPLE_GROUP_MAX 64
+#endif
+#ifndef CRH_SLOT_SAMPLE_MAJOR
+#define CRH_SLOT_SAMPLE_MAJOR 0      // lane = pixel * G + sample (0) or sample * P + pixel (1) inside a wavefront's 64 slots
+#endif
+__device__ __forceinline__ uint32_t sample_group(uint32_t ns) { return min(ns & (0u - ns), (uint32_t)CRH_SAMPLE_GROUP_MAX); }
+__device__ __forceinline__ void slot_to_pixel_sample(uint32_t pid, uint32_t ns, uint32_t& local, uint32_t& s)
+{
+  const uint32_t G = sample_group(ns), lg = 31u - (uint32_t)__clz((int)G);      // G is a power of two
+  const uint32_t B = pid / (64u * ns), r = pid - B * 64u * ns, w = r >> 6, l = r & 63u;
+  const uint32_t P = 64u >> lg;
+  const uint32_t c = w >> lg, b = w & (G - 1u), pi_ = CRH_SLOT_SAMPLE_MAJOR ? l & (P - 1u) : l >> lg, si = CRH_SLOT_SAMPLE_MAJOR ? l / P : l & (G - 1u);
+  local = B * 64u + b * P + pi_;
+  s = (c << lg) + si;
+}
+__device__ __forceinline__ uint32_t pixel_sample_to_slot(uint32_t local, uint32_t s, uint32_t ns)
+{
+  const uint32_t G = sample_group(ns), lg = 31u - (uint32_t)__clz((int)G), P = 64u >> lg;
+  const uint32_t B = local >> 6, p = local & 63u, b = p / P, pi_ = p - b * P, c = s >> lg, si = s & (G - 1u);
+  return B * 64u * ns + (((c << lg) + b) << 6) + (CRH_SLOT_SAMPLE_MAJOR ? si * P + pi_ : (pi_ << lg) + si);
+}
+
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t* __restrict__ q, uint32_t* __restrict__ count,
                                                     uint32_t* __restrict__ cursors,
                                                     const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
@@ -866,7 +895,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
       const uint32_t pid = cbase + it * kBlock + threadIdx.x;
       bool valid = pid < total;
       uint32_t px, py;
-      if (valid) { const uint32_t s = pid / per_sample; valid = slot_pixel(S, tile_ids, pid - s * per_sample, px, py); }
+      if (valid) { uint32_t local, s; slot_to_pixel_sample(pid, n_samples, local, s); valid = slot_pixel(S, tile_ids, local, px, py); }
       const unsigned long long m = __ballot(valid);
       if (lane == 0) s_cnt[it * 4u + wv] = (uint32_t)__popcll(m);
     }
@@ -883,12 +912,12 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
     for (uint32_t it = 0; it < kGenIters; ++it) {
     const uint32_t pid = cbase + it * kBlock + threadIdx.x;
     bool valid = pid < total;
-    uint32_t px = 0, py = 0, s = 0;
-    if (valid) { s = pid / per_sample; valid = slot_pixel(S, tile_ids, pid - s * per_sample, px, py); }
+    uint32_t px = 0, py = 0, s = 0, local = 0;
+    if (valid) { slot_to_pixel_sample(pid, n_samples, local, s); valid = slot_pixel(S, tile_ids, local, px, py); }
     if (valid) {
       const uint32_t pix = S.coherent ? ((py / 16u) * ((S.width + 15u) / 16u) + (px / 16u)) : (py * S.width + px);
       // whole-frame passes share one frame seed per sample; adaptive passes give every tile its own sample index
-      const uint32_t fseed = seed_per_tile ? seeds[(pid - s * per_sample) / (S.tile_size * S.tile_size)] : seeds[s];
+      const uint32_t fseed = seed_per_tile ? seeds[local / (S.tile_size * S.tile_size)] : seeds[s];
       uint32_t rng = crh_rng_seed(pix, fseed);
       const float jx = crh_rng_next(&rng), jy = crh_rng_next(&rng);
       const float nx = CRH_FMA(((float)px + jx) / (float)S.width, 2.0f, -1.0f);
@@ -1119,40 +1148,76 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
 // ================================================================== accumulate / display
 __global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float4* __restrict__ accum, float* __restrict__ m2,
                                                         const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
-                                                        uint32_t first_sample, uint32_t n_samples, DCounters* C,
+                                                        uint32_t first_sample, uint32_t n_samples, uint32_t batch_samples, DCounters* C,
                                                         const uint32_t* __restrict__ n_tiles_dev)
 {
   if (n_tiles_dev) n_tiles = *n_tiles_dev;
-  // samples [first_sample, first_sample + n_samples) of the batch in the path buffer are folded in, in order
+  // samples [first_sample, first_sample + n_samples) of the batch of batch_samples in the path buffer are folded in, in order
   const uint32_t per_sample = n_tiles * S.tile_size * S.tile_size;
+  const uint32_t last = first_sample + n_samples;
   uint32_t done = 0;
-  for (uint32_t local = blockIdx.x * kBlock + threadIdx.x; local < per_sample; local += gridDim.x * kBlock) {
-    uint32_t px, py;
-    if (!slot_pixel(S, tile_ids, local, px, py)) continue;
-    const size_t pi = (size_t)py * S.width + px;
-    float4 a = accum[pi];
-    float q = m2 ? m2[pi] : 0.f;
-    for (uint32_t s = first_sample; s < first_sample + n_samples; ++s) {
-      const float4 r = P.rad[s * per_sample + local];
-      const float w = 1.0f / (a.w + 1.0f);
-      float v[3] = {r.x, r.y, r.z};
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f); float q = 0.f;
+  auto fold = [&](const float4 r) {
+    const float w = 1.0f / (a.w + 1.0f);
+    float v[3] = {r.x, r.y, r.z};
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        if (!(v[k] == v[k])) v[k] = 0.f;
-        if (S.clampv > 0.f && v[k] > S.clampv) v[k] = S.clampv;
-      }
-      a.x = CRH_FMA(v[0] - a.x, w, a.x);
-      a.y = CRH_FMA(v[1] - a.y, w, a.y);
-      a.z = CRH_FMA(v[2] - a.z, w, a.z);
-      a.w = a.w + 1.0f;
-      if (m2) {      // running mean of the squared luminance (adaptive sampling's variance estimate)
-        const float l = CRH_FMA(0.0722f, v[2], CRH_FMA(0.7152f, v[1], 0.2126f * v[0]));
-        q = CRH_FMA(l * l - q, w, q);
-      }
-      ++done;
+    for (int k = 0; k < 3; ++k) {
+      if (!(v[k] == v[k])) v[k] = 0.f;
+      if (S.clampv > 0.f && v[k] > S.clampv) v[k] = S.clampv;
     }
-    accum[pi] = a;
-    if (m2) m2[pi] = q;
+    a.x = CRH_FMA(v[0] - a.x, w, a.x);
+    a.y = CRH_FMA(v[1] - a.y, w, a.y);
+    a.z = CRH_FMA(v[2] - a.z, w, a.z);
+    a.w = a.w + 1.0f;
+    if (m2) {      // running mean of the squared luminance (adaptive sampling's variance estimate)
+      const float l = CRH_FMA(0.0722f, v[2], CRH_FMA(0.7152f, v[1], 0.2126f * v[0]));
+      q = CRH_FMA(l * l - q, w, q);
+    }
+    ++done;
+  };
+  if (sample_group(batch_samples) >= 8u) {
+    // Wide batches: a pixel's samples sit in runs of >= 8 consecutive slots (one 128-B line), the pixels of a block far apart -- a
+    // lane walking its own pixel would touch 64 lines per load.  A wavefront therefore takes one 8x8 block, fetches 64 pixels x 8
+    // samples with eight coalesced loads (eight whole lines each) into LDS, and every lane folds ITS pixel's eight samples from
+    // there, in sample order: the same arithmetic in the same order (4.05 -> ~1 ms per 128-spp step at 1080p).
+    __shared__ float4 s_tile[4][64 * 9];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    float4* tile = s_tile[wave];
+    const uint32_t n_blocks = per_sample >> 6, stride_b = gridDim.x * 4u, rounds = (n_blocks + stride_b - 1u) / stride_b;
+    for (uint32_t k = 0; k < rounds; ++k) {
+      const uint32_t B = blockIdx.x * 4u + wave + k * stride_b;
+      const bool live = B < n_blocks;                                  // uniform per wavefront; every wavefront keeps the barriers
+      uint32_t px = 0, py = 0;
+      const bool mine = live && slot_pixel(S, tile_ids, B * 64u + lane, px, py);
+      const size_t pi = (size_t)py * S.width + px;
+      if (mine) { a = accum[pi]; q = m2 ? m2[pi] : 0.f; }
+      for (uint32_t s0 = first_sample & ~7u; s0 < last; s0 += 8u) {
+        if (live) {
+#pragma unroll
+          for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t qp = 8u * j + (lane >> 3), ks = lane & 7u;
+            tile[qp * 9u + ks] = P.rad[pixel_sample_to_slot(B * 64u + qp, s0 + ks, batch_samples)];
+          }
+        }
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+          for (uint32_t ks = 0; ks < 8u; ++ks) { const uint32_t s = s0 + ks; if (s >= first_sample && s < last) fold(tile[lane * 9u + ks]); }
+        }
+        __syncthreads();
+      }
+      if (mine) { accum[pi] = a; if (m2) m2[pi] = q; }
+    }
+  } else {
+    for (uint32_t local = blockIdx.x * kBlock + threadIdx.x; local < per_sample; local += gridDim.x * kBlock) {
+      uint32_t px, py;
+      if (!slot_pixel(S, tile_ids, local, px, py)) continue;
+      const size_t pi = (size_t)py * S.width + px;
+      a = accum[pi]; q = m2 ? m2[pi] : 0.f;
+      for (uint32_t s = first_sample; s < last; ++s) fold(P.rad[pixel_sample_to_slot(local, s, batch_samples)]);
+      accum[pi] = a;
+      if (m2) m2[pi] = q;
+    }
   }
   done = wave_sum(done);
   if (lane_id() == 0 && done) atomicAdd(&C->samples, (unsigned long long)done);
@@ -1414,9 +1479,9 @@ void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const D
 #undef CRH_LAUNCH_TA
 }
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,
-                       uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, DCounters* C, const uint32_t* d_n_tiles)
+                       uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, uint32_t batch_samples, DCounters* C, const uint32_t* d_n_tiles)
 {
-  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, m2, d_tile_ids, n_tiles, first_sample, n_samples, C, d_n_tiles);
+  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, m2, d_tile_ids, n_tiles, first_sample, n_samples, batch_samples, C, d_n_tiles);
 }
 void launch_tile_error(const Launch& L, const DScene& S, const float4* accum, const float* m2, float* tile_err, uint32_t* tile_min_count,
                        uint32_t n_tiles_total)
