@@ -95,6 +95,10 @@ def roofline_report(config, spp, modified, alg_bytes_per_launch, avg_ms, scene_b
                   "traffic_over_alg": round(traffic / max(alg_bytes_per_launch, 1.0), 3),
                   "l2_hit_rate": round(hit / (hit + miss), 3) if hit and miss else None,
                   "pmc_avg_launch_ms": ent.get("avg_launch_ms")})
+        if resident and t_gbps < 0.75 * HBM_ACHIEVABLE_GBPS:
+            # the L2s serve most of the gather (block-major path order keeps the rays in flight in a few thousand pixels): what limits the
+            # kernel is the latency of L2 hits and VALU issue, not the memory side
+            r["bound"] = "L2-hit latency + VALU issue (Infinity-Cache resident; memory side not saturated)"
         if resident:
             r["achieved"] = round(min(alg_gbps, t_gbps), 1)
             r["achieved_basis"] = "min(algorithmic, memory-side counter traffic): bytes that were both needed and crossed the L2's memory side"
