@@ -26,7 +26,9 @@ struct crh_ctx {
   int device = 0;
   hipStream_t stream_ = nullptr;   // use cstream(c): it first joins frames still in flight on the pipeline streams
   int cus = 0;            // compute units (0: unknown)
-  int grid = 2048;        // streaming / shading kernels: 8 workgroups per CU
+  int grid = 1024;        // streaming / shading kernels: 4 workgroups per CU = what k_shade's 128 VGPRs keep resident; every workgroup of the
+                          // persistent loops then starts at once and the next bounce's queue keeps the block-major order.  Measured, workgroups
+                          // 512 / 768 / 1024 / 1280 / 2048: C5 2842 / 2874 / 2925 / 2839 / 2813, C3 3507 / 3688 / 3807 / 3787 / 3777, C2 4649 / 4849 / 4967 / 4975 / 4941 Mrays/s
   int grid_trace = 1536;  // traversal kernels: 6 workgroups (= 6 waves/SIMD) per CU -- measured: 4 / 5 / 6 / 7 / 8 per CU -> 3300 / 3424 /
                           // 3448 / 3448 / 3443 Mrays/s on C3 (more rays in flight enlarge the working set the 4 MB-per-XCD L2s hold)
   std::string err;
@@ -766,7 +768,7 @@ crh_ctx* crh_create(int device_ordinal)
     delete c; return nullptr;
   }
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->cus = prop.multiProcessorCount; c->grid = prop.multiProcessorCount * 8; c->grid_trace = prop.multiProcessorCount * 6; }
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->cus = prop.multiProcessorCount; c->grid = prop.multiProcessorCount * 4; c->grid_trace = prop.multiProcessorCount * 6; }
   if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)std::min<long>(v, 1l << 30); }   // a path slot travels in 31 bits
   if (const char* e = getenv("CRH_GRID")) { int v = atoi(e); if (v > 0) c->grid = v; }
   if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }
