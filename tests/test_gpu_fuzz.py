@@ -207,3 +207,37 @@ def test_random_sequences_two_level_adaptive_checkpoint(view_cls, Oracle, seed):
         assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), (seed, step, op)
     v.render(2); o.render(2)
     assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr()))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_wide_batch_slot_layouts(view_cls, Oracle, seed):
+    """The slot layout of wide batches (kernels.hip: 64 / G pixels x G samples per wavefront, G = the largest power of two dividing the
+    batch's sample count, and the LDS-tiled accumulate): sample counts for every G, in one call, split in two, under look-ahead and
+    through crh_render_tiles with a tile subset and a first-sample offset.  Image and counters against the oracle
+    (tools/wide_batch_fuzz.py is the same hunt with more seeds)."""
+    import dataclasses
+    r = np.random.default_rng(seed)
+    sc = random_scene(seed + 900)
+    sc = dataclasses.replace(sc, params=dataclasses.replace(sc.params, width=int(r.integers(9, 50)), height=int(r.integers(9, 34)), max_depth=min(sc.params.max_depth, 4),
+                                                            tile_size=int(r.choice([8, 16, 32]))))
+    ns = [16, 24, 32, 40, 48, 64, 72, 96, 128, 130, 192, 8, 12, 56, 88, 160][seed]
+    v = view_cls(0).load_scene(sc); o = Oracle().load_scene(sc)
+    mode = seed % 4
+    if mode == 0:
+        v.enable_counters(True); v.reset(); v.render(ns); o.render(ns)
+    elif mode == 1:
+        k = int(r.integers(1, ns)); v.render(k); v.render(ns - k); o.render(ns)
+    elif mode == 2:
+        v.set_lookahead(int(r.choice([16, 32, 64]))); done = 0
+        while done < ns:
+            k = min(int(r.integers(1, 20)), ns - done); v.render(k); done += k
+        o.render(ns)
+    else:
+        tiles = np.arange(v.n_tiles(), dtype=np.uint32); sel = tiles[r.random(len(tiles)) < 0.6]
+        sel = sel if len(sel) else tiles[:1]
+        first = int(r.integers(0, 50)); v.render_tiles(sel, first, ns); o.render_tiles(sel, first, ns)
+    assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), (seed, ns, mode)
+    if mode == 0:
+        gs, cs = v.stats(), o.stats()
+        for k in ("rays_nearest", "nodes_nearest", "tris_nearest", "rays_any", "samples"):
+            assert gs[k] == cs[k], k
