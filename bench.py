@@ -328,7 +328,7 @@ def main():
                        "tiles_per_rank": int(len(tiles)), "parallelism": f"tiles x{n_gpus} + RCCL reduce" if n_gpus > 1 else "single GPU",
                        "rccl_ranks": int(rccl_ranks), "backend": backend,
                        "msamples_per_s": round(samples / dt / 1e6, 3), "rays_nearest": int(rays_n), "rays_any": int(rays_a),
-                       "build_upload_s": round(build_s, 2), "host_cores": os.cpu_count(), "interactive": interactive},
+                       "build_upload_s": round(build_s, 2), "host_cores": os.cpu_count(), "host_usable_cpus": usable_cpus(), "interactive": interactive},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
@@ -347,12 +347,17 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cpus():
+    from cadrays_amd.hostinfo import usable_cpus as f       # pure Python: the launcher parent still never imports torch
+    return f()
+
+
 def cpu_baseline(sc, seconds):
     """The CPU oracle on a bounded tile sample of the same workload: the parity build (what the tests compare against) and,
     when built, the fast build (-O3 -march=native, contraction allowed, counters compiled out; oracle/Makefile)."""
     import numpy as np
     from oracle import pyoracle
-    ncores = os.cpu_count() or 1
+    ncores = usable_cpus()
     out = None
     for kind in ("fast", "parity"):
         try:
@@ -381,7 +386,8 @@ def cpu_baseline(sc, seconds):
                "sample": f"{len(sample)} of {nt} 32x32 tiles of the same workload, {spp_cpu} spp, {s1['seconds']:.1f} s, OpenMP oracle ({kind} build)"}
         if out is None:
             out = {"value": leg["value"], "unit": "Mrays/s", "cores": ncores, "kind": "port", "sample": leg["sample"],
-                   "cpu_model": cpu_model(), "build": kind}
+                   "cpu_model": cpu_model(), "build": kind, "hardware_threads": os.cpu_count(),
+                   "cores_note": "threads used = CPUs this container may run on at once (affinity mask and cgroup CPU quota)"}
         out[f"{kind}_build"] = leg
         o.close()
     return out

@@ -11,6 +11,10 @@
 // Large subtrees are built by separate threads; the result does not depend on the thread count because every
 // subtree owns a disjoint index range and numbering happens afterwards.
 #include "bvh_builder.h"
+#include <sched.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "../../include/crh_bvh_format.h"
 #include "../../include/crh_xform.h"
@@ -365,6 +369,24 @@ struct Collapser {
 
 }  // namespace
 
+// CPUs this process can run on at once: hardware threads, cut down to the scheduler affinity mask and to the cgroup CPU quota (a
+// container throttled to 16 CPUs of time on a 256-thread host builds FASTER with 16 threads than with 256)
+static int usable_cpus()
+{
+  int n = (int)std::thread::hardware_concurrency(); if (n < 1) n = 1;
+  cpu_set_t set; CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0 && a < n) n = a; }
+  double quota = 0.0;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) { char q[64]; double per = 0; if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / per; fclose(f); }
+  else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+    double q = 0, per = 0; if (fscanf(g, "%lf", &q) != 1) q = 0; fclose(g);
+    if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &per) != 1) per = 0; fclose(h); }
+    if (q > 0 && per > 0) quota = q / per;
+  }
+  if (quota > 0.0) { const int qn = (int)(quota + 0.999); if (qn >= 1 && qn < n) n = qn; }
+  return n;
+}
+
 uint32_t build_tree(const float* boxes, uint32_t n, bool instance_leaves, uint32_t leaf0,
                     std::vector<QNode>& nodes, std::vector<uint32_t>& order, float bmin[3], float bmax[3], int threads) {
   Builder B;
@@ -383,7 +405,7 @@ uint32_t build_tree(const float* boxes, uint32_t n, bool instance_leaves, uint32
     B.idx[t] = t;
   }
   B.nodes.resize(2 * (size_t)cap + 1);
-  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  if (threads <= 0) threads = usable_cpus();
   if (threads < 1) threads = 1;
   B.spare_threads.store(threads - 1);
   const auto t0_ = std::chrono::steady_clock::now();

@@ -3,6 +3,7 @@ imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- n
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -30,7 +31,20 @@ def lib():
     if _LIB is None:
         # CRH_ORACLE_LIB: another build of the same file (tools/run_sanitizers.sh loads the ASan / UBSan builds this way)
         _LIB = C.CDLL(os.environ.get("CRH_ORACLE_LIB") or build())
+        _default_threads(_LIB)
     return _LIB
+
+
+def _default_threads(l):
+    """OpenMP would start one thread per hardware thread; a container with a CPU quota (16 of 256 on the pool's GPU boxes) is far slower
+    that way than with as many threads as it may run"""
+    try:
+        sys.path.insert(0, os.path.join(_HERE, ".."))
+        from cadrays_amd.hostinfo import usable_cpus
+        if not os.environ.get("OMP_NUM_THREADS"):
+            l.orc_set_threads(int(usable_cpus()))
+    except Exception:
+        pass
 
 
 class Oracle(Backend):
@@ -70,6 +84,7 @@ def fast_lib():
         if stale:
             subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libcrh_oracle_fast.so"])
         _FAST = C.CDLL(so)
+        _default_threads(_FAST)
     return _FAST
 
 
