@@ -44,6 +44,7 @@ struct crh_ctx {
   crh_params par{};
   // ---- two-level mode (per-object transforms)
   bool two_level = false; uint32_t nO = 0;
+  bool flat = false;      // two_level scene whose transforms are ALL the identity: built and rendered as one world-space tree (crh_build)
   std::vector<float> xf; std::vector<int32_t> tri_obj;
   struct Inst { float fwd[12], inv[12], bmin[3], bmax[3]; uint32_t root, obj; };
   std::vector<Inst> inst; uint32_t n_blas_nodes = 0, root = 0;
@@ -266,7 +267,7 @@ void fill_scene(const crh_ctx* c, DScene& S)
 {
   std::memset(&S, 0, sizeof S);
   S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = (c->envW && c->envH) ? c->d_env : nullptr;
-  S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * c->inst.size() : nullptr; S.root = c->root; S.two_level = c->two_level ? 1 : 0;
+  S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * c->inst.size() : nullptr; S.root = c->root; S.two_level = c->two_level && !c->flat ? 1 : 0;
   {
     const float* lo = c->bvh.bbmin; const float* hi = c->bvh.bbmax;      // bounds of the tree the walk starts in (the world box of a two-level scene)
     S.guard_box = make_float4((lo[0] + hi[0]) * 0.5f, (lo[1] + hi[1]) * 0.5f, (lo[2] + hi[2]) * 0.5f, (((hi[0] - lo[0]) + (hi[1] - lo[1])) + (hi[2] - lo[2])) * 0.5f);
@@ -848,6 +849,14 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
   return CRH_OK;
 }
 
+// every object at the identity (the state of a CADRays scene until something is dragged): one world-space tree, the single-level kernels
+static bool all_identity(const float* xf, uint32_t nO)
+{
+  static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  for (uint32_t o = 0; o < nO; ++o) for (int k = 0; k < 12; ++k) if (xf[12 * (size_t)o + k] != I[k]) return false;
+  return true;
+}
+
 int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
 {
   if (!c || !xf) return fail(c, CRH_E_INVALID, "null transforms");
@@ -855,6 +864,8 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
   if (!all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return fail(c, CRH_E_INVALID, "transform holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   c->xf.assign(xf, xf + 12 * (size_t)nO);
+  if (c->built && all_identity(xf, nO) != c->flat) return crh_build(c);      // between one tree and object trees + top level: a full build, once
+  if (c->built && c->flat) return do_reset(c);                                // identity again: nothing moved
   if (c->built) {
     // the manipulator calls this every frame (ImRaytraceControls.cxx:58-89): rebuild the top-level tree on the host and send only
     // its nodes (the tail of the node array, behind the untouched object trees) and the instance table, stream-ordered into
@@ -964,7 +975,8 @@ int crh_build(crh_ctx* c)
   int threads = 0; if (const char* e = getenv("CRH_BUILD_THREADS")) threads = atoi(e);
   std::vector<int32_t> tri_inst(nT ? nT : 1, -1);   // triangle -> instance (two-level only)
   c->inst.clear(); c->root = 0;
-  if (!c->two_level) {
+  c->flat = c->two_level && all_identity(c->xf.data(), c->nO);
+  if (!c->two_level || c->flat) {
     build_qbvh(c->pos.data(), c->tri.data(), nT, c->bvh, threads);
     c->n_blas_nodes = (uint32_t)c->bvh.nodes.size();
   } else {

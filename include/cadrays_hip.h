@@ -128,7 +128,9 @@ CRH_API const char* crh_last_error(crh_ctx* ctx);
  * (AisMesh.cxx:357-423), per-object 3x4 row-major transforms (DataNode.cxx:239-242).
  * With tri_object + obj_xform the scene is a TWO-LEVEL BVH like OCCT's: vertices are in object space, every
  * object gets its own tree, a top-level tree over the instances' world boxes carries the transforms (each vertex
- * must belong to one object).  Without them the arrays are world space and one tree is built. */
+ * must belong to one object).  Without them the arrays are world space and one tree is built.  A scene whose obj_xform are ALL exactly
+ * the identity (a CADRays scene until something is dragged) is built as that one tree too -- same images and counters as without
+ * objects, single-level speed -- until crh_set_transforms moves an object. */
 CRH_API int crh_set_geometry(crh_ctx* ctx,
                      const float* pos, const float* nrm, const float* uv, uint32_t n_vertices,
                      const int32_t* tri /* 4*nT: i0,i1,i2,material */, uint32_t n_triangles,
@@ -136,7 +138,8 @@ CRH_API int crh_set_geometry(crh_ctx* ctx,
                      const float* obj_xform /* 12*nO or NULL */, uint32_t n_objects);
 /* == AIS_InteractiveObject::SetLocalTransformation / the manipulator moving an object (ImRaytraceControls.cxx:58-89,
  * DataNode.cxx:239-242): new 3x4 transforms for the n_objects of the two-level scene.  Only the top-level tree is
- * rebuilt (object trees and triangles stay in HBM untouched); restarts accumulation. */
+ * rebuilt (object trees and triangles stay in HBM untouched); restarts accumulation.  One exception: the call that takes a scene
+ * from "every object at the identity" (built as one tree) to "something moved", or back, is a full crh_build. */
 CRH_API int crh_set_transforms(crh_ctx* ctx, const float* obj_xform /* 12*nO */, uint32_t n_objects);
 /* == Graphic3d_MaterialAspect::SetBSDF + SynchronizeAspects (MaterialEditor.cxx:331-337, Utils.cxx:57-93) */
 CRH_API int crh_set_materials(crh_ctx* ctx, const crh_bsdf* m, uint32_t n);

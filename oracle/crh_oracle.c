@@ -78,6 +78,7 @@ typedef struct orc_ctx {
   qnode* nodes; uint32_t nNodes; qtri* qtris; uint32_t nQT;
   /* two-level mode (per-object transforms): object-space BLAS per object + TLAS over instance boxes */
   int two_level; uint32_t nO; float* xf; int32_t* tri_obj;
+  int flat;                        /* two_level scene whose transforms are ALL the identity: built and walked as ONE tree */
   struct orc_instance* inst; uint32_t nInst; uint32_t nBlasNodes; uint32_t root;
   uint32_t* tlas_order;          /* instance at top-level leaf position i */
   float bbmin[3], bbmax[3]; float eps;
@@ -322,13 +323,23 @@ static void build_tlas(orc_ctx* c)
   free(pb);
 }
 
+/* every object at the identity: the scene is one world-space tree -- no top level, no ray transforms (spec: same result as the same
+ * triangles handed over without objects); the first crh_set_transforms that moves an object rebuilds it two-level */
+static int all_identity(const float* xf, uint32_t nO)
+{
+  static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  for (uint32_t o = 0; o < nO; ++o) for (int k = 0; k < 12; ++k) if (xf[12 * o + k] != I[k]) return 0;
+  return 1;
+}
+
 static int do_build(orc_ctx* c)
 {
   uint32_t n = c->nT;
+  c->flat = c->two_level && all_identity(c->xf, c->nO);
   free(c->nodes); free(c->qtris); free(c->inst); c->nodes = NULL; c->qtris = NULL; c->inst = NULL; c->nInst = 0; c->root = 0;
   c->qtris = (qtri*)malloc(sizeof(qtri) * (n ? n : 1)); c->nQT = n;
   collapser C; C.capq = 1024; C.nq = 0; C.qn = (qnode*)malloc(sizeof(qnode) * C.capq);
-  if (!c->two_level) {
+  if (!c->two_level || c->flat) {
     aabb* pb = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
     uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
     for (uint32_t t = 0; t < n; ++t) tri_box(c, t, &pb[t]);
@@ -834,7 +845,7 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
     v3 p0 = crh_mk3(c->pos[3 * ti[0]], c->pos[3 * ti[0] + 1], c->pos[3 * ti[0] + 2]);
     v3 p1 = crh_mk3(c->pos[3 * ti[1]], c->pos[3 * ti[1] + 1], c->pos[3 * ti[1] + 2]);
     v3 p2 = crh_mk3(c->pos[3 * ti[2]], c->pos[3 * ti[2] + 1], c->pos[3 * ti[2] + 2]);
-    const float* M = c->two_level ? &c->xf[12 * c->tri_obj[h.prim]] : NULL;      /* object -> world */
+    const float* M = c->two_level && !c->flat ? &c->xf[12 * c->tri_obj[h.prim]] : NULL;      /* object -> world */
     if (M) { p0 = crh_xform_point(M, p0); p1 = crh_xform_point(M, p1); p2 = crh_xform_point(M, p2); }
     v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
     float w0 = (1.0f - h.u) - h.v;
@@ -1055,7 +1066,10 @@ ORC_API int orc_set_transforms(orc_ctx* c, const float* xf, uint32_t nO)
 {
   if (!c || !xf || !c->two_level || nO != c->nO || !all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return CRH_E_INVALID;
   memcpy(c->xf, xf, sizeof(float) * 12 * nO);
-  if (c->built) build_tlas(c);                      /* object trees are untouched */
+  if (c->built) {
+    if (all_identity(xf, nO) != c->flat) do_build(c);          /* the scene changes between one tree and object trees + top level */
+    else if (!c->flat) build_tlas(c);                          /* object trees are untouched */
+  }
   return orc_reset(c);
 }
 ORC_API int orc_get_tlas(orc_ctx* c, uint32_t* root, uint32_t* n_instances, uint32_t* n_blas_nodes)

@@ -88,7 +88,8 @@ def test_oracle_two_level_moved_objects_match_flat(oracle_lib):
 
 
 def test_oracle_set_transforms_equals_fresh_build(oracle_lib):
-    base = object_scene()
+    start = np.tile(rigid(), (7, 1)); start[2] = rigid(0.0, (0, 0, 1), (0.0, 0.0, 0.001))       # one object off the identity: the scene is two-level from the start
+    base = object_scene(start)
     moved = dataclasses.replace(base, obj_xform=moved_xforms(7))
     a = oracle_lib.Oracle().load_scene(base); a.render(2)
     blas_before = a.get_bvh()[0][:a.get_tlas()["n_blas_nodes"]].copy()
@@ -99,6 +100,62 @@ def test_oracle_set_transforms_equals_fresh_build(oracle_lib):
     assert np.array_equal(a.get_bvh()[0][:len(blas_before)].view(np.uint32), blas_before.view(np.uint32))   # object trees untouched
     info = a.get_tlas()
     assert info["n_instances"] == 7 and info["root"] == info["n_blas_nodes"]
+
+
+def test_oracle_identity_objects_are_one_tree(oracle_lib):
+    """A scene whose objects all sit at the identity -- a CADRays scene until something is dragged -- is built and walked as ONE
+    world-space tree: same nodes, same images, same counters as the same triangles handed over without objects.  The first
+    crh_set_transforms that moves an object rebuilds it as object trees + top level (== a fresh build of the moved scene); moving
+    everything back to the identity flattens it again."""
+    sc = object_scene()
+    plain = dataclasses.replace(sc, tri_object=None, obj_xform=None)
+    a = oracle_lib.Oracle().load_scene(sc); b = oracle_lib.Oracle().load_scene(plain)
+    assert np.array_equal(a.get_bvh()[0].view(np.uint32), b.get_bvh()[0].view(np.uint32)) and a.get_tlas()["n_instances"] == 0
+    a.render(3); b.render(3)
+    assert np.array_equal(a.read_hdr().view(np.uint32), b.read_hdr().view(np.uint32))
+    sa, sb = a.stats(), b.stats()
+    assert all(sa[k] == sb[k] for k in ("rays_nearest", "nodes_nearest", "tris_nearest", "rays_any", "nodes_any"))
+    moved = moved_xforms(7)
+    a.set_transforms(moved); a.render(3)
+    c = oracle_lib.Oracle().load_scene(dataclasses.replace(sc, obj_xform=moved)); c.render(3)
+    assert a.get_tlas()["n_instances"] == 7
+    assert np.array_equal(a.get_bvh()[0].view(np.uint32), c.get_bvh()[0].view(np.uint32)) and np.array_equal(a.read_hdr().view(np.uint32), c.read_hdr().view(np.uint32))
+    a.set_transforms(sc.obj_xform); a.render(3)                       # everything back in place
+    b.reset(); b.render(3)
+    assert a.get_tlas()["n_instances"] == 0 and np.array_equal(a.read_hdr().view(np.uint32), b.read_hdr().view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_identity_objects_are_one_tree(hip_lib, oracle_lib):
+    """the same on the HIP path, against the oracle at every stage: flat -> moved (full rebuild) -> moved again (top level only) -> identity"""
+    from cadrays_amd.view import View
+    sc = object_scene(None, 128, 96)
+    v = View(0).load_scene(sc); v.enable_counters(True); v.reset(); o = oracle_lib.Oracle().load_scene(sc)
+    plain = View(0).load_scene(dataclasses.replace(sc, tri_object=None, obj_xform=None)); plain.enable_counters(True); plain.reset()
+    assert v.get_tlas() == o.get_tlas() and v.get_tlas()["n_instances"] == 0
+    assert np.array_equal(v.get_bvh()[0].view(np.uint32), plain.get_bvh()[0].view(np.uint32))
+    stages = [None, moved_xforms(7), None, sc.obj_xform]
+    stages[2] = moved_xforms(7).copy(); stages[2][3] = rigid(50.0, (0, 0, 1), (-0.2, 0.1, 0.0))
+    for k, xf in enumerate(stages):
+        if xf is not None:
+            v.set_transforms(xf); o.set_transforms(xf)
+        v.render(3); o.render(3)
+        assert np.array_equal(v.read_hdr().view(np.uint32), o.read_hdr().view(np.uint32)), k
+        gs, cs = v.stats(), o.stats()
+        for key in ("rays_nearest", "nodes_nearest", "tris_nearest", "rays_any", "nodes_any", "shaded_hits"):
+            assert gs[key] == cs[key], (k, key)
+        assert v.get_tlas() == o.get_tlas() and np.array_equal(v.get_bvh()[0].view(np.uint32), o.get_bvh()[0].view(np.uint32))
+    plain.render(3)
+    v.reset(); v.render(3)
+    assert np.array_equal(v.read_hdr().view(np.uint32), plain.read_hdr().view(np.uint32))       # flat again == no objects at all
+    # the one-stream / look-ahead / frames-in-flight schedules see the rebuild too
+    w = View(0).load_scene(dataclasses.replace(sc, params=dataclasses.replace(sc.params, width=1216, height=896))); w.set_lookahead(1)
+    o2 = oracle_lib.Oracle().load_scene(dataclasses.replace(sc, params=dataclasses.replace(sc.params, width=1216, height=896)))
+    for _ in range(3): w.Redraw()
+    w.set_transforms(moved_xforms(7)); o2.set_transforms(moved_xforms(7))
+    for _ in range(2): w.Redraw()
+    o2.render(2)
+    assert np.array_equal(w.read_hdr().view(np.uint32), o2.read_hdr().view(np.uint32))
 
 
 @pytest.mark.gpu
@@ -137,7 +194,7 @@ def test_hip_set_transforms_rebuilds_only_the_top_level(hip_lib, oracle_lib):
     # a scene of 64 objects x 4096 triangles: moving them costs a top-level rebuild, not 262 k triangles of BVH build
     pos, nrm, tri = scenes.gen_scene(64 * 4096, 5, 1)
     tri_obj = (np.arange(len(tri)) // 4096).astype(np.int32)
-    xf = np.tile(rigid(), (64, 1))
+    xf = np.stack([rigid(0.0, (0, 0, 1), (0.001 * (i + 1), 0, 0)) for i in range(64)])       # off the identity: object trees + top level from the start
     big = scenes.Scene(pos, nrm, tri, [scenes.BSDF.CreateDiffuse(0.7)], tri_object=tri_obj, obj_xform=xf,
                        params=scenes.Params(width=64, height=64, background=(1, 1, 1)))
     t0 = time.time(); w = View(0).load_scene(big); t_build = time.time() - t0
