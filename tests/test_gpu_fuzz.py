@@ -241,3 +241,44 @@ def test_wide_batch_slot_layouts(view_cls, Oracle, seed):
         gs, cs = v.stats(), o.stats()
         for k in ("rays_nearest", "nodes_nearest", "tris_nearest", "rays_any", "samples"):
             assert gs[k] == cs[k], k
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sequences_between_one_tree_and_object_trees(view_cls, Oracle, seed):
+    """Scenes whose objects all sit at the identity are ONE tree; the first object that moves makes them object
+    trees + top level, all-identity transforms flatten them again.  Random walks over that boundary -- renders, look-ahead, single
+    moves, everything back in place, resets -- with the oracle in step after every call (images, counters, tree bytes)."""
+    import dataclasses
+    r = np.random.default_rng(7000 + seed)
+    sc = None
+    for s_ in range(seed * 5, seed * 5 + 200):
+        cand = random_scene(s_)
+        if cand.tri_object is not None:
+            sc = cand; break
+    nO = len(sc.obj_xform)
+    ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (nO, 1))
+    sc = dataclasses.replace(sc, obj_xform=ident.copy(), params=dataclasses.replace(sc.params, max_depth=min(sc.params.max_depth, 4), width=48, height=32, tile_size=8))
+    v = view_cls(0).load_scene(sc); v.enable_counters(bool(seed % 2)); v.reset(); o = Oracle().load_scene(sc)
+    assert v.get_tlas()["n_instances"] == 0 == o.get_tlas()["n_instances"]
+    counted = bool(seed % 2)                                      # speculative look-ahead traces (and counts) frames the oracle has not rendered yet
+    v.set_lookahead(1 if counted else int(r.choice([1, 4])))
+    xf = ident.copy()
+    for step in range(12):
+        op = int(r.integers(0, 6))
+        if op <= 1:
+            n = int(r.integers(1, 4)); v.render(n); o.render(n)
+        elif op == 2:
+            xf = xf.copy(); k = int(r.integers(0, nO)); xf[k, 3::4] += (0.05 * r.normal(size=3)).astype(np.float32)
+            v.set_transforms(xf); o.set_transforms(xf)
+        elif op == 3:
+            xf = ident.copy(); v.set_transforms(xf); o.set_transforms(xf)         # everything back in place
+        elif op == 4:
+            v.reset(); o.reset()
+        elif not counted:
+            v.set_lookahead(int(r.choice([1, 3, 8])))
+        assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), (seed, step, op)
+        assert v.get_tlas() == o.get_tlas() and np.array_equal(v.get_bvh()[0].view(np.uint32), o.get_bvh()[0].view(np.uint32)), (seed, step, op)
+    if counted:
+        gs, cs = v.stats(), o.stats()
+        for k in ("rays_nearest", "nodes_nearest", "tris_nearest", "rays_any", "nodes_any", "shaded_hits"):
+            assert gs[k] == cs[k], k
