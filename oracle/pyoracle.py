@@ -29,7 +29,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        # CRH_ORACLE_LIB: another build of the same file (tools/run_sanitizers.sh loads the ASan / UBSan builds this way)
+        # CRH_ORACLE_LIB: another build of the same file (tests/hunts/run_sanitizers.sh loads the ASan / UBSan builds this way)
         _LIB = C.CDLL(os.environ.get("CRH_ORACLE_LIB") or build())
         _default_threads(_LIB)
     return _LIB

@@ -1,6 +1,6 @@
 // sanitize_host.cpp -- drives the product's host-side BVH builder (cadrays_amd/csrc/bvh_builder.cpp: worker threads, atomics,
 // futures) under AddressSanitizer / UBSan / ThreadSanitizer.  CPU only; built by `make -C oracle asan|ubsan|tsan`, run by
-// tools/run_sanitizers.sh.  Checks on top of what the sanitizer reports: the tree bytes do not depend on the thread count, and
+// tests/hunts/run_sanitizers.sh.  Checks on top of what the sanitizer reports: the tree bytes do not depend on the thread count, and
 // a top-level tree over instance boxes builds on the same code path.
 #include <algorithm>
 #include <cmath>

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off hunt: 400 more seeded random scenes (tests/test_gpu_fuzz.random_scene) through the HIP path and the oracle; prints the seeds
-whose images or counters differ (none so far).  Run on a GPU box: python tools/big_fuzz.py"""
+whose images or counters differ (none so far).  Run on a GPU box: python tests/hunts/big_fuzz.py"""
 import sys, importlib.util, numpy as np
 sys.path.insert(0, '.')
 import torch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""One-off hunt beside tools/big_fuzz.py: the random CALL-SEQUENCE tests of tests/test_gpu_fuzz.py with many more seeds (renders,
+"""One-off hunt beside tests/hunts/big_fuzz.py: the random CALL-SEQUENCE tests of tests/test_gpu_fuzz.py with many more seeds (renders,
 Redraws under look-ahead, tile subsets, resets, camera / material / light / environment / parameter changes, object moves,
-adaptive on / off, checkpoints), GPU vs oracle after every step.  python tools/big_seq_fuzz.py [first] [last]"""
+adaptive on / off, checkpoints), GPU vs oracle after every step.  python tests/hunts/big_seq_fuzz.py [first] [last]"""
 import os, sys, importlib.util
 sys.path.insert(0, '.')
 import torch  # noqa: F401

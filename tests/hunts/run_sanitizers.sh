@@ -1,8 +1,8 @@
 #!/bin/bash
 # CPU-side sanitizer pass: the oracle (C, OpenMP) and the product's host-side BVH builder (C++ threads,
 # atomics, futures) under AddressSanitizer, UndefinedBehaviorSanitizer and ThreadSanitizer.  Never on the GPU.
-#   tools/run_sanitizers.sh [asan ubsan tsan]      -> sanitizers/<kind>.log (+ readers_malformed.log), exit status 1 on any report
-cd "$(dirname "$0")/.."
+#   tests/hunts/run_sanitizers.sh [asan ubsan tsan]      -> sanitizers/<kind>.log (+ readers_malformed.log), exit status 1 on any report
+cd "$(dirname "$0")/../.."
 KINDS=${@:-asan ubsan tsan}
 OUT=sanitizers; mkdir -p $OUT
 rc=0

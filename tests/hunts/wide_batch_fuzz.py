@@ -2,7 +2,7 @@
 """Hunt for the slot layout of wide batches (k_raygen / k_accumulate: 64 / G pixels x G samples per wavefront, LDS-tiled accumulate):
 random small scenes rendered with sample counts that exercise every G (1 .. 64, multiples and non-multiples of 8 and 64), in one call, in
 two calls, under look-ahead and through crh_render_tiles with a tile subset and a sample offset; image and counters against the oracle.
-    python tools/wide_batch_fuzz.py [first] [last]"""
+    python tests/hunts/wide_batch_fuzz.py [first] [last]"""
 import dataclasses, importlib.util, sys
 sys.path.insert(0, '.')
 import numpy as np

@@ -214,7 +214,7 @@ def test_wide_batch_slot_layouts(view_cls, Oracle, seed):
     """The slot layout of wide batches (kernels.hip: 64 / G pixels x G samples per wavefront, G = the largest power of two dividing the
     batch's sample count, and the LDS-tiled accumulate): sample counts for every G, in one call, split in two, under look-ahead and
     through crh_render_tiles with a tile subset and a first-sample offset.  Image and counters against the oracle
-    (tools/wide_batch_fuzz.py is the same hunt with more seeds)."""
+    (tests/hunts/wide_batch_fuzz.py is the same hunt with more seeds)."""
     import dataclasses
     r = np.random.default_rng(seed)
     sc = random_scene(seed + 900)

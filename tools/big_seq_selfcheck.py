@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU-only variant of tools/big_seq_fuzz.py: the oracle's seat is taken by a second context of the product on the plain schedule
+"""GPU-only variant of tests/hunts/big_seq_fuzz.py: the oracle's seat is taken by a second context of the product on the plain schedule
 (CRH_PIPELINE=0, CRH_DONATE=0, CRH_LANES=1: one stream, no frames in flight, no work donation), so the random call sequences of
 tests/test_gpu_fuzz.py run several times faster, two contexts share the GPU, and a crash or mismatch can only come from the HIP
 side.    python tools/big_seq_selfcheck.py [first] [last]"""

@@ -82,7 +82,7 @@ struct Wide { std::vector<uint32_t> words; uint32_t n_nodes = 0, stride = 0; std
 static float harea(const BNode& b) { const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; }
 
 // octant = 1: children are put into slots so that slot index bit a says "upper half along axis a" (greedy assignment by centre
-// offset, as in tools/experiments/wide_bvh_visits.c); empty slots allowed; inner/leaf kind per slot comes from a mask
+// offset); empty slots allowed; inner/leaf kind per slot comes from a mask
 static Wide collapse(const std::vector<BNode>& bn, int W, bool octant)
 {
   Wide out; out.stride = W == 4 ? 16u : 32u;
