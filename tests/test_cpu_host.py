@@ -55,6 +55,12 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f in ("binding.py", "kernels.hip", "sharding.py", "abi.py", "bvh_builder.cpp"), f
                 assert "pyoracle" not in txt and "crh_oracle" not in txt and "libcrh_oracle" not in txt, f
+    # tools/ neither: hunts that use the checker live in tests/hunts/
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
+        for f in files:
+            if f.endswith((".py", ".sh", ".c", ".cpp", ".hip")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in txt and "crh_oracle" not in txt and "libcrh_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
 
 
 @pytest.mark.parametrize("n,threads", [(0, 1), (1, 1), (4, 1), (5, 2), (257, 3), (20000, 8), (150000, 8)])
