@@ -102,6 +102,8 @@ def roofline_report(config, spp, modified, alg_bytes_per_launch, avg_ms, scene_b
         if resident:
             r["achieved"] = round(min(alg_gbps, t_gbps), 1)
             r["achieved_basis"] = "min(algorithmic, memory-side counter traffic): bytes that were both needed and crossed the L2's memory side"
+            r["frac_note"] = ("cache-resident scene: frac counts only what crossed the L2s' memory side, so it FALLS when the L2s serve more of the gather "
+                              "(the kernel gets faster): the rate against the algorithmic bytes is alg_frac_of_hbm_peak; the HBM-resident config is C5")
         else:
             r["achieved"] = round(alg_gbps, 1)
             r["achieved_basis"] = "algorithmic bytes / kernel time (traffic_over_alg > 1 = over-fetch)"
