@@ -15,9 +15,26 @@
 #include <fstream>
 #include <string>
 #include <vector>
+#include <cstdio>
+#include <sys/stat.h>
 
 namespace crh_host {
 namespace detail {
+
+// whole file -> bytes; false (with a message) for anything that is not a readable regular file -- a directory opens fine as an ifstream
+// and only throws once it is read
+inline bool read_file_bytes(const std::string& path, std::vector<uint8_t>& d, std::string& err)
+{
+  struct stat st;
+  if (path.find('\0') != std::string::npos || stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) { err = "cannot open " + std::string(path.c_str()); return false; }
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { err = "cannot open " + path; return false; }
+  d.resize((size_t)st.st_size);
+  const size_t got = d.empty() ? 0 : fread(d.data(), 1, d.size(), f);
+  fclose(f);
+  d.resize(got);
+  return true;
+}
 
 struct JpegHuff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool set = false; };
 
@@ -119,9 +136,8 @@ inline void jpeg_idct_islow(const long long* in, uint8_t* out, int out_stride)
 // out: RGB, 3 bytes per pixel
 inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::vector<uint8_t>& out, std::string& err)
 {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) { err = "cannot open " + path; return false; }
-  const std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::vector<uint8_t> d;
+  if (!read_file_bytes(path, d, err)) return false;
   if (d.size() < 4 || d[0] != 0xFF || d[1] != 0xD8) { err = path + ": not a JPEG file"; return false; }
   static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};

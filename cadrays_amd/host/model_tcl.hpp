@@ -65,9 +65,8 @@ inline bool is_number(const std::string& s)
 // ---- minimal PNG (8-bit, non-interlaced, colour types 0 / 2 / 3 / 4 / 6) over zlib
 inline bool read_png(const std::string& path, uint32_t& w, uint32_t& h, uint32_t& ch, std::vector<uint8_t>& out, std::string& err)
 {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) { err = "cannot open " + path; return false; }
-  std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::vector<uint8_t> d;
+  if (!read_file_bytes(path, d, err)) return false;
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
   if (d.size() < 8 || memcmp(d.data(), sig, 8) != 0) { err = path + ": not a PNG file"; return false; }
   auto be32 = [&](size_t o) { return ((uint32_t)d[o] << 24) | ((uint32_t)d[o + 1] << 16) | ((uint32_t)d[o + 2] << 8) | d[o + 3]; };
@@ -153,7 +152,7 @@ inline bool write_png(const std::string& path, const uint8_t* px, uint32_t w, ui
 inline bool read_image_u8(const std::string& path, uint32_t& w, uint32_t& h, uint32_t& ch, std::vector<uint8_t>& px, std::string& err)
 {
   uint8_t sig[2] = {0, 0};
-  { std::ifstream f(path, std::ios::binary); if (f) f.read((char*)sig, 2); }
+  { std::vector<uint8_t> head; std::string e2; struct stat st; if (stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode)) if (FILE* f = fopen(path.c_str(), "rb")) { if (fread(sig, 1, 2, f) != 2) sig[0] = sig[1] = 0; fclose(f); } }
   if (sig[0] == 0xFF && sig[1] == 0xD8) { ch = 3; return read_jpeg(path, w, h, px, err); }
   return read_png(path, w, h, ch, px, err);
 }
@@ -176,9 +175,9 @@ struct Mesh { std::vector<float> pos, nrm, uv; std::vector<int32_t> faces; bool 
 // PLY: vertex element with x y z [nx ny nz] [s t | u v | texture_u texture_v], face element with one index list; binary LE or ascii
 inline bool read_ply(const std::string& path, Mesh& m, std::string& err)
 {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) { err = "cannot open " + path; return false; }
-  std::vector<char> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::vector<uint8_t> d8;
+  if (!read_file_bytes(path, d8, err)) return false;
+  std::vector<char> d(d8.begin(), d8.end());
   const std::string all(d.begin(), d.end());
   const size_t eh = all.find("end_header");
   if (eh == std::string::npos) { err = path + ": not a PLY file"; return false; }
@@ -320,8 +319,9 @@ inline std::vector<std::string> split_words(const std::string& line, const std::
 inline bool read_model_tcl(const std::string& path, uint32_t width, uint32_t height, TclScene& out, std::string& err)
 {
   using namespace detail;
-  std::ifstream f(path);
-  if (!f) { err = "cannot open " + path; return false; }
+  std::vector<uint8_t> script;
+  if (!read_file_bytes(path, script, err)) return false;
+  std::istringstream f(std::string(script.begin(), script.end()));
   std::string root = "."; { const size_t sl = path.find_last_of('/'); if (sl != std::string::npos) root = path.substr(0, sl); }
   if (root.empty()) root = "/";
   std::vector<std::string> order; std::map<std::string, Object> objs;
