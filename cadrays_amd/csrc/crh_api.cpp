@@ -96,6 +96,7 @@ struct crh_ctx {
   // the drain-bound late bounces of frame n overlap the throughput-bound first bounces of frame n + 1; accumulation stays in
   // frame order (an event between the two accumulate launches)
   bool pipeline = true; bool pipe_pending[4] = {false, false, false, false}; uint32_t pipe_seq = 0; uint32_t* d_pipe_seeds = nullptr; int pipe_div = 4096;
+  uint64_t pipe_total = 0;         // batch size of the frames in flight (their path-state slices are laid out by it)
   uint32_t pipe_depth = 3;         // frames in flight: 2 / 3 / 4 -> 323 / 391 / 312 Redraw/s on C3, 448 / 558 / 453 on C2
   // asynchronous LDR read-back (crh_read_ldr_begin / _end): tone map + device-to-host copy of the frame as submitted so far run on their
   // own stream into one of two device / pinned-host buffer pairs while the next Redraw()s are already rendering; only the NEXT
@@ -531,6 +532,12 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base;
     ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.counts = c->d_lane_counts + 8 * k;
     CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
+    // the frames in flight own path-state slices [k * total, (k + 1) * total): a batch of ANOTHER size (crh_render_tiles with another
+    // sample count or tile list) would lay its slice across theirs -- it starts only when they are all done
+    if (total != c->pipe_total) {
+      for (int j = 0; j < 4; ++j) if (c->pipe_pending[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));
+      c->pipe_total = total;
+    }
     c->pending_n = 0;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);          // crh_stats.seconds: device time of this frame (frames in flight overlap)
     hipEventRecord(e0, ln.stream);

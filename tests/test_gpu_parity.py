@@ -670,3 +670,25 @@ def test_random_sequences_with_async_readbacks_in_flight(view_cls, monkeypatch, 
     assert len(got) == len(ref) and len(got) >= 3
     for i, (a, b) in enumerate(zip(got, ref)):
         assert np.array_equal(a, b), (seed, i)
+
+
+def test_pipelined_batches_of_different_sizes_do_not_share_path_state(view_cls, monkeypatch):
+    """Frames in flight own path-state slices laid out by the batch size; back-to-back crh_render_tiles calls with different sample counts
+    (or tile lists) are batches of different sizes: the later one must not start inside the earlier ones' slices.  Found by
+    tools/big_async_fuzz.py (seed 853): without a read in between, three such calls overlapped and corrupted each other's paths."""
+    sc = scenes.cornell_box(True, 1216, 896)
+    tiles3 = None
+
+    def run(v):
+        nonlocal tiles3
+        tiles3 = np.arange(0, v.n_tiles(), 3, dtype=np.uint32)
+        v.reset()
+        v.render_tiles(tiles3, 44, 4); v.render_tiles(tiles3, 44, 4); v.render_tiles(tiles3, 43, 3)        # 1.45 M, 1.45 M, 1.09 M paths
+        v.render_tiles(np.arange(0, v.n_tiles(), 2, dtype=np.uint32), 7, 2); v.Redraw(); v.render_tiles(tiles3, 50, 5)
+        return v.read_hdr().copy()
+
+    monkeypatch.setenv("CRH_PIPELINE", "0"); monkeypatch.setenv("CRH_DONATE", "0"); monkeypatch.setenv("CRH_LANES", "1")
+    ref = run(view_cls(0).load_scene(sc))
+    monkeypatch.delenv("CRH_PIPELINE"); monkeypatch.delenv("CRH_DONATE"); monkeypatch.delenv("CRH_LANES")
+    got = run(view_cls(0).load_scene(sc))
+    assert np.array_equal(bits(got), bits(ref))
