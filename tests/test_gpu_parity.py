@@ -535,7 +535,7 @@ def test_pipelined_frames_equal_unpipelined(view_cls, monkeypatch):
     assert got[0][..., 0].max() > 0
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_random_call_sequences_with_frames_in_flight(view_cls, monkeypatch, seed):
     """Random API sequences on a frame large enough to be pipelined (>= 1 M paths): bursts of Redraw()s with setters, resets,
     tile subsets, look-ahead and adaptive switches and read-outs in between.  Every read-out must be bit-identical to the same
