@@ -39,13 +39,24 @@ HBM_ACHIEVABLE_GBPS = 6300.0
 INFINITY_CACHE_BYTES = 256 << 20
 NODE_BYTES_FETCHED = 48          # 3 x dwordx4 of the 64-B-stride node are fetched per inner visit (SURVEY 8d assumed 128 B)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-PMC_HASH_FILES = ("cadrays_amd/csrc/kernels.hip", "include/crh_bvh_format.h")
+PMC_HASH_GLOBS = ("cadrays_amd/csrc/*.hip", "cadrays_amd/csrc/*.cpp", "cadrays_amd/csrc/*.h", "include/*.h")
+
+
+def pmc_hash_files():
+    """Every source that goes into libcadrays_hip.so: the bytes a launch moves depend on the kernels, the node format, the grids and
+    batch shapes of crh_api.cpp, the stack sizes of device_types.h and the tree the builder produces."""
+    import glob
+    out = []
+    for g in PMC_HASH_GLOBS:
+        out += sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, g)))
+    return out
 
 
 def kernel_source_hash():
-    """Identity of the traversal kernel + node format a PMC measurement belongs to."""
+    """Identity of the build a PMC measurement belongs to."""
     h = hashlib.sha256()
-    for rel in PMC_HASH_FILES:
+    for rel in pmc_hash_files():
+        h.update(rel.encode())
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -164,6 +175,8 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (the oracle re-renders sampled tiles of the TIMED frames)")
+    ap.add_argument("--parity-seconds", type=float, default=8.0, help="CPU budget of the parity gate")
     ap.add_argument("--no-interactive", action="store_true", help="skip the 1-spp-per-Redraw figure")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args(argv)
@@ -262,6 +275,9 @@ def main():
     v.enable_kernel_timing(False)
     kt = v.kernel_timing()
     st = v.stats()
+    # what the TIMED steps themselves accumulated (rank 0, N = 1): the parity gate below compares exactly these pixels with the oracle
+    timed_hdr = v.read_hdr() if (rank == 0 and world == 1 and not args.no_parity) else None
+    timed_first, timed_n = args.warmup * spp_step, args.steps * spp_step
     if dist is not None:
         dev = torch.device(f"cuda:{local}") if backend == "nccl" else torch.device("cpu")
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -312,11 +328,27 @@ def main():
         v.set_lookahead(1); v.reset()
         interactive["note"] = "one crh_render(1) per call over the whole frame, no read-back; NOT part of `value`"
 
+    # ---- parity gate ("parity gate accompanying every number"; the reference's own gate is pixel-exact,
+    # testing/CADRays_Testing.py:226-230): the oracle renders the SAME samples the timed steps rendered on sampled tiles; those pixels of
+    # the accumulator the timed region left behind must be bit-identical (rel L2 <= 1e-4 is north_star's bar)
+    parity = None
+    if timed_hdr is not None:
+        try:
+            parity = parity_gate(sc, timed_hdr, timed_first, timed_n, args.parity_seconds)
+            parity["schedule"] = ("big-batch (wide), counters off" if (spp_step * len(tiles) * sc.params.tile_size ** 2) > (12 << 20)
+                                  else "small-batch, counters off") + " -- the timed steps' own output"
+        except Exception as e:                                  # a broken checker must not lose the measurement
+            parity = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- CPU baseline: the oracle (a port, not the reference: OCCT has no CPU path tracer) on this box's cores
     cpu = None
     if rank == 0 and not args.no_cpu and world == 1:          # reported on rank 0 at N = 1 only
-        cpu = cpu_baseline(sc, args.cpu_seconds)
+        try:
+            cpu = cpu_baseline(sc, args.cpu_seconds)
+        except Exception as e:
+            cpu = {"value": None, "error": f"{type(e).__name__}: {e}"}
 
+    failed = False
     if rank == 0:
         mrays = (rays_n + rays_a) / dt / 1e6
         out = {
@@ -331,12 +363,16 @@ def main():
                        "rccl_ranks": int(rccl_ranks), "backend": backend,
                        "msamples_per_s": round(samples / dt / 1e6, 3), "rays_nearest": int(rays_n), "rays_any": int(rays_a),
                        "build_upload_s": round(build_s, 2), "host_cores": os.cpu_count(), "host_usable_cpus": usable_cpus(), "interactive": interactive},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(out), flush=True)
+        if parity is not None and not (parity.get("rel_l2") is not None and parity["rel_l2"] <= 1e-4):
+            failed = True
     if dist is not None:
         dist.barrier()                                       # rank 0 may still be in its counting pass
         dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: PARITY GATE FAILED -- the timed frames differ from the oracle (see \"parity\" in the JSON line)")
 
 
 def cpu_model():
@@ -364,7 +400,7 @@ def cpu_baseline(sc, seconds):
     for kind in ("fast", "parity"):
         try:
             Or = pyoracle.oracle_class(kind)
-        except (OSError, AttributeError, RuntimeError):
+        except (OSError, AttributeError, RuntimeError, subprocess.SubprocessError):      # e.g. a failing -march=native build on this host
             continue
         Or.set_threads(ncores)
         o = Or().load_scene(sc)
@@ -393,6 +429,38 @@ def cpu_baseline(sc, seconds):
         out[f"{kind}_build"] = leg
         o.close()
     return out
+
+
+def parity_gate(sc, gpu_hdr, first_sample, n_samples, seconds):
+    """The CPU oracle (parity build: -O2, no contraction) renders samples [first_sample, first_sample + n_samples) of a bounded tile
+    sample of the same workload -- the samples the timed steps rendered -- and the timed accumulator must hold the same bits there."""
+    import numpy as np
+    from oracle import pyoracle
+    Or = pyoracle.oracle_class("parity")
+    Or.set_threads(usable_cpus())
+    o = Or().load_scene(sc)
+    nt = o.n_tiles()
+    probe = np.unique(np.linspace(0, nt - 1, 16).astype(np.uint32))
+    o.render_tiles(probe, first_sample, 1)                       # calibration: rays per tile-sample and the rate on this host
+    s0 = o.stats()
+    per_tile_sample = (s0["rays_nearest"] + s0["rays_any"]) / len(probe)
+    rate = (s0["rays_nearest"] + s0["rays_any"]) / max(s0["seconds"], 1e-9)
+    want = int(max(4, min(64, nt, rate * seconds / max(per_tile_sample * n_samples, 1))))
+    sample = np.unique(np.linspace(0, nt - 1, want).astype(np.uint32))
+    o.reset()
+    t0 = time.perf_counter()
+    o.render_tiles(sample, first_sample, n_samples)
+    dt = time.perf_counter() - t0
+    ref = o.read_accum()
+    o.close()
+    mask = ref[..., 3] == n_samples
+    g = np.ascontiguousarray(gpu_hdr[mask], np.float32)
+    r = np.ascontiguousarray(ref[..., :3][mask], np.float32)
+    rel = float(np.linalg.norm(g.astype(np.float64) - r) / max(np.linalg.norm(r.astype(np.float64)), 1e-300))
+    diff = int((g.view(np.uint32) != r.view(np.uint32)).sum())
+    return {"rel_l2": rel, "bit_exact": diff == 0, "words_differing": diff, "tiles": int(len(sample)), "pixels": int(mask.sum()),
+            "spp": int(n_samples), "first_sample": int(first_sample), "tolerance_rel_l2": 1e-4,
+            "oracle": f"CPU oracle, parity build, {usable_cpus()} threads, {dt:.1f} s"}
 
 
 if __name__ == "__main__":

@@ -46,13 +46,15 @@ class crh_stats(C.Structure):
 
 assert C.sizeof(crh_bsdf) == 128 and C.sizeof(crh_light) == 32
 
+SCHEDULE_AUTO, SCHEDULE_WIDE, SCHEDULE_SMALL = 0, 1, 2      # crh_set_schedule
+
 NODE_DWORDS = 16          # CRH_NODE_DWORDS of include/crh_bvh_format.h: 4-wide BVH node, 12 dwords used on a 64-B stride
 
 # every symbol include/cadrays_hip.h declares (tests check the built library exports them all)
 EXPORTS = [
     "crh_create", "crh_destroy", "crh_last_error", "crh_set_geometry", "crh_set_transforms", "crh_set_materials",
     "crh_set_lights", "crh_set_envmap", "crh_set_texture", "crh_set_camera", "crh_set_params", "crh_build", "crh_reset",
-    "crh_render", "crh_render_tiles", "crh_set_adaptive", "crh_set_show_tiles", "crh_set_lookahead", "crh_set_path_budget", "crh_get_tile_stats", "crh_sync", "crh_read_hdr", "crh_read_ldr", "crh_read_ldr_begin", "crh_read_ldr_end",
+    "crh_render", "crh_render_tiles", "crh_set_adaptive", "crh_set_show_tiles", "crh_set_lookahead", "crh_set_schedule", "crh_set_path_budget", "crh_get_tile_stats", "crh_sync", "crh_read_hdr", "crh_read_ldr", "crh_read_ldr_begin", "crh_read_ldr_end",
     "crh_save_accum", "crh_load_accum", "crh_accum_device_ptr", "crh_reduce", "crh_enable_counters", "crh_get_stats", "crh_trace_nearest",
     "crh_trace_any", "crh_get_bvh", "crh_get_tlas", "crh_build_bvh_host", "crh_bench_trace", "crh_debug_math", "crh_debug_bsdf", "crh_enable_kernel_timing",
     "crh_get_kernel_timing",

@@ -115,6 +115,7 @@ struct crh_ctx {
   // the batch is made as wide as the memory comfortably allows: 32 M / 64 M / 128 M / 256 M / 512 M slots -> 2745 / 2960 / 3114 /
   // 3205 / 3243 Mrays/s on C3
   uint32_t max_paths = 256u << 20;
+  int schedule = CRH_SCHEDULE_AUTO; uint32_t auto_lane_max_paths = 12u << 20; bool auto_donate = true, auto_pipeline = true;   // crh_set_schedule
 };
 
 // The context's stream.  Small whole-frame batches alternate between two pipeline streams (render_impl) and are joined lazily:
@@ -1139,6 +1140,20 @@ int crh_set_lookahead(crh_ctx* c, uint32_t frames)
 {
   if (!c || frames == 0) return fail(c, CRH_E_INVALID, "lookahead must be >= 1");
   c->lookahead = frames; c->pending_n = 0;
+  return CRH_OK;
+}
+
+int crh_set_schedule(crh_ctx* c, int mode)
+{
+  if (!c || mode < CRH_SCHEDULE_AUTO || mode > CRH_SCHEDULE_SMALL) return fail(c, CRH_E_INVALID, "schedule must be CRH_SCHEDULE_AUTO / _WIDE / _SMALL");
+  if (c->schedule == CRH_SCHEDULE_AUTO) { c->auto_lane_max_paths = c->lane_max_paths; c->auto_donate = c->donate; c->auto_pipeline = c->pipeline; }
+  c->schedule = mode; c->pending_n = 0;
+  c->read_since_render = true;                           // the next frame is not pipelined behind frames of the other schedule
+  // WIDE: no batch counts as small (run_batch: one stream, full grids, plain kernels; render_impl: no frame pipelining; adaptive
+  // iterations: plain kernels).  SMALL: every batch up to the path budget does.
+  c->lane_max_paths = mode == CRH_SCHEDULE_WIDE ? 0u : (mode == CRH_SCHEDULE_SMALL ? (1u << 30) : c->auto_lane_max_paths);
+  c->donate = mode == CRH_SCHEDULE_WIDE ? false : c->auto_donate;
+  c->pipeline = mode == CRH_SCHEDULE_WIDE ? false : c->auto_pipeline;
   return CRH_OK;
 }
 

@@ -61,6 +61,10 @@ class View(Backend):
         """crh_set_path_budget: at most this many path slots (188 B each) in flight per batch; images do not depend on it"""
         self._call("set_path_budget", C.c_uint64(int(max_paths)))
 
+    def set_schedule(self, mode):
+        """crh_set_schedule: abi.SCHEDULE_AUTO / _WIDE (the big-batch schedule bench.py times) / _SMALL; images do not depend on it"""
+        self._call("set_schedule", C.c_int(int(mode)))
+
     def enable_counters(self, on=True):
         self._call("enable_counters", C.c_int(int(on)))
 

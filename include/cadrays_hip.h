@@ -114,7 +114,9 @@ typedef struct crh_stats {
   uint64_t tris_any;
   uint64_t shaded_hits;           /* H                                  */
   uint64_t samples;               /* pixel-samples accumulated (S)      */
-  double   seconds;               /* device time inside crh_render*     */
+  double   seconds;               /* sum of the device time spans of the crh_render* calls (HIP events around each call's launches).  Frames that are
+                                   * pipelined (back-to-back Redraw()s overlap on up to three streams) each contribute their own span, so the sum can
+                                   * exceed wall time by up to the pipeline depth: use wall time around crh_sync for rates of a free-running loop */
 } crh_stats;
 
 /* create/destroy == new OpenGl_GraphicDriver + V3d_Viewer + CreateView + FBOCreate
@@ -184,6 +186,16 @@ CRH_API int crh_set_show_tiles(crh_ctx* ctx, int on);
  * change of scene / camera / parameters, crh_reset, crh_render_tiles or adaptive mode discards what is pending.  Ray
  * counters include the speculative samples.  frames = 1 (default) disables it. */
 CRH_API int crh_set_lookahead(crh_ctx* ctx, uint32_t frames);
+/* Which of the two wavefront schedules a batch takes.  CRH_SCHEDULE_AUTO (default): batches above ~12 M paths run the WIDE schedule
+ * (one stream, full persistent grids, the plain traversal kernels); smaller ones -- one Redraw(), adaptive iterations, tile subsets --
+ * run the SMALL one (two tile ranges on two streams or pipelined frames, grids that follow the batch, the work-donating traversal
+ * kernels).  Both produce the same image bit for bit; the switch exists so that the parity tests and bench.py's parity gate can put
+ * ANY workload through the exact kernel instantiations and launch order the headline number is measured on (CRH_SCHEDULE_WIDE), or
+ * through the small-batch ones (CRH_SCHEDULE_SMALL: every batch that fits, whatever its size). */
+#define CRH_SCHEDULE_AUTO  0
+#define CRH_SCHEDULE_WIDE  1
+#define CRH_SCHEDULE_SMALL 2
+CRH_API int crh_set_schedule(crh_ctx* ctx, int mode);
 /* Device-memory budget of the wavefront path state: at most `max_paths` path slots (188 B each) are in flight per batch; a render
  * that needs more is cut into tile groups / sample batches (same image, bit for bit).  Default 2^28 slots = 50 GB of the
  * 288 GB, allocated on demand (a 1080p Redraw() takes 0.4 GB): every launch of the schedule ends in a drain phase of fixed

@@ -43,7 +43,7 @@ def main():
         if "configs" in old:
             data = old
     data["kernel"] = "k_trace_nearest"
-    data["hash_of"] = list(bench.PMC_HASH_FILES)
+    data["hash_of"] = list(bench.pmc_hash_files())
     for cfg in cfgs:
         vals = {}
         for grp in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum"):
