@@ -10,7 +10,7 @@ triangles, glass + glossy double-layer BSDFs, HDR sky, 1080p; `--spp` samples pe
 N > 1: one process per GPU.  Under `python -m torch.distributed.run` (WORLD_SIZE set) this process is one of the ranks;
 started by hand as `python bench.py --gpus N` it SPAWNS the N rank processes itself -- before torch or the HIP runtime is
 touched in the parent, which only waits for them -- so the advertised command measures N GPUs.  Tiles are interleaved
-across ranks (tile t -> rank t mod N, cadrays_amd/sharding.py), no collective while rendering, and every step ends with
+across ranks (k-th tile of the Z-order curve -> rank k mod N, cadrays_amd/sharding.py), no collective while rendering, and every step ends with
 the RCCL reduce of the float4 framebuffer to rank 0.
   --scaling weak   (default) per-GPU work fixed: every rank renders spp*N samples of its 1/N of the tiles per step
   --scaling strong the job is fixed: every rank renders spp samples of its 1/N of the tiles; `--config C4` = C3's scene,
@@ -233,13 +233,19 @@ def main():
     from cadrays_amd import scenes, sharding
     from cadrays_amd.view import View
 
+    # N ranks on one host share its CPUs: every rank builds the same BVH, each with its share of the threads (8 ranks x all threads
+    # oversubscribed the 16 usable CPUs of a GPU box 8-fold)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > 1 and not os.environ.get("CRH_BUILD_THREADS"):
+        os.environ["CRH_BUILD_THREADS"] = str(max(1, usable_cpus() // local_world))
+
     scene_cfg = "C3" if args.config == "C4" else args.config
     sc = scenes.baseline_config(scene_cfg, args.width or None, args.height or None, args.tris or None)
     t0 = time.time()
     v = View(local).load_scene(sc)
     build_s = time.time() - t0
     fb = sharding.DeviceFramebuffer(v) if world > 1 else None
-    tiles = sharding.tiles_for_rank(v.n_tiles(), rank, world)
+    tiles = sharding.tiles_for_rank(v.n_tiles(), rank, world, sharding.tiles_x_of(v))       # Morton-interleaved across the ranks
     if args.spp <= 0:                     # one full path batch per step: 2^28 slots / (tiles x 32 x 32 pixels); C4: the named 4096 spp
         args.spp = 4096 if args.config == "C4" else max(1, (256 << 20) // (v.n_tiles() * sc.params.tile_size ** 2))
     spp_step = args.spp * world if args.scaling == "weak" else args.spp      # samples per pixel each rank renders per step

@@ -155,6 +155,24 @@ class Backend:
         self._call("set_params", C.byref(q))
         self.width, self.height, self.tile_size = int(p.width), int(p.height), int(p.tile_size)
 
+    def set_spec(self, **switches):
+        """crh_set_spec: flip switches of include/crh_spec.h (uniform_32bit, texel_gamma2, mis_single_lobe, eps_rule,
+        eta_no_dielectric); the ones not named return to their defaults.  Restarts accumulation."""
+        vals = dict(abi.SPEC_DEFAULTS); vals.update(switches)
+        sp = abi.crh_spec(C.sizeof(abi.crh_spec), int(vals["uniform_32bit"]), int(vals["texel_gamma2"]), int(vals["mis_single_lobe"]),
+                          int(vals["eps_rule"]), float(vals["eta_no_dielectric"]))
+        self._call("set_spec", C.byref(sp))
+
+    def get_spec(self):
+        sp = abi.crh_spec()
+        self._call("get_spec", C.byref(sp))
+        return sp.as_dict()
+
+    def spec_order_exact(self):
+        """the build-time switch CRH_SPEC_ORDER_EXACT of the loaded library (crh_spec.h #4)"""
+        f = self._fn("spec_order_exact"); f.restype = C.c_int
+        return int(f())
+
     def load_scene(self, scene):
         self.set_geometry(scene.pos, scene.nrm, scene.tri, scene.uv, getattr(scene, "tri_object", None), getattr(scene, "obj_xform", None))
         self.set_materials(scene.materials)
@@ -164,6 +182,8 @@ class Backend:
         self.set_params(scene.params)
         for slot, img in enumerate(getattr(scene, "textures", []) or []):
             self.set_texture(slot, img)
+        if getattr(scene, "spec", None):
+            self.set_spec(**scene.spec)
         self.build()
         return self
 

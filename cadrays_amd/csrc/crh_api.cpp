@@ -42,12 +42,22 @@ struct crh_ctx {
   std::vector<HostTex> textures; bool textures_dirty = false;
   crh_camera cam{};
   crh_params par{};
+  crh_spec spec = CRH_SPEC_DEFAULTS;      // include/crh_spec.h
   // ---- two-level mode (per-object transforms)
   bool two_level = false; uint32_t nO = 0;
-  bool flat = false;      // two_level scene whose transforms are ALL the identity: built and rendered as one world-space tree (crh_build)
   std::vector<float> xf; std::vector<int32_t> tri_obj;
   struct Inst { float fwd[12], inv[12], bmin[3], bmax[3]; uint32_t root, obj; };
-  std::vector<Inst> inst; uint32_t n_blas_nodes = 0, root = 0;
+  std::vector<Inst> inst;                 // the objects rendered as instances RIGHT NOW, ascending object index (empty: the scene is one world-space tree)
+  uint32_t n_blas_nodes = 0, root = 0;    // nodes of the static tree + the object trees built so far (the top-level tree follows them); entry point of the walk
+  // static / moved split (reference: the gizmo moves ONE object per drag, ImRaytraceControls.cxx:64,88): the objects that sat at
+  // the identity when the scene was built share one world-space tree; an object that leaves the identity has its triangles there disabled and gets an
+  // object tree of its own (built on first need, kept); nothing else is ever rebuilt by crh_set_transforms but the top-level tree
+  struct Obj { bool static0 = false, built = false, is_inst = false; uint32_t root = 0, first = 0, ntri = 0; float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}; };
+  std::vector<Obj> objs; std::vector<uint32_t> obj_tris, static_pos, pos_obj;   // pos_obj: object of the triangle at a leaf position >= n_static
+  uint32_t n_static = 0, n_static_live = 0, n_pos = 0; float sbmin[3] = {0, 0, 0}, sbmax[3] = {0, 0, 0};
+  uint32_t root2 = 0xFFFFFFFFu; float tlas_lo[3] = {0, 0, 0}, tlas_hi[3] = {0, 0, 0};
+  size_t cap_pos = 0;                     // leaf positions the triangle / shading / uv arrays have room for
+  void* d_patch = nullptr; size_t cap_patch = 0;
   float4* d_inst = nullptr;
   // ---- built scene
   QBvh bvh;
@@ -269,7 +279,9 @@ void fill_scene(const crh_ctx* c, DScene& S)
 {
   std::memset(&S, 0, sizeof S);
   S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = (c->envW && c->envH) ? c->d_env : nullptr;
-  S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * c->inst.size() : nullptr; S.root = c->root; S.two_level = c->two_level && !c->flat ? 1 : 0;
+  S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * (size_t)c->nO : nullptr; S.root = c->root; S.two_level = c->inst.empty() ? 0 : 1;
+  S.root2 = c->inst.empty() ? kQEmpty : c->root2;
+  for (int a = 0; a < 3; ++a) { S.tlas_lo[a] = c->tlas_lo[a]; S.tlas_hi[a] = c->tlas_hi[a]; }
   {
     const float* lo = c->bvh.bbmin; const float* hi = c->bvh.bbmax;      // bounds of the tree the walk starts in (the world box of a two-level scene)
     S.guard_box = make_float4((lo[0] + hi[0]) * 0.5f, (lo[1] + hi[1]) * 0.5f, (lo[2] + hi[2]) * 0.5f, (((hi[0] - lo[0]) + (hi[1] - lo[1])) + (hi[2] - lo[2])) * 0.5f);
@@ -289,8 +301,10 @@ void fill_scene(const crh_ctx* c, DScene& S)
   S.width = c->par.width; S.height = c->par.height; S.max_depth = c->par.max_depth; S.tile_size = c->par.tile_size;
   S.clampv = c->par.radiance_clamp;
   const crh_v3 dg = crh_mk3(c->bvh.bbmax[0] - c->bvh.bbmin[0], c->bvh.bbmax[1] - c->bvh.bbmin[1], c->bvh.bbmax[2] - c->bvh.bbmin[2]);
-  S.eps = c->par.scene_epsilon > 0.f ? c->par.scene_epsilon : crh_max(1.0e-6f, 1.0e-5f * crh_len3(dg));
+  S.eps = c->par.scene_epsilon > 0.f ? c->par.scene_epsilon
+        : (c->spec.eps_rule ? crh_max(1.0e-6f, 1.0e-4f * (crh_len3(dg) * 0.5f)) : crh_max(1.0e-6f, 1.0e-5f * crh_len3(dg)));      // crh_spec.h #6
   S.two_sided = c->par.two_sided; S.coherent = c->par.coherent_rng; S.rr = c->par.russian_roulette;
+  S.spec_u32 = c->spec.uniform_32bit; S.spec_gamma2 = c->spec.texel_gamma2; S.spec_mis1 = c->spec.mis_single_lobe; S.spec_eta_nd = c->spec.eta_no_dielectric;
 }
 
 int upload_lights(crh_ctx* c)
@@ -309,34 +323,113 @@ int upload_lights(crh_ctx* c)
   return dev_put(c, c->d_lights, c->cap_lights, l.data(), l.size() * sizeof(float), 8 * 32);
 }
 
-// (Re)build the top-level tree over the instances' world boxes behind the object trees [0, n_blas_nodes) and refresh the
-// instance table on the device.  Object trees and triangle records are not touched.
+static bool is_identity(const float* m)
+{
+  static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  for (int k = 0; k < 12; ++k) if (m[k] != I[k]) return false;
+  return true;
+}
+
+// (Re)build the top-level tree over the world boxes of the objects rendered as instances right now, behind the static tree and the object
+// trees [0, n_blas_nodes), and refresh the instance table on the device.  Sets the walk's entry points (fill_scene): no instance -> the static
+// tree alone; instances + live static triangles -> the static tree, then the top level (root2); no live static triangle -> the top level.
 int build_tlas(crh_ctx* c)
 {
   c->bvh.nodes.resize(c->n_blas_nodes);
+  c->inst.clear();
+  for (uint32_t ob = 0; ob < c->nO; ++ob) {
+    const crh_ctx::Obj& o = c->objs[ob];
+    if (!o.is_inst) continue;
+    crh_ctx::Inst in{}; in.obj = ob; in.root = o.root;
+    std::memcpy(in.bmin, o.bmin, sizeof in.bmin); std::memcpy(in.bmax, o.bmax, sizeof in.bmax);
+    c->inst.push_back(in);
+  }
   const uint32_t n = (uint32_t)c->inst.size();
-  // instance table: n records in instance order (shading looks the hit triangle's instance up) followed by the same n
-  // records in top-level LEAF order (a top-level leaf reference is a position in that order)
-  std::vector<float> boxes(6 * (size_t)std::max(n, 1u), 0.f), table(64 * (size_t)std::max(n, 1u), 0.f);
+  c->root2 = kQEmpty;
+  if (n == 0) {                                 // one world-space tree
+    c->root = 0;
+    for (int a = 0; a < 3; ++a) { c->bvh.bbmin[a] = c->n_static ? c->sbmin[a] : 0.f; c->bvh.bbmax[a] = c->n_static ? c->sbmax[a] : 0.f; }
+    return CRH_OK;
+  }
+  // instance table: one record per OBJECT (shading looks the hit triangle's object up; only the instances' records are filled) followed
+  // by the instances' records in top-level LEAF order (a top-level leaf reference is a position in that order)
+  std::vector<float> boxes(6 * (size_t)n, 0.f), table(32 * ((size_t)c->nO + n), 0.f);
   for (uint32_t i = 0; i < n; ++i) {
     crh_ctx::Inst& in = c->inst[i];
+    float* rec = &table[32 * (size_t)in.obj];
     std::memcpy(in.fwd, &c->xf[12 * (size_t)in.obj], sizeof in.fwd);
     if (!crh_xform_inverse(in.fwd, in.inv)) std::memset(in.inv, 0, sizeof in.inv);
     crh_xform_box(in.fwd, in.bmin, in.bmax, &boxes[6 * (size_t)i], &boxes[6 * (size_t)i + 3]);
-    std::memcpy(&table[32 * (size_t)i], in.inv, 48); std::memcpy(&table[32 * (size_t)i + 12], in.fwd, 48);
-    std::memcpy(&table[32 * (size_t)i + 24], &in.root, 4); std::memcpy(&table[32 * (size_t)i + 25], &in.obj, 4);
+    std::memcpy(rec, in.inv, 48); std::memcpy(rec + 12, in.fwd, 48);
+    std::memcpy(rec + 24, &in.root, 4); std::memcpy(rec + 25, &in.obj, 4);
     const float* iv = in.inv;                    // meta.z = 1: the inverse's 3x3 part is exactly the identity (translation only)
     const uint32_t pure_translation = (iv[0] == 1.f && iv[5] == 1.f && iv[10] == 1.f && iv[1] == 0.f && iv[2] == 0.f && iv[4] == 0.f &&
                                        iv[6] == 0.f && iv[8] == 0.f && iv[9] == 0.f) ? 1u : 0u;
-    std::memcpy(&table[32 * (size_t)i + 26], &pure_translation, 4);
+    std::memcpy(rec + 26, &pure_translation, 4);
     // the object's own box {centre, L1 half-extent}: the guard band of the slab test inside the object
-    for (int a = 0; a < 3; ++a) table[32 * (size_t)i + 28 + a] = (in.bmin[a] + in.bmax[a]) * 0.5f;
-    table[32 * (size_t)i + 31] = (((in.bmax[0] - in.bmin[0]) + (in.bmax[1] - in.bmin[1])) + (in.bmax[2] - in.bmin[2])) * 0.5f;
+    for (int a = 0; a < 3; ++a) rec[28 + a] = (in.bmin[a] + in.bmax[a]) * 0.5f;
+    rec[31] = (((in.bmax[0] - in.bmin[0]) + (in.bmax[1] - in.bmin[1])) + (in.bmax[2] - in.bmin[2])) * 0.5f;
   }
   std::vector<uint32_t> order;
-  c->root = build_tree(boxes.data(), n, true, 0, c->bvh.nodes, order, c->bvh.bbmin, c->bvh.bbmax, n >= 4096 ? 0 : 1);   // small trees: one thread beats the hand-off
-  for (uint32_t p = 0; p < n; ++p) std::memcpy(&table[32 * (size_t)(n + p)], &table[32 * (size_t)order[p]], 128);
-  return dev_put(c, c->d_inst, c->cap_inst, table.data(), table.size() * sizeof(float));
+  const uint32_t troot = build_tree(boxes.data(), n, true, 0, c->bvh.nodes, order, c->tlas_lo, c->tlas_hi, n >= 4096 ? 0 : 1);   // small trees: one thread beats the hand-off
+  for (uint32_t p = 0; p < n; ++p) std::memcpy(&table[32 * ((size_t)c->nO + p)], &table[32 * (size_t)c->inst[order[p]].obj], 128);
+  if (c->n_static_live) {
+    c->root = 0; c->root2 = troot;
+    for (int a = 0; a < 3; ++a) { c->bvh.bbmin[a] = crh_min(c->tlas_lo[a], c->sbmin[a]); c->bvh.bbmax[a] = crh_max(c->tlas_hi[a], c->sbmax[a]); }
+  } else {
+    c->root = troot;
+    for (int a = 0; a < 3; ++a) { c->bvh.bbmin[a] = c->tlas_lo[a]; c->bvh.bbmax[a] = c->tlas_hi[a]; }
+  }
+  return dev_put(c, c->d_inst, c->cap_inst, table.data(), table.size() * sizeof(float), 32 * sizeof(float) * ((size_t)c->nO + 64));
+}
+
+// the object-space tree of object ob, appended behind the trees built so far; its triangles take the next leaf positions
+void build_object_tree(crh_ctx* c, uint32_t ob, int threads)
+{
+  crh_ctx::Obj& o = c->objs[ob];
+  const uint32_t m = o.ntri; const uint32_t* mem = &c->obj_tris[o.first];
+  std::vector<float> boxes(6 * (size_t)m); std::vector<uint32_t> order;
+  for (uint32_t i = 0; i < m; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const uint32_t t = mem[i];
+      const float v0 = c->pos[3 * c->tri[4 * t + 0] + a], v1 = c->pos[3 * c->tri[4 * t + 1] + a], v2 = c->pos[3 * c->tri[4 * t + 2] + a];
+      boxes[6 * (size_t)i + a] = std::min(v0, std::min(v1, v2)); boxes[6 * (size_t)i + 3 + a] = std::max(v0, std::max(v1, v2));
+    }
+  o.root = build_tree(boxes.data(), m, false, c->n_pos, c->bvh.nodes, order, o.bmin, o.bmax, threads);
+  for (uint32_t i = 0; i < m; ++i) { c->bvh.prim_order.push_back(mem[order[i]]); c->pos_obj.push_back(ob); }
+  c->n_pos += m; o.built = true;
+}
+
+// Leaf-ordered device records of positions [p0, p1): 16 floats of triangle (48 B used), 16 floats of shading record, 8 floats of uv.
+// Also refreshes the host copy h_tris (12 floats per position, crh_get_bvh).
+void fill_records(crh_ctx* c, uint32_t p0, uint32_t p1, std::vector<float>& tr, std::vector<float>& sh, std::vector<float>& uvr)
+{
+  const size_t n = p1 - p0;
+  tr.assign(4 * (size_t)kTriStride * std::max<size_t>(n, 1), 0.f); sh.assign(16 * std::max<size_t>(n, 1), 0.f);
+  if (!c->uv.empty()) uvr.assign(8 * std::max<size_t>(n, 1), 0.f); else uvr.clear();
+  c->h_tris.resize(12 * (size_t)std::max(p1, 1u), 0.f);
+  for (uint32_t p = p0; p < p1; ++p) {
+    const uint32_t t = c->bvh.prim_order[p]; const size_t i = p - p0;
+    float* q = &c->h_tris[12 * (size_t)p]; float* s_ = &sh[16 * i];
+    for (int k = 0; k < 3; ++k) {
+      const int32_t vi = c->tri[4 * t + k];
+      for (int a = 0; a < 3; ++a) { q[4 * k + a] = c->pos[3 * vi + a]; s_[4 * k + a] = c->nrm[3 * vi + a]; }
+      q[4 * k + 3] = 0.f;
+      if (!uvr.empty()) { uvr[8 * i + 2 * k] = c->uv[2 * vi]; uvr[8 * i + 2 * k + 1] = c->uv[2 * vi + 1]; }
+    }
+    {
+      // the kernel's former expression on the three vertices, evaluated once here with the same inline arithmetic (same bits)
+      const crh_v3 a0 = crh_mk3(q[0], q[1], q[2]), a1 = crh_mk3(q[4], q[5], q[6]), a2 = crh_mk3(q[8], q[9], q[10]);
+      const crh_v3 ng = crh_norm3(crh_cross3(crh_sub3(a0, a2), crh_sub3(a1, a0)));
+      s_[12] = ng.x; s_[13] = ng.y; s_[14] = ng.z;
+    }
+    std::memcpy(&q[3], &t, 4);
+    const int32_t mat = c->tri[4 * t + 3];
+    std::memcpy(&s_[3], &mat, 4);
+    const int32_t ob = (c->two_level && p >= c->n_static) ? (int32_t)c->pos_obj[p - c->n_static] : -1;      // n1.w: the object whose transform shading applies (-1: world space)
+    std::memcpy(&s_[7], &ob, 4);
+    std::memcpy(&tr[4 * (size_t)kTriStride * i], q, 48);
+  }
 }
 
 int upload_textures(crh_ctx* c)
@@ -807,7 +900,7 @@ void crh_destroy(crh_ctx* c)
   void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o[0], c->paths.ray_d[0], c->paths.ray_o[1], c->paths.ray_d[1], c->paths.thr[1],
                   c->paths.hit, c->paths.thr[0], c->paths.rad, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
                   c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
-                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst};
+                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst, c->d_patch};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->d_assembled) hipFree(c->d_assembled);
   if (c->d_peer_stage) hipFree(c->d_peer_stage);
@@ -857,14 +950,6 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
   return CRH_OK;
 }
 
-// every object at the identity (the state of a CADRays scene until something is dragged): one world-space tree, the single-level kernels
-static bool all_identity(const float* xf, uint32_t nO)
-{
-  static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-  for (uint32_t o = 0; o < nO; ++o) for (int k = 0; k < 12; ++k) if (xf[12 * (size_t)o + k] != I[k]) return false;
-  return true;
-}
-
 int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
 {
   if (!c || !xf) return fail(c, CRH_E_INVALID, "null transforms");
@@ -872,17 +957,77 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
   if (!all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return fail(c, CRH_E_INVALID, "transform holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
   c->xf.assign(xf, xf + 12 * (size_t)nO);
-  if (c->built && all_identity(xf, nO) != c->flat) return crh_build(c);      // between one tree and object trees + top level: a full build, once
-  if (c->built && c->flat) return do_reset(c);                                // identity again: nothing moved
-  if (c->built) {
-    // the manipulator calls this every frame (ImRaytraceControls.cxx:58-89): rebuild the top-level tree on the host and send only
-    // its nodes (the tail of the node array, behind the untouched object trees) and the instance table, stream-ordered into
-    // the allocations crh_build left head-room in
-    int rc = build_tlas(c); if (rc) return rc;
-    const size_t tail = c->bvh.nodes.size() - c->n_blas_nodes;
-    if (c->bvh.nodes.size() * sizeof(QNode) > c->cap_nodes) {          // cannot happen for an unchanged instance count; kept for safety
-      if ((rc = dev_put(c, c->d_nodes, c->cap_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode), (size_t)(c->inst.size() + 64) * sizeof(QNode)))) return rc;
-    } else if ((rc = stage_copy(c, (char*)c->d_nodes + (size_t)c->n_blas_nodes * sizeof(QNode), c->bvh.nodes.data() + c->n_blas_nodes, tail * sizeof(QNode)))) return rc;
+  if (!c->built) return do_reset(c);
+  // The manipulator calls this every frame (ImRaytraceControls.cxx:58-89).  Nothing big is ever rebuilt here: an object of the static tree that
+  // leaves the identity has its triangles THERE disabled (a scatter of all-zero records) and, the first time, gets an object tree of its own,
+  // appended behind the trees built so far; back at the identity its triangles are restored and the instance dropped.  Then the top-level tree
+  // over the instances of this moment is rebuilt on the host and only the new nodes and the instance table travel, stream-ordered.
+  int threads = 0; if (const char* e = getenv("CRH_BUILD_THREADS")) threads = atoi(e);
+  const uint32_t old_nodes = c->n_blas_nodes, old_pos = c->n_pos;
+  c->bvh.nodes.resize(c->n_blas_nodes);
+  std::vector<uint32_t> ppos; std::vector<float> prec;
+  for (uint32_t ob = 0; ob < nO; ++ob) {
+    crh_ctx::Obj& o = c->objs[ob];
+    if (!o.ntri) continue;
+    const bool want = !(o.static0 && is_identity(&xf[12 * (size_t)ob]));
+    if (want == o.is_inst) continue;
+    // static0 object changing sides: its records in the static tree die / come back
+    for (uint32_t i = 0; i < o.ntri; ++i) {
+      const uint32_t t = c->obj_tris[o.first + i], p = c->static_pos[t];
+      float* q = &c->h_tris[12 * (size_t)p];
+      if (want) { std::memset(q, 0, 48); std::memcpy(&q[3], &t, 4); }
+      else {
+        for (int k = 0; k < 3; ++k) { const int32_t vi = c->tri[4 * t + k]; for (int a = 0; a < 3; ++a) q[4 * k + a] = c->pos[3 * vi + a]; q[4 * k + 3] = 0.f; }
+        std::memcpy(&q[3], &t, 4);
+      }
+      ppos.push_back(p); prec.insert(prec.end(), q, q + 12);
+    }
+    if (want) { c->n_static_live -= o.ntri; if (!o.built) build_object_tree(c, ob, threads); }
+    else c->n_static_live += o.ntri;
+    o.is_inst = want;
+  }
+  c->n_blas_nodes = (uint32_t)c->bvh.nodes.size();
+  int rc;
+  if (c->n_pos > old_pos) {                               // records of the object trees just built
+    if (c->n_pos > c->cap_pos || c->n_pos >= (1u << 28)) return fail(c, CRH_E_NOMEM, "leaf positions exhausted (object trees of moved objects)");
+    std::vector<float> tr, sh, uvr;
+    fill_records(c, old_pos, c->n_pos, tr, sh, uvr);
+    const size_t n = c->n_pos - old_pos;
+    auto put = [&](void* dst, const std::vector<float>& v, size_t rec_floats) -> int {
+      const size_t bytes = n * rec_floats * sizeof(float);
+      if (bytes <= (4u << 20)) return stage_copy(c, dst, v.data(), bytes);
+      CRH_HIP(hipMemcpyAsync(dst, v.data(), bytes, hipMemcpyHostToDevice, cstream(c))); CRH_HIP(hipStreamSynchronize(cstream(c))); return CRH_OK;
+    };
+    if ((rc = put(c->d_tris + (size_t)kTriStride * old_pos, tr, 4 * kTriStride))) return rc;
+    if ((rc = put(c->d_shade + 4 * (size_t)old_pos, sh, 16))) return rc;
+    if (c->d_uvs && !uvr.empty() && (rc = put(c->d_uvs + 2 * (size_t)old_pos, uvr, 8))) return rc;
+  }
+  if (!ppos.empty()) {
+    const size_t nb = ppos.size() * 4, rb = prec.size() * 4, need = ((nb + 255) & ~(size_t)255) + rb;
+    if (need > c->cap_patch) {
+      CRH_HIP(hipStreamSynchronize(cstream(c)));
+      if (c->d_patch) { CRH_HIP(hipFree(c->d_patch)); c->d_patch = nullptr; c->cap_patch = 0; }
+      CRH_HIP(hipMalloc(&c->d_patch, need + need / 2)); c->cap_patch = need + need / 2;
+    }
+    char* base = (char*)c->d_patch; char* recs = base + ((nb + 255) & ~(size_t)255);
+    auto put = [&](void* dst, const void* src, size_t bytes) -> int {
+      if (bytes <= (4u << 20)) return stage_copy(c, dst, src, bytes);
+      CRH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cstream(c))); CRH_HIP(hipStreamSynchronize(cstream(c))); return CRH_OK;
+    };
+    if ((rc = put(base, ppos.data(), nb))) return rc;
+    if ((rc = put(recs, prec.data(), rb))) return rc;
+    Launch L{cstream(c), c->grid, false};
+    launch_scatter_tris(L, c->d_tris, (const uint32_t*)base, (const float4*)recs, (uint32_t)ppos.size());
+    CRH_HIP(hipGetLastError());
+  }
+  if ((rc = build_tlas(c))) return rc;
+  const size_t tail = c->bvh.nodes.size() - old_nodes;
+  if (c->bvh.nodes.size() * sizeof(QNode) > c->cap_nodes) {          // more object trees than crh_build left room for: the whole array again, with head-room
+    if ((rc = dev_put(c, c->d_nodes, c->cap_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode), c->bvh.nodes.size() * sizeof(QNode) / 2 + (size_t)(4 * c->nO + 64) * sizeof(QNode)))) return rc;
+  } else if (tail) {
+    const size_t bytes = tail * sizeof(QNode); void* dst = (char*)c->d_nodes + (size_t)old_nodes * sizeof(QNode);
+    if (bytes <= (4u << 20)) { if ((rc = stage_copy(c, dst, c->bvh.nodes.data() + old_nodes, bytes))) return rc; }
+    else { CRH_HIP(hipMemcpyAsync(dst, c->bvh.nodes.data() + old_nodes, bytes, hipMemcpyHostToDevice, cstream(c))); CRH_HIP(hipStreamSynchronize(cstream(c))); }
   }
   return do_reset(c);
 }
@@ -891,7 +1036,8 @@ int crh_get_tlas(crh_ctx* c, uint32_t* root, uint32_t* n_inst, uint32_t* n_blas)
 {
   if (!c) return CRH_E_INVALID;
   if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
-  if (root) *root = c->root; if (n_inst) *n_inst = (uint32_t)c->inst.size(); if (n_blas) *n_blas = c->n_blas_nodes;
+  if (root) *root = c->inst.empty() ? 0u : (c->root2 != kQEmpty ? c->root2 : c->root);
+  if (n_inst) *n_inst = (uint32_t)c->inst.size(); if (n_blas) *n_blas = c->n_blas_nodes;
   return CRH_OK;
 }
 
@@ -973,6 +1119,26 @@ int crh_set_params(crh_ctx* c, const crh_params* p)
   return do_reset(c);
 }
 
+int crh_set_spec(crh_ctx* c, const crh_spec* sp)
+{
+  if (!c || !sp) return fail(c, CRH_E_INVALID, "null spec");
+  if (sp->size != sizeof(crh_spec)) return fail(c, CRH_E_INVALID, "crh_spec.size does not match this library's struct");
+  if (!(sp->eta_no_dielectric >= 1.0e-2f && sp->eta_no_dielectric <= 1.0e3f)) return fail(c, CRH_E_INVALID, "eta_no_dielectric must be in 1e-2 .. 1e3");
+  c->spec = *sp;
+  c->spec.uniform_32bit = sp->uniform_32bit != 0; c->spec.texel_gamma2 = sp->texel_gamma2 != 0; c->spec.mis_single_lobe = sp->mis_single_lobe != 0;
+  c->spec.eps_rule = sp->eps_rule != 0;
+  return do_reset(c);                                     // like every rendering-parameter change (pending look-ahead samples are dropped there)
+}
+
+int crh_get_spec(crh_ctx* c, crh_spec* out)
+{
+  if (!c || !out) return fail(c, CRH_E_INVALID, "null spec");
+  *out = c->spec; out->size = (uint32_t)sizeof(crh_spec);
+  return CRH_OK;
+}
+
+int crh_spec_order_exact(void) { return CRH_SPEC_ORDER_EXACT; }
+
 int crh_build(crh_ctx* c)
 {
   if (!c) return CRH_E_INVALID;
@@ -981,77 +1147,87 @@ int crh_build(crh_ctx* c)
   CRH_HIP(hipSetDevice(c->device));
   CRH_HIP(hipStreamSynchronize(cstream(c)));
   int threads = 0; if (const char* e = getenv("CRH_BUILD_THREADS")) threads = atoi(e);
-  std::vector<int32_t> tri_inst(nT ? nT : 1, -1);   // triangle -> instance (two-level only)
-  c->inst.clear(); c->root = 0;
-  c->flat = c->two_level && all_identity(c->xf.data(), c->nO);
-  if (!c->two_level || c->flat) {
+  c->inst.clear(); c->root = 0; c->root2 = kQEmpty; c->objs.clear(); c->obj_tris.clear(); c->static_pos.clear(); c->pos_obj.clear();
+  c->bvh.nodes.clear(); c->bvh.prim_order.clear();
+  if (!c->two_level) {
     build_qbvh(c->pos.data(), c->tri.data(), nT, c->bvh, threads);
-    c->n_blas_nodes = (uint32_t)c->bvh.nodes.size();
+    c->n_static = c->n_static_live = c->n_pos = nT;
+    for (int a = 0; a < 3; ++a) { c->sbmin[a] = c->bvh.bbmin[a]; c->sbmax[a] = c->bvh.bbmax[a]; }
   } else {
-    // one object-space tree per non-empty object, triangles in input order inside an object
-    std::vector<std::vector<uint32_t>> members(c->nO);
-    for (uint32_t t = 0; t < nT; ++t) members[c->tri_obj[t]].push_back(t);
-    c->bvh.nodes.clear(); c->bvh.prim_order.clear(); c->bvh.prim_order.reserve(nT);
-    std::vector<float> boxes; std::vector<uint32_t> order;
-    uint32_t tri_base = 0;
-    for (uint32_t ob = 0; ob < c->nO; ++ob) {
-      const std::vector<uint32_t>& mem = members[ob];
-      if (mem.empty()) continue;
-      boxes.assign(6 * mem.size(), 0.f);
-      for (size_t i = 0; i < mem.size(); ++i)
+    // static / moved split: the objects at the identity share ONE world-space tree (first in the node array, its triangles first in leaf
+    // order); every other non-empty object gets an object-space tree (triangles in input order); then the top-level tree over the instances
+    c->objs.assign(c->nO, crh_ctx::Obj{}); c->obj_tris.resize(nT ? nT : 1); c->static_pos.assign(nT ? nT : 1, 0u);
+    for (uint32_t t = 0; t < nT; ++t) c->objs[c->tri_obj[t]].ntri++;
+    { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { crh_ctx::Obj& o = c->objs[ob]; o.first = acc; acc += o.ntri; o.ntri = 0; o.static0 = is_identity(&c->xf[12 * (size_t)ob]); } }
+    for (uint32_t t = 0; t < nT; ++t) { crh_ctx::Obj& o = c->objs[c->tri_obj[t]]; c->obj_tris[o.first + o.ntri++] = t; }
+    std::vector<uint32_t> list; list.reserve(nT);
+    for (uint32_t t = 0; t < nT; ++t) if (c->objs[c->tri_obj[t]].static0) list.push_back(t);
+    const uint32_t nS = (uint32_t)list.size();
+    c->n_static = c->n_static_live = nS; c->n_pos = nS;
+    if (nS) {
+      std::vector<float> boxes(6 * (size_t)nS); std::vector<uint32_t> order;
+      for (uint32_t i = 0; i < nS; ++i)
         for (int a = 0; a < 3; ++a) {
-          const uint32_t t = mem[i];
+          const uint32_t t = list[i];
           const float v0 = c->pos[3 * c->tri[4 * t + 0] + a], v1 = c->pos[3 * c->tri[4 * t + 1] + a], v2 = c->pos[3 * c->tri[4 * t + 2] + a];
-          boxes[6 * i + a] = std::min(v0, std::min(v1, v2)); boxes[6 * i + 3 + a] = std::max(v0, std::max(v1, v2));
+          boxes[6 * (size_t)i + a] = std::min(v0, std::min(v1, v2)); boxes[6 * (size_t)i + 3 + a] = std::max(v0, std::max(v1, v2));
         }
-      crh_ctx::Inst in{}; in.obj = ob;
-      in.root = build_tree(boxes.data(), (uint32_t)mem.size(), false, tri_base, c->bvh.nodes, order, in.bmin, in.bmax, threads);
-      for (size_t i = 0; i < mem.size(); ++i) { c->bvh.prim_order.push_back(mem[order[i]]); tri_inst[mem[order[i]]] = (int32_t)c->inst.size(); }
-      c->inst.push_back(in);
-      tri_base += (uint32_t)mem.size();
+      c->bvh.nodes.reserve(nS / 2 + 16);
+      build_tree(boxes.data(), nS, false, 0, c->bvh.nodes, order, c->sbmin, c->sbmax, threads);
+      c->bvh.prim_order.resize(nS);
+      for (uint32_t i = 0; i < nS; ++i) { c->bvh.prim_order[i] = list[order[i]]; c->static_pos[list[order[i]]] = i; }
     }
-    c->n_blas_nodes = (uint32_t)c->bvh.nodes.size();
-    int rc_t = build_tlas(c); if (rc_t) return rc_t;
+    for (uint32_t ob = 0; ob < c->nO; ++ob) {
+      crh_ctx::Obj& o = c->objs[ob];
+      if (o.static0 || !o.ntri) continue;
+      build_object_tree(c, ob, threads);
+      o.is_inst = true;
+    }
   }
-  // leaf-ordered triangle and shading records
-  c->h_tris.assign(12 * (size_t)std::max(nT, 1u), 0.f);
-  std::vector<float> sh(16 * (size_t)std::max(nT, 1u), 0.f);      // 64-B shading records: three vertex normals (+ material, instance) and the geometric normal
-  for (uint32_t i = 0; i < nT; ++i) {
-    const uint32_t t = c->bvh.prim_order[i];
-    for (int k = 0; k < 3; ++k) {
-      const int32_t vi = c->tri[4 * t + k];
-      for (int a = 0; a < 3; ++a) { c->h_tris[12 * (size_t)i + 4 * k + a] = c->pos[3 * vi + a]; sh[16 * (size_t)i + 4 * k + a] = c->nrm[3 * vi + a]; }
+  c->n_blas_nodes = (uint32_t)c->bvh.nodes.size();
+  if (c->n_pos >= (1u << 28)) return fail(c, CRH_E_INVALID, "too many leaf positions (limit 2^28)");
+  if (c->two_level) {
+    // room for the instance table of ANY later placement (one record per object + one per instance), so that the first crh_set_transforms --
+    // the user has just grabbed the gizmo -- allocates nothing
+    const size_t want_inst = 128 * (2 * (size_t)c->nO + 64);
+    if (c->cap_inst < want_inst) {
+      if (c->d_inst) { CRH_HIP(hipFree(c->d_inst)); c->d_inst = nullptr; c->cap_inst = 0; }
+      CRH_HIP(hipMalloc((void**)&c->d_inst, want_inst)); c->cap_inst = want_inst;
+      CRH_HIP(hipMemsetAsync(c->d_inst, 0, want_inst, cstream(c)));
     }
-    {
-      // the kernel's former expression on the three vertices, evaluated once here with the same inline arithmetic (same bits)
-      const float* q = &c->h_tris[12 * (size_t)i];
-      const crh_v3 p0 = crh_mk3(q[0], q[1], q[2]), p1 = crh_mk3(q[4], q[5], q[6]), p2 = crh_mk3(q[8], q[9], q[10]);
-      const crh_v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
-      sh[16 * (size_t)i + 12] = ng.x; sh[16 * (size_t)i + 13] = ng.y; sh[16 * (size_t)i + 14] = ng.z;
-    }
-    std::memcpy(&c->h_tris[12 * (size_t)i + 3], &t, 4);
-    const int32_t mat = c->tri[4 * t + 3];
-    std::memcpy(&sh[16 * (size_t)i + 3], &mat, 4);
-    std::memcpy(&sh[16 * (size_t)i + 7], &tri_inst[t], 4);       // n1.w = instance index (two-level shading fetches its transform)
   }
+  { int rc_t = build_tlas(c); if (rc_t) return rc_t; }
+  // leaf-ordered triangle, shading and uv records.  A two-level scene keeps room for an object tree of every object of the static tree
+  // (each may be dragged away once; the copies cost 2 x 64 B per triangle of HBM, nothing at run time)
+  std::vector<float> tr, sh, uvr;
+  c->h_tris.clear();
+  fill_records(c, 0, c->n_pos, tr, sh, uvr);
+  c->cap_pos = (size_t)std::max(c->n_pos, 1u) + (c->two_level ? c->n_static : 0u);
   int rc;
-  // head-room behind the node array: crh_set_transforms rebuilds the top-level tree into it (<= one node per instance + alignment holes)
-  if ((rc = dev_put(c, c->d_nodes, c->cap_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode), (size_t)(2 * c->inst.size() + 64) * sizeof(QNode)))) return rc;
-  if (kTriStride == 3) { if ((rc = dev_upload(c, c->d_tris, c->h_tris.data(), c->h_tris.size() * sizeof(float)))) return rc; }
-  else {
-    std::vector<float> padded(4 * (size_t)kTriStride * std::max(nT, 1u), 0.f);
-    for (size_t i = 0; i < (size_t)nT; ++i) std::memcpy(&padded[4 * (size_t)kTriStride * i], &c->h_tris[12 * i], 48);
-    if ((rc = dev_upload(c, c->d_tris, padded.data(), padded.size() * sizeof(float)))) return rc;
-  }
-  if ((rc = dev_upload(c, c->d_shade, sh.data(), sh.size() * sizeof(float)))) return rc;
-  if (!c->uv.empty()) {
-    std::vector<float> uvr(8 * (size_t)std::max(nT, 1u), 0.f);
-    for (uint32_t i = 0; i < nT; ++i) {
-      const uint32_t t = c->bvh.prim_order[i];
-      for (int k = 0; k < 3; ++k) { const int32_t vi = c->tri[4 * t + k]; uvr[8 * (size_t)i + 2 * k] = c->uv[2 * vi]; uvr[8 * (size_t)i + 2 * k + 1] = c->uv[2 * vi + 1]; }
+  // head-room behind the node array: object trees built later by crh_set_transforms (<= ~1.5 nodes per triangle incl. alignment holes) and the top-level tree
+  if ((rc = dev_put(c, c->d_nodes, c->cap_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode),
+                    (size_t)((c->two_level ? 2 * (size_t)c->n_static : 0) + 4 * (size_t)c->nO + 64) * sizeof(QNode)))) return rc;
+  auto alloc_put = [&](float4*& dptr, const std::vector<float>& v, size_t rec_floats) -> int {
+    CRH_HIP(hipStreamSynchronize(cstream(c)));
+    if (dptr) { CRH_HIP(hipFree(dptr)); dptr = nullptr; }
+    CRH_HIP(hipMalloc((void**)&dptr, c->cap_pos * rec_floats * sizeof(float)));
+    CRH_HIP(hipMemcpyAsync(dptr, v.data(), (size_t)std::max(c->n_pos, 1u) * rec_floats * sizeof(float), hipMemcpyHostToDevice, cstream(c)));
+    CRH_HIP(hipStreamSynchronize(cstream(c)));
+    return CRH_OK;
+  };
+  if ((rc = alloc_put(c->d_tris, tr, 4 * kTriStride))) return rc;
+  if ((rc = alloc_put(c->d_shade, sh, 16))) return rc;
+  if (!c->uv.empty()) { if ((rc = alloc_put(c->d_uvs, uvr, 8))) return rc; }
+  else if (c->d_uvs) { CRH_HIP(hipFree(c->d_uvs)); c->d_uvs = nullptr; }
+  if (c->two_level) {
+    // what the FIRST crh_set_transforms would otherwise allocate while the user is dragging: the staging of the triangle patches of the largest object
+    uint32_t biggest = 0; for (const crh_ctx::Obj& o : c->objs) biggest = std::max(biggest, o.ntri);
+    const size_t want_patch = 2 * ((size_t)biggest * 52 + 512);
+    if (c->cap_patch < want_patch) {
+      if (c->d_patch) { CRH_HIP(hipFree(c->d_patch)); c->d_patch = nullptr; c->cap_patch = 0; }
+      CRH_HIP(hipMalloc(&c->d_patch, want_patch)); c->cap_patch = want_patch;
     }
-    if ((rc = dev_upload(c, c->d_uvs, uvr.data(), uvr.size() * sizeof(float)))) return rc;
-  } else if (c->d_uvs) { CRH_HIP(hipFree(c->d_uvs)); c->d_uvs = nullptr; }
+  }
   c->built = true;
   rc = do_reset(c); if (rc) return rc;
   CRH_HIP(hipStreamSynchronize(cstream(c)));
@@ -1350,11 +1526,11 @@ int crh_get_bvh(crh_ctx* c, float* nodes, uint32_t* nn, float* tris, uint32_t* n
 {
   if (!c) return CRH_E_INVALID;
   if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
-  const uint32_t nT = (uint32_t)(c->tri.size() / 4);
+  const uint32_t nP = c->n_pos;                         // leaf positions in use: the triangles, + the object-tree copies of objects dragged out of the static tree
   if (nn) *nn = (uint32_t)c->bvh.nodes.size();
-  if (nt) *nt = nT;
+  if (nt) *nt = nP;
   if (nodes) std::memcpy(nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode));
-  if (tris && nT) std::memcpy(tris, c->h_tris.data(), 48 * (size_t)nT);
+  if (tris && nP) std::memcpy(tris, c->h_tris.data(), 48 * (size_t)nP);
   return CRH_OK;
 }
 

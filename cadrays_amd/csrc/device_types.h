@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/crh_math.h"
+#include "../../include/crh_spec.h"
 
 namespace crh {
 
@@ -38,11 +39,13 @@ struct DScene {
   const float4* texels;   // all diffuse textures back to back
   const uint4*  tex_desc; // per slot: {first texel, width, height, 0}; width 0 = empty slot
   uint32_t n_tex;
-  const float4* inst;     // two-level: 8 x float4 per instance: inverse rows (3), forward rows (3), {root, object, translation-only, -}, {object box centre.xyz, L1 half-extent}
-  const float4* inst_leaf;  // the same records in top-level leaf order (a top-level leaf reference is a position in this list)
+  const float4* inst;     // two-level: 8 x float4 per OBJECT (valid for the objects rendered as instances): inverse rows (3), forward rows (3), {root, object, translation-only, -}, {object box centre.xyz, L1 half-extent}
+  const float4* inst_leaf;  // the records of the instances in top-level leaf order (a top-level leaf reference is a position in this list)
   float4 guard_box;       // {centre.xyz, L1 half-extent} of the tree traversal starts in: scales the slab test's guard band (kSlabGuard)
-  uint32_t root;          // node index traversal starts at (0 for a single-level scene, the top-level root otherwise)
-  int two_level;
+  uint32_t root;          // node index traversal starts at: the (static) world-space tree; the top-level root when no static triangle is live
+  uint32_t root2;         // static / moved split: top-level root walked AFTER the static tree (kQEmpty: none) ...
+  float tlas_lo[3], tlas_hi[3];   // ... if the ray touches the bounds of all instances
+  int two_level;          // some object is rendered as an instance right now (object trees + top level exist)
   uint32_t n_mats, n_lights, env_w, env_h;
   float bg[3]; int env_as_bg;
   // camera frame
@@ -53,6 +56,8 @@ struct DScene {
   uint32_t width, height, max_depth, tile_size;
   float clampv, eps;
   int two_sided, coherent, rr;
+  // crh_spec.h switches (wave-uniform; the defaults 0 / 0 / 0 / 1.0f are the frozen spec)
+  int spec_u32, spec_gamma2, spec_mis1; float spec_eta_nd;
 };
 
 // Wavefront path state, structure-of-arrays.  A queue entry is a POSITION in these arrays, not a pixel slot: k_raygen puts

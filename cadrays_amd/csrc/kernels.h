@@ -38,6 +38,8 @@ void launch_tonemap(const Launch&, const float4* accum, uint8_t* out_rgb, uint32
                     const uint8_t* tile_mask /* nullptr: no overlay */, uint32_t width, uint32_t tile_size);
 void launch_hdr(const Launch&, const float4* accum, float* out_rgb, uint32_t n_pixels);
 void launch_add4(const Launch&, float4* dst, const float4* src, uint32_t n_float4);
+// overwrite the triangle records at leaf positions pos[0..n) with recs (3 x float4 each): static / moved split of crh_set_transforms
+void launch_scatter_tris(const Launch&, float4* tris, const uint32_t* pos, const float4* recs, uint32_t n);
 // API-level ray tracing on a plain ray buffer (8 floats per ray)
 void launch_trace_rays(const Launch&, const DScene&, const float4* rays, uint32_t n, int any_hit,
                        float4* out_hit, uint32_t* out_vis, uint32_t* d_cursor, DCounters*);

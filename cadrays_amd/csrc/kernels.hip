@@ -105,7 +105,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float inv_dir(float d)
 { return 1.0f / (crh_abs(d) < kDirEps ? (d < 0.f ? -kDirEps : kDirEps) : d); }
 
-#define CRH_CE(a, b) { const uint32_t lo_ = min(a, b); const uint32_t hi_ = max(a, b); a = lo_; b = hi_; }
+// Child order key (crh_spec.h #4).  Default: the entry distance's bits with the slot index in the two low mantissa bits -- unique
+// 32-bit keys, unsigned order = near to far, ties by slot.  CRH_SPEC_ORDER_EXACT: the full bits with the slot appended (64-bit keys).
+#if CRH_SPEC_ORDER_EXACT
+typedef unsigned long long okey_t;
+#define CRH_KEY_MISS 0xFFFFFFFFFFFFFFFFull
+#define CRH_MAKE_KEY(BITS, K) ((((okey_t)(uint32_t)(BITS)) << 2) | (okey_t)(K))
+#else
+typedef uint32_t okey_t;
+#define CRH_KEY_MISS 0xFFFFFFFFu
+#define CRH_MAKE_KEY(BITS, K) (((uint32_t)(BITS) & ~3u) | (uint32_t)(K))
+#endif
+#define CRH_CE(a, b) { const okey_t lo_ = min(a, b); const okey_t hi_ = max(a, b); a = lo_; b = hi_; }
 
 // Persistent-wave traversal engine shared by every tracing kernel.
 //
@@ -149,9 +160,15 @@ constexpr uint32_t kNoLane = 64u;
 // has absorbed before (`chit`), and the head of the list stores fold(own, chit).  Hits are bit-identical to the sequential walk;
 // only pruning differs (the parts do not see each other's `best`), i.e. the number of visits -- which is why the counting kernels
 // never donate.
+// Static / moved split of a two-level scene: the walk starts in the static world-space tree (`root`) and the top-level
+// tree over the moved objects (`root2`) waits at the bottom of the stack -- pushed only when the ray touches the instances' bounds.
+struct Top2 { uint32_t root2; float lo[3], hi[3]; };
+__device__ __forceinline__ Top2 top2_of(const DScene& S)
+{ Top2 t; t.root2 = S.root2; for (int a = 0; a < 3; ++a) { t.lo[a] = S.tlas_lo[a]; t.hi[a] = S.tlas_hi[a]; } return t; }
+
 template <bool ANY, bool COUNT, bool TWO, bool DON, class Load, class Store>
 __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                             const float4* __restrict__ inst, uint32_t root, float4 gbox,
+                                             const float4* __restrict__ inst, uint32_t root, float4 gbox, const Top2 t2,
                                              uint32_t* __restrict__ cursor, uint32_t n, uint32_t* lds,
                                              Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris, uint32_t* bound = nullptr)
 {
@@ -226,6 +243,14 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           set_guard(gbox);
           if (TWO) save_world();
           best = tmax; found = false; sp = 0; cur = root; have = true;
+          if (TWO && t2.root2 != kQEmpty) {
+            // same planes + guard band as a node's child test, against the bounds of all instances (the oracle's traverse() has the twin)
+            const float ax_ = (t2.lo[0] - o.x) * ix, bx_ = (t2.hi[0] - o.x) * ix, ay_ = (t2.lo[1] - o.y) * iy, by_ = (t2.hi[1] - o.y) * iy;
+            const float az_ = (t2.lo[2] - o.z) * iz, bz_ = (t2.hi[2] - o.z) * iz;
+            const float tn_ = fmaxf(fmaxf(fmaxf(fminf(ax_, bx_) - gx, fminf(ay_, by_) - gy), fminf(az_, bz_) - gz), 0.f);
+            const float tf_ = fminf(fminf(fminf(fmaxf(ax_, bx_) + gx, fmaxf(ay_, by_) + gy), fmaxf(az_, bz_) + gz), tmax);
+            if (tn_ <= tf_) { lds[0] = t2.root2; sp = 1; }
+          }
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
           if (DON) { sbase = 0; is_child = false; cfound = false; next = kNoLane; head = lane; bound[lane] = __float_as_uint(tmax); }
         }
@@ -326,7 +351,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ddx, ddx}, (f32x2){ix, ix}, (f32x2){-gx, gx});      // {entry, exit} offsets
       const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (f32x2){-gy, gy});
       const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ddz, ddz}, (f32x2){iz, iz}, (f32x2){-gz, gz});
-      uint32_t key[4];
+      okey_t key[4];
 #define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))      /* v_cvt_f32_ubyteK */
 #define CRH_CHILD(K)                                                                                         \
       {                                                                                                     \
@@ -336,7 +361,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
         const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), prune);                                   \
         const int bits = max(__float_as_int(tmin), 0);                                                     \
-        key[K] = ((uint32_t)K < nch && tmin <= tmx) ? (((uint32_t)bits & ~3u) | (uint32_t)K) : 0xFFFFFFFFu;   \
+        key[K] = ((uint32_t)K < nch && tmin <= tmx) ? CRH_MAKE_KEY(bits, K) : CRH_KEY_MISS;                   \
       }
       CRH_CHILD(0)
       CRH_CHILD(1)
@@ -349,10 +374,14 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       // stack, the nearest continues in registers.  Common case (room for three entries in the LDS part of
       // the stack): three UNCONDITIONAL stores -- hit children land at sp + (nh-1-j), the others in the dead
       // slots above the new top -- so the step has no per-child branches.
-#define CRH_REF(KEY) (((((KEY) & 3u) < ni) ? base_inner : base_leaf) + ((KEY) & 3u))
+#define CRH_REF(KEY) ((((uint32_t)((KEY) & 3u) < ni) ? base_inner : base_leaf) + (uint32_t)((KEY) & 3u))
       const uint32_t r0 = CRH_REF(key[0]), r1 = CRH_REF(key[1]), r2 = CRH_REF(key[2]), r3 = CRH_REF(key[3]);
 #undef CRH_REF
+#if CRH_SPEC_ORDER_EXACT
+      const int nh = 4 - (((key[0] == CRH_KEY_MISS) + (key[1] == CRH_KEY_MISS)) + ((key[2] == CRH_KEY_MISS) + (key[3] == CRH_KEY_MISS)));
+#else
       const int nh = 4 + ((((int)key[0] >> 31) + ((int)key[1] >> 31)) + (((int)key[2] >> 31) + ((int)key[3] >> 31)));
+#endif
       if (__builtin_expect(sp <= kLdsStack - 3, 1)) {
         uint32_t* top = lds + sp * kBlock;
         const int p1 = max(nh, 2) - 2, p2 = (nh == 3) ? 0 : 1, p3 = (nh == 4) ? 0 : 2;
@@ -460,7 +489,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, int cur, co
   }
   uint32_t nn = 0, nt = 0;
   const float4* __restrict__ ray_o = P.ray_o[cur]; const float4* __restrict__ ray_d = P.ray_d[cur];
-  trace_engine<false, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursors + 0, n, &stk[threadIdx.x],
+  trace_engine<false, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, top2_of(S), cursors + 0, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = ld_stream(&ray_o[tag]), d4 = ld_stream(&ray_d[tag]);      // .w lanes carry the path's rng state / slot + flags, not ray data
@@ -482,7 +511,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
   const uint32_t n = *count;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
   uint32_t nn = 0, nt = 0;
-  trace_engine<true, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursors + 2, n, &stk[threadIdx.x],
+  trace_engine<true, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, top2_of(S), cursors + 2, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
@@ -510,7 +539,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   uint32_t nn = 0, nt = 0;
-  trace_engine<ANY, COUNT, TWO, false>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, cursor, n, &stk[threadIdx.x],
+  trace_engine<ANY, COUNT, TWO, false>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, top2_of(S), cursor, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = idx;
       const float4 o4 = rays[2u * idx], d4 = rays[2u * idx + 1u];
@@ -633,7 +662,9 @@ __device__ float blinn_pdf(float hz, float dih, float rough)
   return (((e + 2.0f) * CRH_INV_TWOPI) * crh_pow(crh_abs(hz), e + 1.0f)) / (4.0f * crh_abs(dih));
 }
 
-__device__ float pdf_layered(const Bsdf& b, v3 wo, v3 wi, v3 W, int two_sided)
+// lobe < 0: the mixture pdf over all non-delta lobes (the spec's MIS pdf); lobe = 0 coat / 1 diffuse / 2 glossy: that lobe's pdf times its
+// selection probability only (crh_spec.h #3, mis_single_lobe)
+__device__ float pdf_layered(const Bsdf& b, v3 wo, v3 wi, v3 W, int two_sided, int lobe = -1)
 {
   const Lobes L = lobe_probs(b, W);
   if (!(L.total > kBsdfEps)) return 0.f;
@@ -642,16 +673,16 @@ __device__ float pdf_layered(const Bsdf& b, v3 wo, v3 wi, v3 W, int two_sided)
   if (wi.z > 0.f && wo.z > 0.f) {
     const v3 h = crh_norm3(crh_add3(wi, wo));
     const float dih = crh_dot3(wi, h);
-    pdf = L.pd * (wi.z * CRH_INV_PI);
-    if (b.Rc > kBsdfEps) pdf = CRH_FMA(L.pc, blinn_pdf(h.z, dih, b.Rc), pdf);
-    if (b.Rs > kBsdfEps) pdf = CRH_FMA(L.ps, blinn_pdf(h.z, dih, b.Rs), pdf);
+    if (lobe < 0 || lobe == 1) pdf = L.pd * (wi.z * CRH_INV_PI);
+    if (b.Rc > kBsdfEps && (lobe < 0 || lobe == 0)) pdf = CRH_FMA(L.pc, blinn_pdf(h.z, dih, b.Rc), pdf);
+    if (b.Rs > kBsdfEps && (lobe < 0 || lobe == 2)) pdf = CRH_FMA(L.ps, blinn_pdf(h.z, dih, b.Rs), pdf);
   }
   return pdf / L.total;
 }
 
-__device__ v3 sample_blinn(v3 wo, v3& wi, float4 fr, float rough, uint32_t& rng, int two_sided, bool& ok)
+__device__ v3 sample_blinn(v3 wo, v3& wi, float4 fr, float rough, uint32_t& rng, int two_sided, bool& ok, int u32)
 {
-  const float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+  const float k1 = crh_rng_next_mode(&rng, u32), k2 = crh_rng_next_mode(&rng, u32);
   const float e = blinn_power(rough);
   const float cm = crh_pow(k1, 1.0f / (e + 2.0f));
   float s, c; crh_sincos2pi(k2, &s, &c);
@@ -671,34 +702,37 @@ __device__ v3 sample_blinn(v3 wo, v3& wi, float4 fr, float rough, uint32_t& rng,
   return crh_scale3(F, w);
 }
 
-// returns alive; W multiplied by the lobe weight; inside toggled on transmission
-__device__ bool sample_layered(const Bsdf& b, v3 wo, v3& wi, v3& W, bool& inside, bool& delta, uint32_t& rng, int two_sided)
+// the crh_spec.h switches the BSDF code sees (wave-uniform)
+struct SpecB { int u32; float eta_nd; };
+
+// returns alive; W multiplied by the lobe weight; inside toggled on transmission; lobe = 0 coat / 1 diffuse / 2 glossy / 3 transmission
+__device__ bool sample_layered(const Bsdf& b, v3 wo, v3& wi, v3& W, bool& inside, bool& delta, uint32_t& rng, int two_sided, SpecB sp, int& lobe)
 {
   const Lobes L = lobe_probs(b, W);
-  const float ksi = L.total * crh_rng_next(&rng);
-  delta = false;
+  const float ksi = L.total * crh_rng_next_mode(&rng, sp.u32);
+  delta = false; lobe = 0;
   if (!(L.total > kBsdfEps)) { W = crh_mk3(0.f, 0.f, 0.f); return false; }
   const v3 mirror = crh_mk3(-wo.x, -wo.y, wo.z);
   bool ok = true; v3 k;
   if (ksi < L.pc) {
     k = crh_scale3(b.Kc, L.total / L.pc);
-    if (b.Rc > kBsdfEps) k = crh_mul3(k, sample_blinn(wo, wi, b.fc, b.Rc, rng, two_sided, ok));
+    if (b.Rc > kBsdfEps) k = crh_mul3(k, sample_blinn(wo, wi, b.fc, b.Rc, rng, two_sided, ok, sp.u32));
     else { k = crh_mul3(k, b.Fc); wi = mirror; delta = true; }
   } else if (ksi < L.pc + L.pd) {
-    k = crh_scale3(crh_mul3(b.Kd, L.Tc), L.total / L.pd);
-    const float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+    k = crh_scale3(crh_mul3(b.Kd, L.Tc), L.total / L.pd); lobe = 1;
+    const float k1 = crh_rng_next_mode(&rng, sp.u32), k2 = crh_rng_next_mode(&rng, sp.u32);
     float s, c; crh_sincos2pi(k1, &s, &c);
     const float r = crh_sqrt(k2);
     wi = crh_mk3(c * r, s * r, crh_sqrt(1.0f - k2));
     if (two_sided) { if (wo.z < 0.f) wi.z = -wi.z; }
     else if (!(wo.z > 0.f)) ok = false;
   } else if (ksi < (L.pc + L.pd) + L.ps) {
-    k = crh_scale3(crh_mul3(b.Ks, L.Tc), L.total / L.ps);
-    if (b.Rs > kBsdfEps) k = crh_mul3(k, sample_blinn(wo, wi, b.fb, b.Rs, rng, two_sided, ok));
+    k = crh_scale3(crh_mul3(b.Ks, L.Tc), L.total / L.ps); lobe = 2;
+    if (b.Rs > kBsdfEps) k = crh_mul3(k, sample_blinn(wo, wi, b.fb, b.Rs, rng, two_sided, ok, sp.u32));
     else { k = crh_mul3(k, fresnel_media(wo.z, b.fb)); wi = mirror; delta = true; }
   } else {
-    k = crh_scale3(crh_mul3(b.Kt, L.Tc), L.total / L.pt);
-    const float ior = b.fc.x > -2.5f ? 1.0f : b.fc.y;        // no dielectric coat: index-matched, straight through
+    k = crh_scale3(crh_mul3(b.Kt, L.Tc), L.total / L.pt); lobe = 3;
+    const float ior = b.fc.x > -2.5f ? sp.eta_nd : b.fc.y;   // no dielectric coat: crh_spec.eta_no_dielectric (default 1 = index-matched, straight through)
     const float eta = wo.z > 0.f ? 1.0f / ior : ior;
     const float sinT2 = (eta * eta) * CRH_FMA(-wo.z, wo.z, 1.0f);
     if (!(sinT2 < 1.0f) || !(L.pt > 0.f)) ok = false;
@@ -746,9 +780,11 @@ __device__ v3 env_lookup(const DScene& S, v3 d)
   int y0 = (int)yf; int y1 = y0 + 1;
   if (y0 < 0) y0 = 0; if (y0 > H - 1) y0 = H - 1; if (y1 < 0) y1 = 0; if (y1 > H - 1) y1 = H - 1;
   const float4 p00 = S.env[y0 * W + x0], p10 = S.env[y0 * W + x1], p01 = S.env[y1 * W + x0], p11 = S.env[y1 * W + x1];
-  return crh_mk3(lerpf(lerpf(p00.x, p10.x, fx), lerpf(p01.x, p11.x, fx), fy),
+  v3 r = crh_mk3(lerpf(lerpf(p00.x, p10.x, fx), lerpf(p01.x, p11.x, fx), fy),
                  lerpf(lerpf(p00.y, p10.y, fx), lerpf(p01.y, p11.y, fx), fy),
                  lerpf(lerpf(p00.z, p10.z, fx), lerpf(p01.z, p11.z, fx), fy));
+  if (S.spec_gamma2) r = crh_mul3(r, r);            // crh_spec.h #2: the filtered texel squared
+  return r;
 }
 
 __device__ __forceinline__ float cone_pdf(float cosmax) { return 1.0f / (CRH_TWO_PI * (1.0f - cosmax)); }
@@ -815,10 +851,12 @@ __device__ __forceinline__ float4 sample_texture(const DScene& S, uint32_t slot,
   int y1 = y0 + 1; if (y1 >= H) y1 = 0;
   const float4* tb = S.texels + td.x;
   const float4 p00 = tb[y0 * W + x0], p10 = tb[y0 * W + x1], p01 = tb[y1 * W + x0], p11 = tb[y1 * W + x1];
-  return make_float4(lerpf(lerpf(p00.x, p10.x, fx), lerpf(p01.x, p11.x, fx), fy),
-                     lerpf(lerpf(p00.y, p10.y, fx), lerpf(p01.y, p11.y, fx), fy),
-                     lerpf(lerpf(p00.z, p10.z, fx), lerpf(p01.z, p11.z, fx), fy),
-                     lerpf(lerpf(p00.w, p10.w, fx), lerpf(p01.w, p11.w, fx), fy));   // RGB images are stored with alpha 1
+  float4 r = make_float4(lerpf(lerpf(p00.x, p10.x, fx), lerpf(p01.x, p11.x, fx), fy),
+                         lerpf(lerpf(p00.y, p10.y, fx), lerpf(p01.y, p11.y, fx), fy),
+                         lerpf(lerpf(p00.z, p10.z, fx), lerpf(p01.z, p11.z, fx), fy),
+                         lerpf(lerpf(p00.w, p10.w, fx), lerpf(p01.w, p11.w, fx), fy));   // RGB images are stored with alpha 1
+  if (S.spec_gamma2) { r.x *= r.x; r.y *= r.y; r.z *= r.z; }      // crh_spec.h #2 (the alpha is a coverage, never squared)
+  return r;
 }
 
 constexpr uint32_t kGenIters = 32;     // k_raygen: 32 x 256 = 8192 path slots per queue reservation
@@ -919,7 +957,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
       // whole-frame passes share one frame seed per sample; adaptive passes give every tile its own sample index
       const uint32_t fseed = seed_per_tile ? seeds[local / (S.tile_size * S.tile_size)] : seeds[s];
       uint32_t rng = crh_rng_seed(pix, fseed);
-      const float jx = crh_rng_next(&rng), jy = crh_rng_next(&rng);
+      const float jx = crh_rng_next_mode(&rng, S.spec_u32), jy = crh_rng_next_mode(&rng, S.spec_u32);
       const float nx = CRH_FMA(((float)px + jx) / (float)S.width, 2.0f, -1.0f);
       const float ny = CRH_FMA(((float)py + jy) / (float)S.height, -2.0f, 1.0f);
       v3 o, d;
@@ -933,7 +971,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
         d = crh_norm3(crh_madd3(crh_madd3(S.fwd, S.right, sx), S.up, sy));
       }
       if (S.aperture > 0.f) {
-        const float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+        const float k1 = crh_rng_next_mode(&rng, S.spec_u32), k2 = crh_rng_next_mode(&rng, S.spec_u32);
         const float ft = S.focal / crh_dot3(d, S.fwd);
         const v3 focus = crh_madd3(o, d, ft);
         const float r = S.aperture * crh_sqrt(k1); float sn, cs; crh_sincos2pi(k2, &sn, &cs);
@@ -1025,7 +1063,9 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
         const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
         float M[12];
         v3 ng;
-        if (S.two_level) {                                   // object -> world through the instance's forward transform
+        // two-level scenes: s1.w = the object of a triangle that lives in an object tree (-1: a triangle of the static world-space tree)
+        const bool in_object = S.two_level && __float_as_int(s1.w) >= 0;
+        if (in_object) {                                     // object -> world through the instance's forward transform
           const float4* tp = S.tris + kTriStride * (uint32_t)hk;
           const float4 a = tp[0], b4 = tp[1], c4 = tp[2];
           const float4* ip = S.inst + 8u * (uint32_t)__float_as_int(s1.w);
@@ -1039,7 +1079,7 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
         v3 ns = crh_norm3(crh_mk3(CRH_FMA(s2.x, h.z, CRH_FMA(s1.x, h.y, s0.x * w0)),
                                   CRH_FMA(s2.y, h.z, CRH_FMA(s1.y, h.y, s0.y * w0)),
                                   CRH_FMA(s2.z, h.z, CRH_FMA(s1.z, h.y, s0.z * w0))));
-        if (S.two_level) ns = crh_norm3(crh_xform_vector(M, ns));
+        if (in_object) ns = crh_norm3(crh_xform_vector(M, ns));
         if (!(crh_dot3(ns, ns) > 0.f)) ns = ng;
         const v3 p = crh_madd3(o, d, h.x);
         int mat = __float_as_int(s0.w); if (mat < 0 || (uint32_t)mat >= S.n_mats) mat = 0;
@@ -1078,9 +1118,9 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
           const v3 z3 = crh_mk3(0.f, 0.f, 0.f);
           const v3 nd = crh_add3(bs.Kd, crh_add3(bs.Rc > kBsdfEps ? bs.Kc : z3, bs.Rs > kBsdfEps ? bs.Ks : z3));
           if (S.n_lights > 0u && crh_dot3(nd, W) > kBsdfEps) {
-            const float fl = crh_rng_next(&rng) * (float)S.n_lights;
+            const float fl = crh_rng_next_mode(&rng, S.spec_u32) * (float)S.n_lights;
             uint32_t li = (uint32_t)fl; if (li > S.n_lights - 1u) li = S.n_lights - 1u;
-            const float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+            const float k1 = crh_rng_next_mode(&rng, S.spec_u32), k2 = crh_rng_next_mode(&rng, S.spec_u32);
             const float4 l0 = S.lights[2u * li], l1 = S.lights[2u * li + 1u];
             v3 axis; float dist, cm;
             if (l0.w != 0.f) { const v3 tl = crh_sub3(xyz(l0), p); dist = crh_len3(tl); axis = crh_scale3(tl, 1.0f / dist); cm = sphere_cosmax(l1.w, dist); }
@@ -1106,13 +1146,13 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
         }
         // ---- BSDF sampling + Russian roulette (the last bounce has no successor ray)
         if (!last) {
-          v3 wi; bool delta; const v3 Wsel = W;
-          const bool alive = sample_layered(bs, wo, wi, W, inside, delta, rng, S.two_sided);
-          if (alive) imp_pdf = delta ? CRH_MAXFLOAT : pdf_layered(bs, wo, wi, Wsel, S.two_sided);
+          v3 wi; bool delta; const v3 Wsel = W; int lobe;
+          const bool alive = sample_layered(bs, wo, wi, W, inside, delta, rng, S.two_sided, SpecB{S.spec_u32, S.spec_eta_nd}, lobe);
+          if (alive) imp_pdf = delta ? CRH_MAXFLOAT : pdf_layered(bs, wo, wi, Wsel, S.two_sided, S.spec_mis1 ? lobe : -1);
           float survive = (W.x > kMinThroughput || W.y > kMinThroughput || W.z > kMinThroughput) ? 1.0f : 0.f;
           if (S.rr && bounce >= 3u)
             survive = crh_min(CRH_FMA(0.0722f, W.z, CRH_FMA(0.7152f, W.y, 0.2126f * W.x)), 0.95f) * survive;
-          const float kr = crh_rng_next(&rng);
+          const float kr = crh_rng_next_mode(&rng, S.spec_u32);
           if (alive && kr < survive) {
             if (S.rr && bounce >= 3u) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
             const v3 nd2 = crh_norm3(from_local(fr, wi));
@@ -1379,6 +1419,16 @@ __global__ __launch_bounds__(kBlock) void k_add4(float4* __restrict__ dst, const
   }
 }
 
+// crh_set_transforms, static / moved split: overwrite the 48-B triangle records at the listed leaf positions (an object leaving the static
+// tree: all-zero vertices, whose test yields NaN and rejects; coming back: the original vertices)
+__global__ __launch_bounds__(kBlock) void k_scatter_tris(float4* __restrict__ tris, const uint32_t* __restrict__ pos, const float4* __restrict__ recs, uint32_t n)
+{
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float4* d = tris + kTriStride * pos[i];
+    d[0] = recs[3u * i]; d[1] = recs[3u * i + 1u]; d[2] = recs[3u * i + 2u];
+  }
+}
+
 __global__ void k_debug_math(int fn, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                              float* __restrict__ out2, uint32_t n)
 {
@@ -1426,8 +1476,8 @@ __global__ void k_debug_bsdf(int fn, const float4* __restrict__ m, const float* 
     } else if (fn == 2) {
       uint32_t rng = __float_as_uint(b[3u * i]);
       bool inside = b[3u * i + 1u] != 0.f, delta = false;
-      v3 W = one, wi = crh_mk3(0.f, 0.f, 0.f);
-      const bool alive = sample_layered(bs, wo, wi, W, inside, delta, rng, two_sided);
+      v3 W = one, wi = crh_mk3(0.f, 0.f, 0.f); int lobe;
+      const bool alive = sample_layered(bs, wo, wi, W, inside, delta, rng, two_sided, SpecB{0, 1.0f}, lobe);
       float* o = out + 8u * i;
       o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; o[3] = W.x; o[4] = W.y; o[5] = W.z;
       o[6] = (float)((alive ? 1 : 0) | (delta ? 2 : 0) | (inside ? 4 : 0)); o[7] = __uint_as_float(rng);
@@ -1501,6 +1551,10 @@ void launch_tonemap(const Launch& L, const float4* accum, uint8_t* out, uint32_t
 void launch_hdr(const Launch& L, const float4* accum, float* out, uint32_t n)
 {
   hipLaunchKernelGGL(k_hdr, dim3(L.grid), dim3(kBlock), 0, L.stream, accum, out, n);
+}
+void launch_scatter_tris(const Launch& L, float4* tris, const uint32_t* pos, const float4* recs, uint32_t n)
+{
+  hipLaunchKernelGGL(k_scatter_tris, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, L.stream, tris, pos, recs, n);
 }
 void launch_add4(const Launch& L, float4* dst, const float4* src, uint32_t n)
 {

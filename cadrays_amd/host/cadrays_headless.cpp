@@ -13,6 +13,7 @@
 // frame on context 0 -- bit-identical to the one-GPU image.
 // A path ending in .tcl is the reference's own saved-scene format (model.tcl + meshes/ + textures/, what File > Export writes and
 // ImportSettingsEditor.cxx:378-380 sources back in): read by host/model_tcl.hpp at WxH (default 512x512).
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -120,15 +121,25 @@ int main(int argc, char** argv)
       if ((rc = crh_render(c, 1))) return die_all(c, "crh_render", rc);
     if ((rc = crh_sync(c))) return die_all(c, "crh_sync", rc);
   } else {
-    // tile t -> context t mod gpus (the RT tile entry point, SettingsWidget.cxx:451-476); every context renders all
+    // k-th tile along the Z-order curve -> context k mod gpus (the RT tile entry point, SettingsWidget.cxx:451-476; the same interleave as
+    // cadrays_amd/sharding.py: neighbouring tiles cost about the same and land on different GPUs); every context renders all
     // frames of its own tiles with the one-GPU RNG, so the assembled image does not depend on the GPU count
-    const uint32_t ts = par.tile_size, n_tiles = ((par.width + ts - 1) / ts) * ((par.height + ts - 1) / ts);
+    const uint32_t ts = par.tile_size, tiles_x = (par.width + ts - 1) / ts, n_tiles = tiles_x * ((par.height + ts - 1) / ts);
+    std::vector<uint32_t> zorder(n_tiles);
+    {
+      auto spread = [](uint64_t v) { v = (v | (v << 16)) & 0x0000FFFF0000FFFFull; v = (v | (v << 8)) & 0x00FF00FF00FF00FFull; v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+                                     v = (v | (v << 2)) & 0x3333333333333333ull; return (v | (v << 1)) & 0x5555555555555555ull; };
+      for (uint32_t t = 0; t < n_tiles; ++t) zorder[t] = t;
+      std::stable_sort(zorder.begin(), zorder.end(), [&](uint32_t a, uint32_t b) {
+        return (spread(a % tiles_x) | (spread(a / tiles_x) << 1)) < (spread(b % tiles_x) | (spread(b / tiles_x) << 1)); });
+    }
     std::vector<int> rcs((size_t)n_gpus, 0);
     std::vector<std::thread> th;
     for (int g = 0; g < n_gpus; ++g)
       th.emplace_back([&, g] {
         std::vector<uint32_t> mine;
-        for (uint32_t t = (uint32_t)g; t < n_tiles; t += (uint32_t)n_gpus) mine.push_back(t);
+        for (uint32_t k = (uint32_t)g; k < n_tiles; k += (uint32_t)n_gpus) mine.push_back(zorder[k]);
+        std::sort(mine.begin(), mine.end());
         int r = mine.empty() ? 0 : crh_render_tiles(ctx[(size_t)g], mine.data(), (uint32_t)mine.size(), 0, (uint32_t)n_frames);
         if (!r) r = crh_sync(ctx[(size_t)g]);
         rcs[(size_t)g] = r;

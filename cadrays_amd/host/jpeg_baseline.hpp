@@ -153,16 +153,17 @@ inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::ve
     if (m == 0xFF) { ++o; continue; }
     if (m == 0xD9) { if (seen_scan) break; err = path + ": no image data"; return false; }
     const int L = be16(o + 2);
-    if (o + 2 + (size_t)L > d.size()) { err = path + ": truncated JPEG segment"; return false; }
-    const uint8_t* p = &d[o + 4]; const int n = L - 2;
-    if (m == 0xDB) { for (int k = 0; k < n;) { const int pq = p[k] >> 4, tq = p[k] & 15; ++k; if (tq > 3 || pq > 1) { err = path + ": bad quantisation table"; return false; }
+    if (L < 2 || o + 2 + (size_t)L > d.size()) { err = path + ": truncated JPEG segment"; return false; }      // L counts its own two bytes
+    const uint8_t* p = &d[o + 4]; const int n = L - 2;       // payload p[0 .. n): every fixed-size read below is checked against n first
+    if (m == 0xDB) { for (int k = 0; k < n;) { const int pq = p[k] >> 4, tq = p[k] & 15; ++k; if (tq > 3 || pq > 1 || k + 64 * (1 + pq) > n) { err = path + ": bad quantisation table"; return false; }
         for (int i = 0; i < 64; ++i) { qt[tq][zz[i]] = pq ? (uint16_t)((p[k] << 8) | p[k + 1]) : p[k]; k += pq ? 2 : 1; } } }
-    else if (m == 0xC4) { for (int k = 0; k < n;) { const int tc = p[k] >> 4, th = p[k] & 15; ++k; if (th > 3 || tc > 1) { err = path + ": bad Huffman table"; return false; }
+    else if (m == 0xC4) { for (int k = 0; k < n;) { const int tc = p[k] >> 4, th = p[k] & 15; ++k; if (th > 3 || tc > 1 || k + 16 > n) { err = path + ": bad Huffman table"; return false; }
         JpegHuff& h = tc ? hac[th] : hdc[th]; int cnt = 0; for (int l = 1; l <= 16; ++l) { h.bits[l] = p[k + l - 1]; cnt += h.bits[l]; } k += 16;
         if (cnt > 256 || k + cnt > n) { err = path + ": bad Huffman table"; return false; }
         memcpy(h.vals, p + k, (size_t)cnt); k += cnt; jpeg_build_huff(h); } }
     else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
       if (have_sof) { err = path + ": second frame header"; return false; }
+      if (n < 6 || n < 6 + 3 * (int)p[5]) { err = path + ": truncated frame header"; return false; }
       if (p[0] != 8) { err = path + ": only 8-bit JPEG images are read"; return false; }
       progressive = m == 0xC2;
       H = (uint32_t)be16(o + 5); W = (uint32_t)be16(o + 7); nc = p[5];
@@ -182,10 +183,11 @@ inline bool read_jpeg(const std::string& path, uint32_t& W, uint32_t& H, std::ve
       have_sof = true;
     }
     else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) { err = path + ": lossless / hierarchical / arithmetic-coded JPEG is not read"; return false; }
-    else if (m == 0xDD) restart = be16(o + 4);
+    else if (m == 0xDD) { if (n < 2) { err = path + ": truncated restart interval"; return false; } restart = be16(o + 4); }
     else if (m == 0xEE && n >= 12 && memcmp(p, "Adobe", 5) == 0) adobe_transform = p[11];
     else if (m == 0xDA) {
       if (!have_sof) { err = path + ": scan before frame header"; return false; }
+      if (n < 1) { err = path + ": bad scan header"; return false; }
       const int ns = p[0]; if (ns < 1 || ns > nc || n < 4 + 2 * ns) { err = path + ": bad scan header"; return false; }
       int sc[3];
       for (int k = 0; k < ns; ++k) { int c = 0; while (c < nc && comp[c].id != p[1 + 2 * k]) ++c; if (c == nc) { err = path + ": scan of an unknown component"; return false; }

@@ -75,7 +75,7 @@ inline bool read_png(const std::string& path, uint32_t& w, uint32_t& h, uint32_t
     const uint32_t len = be32(o); const std::string type((const char*)&d[o + 4], 4);
     if (o + 12 + len > d.size()) break;
     const uint8_t* p = &d[o + 8];
-    if (type == "IHDR") { w = be32(o + 8); h = be32(o + 12); depth = p[8]; ctype = p[9]; interlace = p[12]; }
+    if (type == "IHDR") { if (len < 13) { err = path + ": truncated PNG header"; return false; } w = be32(o + 8); h = be32(o + 12); depth = p[8]; ctype = p[9]; interlace = p[12]; }
     else if (type == "PLTE") plte.assign(p, p + len);
     else if (type == "tRNS") trns.assign(p, p + len);
     else if (type == "IDAT") idat.insert(idat.end(), p, p + len);

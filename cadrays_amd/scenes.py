@@ -76,6 +76,7 @@ class Scene:
     tri_object: Optional[np.ndarray] = None   # (nT,) int32 object id per triangle  } two-level BVH: vertices in object space,
     obj_xform: Optional[np.ndarray] = None    # (nO, 12) row-major 3x4 transforms   } one tree per object + a top-level tree
     name: str = "scene"
+    spec: Optional[dict] = None               # switches of include/crh_spec.h that differ from the defaults (None: the frozen spec)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -323,3 +324,39 @@ def baseline_config(which, width=None, height=None, n_tris=None):
                      params=Params(width=width or w, height=height or h, max_depth=10, radiance_clamp=30.0, seed=1),
                      name=f"{which}_{n}")
     raise ValueError(which)
+
+
+def spec_switch_scene(width=96, height=80):
+    """A small scene in which EVERY switch of include/crh_spec.h changes the image (the reference's own CornellBox.tcl / Materials.tcl
+    have no texture, no environment map and no transmitting material under a non-dielectric coat, so they cannot tell switches 2 and 7
+    apart): the Cornell room of data/scripts/CornellBox.tcl with an 8-bit-range environment and a textured, coated, glossy wall material
+    (texel_gamma2), a sphere light + a cone light over glossy and coated lobes (mis_single_lobe), a transmitting box under a Schlick
+    coat (eta_no_dielectric), several bounces (eps_rule) -- and random numbers everywhere (uniform_32bit).  Exportable in the
+    application's own scene format (cadrays_amd.scene_tcl.write_scene), so the real renderer can load it: tools/occt_pin."""
+    import dataclasses
+    sc = cornell_box(True, width, height)
+    mats = list(sc.materials)
+    thin = BSDF.CreateDiffuse((0.2, 0.2, 0.2))
+    thin.Kt = np.array([0.7, 0.7, 0.7], np.float32)
+    thin.Kc = np.array([0.3, 0.3, 0.3, 0.2], np.float32)
+    thin.FresnelCoat = Fresnel.CreateSchlick((0.1, 0.1, 0.1))
+    thin.Normalize()
+    mats[4] = thin                                     # the second inner box: transmission under a NON-dielectric coat
+    glossy = BSDF.CreateDiffuse((0.4, 0.4, 0.4))
+    glossy.Ks = np.array([0.5, 0.5, 0.5, 0.15], np.float32); glossy.FresnelBase = Fresnel.CreateSchlick((0.8, 0.8, 0.8))
+    glossy.Kc = np.array([0.6, 0.6, 0.6, 0.25], np.float32); glossy.FresnelCoat = Fresnel.CreateDielectric(1.5)
+    glossy.texture = 0
+    glossy.Normalize()
+    mats[2] = glossy                                   # the white walls: diffuse + glossy + rough coat, textured
+    r = np.random.default_rng(3)
+    uv = r.random((len(sc.pos), 2)).astype(np.float32)
+    tex = (np.round((0.25 + 0.75 * r.random((5, 7, 4))) * 255.0) / 255.0).astype(np.float32)      # exactly representable in an 8-bit PNG
+    tex[..., :3] = tex[..., :3] * tex[..., :3]                                                      # as a reader hands it over: rgb squared
+    env = np.clip(procedural_sky(32, 16, 2, sun=1.0), 0.0, 1.0)
+    env = (np.round(np.sqrt(env) * 255.0) / 255.0).astype(np.float32) ** 2                          # an 8-bit image, linearised by squaring
+    par = dataclasses.replace(sc.params, max_depth=6, env_as_background=True)
+    cam = dataclasses.replace(sc.camera, eye=(0.5, -1.2, 0.5))
+    return dataclasses.replace(sc, materials=mats, uv=uv, textures=[tex], env=env.astype(np.float32),
+                               lights=[Light.positional((0.5, 0.5, 0.85), smoothness=0.12, intensity=12.0),
+                                       Light.directional((-0.2, 0.4, -1.0), smoothness=0.2, intensity=2.0)],
+                               params=par, camera=cam, name="switches")

@@ -14,6 +14,8 @@
 
 #include <stdint.h>
 
+#include "crh_spec.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -128,20 +130,23 @@ CRH_API const char* crh_last_error(crh_ctx* ctx);
 /* geometry == what AIS Display/SetLocation feeds OpenGl_SceneGeometry: indexed
  * triangle arrays with normals (+uv) and a material id per triangle
  * (AisMesh.cxx:357-423), per-object 3x4 row-major transforms (DataNode.cxx:239-242).
- * With tri_object + obj_xform the scene is a TWO-LEVEL BVH like OCCT's: vertices are in object space, every
- * object gets its own tree, a top-level tree over the instances' world boxes carries the transforms (each vertex
- * must belong to one object).  Without them the arrays are world space and one tree is built.  A scene whose obj_xform are ALL exactly
- * the identity (a CADRays scene until something is dragged) is built as that one tree too -- same images and counters as without
- * objects, single-level speed -- until crh_set_transforms moves an object. */
+ * With tri_object + obj_xform the scene is a TWO-LEVEL BVH like OCCT's: vertices are in object space (each vertex must belong to one
+ * object), an object with a transform gets its own tree and a top-level tree over the instances' world boxes carries the transforms.
+ * Without them the arrays are world space and one tree is built.  STATIC / MOVED SPLIT: the objects whose obj_xform is exactly the
+ * identity at crh_build (imported meshes and shapes sit where their vertices say until something is dragged) share ONE world-space tree;
+ * a scene in which every object is at the identity is that tree alone -- same images, counters and speed as without objects.  Rays walk the
+ * static tree first and then the top-level tree of the moved objects (skipped when the ray misses their bounds). */
 CRH_API int crh_set_geometry(crh_ctx* ctx,
                      const float* pos, const float* nrm, const float* uv, uint32_t n_vertices,
                      const int32_t* tri /* 4*nT: i0,i1,i2,material */, uint32_t n_triangles,
                      const int32_t* tri_object /* nT or NULL */,
                      const float* obj_xform /* 12*nO or NULL */, uint32_t n_objects);
 /* == AIS_InteractiveObject::SetLocalTransformation / the manipulator moving an object (ImRaytraceControls.cxx:58-89,
- * DataNode.cxx:239-242): new 3x4 transforms for the n_objects of the two-level scene.  Only the top-level tree is
- * rebuilt (object trees and triangles stay in HBM untouched); restarts accumulation.  One exception: the call that takes a scene
- * from "every object at the identity" (built as one tree) to "something moved", or back, is a full crh_build. */
+ * DataNode.cxx:239-242): new 3x4 transforms for the n_objects of the two-level scene.  Only the top-level tree is rebuilt; restarts
+ * accumulation.  The static tree is never rebuilt: when an object in it leaves the identity, its triangles there are disabled in place
+ * (their leaves stay, the test rejects) and the object gets a tree of its own -- built the first time, a few hundred microseconds per
+ * thousand triangles, and kept; when it returns to the identity its triangles are restored and the instance is dropped.  The result
+ * depends on the transforms given to crh_build (which objects share the static tree) and on the current ones, not on the calls in between. */
 CRH_API int crh_set_transforms(crh_ctx* ctx, const float* obj_xform /* 12*nO */, uint32_t n_objects);
 /* == Graphic3d_MaterialAspect::SetBSDF + SynchronizeAspects (MaterialEditor.cxx:331-337, Utils.cxx:57-93) */
 CRH_API int crh_set_materials(crh_ctx* ctx, const crh_bsdf* m, uint32_t n);
@@ -159,6 +164,12 @@ CRH_API int crh_set_texture(crh_ctx* ctx, uint32_t slot, const float* texels, ui
 CRH_API int crh_set_camera(crh_ctx* ctx, const crh_camera* cam);
 /* == ChangeRenderingParams() field writes (SettingsWidget.cxx:263-477) */
 CRH_API int crh_set_params(crh_ctx* ctx, const crh_params* p);
+/* The switches of crh_spec.h: where this backend's frozen spec departs from the (recollected, unverifiable) arithmetic of OCCT's
+ * shaders behind V3d_View::Redraw() (AppViewer.cxx:1047).  Defaults = the spec every golden vector was generated with.  Setting
+ * them restarts accumulation.  crh_spec_order_exact() reports the one build-time switch (CRH_SPEC_ORDER_EXACT) of this library. */
+CRH_API int crh_set_spec(crh_ctx* ctx, const crh_spec* spec);
+CRH_API int crh_get_spec(crh_ctx* ctx, crh_spec* spec_out);
+CRH_API int crh_spec_order_exact(void);
 /* == OCCT updateRaytraceGeometry + uploadRaytraceData on a changed scene: BVH build,
  * QBVH collapse, upload.  Invalidates the accumulator. */
 CRH_API int crh_build(crh_ctx* ctx);
@@ -254,9 +265,11 @@ CRH_API int crh_get_stats(crh_ctx* ctx, crh_stats* out);
 CRH_API int crh_trace_nearest(crh_ctx* ctx, const float* rays, uint32_t n, float* out_hit);
 CRH_API int crh_trace_any(crh_ctx* ctx, const float* rays, uint32_t n, uint32_t* out_vis);
 /* Copy out the built QBVH: nodes (16 dwords = 64 B each, layout in crh_bvh_format.h) and the leaf-ordered triangle
- * records (12 floats = 48 B each).  Pass NULL buffers to query the counts. */
+ * records (12 floats = 48 B each; n_tris = leaf positions in use: a two-level scene holds a second, object-tree copy of every object that
+ * was dragged out of the static tree, and all-zero vertices where such an object's triangles are disabled).  Pass NULL buffers to query the counts. */
 CRH_API int crh_get_bvh(crh_ctx* ctx, float* nodes, uint32_t* n_nodes, float* tris, uint32_t* n_tris);
-/* Two-level scenes: index of the top-level root in the node array, instance count, number of object-tree nodes. */
+/* Two-level scenes: index of the top-level root in the node array (0 when no object is an instance), number of objects rendered as
+ * instances right now, number of nodes in front of the top-level tree (static tree + object trees built so far). */
 CRH_API int crh_get_tlas(crh_ctx* ctx, uint32_t* root, uint32_t* n_instances, uint32_t* n_blas_nodes);
 /* Host-only: run the BVH builder (no device needed) and copy out nodes / leaf-ordered triangles.
  * Call with NULL outputs to get the counts.  == BVH_BinnedBuilder + CollapseToQuadTree. */

@@ -246,5 +246,14 @@ CRH_HD float crh_rng_next(uint32_t* state)
   *state = s;
   return (float)(s >> 8) * 5.9604644775390625e-8f;  /* 2^-24 */
 }
+/* the same stream with crh_spec.uniform_32bit (crh_spec.h #1) selectable: full32 != 0 -> float(state) * 2^-32 (round to nearest;
+ * the top 128 states give exactly 1.0), as recollected from OCCT's RandFloat() */
+CRH_HD float crh_rng_next_mode(uint32_t* state, int full32)
+{
+  uint32_t s = *state;
+  s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+  *state = s;
+  return full32 ? (float)s * 2.3283064365386963e-10f : (float)(s >> 8) * 5.9604644775390625e-8f;
+}
 
 #endif /* CRH_MATH_H */

@@ -65,6 +65,11 @@ typedef struct { uint64_t nodes, tris, nodes_any, tris_any; } trav_counters;
 #define ORC_COUNT(x) (x)
 #endif
 typedef struct orc_instance { float fwd[12], inv[12]; float bmin[3], bmax[3]; uint32_t root, obj; } orc_instance;
+/* per object of a two-level scene ("static / moved split"): static0 = at the identity when the scene was built (its
+ * triangles are in the static world-space tree); is_inst = rendered through its own object tree + the top level right now (static0 objects:
+ * while they are off the identity -- their triangles in the static tree are disabled meanwhile); the object tree is built the first time
+ * it is needed and kept */
+typedef struct orc_object { uint8_t static0, built, is_inst; uint32_t root, first, ntri; float bmin[3], bmax[3]; } orc_object;
 
 typedef struct orc_ctx {
   /* inputs */
@@ -74,13 +79,20 @@ typedef struct orc_ctx {
   float* env; uint32_t envW, envH;
   struct { float* rgb; uint32_t w, h, ch; } tex[64]; uint32_t nTex;   /* ch = 3 (RGB) or 4 (RGBA) floats per texel */
   crh_camera cam; crh_params par;
+  crh_spec spec;                  /* include/crh_spec.h: the switchable departures from the recollected OCCT behaviour */
   /* derived */
   qnode* nodes; uint32_t nNodes; qtri* qtris; uint32_t nQT;
   /* two-level mode (per-object transforms): object-space BLAS per object + TLAS over instance boxes */
   int two_level; uint32_t nO; float* xf; int32_t* tri_obj;
-  int flat;                        /* two_level scene whose transforms are ALL the identity: built and walked as ONE tree */
+  int flat;                        /* no object is rendered as an instance right now: the scene is ONE world-space tree */
   struct orc_instance* inst; uint32_t nInst; uint32_t nBlasNodes; uint32_t root;
   uint32_t* tlas_order;          /* instance at top-level leaf position i */
+  orc_object* obj; uint32_t* obj_tris;   /* per object; its triangles (input order) at obj_tris[first .. first + ntri) */
+  uint32_t* static_pos;          /* leaf position of triangle t in the static tree (objects with static0) */
+  uint32_t n_static, n_static_live; float sbmin[3], sbmax[3];   /* triangles in the static tree, those not disabled; its bounds */
+  uint32_t root2;                /* top-level root to walk AFTER the static tree (QBVH_EMPTY: none) and the bounds of the instances */
+  float tlas_lo[3], tlas_hi[3];
+  uint32_t capNodes, capQT;
   float bbmin[3], bbmax[3]; float eps;
   int built;
   uint32_t frames_done;          /* whole-frame iterations since the last restart: orc_render continues from here (like crh_render) */
@@ -300,46 +312,101 @@ static void emit_tri(const orc_ctx* c, qtri* q, uint32_t t)
   q->f[3] = crh_u2f(t);
 }
 
-/* (re)build the top-level tree over the instances' world boxes; keeps the BLAS nodes [0, nBlasNodes) */
+/* every object at the identity: the scene is one world-space tree -- no top level, no ray transforms (spec: same result as the same
+ * triangles handed over without objects) */
+static int is_identity(const float* m)
+{
+  static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  for (int k = 0; k < 12; ++k) if (m[k] != I[k]) return 0;
+  return 1;
+}
+
+/* (re)build the top-level tree over the world boxes of the objects that are rendered as instances right now (ascending object
+ * index); keeps the static tree and the object trees [0, nBlasNodes).  Sets the walk's entry points: no instance -> the static tree
+ * alone (flat); instances and live static triangles -> static tree first, then the top level (root2) if the ray touches the
+ * instances' bounds; no live static triangle -> the top level alone. */
 static void build_tlas(orc_ctx* c)
 {
-  uint32_t n = c->nInst;
+  uint32_t n = 0;
+  for (uint32_t ob = 0; ob < c->nO; ++ob) if (c->obj[ob].is_inst) ++n;
+  free(c->inst); c->inst = (orc_instance*)calloc(n ? n : 1, sizeof(orc_instance)); c->nInst = n;
   aabb* pb = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
   uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
   aabb sb; aabb_empty(&sb);
-  for (uint32_t i = 0; i < n; ++i) {
+  uint32_t i = 0;
+  for (uint32_t ob = 0; ob < c->nO; ++ob) {
+    if (!c->obj[ob].is_inst) continue;
     orc_instance* in = &c->inst[i];
-    memcpy(in->fwd, &c->xf[12 * in->obj], sizeof in->fwd);
+    in->obj = ob; in->root = c->obj[ob].root;
+    for (int a = 0; a < 3; ++a) { in->bmin[a] = c->obj[ob].bmin[a]; in->bmax[a] = c->obj[ob].bmax[a]; }
+    memcpy(in->fwd, &c->xf[12 * ob], sizeof in->fwd);
     if (!crh_xform_inverse(in->fwd, in->inv)) memset(in->inv, 0, sizeof in->inv);
     crh_xform_box(in->fwd, in->bmin, in->bmax, pb[i].mn, pb[i].mx);
     aabb_grow(&sb, &pb[i]);
+    ++i;
   }
-  collapser C; C.qn = c->nodes; C.nq = c->nBlasNodes; C.capq = c->nBlasNodes > 1024 ? c->nBlasNodes : 1024;
-  C.qn = (qnode*)realloc(C.qn, sizeof(qnode) * C.capq);
-  c->root = build_tree(&C, pb, n, 1, 1, 0, order, NULL);
-  c->nodes = C.qn; c->nNodes = C.nq;
-  for (int a = 0; a < 3; ++a) { c->bbmin[a] = n ? sb.mn[a] : 0.f; c->bbmax[a] = n ? sb.mx[a] : 0.f; }
+  c->flat = n == 0; c->root2 = QBVH_EMPTY;
   free(c->tlas_order); c->tlas_order = order;
+  if (n == 0) {                                   /* one world-space tree */
+    c->root = 0; c->nNodes = c->nBlasNodes;
+    for (int a = 0; a < 3; ++a) { c->bbmin[a] = c->n_static ? c->sbmin[a] : 0.f; c->bbmax[a] = c->n_static ? c->sbmax[a] : 0.f; }
+    free(pb);
+    return;
+  }
+  collapser C; C.qn = c->nodes; C.nq = c->nBlasNodes; C.capq = c->capNodes;
+  const uint32_t troot = build_tree(&C, pb, n, 1, 1, 0, order, NULL);
+  c->nodes = C.qn; c->nNodes = C.nq; c->capNodes = C.capq;
+  for (int a = 0; a < 3; ++a) { c->tlas_lo[a] = sb.mn[a]; c->tlas_hi[a] = sb.mx[a]; }
+  if (c->n_static_live) {
+    c->root = 0; c->root2 = troot;
+    for (int a = 0; a < 3; ++a) { c->bbmin[a] = crh_min(sb.mn[a], c->sbmin[a]); c->bbmax[a] = crh_max(sb.mx[a], c->sbmax[a]); }
+  } else {
+    c->root = troot;
+    for (int a = 0; a < 3; ++a) { c->bbmin[a] = sb.mn[a]; c->bbmax[a] = sb.mx[a]; }
+  }
   free(pb);
 }
 
-/* every object at the identity: the scene is one world-space tree -- no top level, no ray transforms (spec: same result as the same
- * triangles handed over without objects); the first crh_set_transforms that moves an object rebuilds it two-level */
-static int all_identity(const float* xf, uint32_t nO)
+/* the object-space tree of object ob, appended behind the trees built so far; its triangles take the next leaf positions */
+static void build_object_tree(orc_ctx* c, collapser* C, uint32_t ob)
 {
-  static const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-  for (uint32_t o = 0; o < nO; ++o) for (int k = 0; k < 12; ++k) if (xf[12 * o + k] != I[k]) return 0;
-  return 1;
+  orc_object* o = &c->obj[ob];
+  const uint32_t m = o->ntri; const uint32_t* mem = &c->obj_tris[o->first];
+  aabb* pb = (aabb*)malloc(sizeof(aabb) * m);
+  uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * m);
+  for (uint32_t i = 0; i < m; ++i) tri_box(c, mem[i], &pb[i]);
+  aabb box;
+  if (c->nQT + m > c->capQT) { c->capQT = 2 * (c->nQT + m); c->qtris = (qtri*)realloc(c->qtris, sizeof(qtri) * c->capQT); }
+  o->root = build_tree(C, pb, m, BVH_LEAF, 0, c->nQT, order, &box);
+  for (int a = 0; a < 3; ++a) { o->bmin[a] = box.mn[a]; o->bmax[a] = box.mx[a]; }
+  for (uint32_t i = 0; i < m; ++i) emit_tri(c, &c->qtris[c->nQT + i], mem[order[i]]);
+  c->nQT += m; o->built = 1;
+  free(pb); free(order);
+}
+
+/* a static0 object leaves / returns to the identity: its triangles in the static tree are disabled (all-zero vertices: the test yields
+ * NaN and rejects) / restored; the tree's boxes do not change */
+static void set_static_triangles(orc_ctx* c, uint32_t ob, int live)
+{
+  const orc_object* o = &c->obj[ob];
+  for (uint32_t i = 0; i < o->ntri; ++i) {
+    const uint32_t t = c->obj_tris[o->first + i];
+    qtri* q = &c->qtris[c->static_pos[t]];
+    if (live) emit_tri(c, q, t);
+    else { memset(q->f, 0, sizeof q->f); q->f[3] = crh_u2f(t); }
+  }
+  if (live) c->n_static_live += o->ntri; else c->n_static_live -= o->ntri;
 }
 
 static int do_build(orc_ctx* c)
 {
   uint32_t n = c->nT;
-  c->flat = c->two_level && all_identity(c->xf, c->nO);
-  free(c->nodes); free(c->qtris); free(c->inst); c->nodes = NULL; c->qtris = NULL; c->inst = NULL; c->nInst = 0; c->root = 0;
-  c->qtris = (qtri*)malloc(sizeof(qtri) * (n ? n : 1)); c->nQT = n;
+  free(c->nodes); free(c->qtris); free(c->inst); free(c->obj); free(c->obj_tris); free(c->static_pos);
+  c->nodes = NULL; c->qtris = NULL; c->inst = NULL; c->obj = NULL; c->obj_tris = NULL; c->static_pos = NULL; c->nInst = 0; c->root = 0; c->root2 = QBVH_EMPTY;
+  c->capQT = n ? n : 1;
+  c->qtris = (qtri*)malloc(sizeof(qtri) * c->capQT); c->nQT = n;
   collapser C; C.capq = 1024; C.nq = 0; C.qn = (qnode*)malloc(sizeof(qnode) * C.capq);
-  if (!c->two_level || c->flat) {
+  if (!c->two_level) {
     aabb* pb = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
     uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
     for (uint32_t t = 0; t < n; ++t) tri_box(c, t, &pb[t]);
@@ -347,31 +414,41 @@ static int do_build(orc_ctx* c)
     build_tree(&C, pb, n, BVH_LEAF, 0, 0, order, &sb);
     for (uint32_t i = 0; i < n; ++i) emit_tri(c, &c->qtris[i], order[i]);
     for (int a = 0; a < 3; ++a) { c->bbmin[a] = n ? sb.mn[a] : 0.f; c->bbmax[a] = n ? sb.mx[a] : 0.f; }
-    c->nodes = C.qn; c->nNodes = C.nq; c->nBlasNodes = C.nq;
+    c->nodes = C.qn; c->nNodes = C.nq; c->nBlasNodes = C.nq; c->capNodes = C.capq; c->flat = 0;
     free(pb); free(order);
     return 0;
   }
-  /* two-level: one object-space tree per non-empty object (triangles in input order), then the top-level tree */
-  c->inst = (orc_instance*)calloc(c->nO ? c->nO : 1, sizeof(orc_instance));
-  uint32_t* members = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
-  aabb* pb = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
-  uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
-  uint32_t tri_base = 0;
-  for (uint32_t ob = 0; ob < c->nO; ++ob) {
-    uint32_t m = 0;
-    for (uint32_t t = 0; t < n; ++t) if ((uint32_t)c->tri_obj[t] == ob) members[m++] = t;
-    if (!m) continue;
-    for (uint32_t i = 0; i < m; ++i) tri_box(c, members[i], &pb[i]);
-    aabb ob_box;
-    orc_instance* in = &c->inst[c->nInst++];
-    in->obj = ob;
-    in->root = build_tree(&C, pb, m, BVH_LEAF, 0, tri_base, order, &ob_box);
-    for (int a = 0; a < 3; ++a) { in->bmin[a] = ob_box.mn[a]; in->bmax[a] = ob_box.mx[a]; }
-    for (uint32_t i = 0; i < m; ++i) emit_tri(c, &c->qtris[tri_base + i], members[order[i]]);
-    tri_base += m;
+  /* two-level: the objects at the identity share ONE world-space tree (the static tree, first in the node array, its triangles first in
+   * leaf order); every other non-empty object gets an object-space tree (triangles in input order); then the top-level tree */
+  c->obj = (orc_object*)calloc(c->nO ? c->nO : 1, sizeof(orc_object));
+  c->obj_tris = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  c->static_pos = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  for (uint32_t t = 0; t < n; ++t) c->obj[c->tri_obj[t]].ntri++;
+  { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { c->obj[ob].first = acc; acc += c->obj[ob].ntri; c->obj[ob].ntri = 0; c->obj[ob].static0 = (uint8_t)is_identity(&c->xf[12 * ob]); } }
+  for (uint32_t t = 0; t < n; ++t) { orc_object* o = &c->obj[c->tri_obj[t]]; c->obj_tris[o->first + o->ntri++] = t; }
+  uint32_t nS = 0;
+  for (uint32_t t = 0; t < n; ++t) if (c->obj[c->tri_obj[t]].static0) ++nS;
+  c->n_static = c->n_static_live = nS; c->nQT = 0;
+  if (nS) {
+    aabb* pb = (aabb*)malloc(sizeof(aabb) * nS);
+    uint32_t* list = (uint32_t*)malloc(sizeof(uint32_t) * nS); uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * nS);
+    uint32_t k = 0;
+    for (uint32_t t = 0; t < n; ++t) if (c->obj[c->tri_obj[t]].static0) { tri_box(c, t, &pb[k]); list[k++] = t; }
+    aabb sb;
+    build_tree(&C, pb, nS, BVH_LEAF, 0, 0, order, &sb);
+    for (uint32_t i = 0; i < nS; ++i) { emit_tri(c, &c->qtris[i], list[order[i]]); c->static_pos[list[order[i]]] = i; }
+    for (int a = 0; a < 3; ++a) { c->sbmin[a] = sb.mn[a]; c->sbmax[a] = sb.mx[a]; }
+    c->nQT = nS;
+    free(pb); free(list); free(order);
   }
-  c->nodes = C.qn; c->nBlasNodes = C.nq; c->nNodes = C.nq;
-  free(members); free(pb); free(order);
+  c->nodes = C.qn;
+  for (uint32_t ob = 0; ob < c->nO; ++ob) {
+    orc_object* o = &c->obj[ob];
+    if (o->static0 || !o->ntri) continue;
+    build_object_tree(c, &C, ob);
+    o->is_inst = 1;
+  }
+  c->nodes = C.qn; c->nBlasNodes = C.nq; c->nNodes = C.nq; c->capNodes = C.capq;
   build_tlas(c);
   return 0;
 }
@@ -415,6 +492,16 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
   h->t = tmax; h->u = 0.f; h->v = 0.f; h->prim = -1;
   const v3 wo = o, wd = d;                       /* the world-space ray (restored when an object is left) */
   uint32_t cur = c->root;
+  if (c->root2 != QBVH_EMPTY) {
+    /* static tree first; the top-level tree over the moved objects waits at the bottom of the stack -- if the ray touches their bounds at
+     * all (same planes + guard band as a node's child test) */
+    const float ax_ = (c->tlas_lo[0] - o.x) * ix, bx_ = (c->tlas_hi[0] - o.x) * ix;
+    const float ay_ = (c->tlas_lo[1] - o.y) * iy, by_ = (c->tlas_hi[1] - o.y) * iy;
+    const float az_ = (c->tlas_lo[2] - o.z) * iz, bz_ = (c->tlas_hi[2] - o.z) * iz;
+    const float tn_ = crh_max(crh_max(crh_max(crh_min(ax_, bx_) - gx, crh_min(ay_, by_) - gy), crh_min(az_, bz_) - gz), 0.f);
+    const float tf_ = crh_min(crh_min(crh_min(crh_max(ax_, bx_) + gx, crh_max(ay_, by_) + gy), crh_max(az_, bz_) + gz), tmax);
+    if (tn_ <= tf_) stack[sp++] = c->root2;
+  }
   for (;;) {
     if ((cur & 0xF0000000u) == CRH_REF_INSTANCE_TAG) {
       /* top-level leaf: express the ray in the object's space (direction NOT renormalised, so t is unchanged),
@@ -443,7 +530,12 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
       const float bix = CRH_FMA(ddx, ix, -gx), box = CRH_FMA(ddx, ix, gx);
       const float biy = CRH_FMA(ddy, iy, -gy), boy = CRH_FMA(ddy, iy, gy);
       const float biz = CRH_FMA(ddz, iz, -gz), boz = CRH_FMA(ddz, iz, gz);
-      uint32_t key[4]; uint32_t rf[4]; int nh = 0;
+#if CRH_SPEC_ORDER_EXACT
+      uint64_t key[4];           /* crh_spec.h #4: exact entry distance, ties by slot */
+#else
+      uint32_t key[4];
+#endif
+      uint32_t rf[4]; int nh = 0;
       const int nch = (int)CRH_NODE_NCHILDREN(ew);
       for (int k = 0; k < nch; ++k) {
         uint32_t r = crh_node_child_ref(q->w, (uint32_t)k);
@@ -461,7 +553,11 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
           /* order key: entry distance with the slot index in the two low mantissa bits -> unique keys,
            * ascending unsigned order == near-to-far, ties by slot */
           int32_t bits = (int32_t)crh_f2u(tmin); if (bits < 0) bits = 0;
+#if CRH_SPEC_ORDER_EXACT
+          uint64_t ky = ((uint64_t)(uint32_t)bits << 2) | (uint64_t)k;
+#else
           uint32_t ky = ((uint32_t)bits & ~3u) | (uint32_t)k;
+#endif
           int j = nh++;
           while (j > 0 && key[j - 1] > ky) { key[j] = key[j - 1]; rf[j] = rf[j - 1]; --j; }
           key[j] = ky; rf[j] = r;
@@ -580,8 +676,9 @@ static float blinn_pdf(float hz, float dotih, float rough)
   return (((e + 2.0f) * CRH_INV_TWOPI) * crh_pow(crh_abs(hz), e + 1.0f)) / (4.0f * crh_abs(dotih));
 }
 
-/* mixture pdf of the non-delta lobes for direction wi (solid angle) */
-static float pdf_layered(const bsdf_t* b, v3 wo, v3 wi, v3 W, int two_sided)
+/* lobe < 0: mixture pdf of the non-delta lobes for direction wi (solid angle); lobe = 0 coat / 1 diffuse / 2 glossy: that lobe's pdf
+ * times its selection probability only (crh_spec.h #3) */
+static float pdf_layered(const bsdf_t* b, v3 wo, v3 wi, v3 W, int two_sided, int lobe)
 {
   lobes_t L; lobe_probs(b, W, &L);
   if (!(L.total > BSDF_EPS)) return 0.f;
@@ -590,17 +687,17 @@ static float pdf_layered(const bsdf_t* b, v3 wo, v3 wi, v3 W, int two_sided)
   if (wi.z > 0.f && wo.z > 0.f) {
     v3 h = crh_norm3(crh_add3(wi, wo));
     float dih = crh_dot3(wi, h);
-    pdf = L.pd * (wi.z * CRH_INV_PI);
-    if (b->Rc > BSDF_EPS) pdf = CRH_FMA(L.pc, blinn_pdf(h.z, dih, b->Rc), pdf);
-    if (b->Rs > BSDF_EPS) pdf = CRH_FMA(L.ps, blinn_pdf(h.z, dih, b->Rs), pdf);
+    if (lobe < 0 || lobe == 1) pdf = L.pd * (wi.z * CRH_INV_PI);
+    if (b->Rc > BSDF_EPS && (lobe < 0 || lobe == 0)) pdf = CRH_FMA(L.pc, blinn_pdf(h.z, dih, b->Rc), pdf);
+    if (b->Rs > BSDF_EPS && (lobe < 0 || lobe == 2)) pdf = CRH_FMA(L.ps, blinn_pdf(h.z, dih, b->Rs), pdf);
   }
   return pdf / L.total;
 }
 
 /* Blinn half-vector sampling; returns f*cos/pdf (without K), sets *ok = 0 for a failed sample */
-static v3 sample_blinn(v3 wo, v3* wi, const float fr[4], float rough, uint32_t* rng, int two_sided, int* ok)
+static v3 sample_blinn(v3 wo, v3* wi, const float fr[4], float rough, uint32_t* rng, int two_sided, int* ok, int u32)
 {
-  float k1 = crh_rng_next(rng), k2 = crh_rng_next(rng);
+  float k1 = crh_rng_next_mode(rng, u32), k2 = crh_rng_next_mode(rng, u32);
   float e = blinn_power(rough);
   float cm = crh_pow(k1, 1.0f / (e + 2.0f));
   float s, c; crh_sincos2pi(k2, &s, &c);
@@ -621,33 +718,35 @@ static v3 sample_blinn(v3 wo, v3* wi, const float fr[4], float rough, uint32_t* 
 
 /* Sample the layered BSDF.  In: wo, throughput *W (updated), *inside (toggled on transmission).
  * Out: wi (local), *delta = 1 when a delta lobe was chosen.  Returns 0 when the path dies. */
-static int sample_layered(const bsdf_t* b, v3 wo, v3* wi, v3* W, int* inside, int* delta, uint32_t* rng, int two_sided)
+static int sample_layered(const bsdf_t* b, v3 wo, v3* wi, v3* W, int* inside, int* delta, uint32_t* rng, int two_sided,
+                          const crh_spec* sp, int* lobe)
 {
+  const int u32 = sp->uniform_32bit;
   lobes_t L; lobe_probs(b, *W, &L);
-  float ksi = L.total * crh_rng_next(rng);
-  *delta = 0;
+  float ksi = L.total * crh_rng_next_mode(rng, u32);
+  *delta = 0; *lobe = 0;
   if (!(L.total > BSDF_EPS)) { *W = crh_mk3(0.f, 0.f, 0.f); return 0; }
   v3 mirror = crh_mk3(-wo.x, -wo.y, wo.z);
   int ok = 1; v3 k;
   if (ksi < L.pc) {                                           /* coat reflection */
     k = crh_scale3(b->Kc, L.total / L.pc);
-    if (b->Rc > BSDF_EPS) k = crh_mul3(k, sample_blinn(wo, wi, b->fc, b->Rc, rng, two_sided, &ok));
+    if (b->Rc > BSDF_EPS) k = crh_mul3(k, sample_blinn(wo, wi, b->fc, b->Rc, rng, two_sided, &ok, u32));
     else { k = crh_mul3(k, b->Fc); *wi = mirror; *delta = 1; }
   } else if (ksi < L.pc + L.pd) {                             /* diffuse base */
-    k = crh_scale3(crh_mul3(b->Kd, L.Tc), L.total / L.pd);
-    float k1 = crh_rng_next(rng), k2 = crh_rng_next(rng);
+    k = crh_scale3(crh_mul3(b->Kd, L.Tc), L.total / L.pd); *lobe = 1;
+    float k1 = crh_rng_next_mode(rng, u32), k2 = crh_rng_next_mode(rng, u32);
     float s, c; crh_sincos2pi(k1, &s, &c);
     float r = crh_sqrt(k2);
     *wi = crh_mk3(c * r, s * r, crh_sqrt(1.0f - k2));
     if (two_sided) { if (wo.z < 0.f) wi->z = -wi->z; }
     else if (!(wo.z > 0.f)) ok = 0;
   } else if (ksi < (L.pc + L.pd) + L.ps) {                    /* glossy base */
-    k = crh_scale3(crh_mul3(b->Ks, L.Tc), L.total / L.ps);
-    if (b->Rs > BSDF_EPS) k = crh_mul3(k, sample_blinn(wo, wi, b->fb, b->Rs, rng, two_sided, &ok));
+    k = crh_scale3(crh_mul3(b->Ks, L.Tc), L.total / L.ps); *lobe = 2;
+    if (b->Rs > BSDF_EPS) k = crh_mul3(k, sample_blinn(wo, wi, b->fb, b->Rs, rng, two_sided, &ok, u32));
     else { k = crh_mul3(k, fresnel_media(wo.z, b->fb)); *wi = mirror; *delta = 1; }
   } else {                                                    /* specular transmission */
-    k = crh_scale3(crh_mul3(b->Kt, L.Tc), L.total / L.pt);
-    float ior = b->fc[0] > -2.5f ? 1.0f : b->fc[1];         /* no dielectric coat: index-matched, straight through */
+    k = crh_scale3(crh_mul3(b->Kt, L.Tc), L.total / L.pt); *lobe = 3;
+    float ior = b->fc[0] > -2.5f ? sp->eta_no_dielectric : b->fc[1];   /* no dielectric coat: crh_spec.h #7 (default 1: index-matched, straight through) */
     float eta = wo.z > 0.f ? 1.0f / ior : ior;
     float sinT2 = (eta * eta) * CRH_FMA(-wo.z, wo.z, 1.0f);
     if (!(sinT2 < 1.0f) || !(L.pt > 0.f)) ok = 0;
@@ -700,9 +799,11 @@ static void apply_texture(const orc_ctx* c, const int32_t* ti, float w0, float u
   const float* img = c->tex[slot].rgb; const int ch = (int)c->tex[slot].ch;
   const float* p00 = &img[ch * (y0 * W + x0)]; const float* p10 = &img[ch * (y0 * W + x1)];
   const float* p01 = &img[ch * (y1 * W + x0)]; const float* p11 = &img[ch * (y1 * W + x1)];
-  b->Kd = crh_mul3(b->Kd, crh_mk3(lerpf(lerpf(p00[0], p10[0], fx), lerpf(p01[0], p11[0], fx), fy),
-                                  lerpf(lerpf(p00[1], p10[1], fx), lerpf(p01[1], p11[1], fx), fy),
-                                  lerpf(lerpf(p00[2], p10[2], fx), lerpf(p01[2], p11[2], fx), fy)));
+  v3 tx = crh_mk3(lerpf(lerpf(p00[0], p10[0], fx), lerpf(p01[0], p11[0], fx), fy),
+                  lerpf(lerpf(p00[1], p10[1], fx), lerpf(p01[1], p11[1], fx), fy),
+                  lerpf(lerpf(p00[2], p10[2], fx), lerpf(p01[2], p11[2], fx), fy));
+  if (c->spec.texel_gamma2) tx = crh_mul3(tx, tx);      /* crh_spec.h #2: the filtered texel squared (never the alpha) */
+  b->Kd = crh_mul3(b->Kd, tx);
   if (ch == 4) {
     float a = lerpf(lerpf(p00[3], p10[3], fx), lerpf(p01[3], p11[3], fx), fy);
     if (a != 1.0f) {
@@ -747,9 +848,11 @@ static v3 env_lookup(const orc_ctx* c, v3 d)
   if (y0 < 0) y0 = 0; if (y0 > H - 1) y0 = H - 1; if (y1 < 0) y1 = 0; if (y1 > H - 1) y1 = H - 1;
   const float* p00 = &c->env[3 * (y0 * W + x0)]; const float* p10 = &c->env[3 * (y0 * W + x1)];
   const float* p01 = &c->env[3 * (y1 * W + x0)]; const float* p11 = &c->env[3 * (y1 * W + x1)];
-  return crh_mk3(lerpf(lerpf(p00[0], p10[0], fx), lerpf(p01[0], p11[0], fx), fy),
+  v3 r = crh_mk3(lerpf(lerpf(p00[0], p10[0], fx), lerpf(p01[0], p11[0], fx), fy),
                  lerpf(lerpf(p00[1], p10[1], fx), lerpf(p01[1], p11[1], fx), fy),
                  lerpf(lerpf(p00[2], p10[2], fx), lerpf(p01[2], p11[2], fx), fy));
+  if (c->spec.texel_gamma2) r = crh_mul3(r, r);         /* crh_spec.h #2 */
+  return r;
 }
 
 static float cone_pdf(float cosmax) { return 1.0f / (CRH_TWO_PI * (1.0f - cosmax)); }
@@ -792,7 +895,8 @@ static v3 intersect_light(const orc_ctx* c, v3 o, v3 d, int bounce, float hit_t_
 /* ================================================================== path integrator (a13) */
 static void gen_camera_ray(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t* rng, v3* o, v3* d)
 {
-  float jx = crh_rng_next(rng), jy = crh_rng_next(rng);
+  const int u32 = c->spec.uniform_32bit;
+  float jx = crh_rng_next_mode(rng, u32), jy = crh_rng_next_mode(rng, u32);
   float W = (float)c->par.width, H = (float)c->par.height;
   float nx = CRH_FMA(((float)px + jx) / W, 2.0f, -1.0f);
   float ny = CRH_FMA(((float)py + jy) / H, -2.0f, 1.0f);
@@ -806,7 +910,7 @@ static void gen_camera_ray(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t*
     *d = crh_norm3(crh_madd3(crh_madd3(c->c_fwd, c->c_right, sx), c->c_up, sy));
   }
   if (c->cam.aperture_radius > 0.f) {
-    float k1 = crh_rng_next(rng), k2 = crh_rng_next(rng);
+    float k1 = crh_rng_next_mode(rng, u32), k2 = crh_rng_next_mode(rng, u32);
     float ft = c->cam.focal_dist / crh_dot3(*d, c->c_fwd);
     v3 focus = crh_madd3(*o, *d, ft);
     float r = c->cam.aperture_radius * crh_sqrt(k1); float s, cc; crh_sincos2pi(k2, &s, &cc);
@@ -830,6 +934,7 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
   v3 rad = crh_mk3(0.f, 0.f, 0.f), W = crh_mk3(1.0f, 1.0f, 1.0f);
   int inside = 0; float imp_pdf = CRH_MAXFLOAT;
   int two = c->par.two_sided;
+  const int u32 = c->spec.uniform_32bit;
   for (uint32_t bounce = 0; bounce < c->par.max_depth; ++bounce) {
     hit_t h; st->rays_nearest++;
     int found = traverse(c, o, d, CRH_MAXFLOAT, 0, &h, cn);
@@ -845,7 +950,7 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
     v3 p0 = crh_mk3(c->pos[3 * ti[0]], c->pos[3 * ti[0] + 1], c->pos[3 * ti[0] + 2]);
     v3 p1 = crh_mk3(c->pos[3 * ti[1]], c->pos[3 * ti[1] + 1], c->pos[3 * ti[1] + 2]);
     v3 p2 = crh_mk3(c->pos[3 * ti[2]], c->pos[3 * ti[2] + 1], c->pos[3 * ti[2] + 2]);
-    const float* M = c->two_level && !c->flat ? &c->xf[12 * c->tri_obj[h.prim]] : NULL;      /* object -> world */
+    const float* M = (c->two_level && c->obj[c->tri_obj[h.prim]].is_inst) ? &c->xf[12 * c->tri_obj[h.prim]] : NULL;      /* object -> world (an object in the static tree is in world space) */
     if (M) { p0 = crh_xform_point(M, p0); p1 = crh_xform_point(M, p1); p2 = crh_xform_point(M, p2); }
     v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
     float w0 = (1.0f - h.u) - h.v;
@@ -870,9 +975,9 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
     {
       v3 nd = crh_add3(b.Kd, crh_add3(b.Rc > BSDF_EPS ? b.Kc : crh_mk3(0.f, 0.f, 0.f), b.Rs > BSDF_EPS ? b.Ks : crh_mk3(0.f, 0.f, 0.f)));
       if (c->nL > 0 && crh_dot3(nd, W) > BSDF_EPS) {
-        float fl = crh_rng_next(&rng) * (float)c->nL;
+        float fl = crh_rng_next_mode(&rng, u32) * (float)c->nL;
         uint32_t li = (uint32_t)fl; if (li > c->nL - 1u) li = c->nL - 1u;
-        float k1 = crh_rng_next(&rng), k2 = crh_rng_next(&rng);
+        float k1 = crh_rng_next_mode(&rng, u32), k2 = crh_rng_next_mode(&rng, u32);
         const crh_light* l = &c->lights[li];
         v3 axis; float dist, cm;
         if (l->is_point != 0.f) { v3 tl = crh_sub3(c->l_vec[li], p); dist = crh_len3(tl); axis = crh_scale3(tl, 1.0f / dist); cm = sphere_cosmax(c->l_par[li], dist); }
@@ -884,7 +989,7 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
         v3 ld = crh_norm3(from_local(&lf, crh_mk3(cc * sn, s * sn, ct)));
         float e_pdf = (cm < 1.0f) ? (1.0f / (float)c->nL) * cone_pdf(cm) : CRH_MAXFLOAT;
         v3 wi = to_local(&fr, ld);
-        float i_pdf = pdf_layered(&b, wo, wi, W, two);
+        float i_pdf = pdf_layered(&b, wo, wi, W, two, -1);
         float mis = (e_pdf == CRH_MAXFLOAT) ? 1.0f : e_pdf / CRH_FMA(e_pdf, e_pdf, i_pdf * i_pdf);
         v3 contrib = crh_scale3(crh_mul3(crh_mk3(l->emission[0], l->emission[1], l->emission[2]), eval_layered(&b, wi, wo, two)), mis);
         v3 wc = crh_mul3(W, contrib);
@@ -896,13 +1001,13 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
       }
     }
     /* BSDF sampling */
-    v3 wi; int delta; v3 Wsel = W;      /* lobe-selection weights = throughput before the bounce */
-    int alive = sample_layered(&b, wo, &wi, &W, &inside, &delta, &rng, two);
-    if (alive) imp_pdf = delta ? CRH_MAXFLOAT : pdf_layered(&b, wo, wi, Wsel, two);
+    v3 wi; int delta, lobe; v3 Wsel = W;      /* lobe-selection weights = throughput before the bounce */
+    int alive = sample_layered(&b, wo, &wi, &W, &inside, &delta, &rng, two, &c->spec, &lobe);
+    if (alive) imp_pdf = delta ? CRH_MAXFLOAT : pdf_layered(&b, wo, wi, Wsel, two, c->spec.mis_single_lobe ? lobe : -1);
     float survive = (W.x > MIN_THROUGHPUT || W.y > MIN_THROUGHPUT || W.z > MIN_THROUGHPUT) ? 1.0f : 0.f;
     if (c->par.russian_roulette && bounce >= 3)
       survive = crh_min(CRH_FMA(LUMA_B, W.z, CRH_FMA(LUMA_G, W.y, LUMA_R * W.x)), 0.95f) * survive;
-    float kr = crh_rng_next(&rng);
+    float kr = crh_rng_next_mode(&rng, u32);
     if (!alive || !(kr < survive)) break;
     if (c->par.russian_roulette && bounce >= 3) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
     v3 nd2 = crh_norm3(from_local(&fr, wi));
@@ -933,7 +1038,8 @@ static void prepare(orc_ctx* c)
     }
   }
   v3 dg = crh_mk3(c->bbmax[0] - c->bbmin[0], c->bbmax[1] - c->bbmin[1], c->bbmax[2] - c->bbmin[2]);
-  c->eps = c->par.scene_epsilon > 0.f ? c->par.scene_epsilon : crh_max(1.0e-6f, 1.0e-5f * crh_len3(dg));
+  c->eps = c->par.scene_epsilon > 0.f ? c->par.scene_epsilon
+         : (c->spec.eps_rule ? crh_max(1.0e-6f, 1.0e-4f * (crh_len3(dg) * 0.5f)) : crh_max(1.0e-6f, 1.0e-5f * crh_len3(dg)));   /* crh_spec.h #6 */
 }
 
 static void accumulate_px(const orc_ctx* c, float* a, v3 s, float* m2)
@@ -1023,13 +1129,14 @@ ORC_API orc_ctx* orc_create(void)
   c->par.width = 64; c->par.height = 64; c->par.max_depth = 5; c->par.radiance_clamp = 0.f; c->par.two_sided = 1;
   c->par.seed = 1; c->par.tile_size = 32; c->par.white_point = 1.0f; c->par.russian_roulette = 1; c->par.env_as_background = 1;
   c->cam.dir[1] = 1.0f; c->cam.up[2] = 1.0f; c->cam.fovy_deg = 45.0f;
+  { const crh_spec d = CRH_SPEC_DEFAULTS; c->spec = d; }
   return c;
 }
 ORC_API void orc_destroy(orc_ctx* c)
 {
   if (!c) return;
   free(c->pos); free(c->nrm); free(c->uv); free(c->tri); free(c->mats); free(c->lights); free(c->env);
-  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->last_picked); free(c->xf); free(c->tri_obj); free(c->inst); free(c->tlas_order); free(c);
+  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->last_picked); free(c->xf); free(c->tri_obj); free(c->inst); free(c->tlas_order); free(c->obj); free(c->obj_tris); free(c->static_pos); free(c);
 }
 ORC_API const char* orc_last_error(orc_ctx* c) { return c ? c->err : "null ctx"; }
 
@@ -1067,15 +1174,26 @@ ORC_API int orc_set_transforms(orc_ctx* c, const float* xf, uint32_t nO)
   if (!c || !xf || !c->two_level || nO != c->nO || !all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return CRH_E_INVALID;
   memcpy(c->xf, xf, sizeof(float) * 12 * nO);
   if (c->built) {
-    if (all_identity(xf, nO) != c->flat) do_build(c);          /* the scene changes between one tree and object trees + top level */
-    else if (!c->flat) build_tlas(c);                          /* object trees are untouched */
+    /* static / moved split: the static tree and the object trees built so far are never rebuilt.  An object of the static tree that
+     * leaves the identity gets its triangles there disabled and (the first time) an object tree of its own; back at the identity, its
+     * triangles are restored and the instance is dropped.  Then the top-level tree over the instances of this moment. */
+    collapser C; C.qn = c->nodes; C.nq = c->nBlasNodes; C.capq = c->capNodes;
+    for (uint32_t ob = 0; ob < nO; ++ob) {
+      orc_object* o = &c->obj[ob];
+      if (!o->ntri) continue;
+      const int want = !(o->static0 && is_identity(&xf[12 * ob]));
+      if (want && !o->is_inst) { set_static_triangles(c, ob, 0); if (!o->built) build_object_tree(c, &C, ob); o->is_inst = 1; }
+      else if (!want && o->is_inst) { set_static_triangles(c, ob, 1); o->is_inst = 0; }
+    }
+    c->nodes = C.qn; c->nBlasNodes = C.nq; c->capNodes = C.capq;
+    build_tlas(c);
   }
   return orc_reset(c);
 }
 ORC_API int orc_get_tlas(orc_ctx* c, uint32_t* root, uint32_t* n_instances, uint32_t* n_blas_nodes)
 {
   if (!c || !c->built) return CRH_E_NOTBUILT;
-  if (root) *root = c->root; if (n_instances) *n_instances = c->nInst; if (n_blas_nodes) *n_blas_nodes = c->nBlasNodes;
+  if (root) *root = c->nInst ? (c->root2 != QBVH_EMPTY ? c->root2 : c->root) : 0u; if (n_instances) *n_instances = c->nInst; if (n_blas_nodes) *n_blas_nodes = c->nBlasNodes;
   return 0;
 }
 ORC_API int orc_set_materials(orc_ctx* c, const crh_bsdf* m, uint32_t n)
@@ -1122,6 +1240,16 @@ ORC_API int orc_set_params(orc_ctx* c, const crh_params* p)
     if (!all_finite(f, sizeof f / sizeof f[0], 3.0e38f)) return CRH_E_INVALID; }
   c->par = *p; return orc_reset(c);
 }
+ORC_API int orc_set_spec(orc_ctx* c, const crh_spec* sp)
+{
+  if (!c || !sp || sp->size != sizeof(crh_spec) || !(sp->eta_no_dielectric >= 1.0e-2f && sp->eta_no_dielectric <= 1.0e3f)) return CRH_E_INVALID;
+  c->spec = *sp;
+  c->spec.uniform_32bit = sp->uniform_32bit != 0; c->spec.texel_gamma2 = sp->texel_gamma2 != 0; c->spec.mis_single_lobe = sp->mis_single_lobe != 0;
+  c->spec.eps_rule = sp->eps_rule != 0;
+  return orc_reset(c);
+}
+ORC_API int orc_get_spec(orc_ctx* c, crh_spec* out) { if (!c || !out) return CRH_E_INVALID; *out = c->spec; out->size = (uint32_t)sizeof(crh_spec); return 0; }
+ORC_API int orc_spec_order_exact(void) { return CRH_SPEC_ORDER_EXACT; }
 ORC_API int orc_build(orc_ctx* c)
 {
   if (!c) return CRH_E_INVALID;
@@ -1301,13 +1429,14 @@ ORC_API void orc_fresnel(float cosI, const float f[4], float out[3]) { v3 r = fr
 ORC_API void orc_bsdf_eval(const crh_bsdf* m, const float wo[3], const float wi[3], int two_sided, float out[3])
 { bsdf_t b; bsdf_from_abi(m, wo, &b); v3 r = eval_layered(&b, crh_mk3(wi[0], wi[1], wi[2]), crh_mk3(wo[0], wo[1], wo[2]), two_sided); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 ORC_API float orc_bsdf_pdf(const crh_bsdf* m, const float wo[3], const float wi[3], const float W[3], int two_sided)
-{ bsdf_t b; bsdf_from_abi(m, wo, &b); return pdf_layered(&b, crh_mk3(wo[0], wo[1], wo[2]), crh_mk3(wi[0], wi[1], wi[2]), crh_mk3(W[0], W[1], W[2]), two_sided); }
+{ bsdf_t b; bsdf_from_abi(m, wo, &b); return pdf_layered(&b, crh_mk3(wo[0], wo[1], wo[2]), crh_mk3(wi[0], wi[1], wi[2]), crh_mk3(W[0], W[1], W[2]), two_sided, -1); }
 /* returns alive; weight_io in/out, rng in/out, flags_out bit0 = delta, bit1 = inside after */
 ORC_API int orc_bsdf_sample(const crh_bsdf* m, const float wo[3], float weight_io[3], uint32_t* rng, int two_sided, int inside_in, float wi_out[3], int* flags_out)
 {
   bsdf_t b; bsdf_from_abi(m, wo, &b);
   v3 W = crh_mk3(weight_io[0], weight_io[1], weight_io[2]), wi = crh_mk3(0.f, 0.f, 0.f); int inside = inside_in, delta = 0;
-  int alive = sample_layered(&b, crh_mk3(wo[0], wo[1], wo[2]), &wi, &W, &inside, &delta, rng, two_sided);
+  const crh_spec sp = CRH_SPEC_DEFAULTS; int lobe;
+  int alive = sample_layered(&b, crh_mk3(wo[0], wo[1], wo[2]), &wi, &W, &inside, &delta, rng, two_sided, &sp, &lobe);
   weight_io[0] = W.x; weight_io[1] = W.y; weight_io[2] = W.z; wi_out[0] = wi.x; wi_out[1] = wi.y; wi_out[2] = wi.z;
   *flags_out = (delta ? 1 : 0) | (inside ? 2 : 0);
   return alive;
@@ -1329,3 +1458,5 @@ ORC_API void orc_math(int fn, const float* a, const float* b, float* out, float*
 ORC_API void orc_rng_stream(uint32_t pixel, uint32_t fseed, float* out, uint32_t n)
 { uint32_t s = crh_rng_seed(pixel, fseed); for (uint32_t i = 0; i < n; ++i) out[i] = crh_rng_next(&s); }
 ORC_API uint32_t orc_frame_seed(uint32_t seed, uint32_t n) { return frame_seed(seed, n); }
+/* the uniform drawn from xorshift state `s_after` under either setting of crh_spec.uniform_32bit (the conversion crh_rng_next_mode applies) */
+ORC_API float orc_rng_float(uint32_t s_after, int full32) { return full32 ? (float)s_after * 2.3283064365386963e-10f : (float)(s_after >> 8) * 5.9604644775390625e-8f; }

@@ -56,3 +56,37 @@ for G in Gs:
         v = View(0).load_scene(two)
         print(json.dumps({"scene": f"two-level, {len(ids)} objects, {kind}", "mrays_per_s": round(rate(v), 1)}), flush=True)
         v.close()
+
+# ---- static / moved split: what a CADRays session does -- the scene is loaded with every object where its vertices say, then the gizmo drags ONE
+# object (src/ImGui/ImRaytraceControls.cxx:64,88).  1000 objects at the identity; 1, then 10 of them translated a little: throughput against the flat
+# rate, latency of the first move (the object's tree is built, its triangles in the static tree disabled) and of the following ones.
+if "split" in KINDS or len(sys.argv) == 1:
+    G = 10
+    cell = np.clip(((cen + 1.0) * 0.5 * G).astype(np.int32), 0, G - 1)
+    obj = (cell[:, 0] * G + cell[:, 1]) * G + cell[:, 2]
+    ids, inv = np.unique(obj, return_inverse=True)
+    ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(ids), 1))
+    v = View(0).load_scene(dataclasses.replace(sc, tri_object=inv.astype(np.int32), obj_xform=ident))
+    flat = rate(v)
+    print(json.dumps({"scene": f"split: {len(ids)} objects, none moved", "mrays_per_s": round(flat, 1)}), flush=True)
+    r = np.random.default_rng(7)
+    picks = r.permutation(len(ids))[:10]
+    for n_moved in (1, 10):
+        xf = ident.copy()
+        lat = []
+        for k in picks[:n_moved]:
+            xf[k, 3::4] = (r.random(3).astype(np.float32) - 0.5) * 0.05
+            v.sync(); t0 = time.perf_counter(); v.set_transforms(xf); t1 = time.perf_counter(); v.Redraw(); v.sync(); t2 = time.perf_counter()
+            lat.append((t1 - t0, t2 - t0))
+        again = []
+        for _ in range(20):                                          # the drag goes on: the same objects, new offsets
+            for k in picks[:n_moved]:
+                xf[k, 3::4] += np.float32(0.001)
+            v.sync(); t0 = time.perf_counter(); v.set_transforms(xf); again.append(time.perf_counter() - t0)
+        m = rate(v)
+        print(json.dumps({"scene": f"split: {len(ids)} objects, {n_moved} moved", "mrays_per_s": round(m, 1), "vs_none_moved": round(m / flat, 4),
+                          "first_move_call_ms": [round(a * 1e3, 3) for a, _ in lat][-3:], "first_move_until_frame_ms": [round(b * 1e3, 3) for _, b in lat][-3:],
+                          "next_moves_call_ms_median": round(float(np.median(again)) * 1e3, 3), "instances": v.get_tlas()["n_instances"]}), flush=True)
+    v.set_transforms(ident)
+    print(json.dumps({"scene": "split: everything back at the identity", "mrays_per_s": round(rate(v), 1), "instances": v.get_tlas()["n_instances"]}), flush=True)
+    v.close()

@@ -60,6 +60,36 @@ def run(args, what, src=None):
         shutil.copyfile(keep, os.path.join("/tmp", "finding_%d_%s" % (findings, os.path.basename(keep))))
 
 
+# ---- deterministic leg: headers cut short INSIDE a segment.  The random mutations above start from full-size files and almost
+# never produce a segment whose declared length is smaller than the fields the reader takes from it.
+def image_case(data, what):
+    path = os.path.join(tmp, "hdr_case.bin"); open(path, "wb").write(data)
+    run(["--image", path, os.path.join(tmp, "o.raw")], what)
+
+
+for tiny in ("FFD8FFDB000300", "FFD8FFC4000300", "FFD8FFC0000308", "FFD8FFDD0002", "FFD8FFDA0002", "FFD8FFDB0000", "FFD8FFC00001", "FFD8FFEE000341",
+             "89504E470D0A1A0A0000000049484452", "89504E470D0A1A0A00000000494844520000000000000000", "89504E470D0A1A0A0000000549484452000000010000000000"):
+    image_case(bytes.fromhex(tiny), "tiny " + tiny)
+for name, data in seeds.items():
+    if name.endswith(".ply"):
+        continue
+    for cut in range(2, min(len(data), 700)):              # every truncation point inside the headers
+        image_case(data[:cut], f"cut {name}@{cut}")
+    if name.endswith(".jpg"):                              # every segment with its declared length shrunk to 0 .. 8 (file kept whole)
+        o = 2
+        while o + 4 <= len(data) and data[o] == 0xFF and data[o + 1] not in (0xDA, 0xD9):
+            L = (data[o + 2] << 8) | data[o + 3]
+            for short in range(0, 9):
+                image_case(data[:o + 2] + bytes([0, short]) + data[o + 4:], f"short {name}@{o}:{short}")
+            o += 2 + L
+    else:                                                  # PNG: every chunk with its length field shrunk to 0 .. 12
+        o = 8
+        while o + 12 <= len(data):
+            L = int.from_bytes(data[o:o + 4], "big")
+            for short in range(0, 13):
+                image_case(data[:o] + short.to_bytes(4, "big") + data[o + 4:], f"short {name}@{o}:{short}")
+            o += 12 + L
+
 for it in range(rounds):
     for name, data in seeds.items():
         path = os.path.join(tmp, "m_" + name); open(path, "wb").write(mutate(data))
