@@ -106,10 +106,14 @@ def roofline_report(config, spp, modified, alg_bytes_per_launch, avg_ms, scene_b
                   "traffic_over_alg": round(traffic / max(alg_bytes_per_launch, 1.0), 3),
                   "l2_hit_rate": round(hit / (hit + miss), 3) if hit and miss else None,
                   "pmc_avg_launch_ms": ent.get("avg_launch_ms")})
-        if resident and t_gbps < 0.75 * HBM_ACHIEVABLE_GBPS:
-            # the L2s serve most of the gather (block-major path order keeps the rays in flight in a few thousand pixels): what limits the
-            # kernel is the latency of L2 hits and VALU issue, not the memory side
-            r["bound"] = "L2-hit latency + VALU issue (Infinity-Cache resident; memory side not saturated)"
+        ceil = roofline_ceilings(ent, avg_ms)
+        if ceil:
+            r["ceilings"] = ceil
+            if ceil.get("binding"):
+                names = {"hbm": "hbm (memory-side traffic)", "l2": "l2 request rate", "valu_issue": "VALU issue"}
+                r["bound"] = f"{names[ceil['binding']]}: {ceil[ceil['binding']]:.2f} of its ceiling (measured: roofline.ceilings)"
+        elif resident and t_gbps < 0.75 * HBM_ACHIEVABLE_GBPS:
+            r["bound"] = "memory side not saturated (Infinity-Cache resident); no SQ counters for this build"
         if resident:
             r["achieved"] = round(min(alg_gbps, t_gbps), 1)
             r["achieved_basis"] = "min(algorithmic, memory-side counter traffic): bytes that were both needed and crossed the L2's memory side"
@@ -129,6 +133,47 @@ def roofline_report(config, spp, modified, alg_bytes_per_launch, avg_ms, scene_b
         else:
             r["frac"] = round(alg_gbps / HBM_PEAK_GBPS, 4)
     return r
+
+
+L2_PEAK_GBPS = 34500.0            # /opt/skills/guides/MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+N_SIMDS = 256 * 4                 # 256 CUs x 4 SIMDs
+
+
+def roofline_ceilings(ent, avg_ms):
+    """Which roof the dominant kernel is under, from the committed SQ / TCC counter passes of THIS build (profiles/pmc_collect.sh):
+      hbm         memory-side bytes / time against the 8 TB/s peak
+      l2          requests that reached the L2s x 128-B line / time against the ~34.5 TB/s the guide measures for the L2s -- an UPPER estimate of
+                  the L2-side load (a divergent 16-B lane request occupies a line slot but moves less)
+      valu_issue  SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES per SIMD: share of the kernel's time a SIMD's VALU is issuing (both in the SQ's cycle unit;
+                  ACTIVE counts are summed over the 4 SIMDs of a CU -> / 4)
+      lane_util   SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU x 4): active lanes per issued VALU instruction cycle
+    `bound` = the largest of hbm / l2 / valu_issue (lane_util is a multiplier on valu_issue, not a ceiling of its own)."""
+    c = ent.get("counters_per_launch") or {}
+    out = {}
+    t = avg_ms * 1e-3
+    if t <= 0:
+        return None
+    out["hbm"] = round(float(ent["hbm_bytes_per_launch"]) / t / 1e9 / HBM_PEAK_GBPS, 4)
+    if c.get("TCC_REQ_sum"):
+        out["l2"] = round(c["TCC_REQ_sum"] * 128.0 / t / 1e9 / L2_PEAK_GBPS, 4)
+        out["l2_requests_per_launch"] = c["TCC_REQ_sum"]
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_BUSY_CYCLES"):
+        # SQ_BUSY_CYCLES is tallied per SQ (one per CU... per shader engine on some parts): report the ratio AND the raw pair so that the unit can be checked
+        out["valu_issue"] = round(c["SQ_ACTIVE_INST_VALU"] / 4.0 / c["SQ_BUSY_CYCLES"], 4)
+        out["valu_issue_raw"] = {"SQ_ACTIVE_INST_VALU": c["SQ_ACTIVE_INST_VALU"], "SQ_BUSY_CYCLES": c["SQ_BUSY_CYCLES"], "SQ_WAVE_CYCLES": c.get("SQ_WAVE_CYCLES"),
+                                 "SQ_WAVES": c.get("SQ_WAVES")}
+    if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+        out["lane_util"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * c["SQ_ACTIVE_INST_VALU"]), 4)
+    if c.get("SQ_INSTS_VALU"):
+        out["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+        # issue floor: every wave-level VALU instruction takes >= 1 issue cycle of its SIMD (4 cycles for a 64-wide op on a 16-lane SIMD)
+        out["valu_issue_floor_ms"] = round(c["SQ_INSTS_VALU"] * 4.0 / N_SIMDS / 2.4e9 * 1e3, 3)
+    if c.get("SQ_INSTS_VMEM_RD"):
+        out["vmem_rd_insts_per_launch"] = c["SQ_INSTS_VMEM_RD"]
+    cands = {k: out[k] for k in ("hbm", "l2", "valu_issue") if k in out}
+    if cands:
+        out["binding"] = max(cands, key=cands.get)
+    return out
 
 
 def free_port():

@@ -173,6 +173,11 @@ class Backend:
         f = self._fn("spec_order_exact"); f.restype = C.c_int
         return int(f())
 
+    def spec_anyhit_slot_order(self):
+        """the build-time switch CRH_SPEC_ANYHIT_SLOT_ORDER of the loaded library (crh_spec.h #8)"""
+        f = self._fn("spec_anyhit_slot_order"); f.restype = C.c_int
+        return int(f())
+
     def load_scene(self, scene):
         self.set_geometry(scene.pos, scene.nrm, scene.tri, scene.uv, getattr(scene, "tri_object", None), getattr(scene, "obj_xform", None))
         self.set_materials(scene.materials)

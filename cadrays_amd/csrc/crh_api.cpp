@@ -66,6 +66,7 @@ struct crh_ctx {
   // ---- device
   float4 *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_env = nullptr;
   float4 *d_uvs = nullptr, *d_texels = nullptr; uint4* d_tex_desc = nullptr;
+  float4* d_verts = nullptr;      // two-level scenes: object-space vertices per leaf position (shading of instance hits)
   float4* d_accum = nullptr; uint32_t accumW = 0, accumH = 0;
   float* d_m2 = nullptr;            // running mean of squared luminance (adaptive sampling only)
   // crh_reduce: the frame assembled from all shards lives beside the root's own accumulator (rendering continues into that)
@@ -278,7 +279,7 @@ int ensure_scratch(crh_ctx* c, size_t bytes)
 void fill_scene(const crh_ctx* c, DScene& S)
 {
   std::memset(&S, 0, sizeof S);
-  S.nodes = c->d_nodes; S.tris = c->d_tris; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = (c->envW && c->envH) ? c->d_env : nullptr;
+  S.nodes = c->d_nodes; S.tris = c->d_tris; S.verts = c->d_verts; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = (c->envW && c->envH) ? c->d_env : nullptr;
   S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * (size_t)c->nO : nullptr; S.root = c->root; S.two_level = c->inst.empty() ? 0 : 1;
   S.root2 = c->inst.empty() ? kQEmpty : c->root2;
   for (int a = 0; a < 3; ++a) { S.tlas_lo[a] = c->tlas_lo[a]; S.tlas_hi[a] = c->tlas_hi[a]; }
@@ -402,10 +403,24 @@ void build_object_tree(crh_ctx* c, uint32_t ob, int threads)
 
 // Leaf-ordered device records of positions [p0, p1): 16 floats of triangle (48 B used), 16 floats of shading record, 8 floats of uv.
 // Also refreshes the host copy h_tris (12 floats per position, crh_get_bvh).
-void fill_records(crh_ctx* c, uint32_t p0, uint32_t p1, std::vector<float>& tr, std::vector<float>& sh, std::vector<float>& uvr)
+// device form of one triangle record from its host form q = {v0 | id, v1, v2}: {v0 | n.x}, {e0 | n.y}, {e1 | n.z}, {id} with e0 = v1 - v0, e1 = v0 - v2,
+// n = e1 x e0 -- the expressions the traversal kernel used to evaluate per test, evaluated here with the same inline arithmetic (same bits).  A
+// disabled triangle (all-zero vertices) stays all zero: n . d = 0, the test yields NaN and rejects.
+static void device_tri_record(const float* q, float* d)
+{
+  const crh_v3 v0 = crh_mk3(q[0], q[1], q[2]), v1 = crh_mk3(q[4], q[5], q[6]), v2 = crh_mk3(q[8], q[9], q[10]);
+  const crh_v3 e0 = crh_sub3(v1, v0), e1 = crh_sub3(v0, v2), n = crh_cross3(e1, e0);
+  d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = n.x;
+  d[4] = e0.x; d[5] = e0.y; d[6] = e0.z; d[7] = n.y;
+  d[8] = e1.x; d[9] = e1.y; d[10] = e1.z; d[11] = n.z;
+  std::memcpy(&d[12], &q[3], 4); d[13] = d[14] = d[15] = 0.f;
+}
+
+void fill_records(crh_ctx* c, uint32_t p0, uint32_t p1, std::vector<float>& tr, std::vector<float>& sh, std::vector<float>& uvr, std::vector<float>* verts = nullptr)
 {
   const size_t n = p1 - p0;
   tr.assign(4 * (size_t)kTriStride * std::max<size_t>(n, 1), 0.f); sh.assign(16 * std::max<size_t>(n, 1), 0.f);
+  if (verts) verts->assign(12 * std::max<size_t>(n, 1), 0.f);
   if (!c->uv.empty()) uvr.assign(8 * std::max<size_t>(n, 1), 0.f); else uvr.clear();
   c->h_tris.resize(12 * (size_t)std::max(p1, 1u), 0.f);
   for (uint32_t p = p0; p < p1; ++p) {
@@ -428,7 +443,8 @@ void fill_records(crh_ctx* c, uint32_t p0, uint32_t p1, std::vector<float>& tr, 
     std::memcpy(&s_[3], &mat, 4);
     const int32_t ob = (c->two_level && p >= c->n_static) ? (int32_t)c->pos_obj[p - c->n_static] : -1;      // n1.w: the object whose transform shading applies (-1: world space)
     std::memcpy(&s_[7], &ob, 4);
-    std::memcpy(&tr[4 * (size_t)kTriStride * i], q, 48);
+    device_tri_record(q, &tr[4 * (size_t)kTriStride * i]);
+    if (verts) std::memcpy(&(*verts)[12 * i], q, 48);
   }
 }
 
@@ -900,7 +916,7 @@ void crh_destroy(crh_ctx* c)
   void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o[0], c->paths.ray_d[0], c->paths.ray_o[1], c->paths.ray_d[1], c->paths.thr[1],
                   c->paths.hit, c->paths.thr[0], c->paths.rad, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
                   c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
-                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst, c->d_patch};
+                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst, c->d_patch, c->d_verts};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->d_assembled) hipFree(c->d_assembled);
   if (c->d_peer_stage) hipFree(c->d_peer_stage);
@@ -980,7 +996,8 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
         for (int k = 0; k < 3; ++k) { const int32_t vi = c->tri[4 * t + k]; for (int a = 0; a < 3; ++a) q[4 * k + a] = c->pos[3 * vi + a]; q[4 * k + 3] = 0.f; }
         std::memcpy(&q[3], &t, 4);
       }
-      ppos.push_back(p); prec.insert(prec.end(), q, q + 12);
+      float d[16]; device_tri_record(q, d);
+      ppos.push_back(p); prec.insert(prec.end(), d, d + 12);
     }
     if (want) { c->n_static_live -= o.ntri; if (!o.built) build_object_tree(c, ob, threads); }
     else c->n_static_live += o.ntri;
@@ -990,8 +1007,8 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
   int rc;
   if (c->n_pos > old_pos) {                               // records of the object trees just built
     if (c->n_pos > c->cap_pos || c->n_pos >= (1u << 28)) return fail(c, CRH_E_NOMEM, "leaf positions exhausted (object trees of moved objects)");
-    std::vector<float> tr, sh, uvr;
-    fill_records(c, old_pos, c->n_pos, tr, sh, uvr);
+    std::vector<float> tr, sh, uvr, vt;
+    fill_records(c, old_pos, c->n_pos, tr, sh, uvr, &vt);
     const size_t n = c->n_pos - old_pos;
     auto put = [&](void* dst, const std::vector<float>& v, size_t rec_floats) -> int {
       const size_t bytes = n * rec_floats * sizeof(float);
@@ -1001,6 +1018,7 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
     if ((rc = put(c->d_tris + (size_t)kTriStride * old_pos, tr, 4 * kTriStride))) return rc;
     if ((rc = put(c->d_shade + 4 * (size_t)old_pos, sh, 16))) return rc;
     if (c->d_uvs && !uvr.empty() && (rc = put(c->d_uvs + 2 * (size_t)old_pos, uvr, 8))) return rc;
+    if ((rc = put(c->d_verts + 3 * (size_t)old_pos, vt, 12))) return rc;
   }
   if (!ppos.empty()) {
     const size_t nb = ppos.size() * 4, rb = prec.size() * 4, need = ((nb + 255) & ~(size_t)255) + rb;
@@ -1138,6 +1156,7 @@ int crh_get_spec(crh_ctx* c, crh_spec* out)
 }
 
 int crh_spec_order_exact(void) { return CRH_SPEC_ORDER_EXACT; }
+int crh_spec_anyhit_slot_order(void) { return CRH_SPEC_ANYHIT_SLOT_ORDER; }
 
 int crh_build(crh_ctx* c)
 {
@@ -1199,9 +1218,9 @@ int crh_build(crh_ctx* c)
   { int rc_t = build_tlas(c); if (rc_t) return rc_t; }
   // leaf-ordered triangle, shading and uv records.  A two-level scene keeps room for an object tree of every object of the static tree
   // (each may be dragged away once; the copies cost 2 x 64 B per triangle of HBM, nothing at run time)
-  std::vector<float> tr, sh, uvr;
+  std::vector<float> tr, sh, uvr, vt;
   c->h_tris.clear();
-  fill_records(c, 0, c->n_pos, tr, sh, uvr);
+  fill_records(c, 0, c->n_pos, tr, sh, uvr, c->two_level ? &vt : nullptr);
   c->cap_pos = (size_t)std::max(c->n_pos, 1u) + (c->two_level ? c->n_static : 0u);
   int rc;
   // head-room behind the node array: object trees built later by crh_set_transforms (<= ~1.5 nodes per triangle incl. alignment holes) and the top-level tree
@@ -1219,6 +1238,8 @@ int crh_build(crh_ctx* c)
   if ((rc = alloc_put(c->d_shade, sh, 16))) return rc;
   if (!c->uv.empty()) { if ((rc = alloc_put(c->d_uvs, uvr, 8))) return rc; }
   else if (c->d_uvs) { CRH_HIP(hipFree(c->d_uvs)); c->d_uvs = nullptr; }
+  if (c->two_level) { if ((rc = alloc_put(c->d_verts, vt, 12))) return rc; }
+  else if (c->d_verts) { CRH_HIP(hipFree(c->d_verts)); c->d_verts = nullptr; }
   if (c->two_level) {
     // what the FIRST crh_set_transforms would otherwise allocate while the user is dragging: the staging of the triangle patches of the largest object
     uint32_t biggest = 0; for (const crh_ctx::Obj& o : c->objs) biggest = std::max(biggest, o.ntri);

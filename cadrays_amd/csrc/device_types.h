@@ -20,7 +20,8 @@ constexpr uint32_t kQLeafBit      = 0x80000000u;
 #ifndef CRH_TRI_STRIDE
 #define CRH_TRI_STRIDE 4
 #endif
-constexpr uint32_t kTriStride = CRH_TRI_STRIDE;   // float4 between consecutive triangle records on the device (3 are used): on a 64-B stride no
+static_assert(CRH_TRI_STRIDE == 4, "the fourth float4 of a triangle record holds the caller's triangle id");
+constexpr uint32_t kTriStride = CRH_TRI_STRIDE;   // float4 between consecutive triangle records on the device (3 are fetched by the traversal): on a 64-B stride no
                                                   // record straddles two 64-B sectors (packed at 48 B half of them do): +2.8 % C3, +4 % C5
 constexpr int kBlock      = 256;   // threads per workgroup (4 waves)
 constexpr int kLdsStack   = 16;    // traversal stack entries per lane kept in LDS
@@ -30,7 +31,9 @@ constexpr int kOvfStack   = 112;   // spill entries per lane (scratch, rarely to
 // Scene as the kernels see it.  All arrays are float4-granular so every fetch is one dwordx4.
 struct DScene {
   const float4* nodes;    // 3 x float4 used per node (64-B stride): {origin.xyz, exps | child counts}, {qlo xyz, qhi x}, {qhi yz, child base, leaf base}  (crh_bvh_format.h)
-  const float4* tris;     // 3 x float4 per triangle in leaf order (kTriStride apart): v0|prim, v1, v2
+  const float4* tris;     // 4 x float4 per triangle in leaf order (kTriStride apart; traversal fetches the first three): v0 | n.x, e0 = v1 - v0 | n.y, e1 = v0 - v2 | n.z
+                          // (n = e1 x e0), {caller's triangle id, -, -, -}
+  const float4* verts;    // two-level scenes: 3 x float4 per leaf position, the object-space vertices (shading transforms them); nullptr otherwise
   const float4* shade;    // 4 x float4 (one 64-B sector) per triangle in leaf order: n0|material, n1|instance, n2, geometric normal (single-level scenes)
   const float4* mats;     // 8 x float4 per material (crh_bsdf)
   const float4* lights;   // 2 x float4 per light: {vec.xyz (unit to-light dir | position), is_point}, {emission.rgb, cosmax | radius}

@@ -110,11 +110,11 @@ __device__ __forceinline__ float inv_dir(float d)
 #if CRH_SPEC_ORDER_EXACT
 typedef unsigned long long okey_t;
 #define CRH_KEY_MISS 0xFFFFFFFFFFFFFFFFull
-#define CRH_MAKE_KEY(BITS, K) ((((okey_t)(uint32_t)(BITS)) << 2) | (okey_t)(K))
+#define CRH_MAKE_KEY(BITS, K) ((((okey_t)((uint32_t)(BITS) & 0x7FFFFFFFu)) << 2) | (okey_t)(K))
 #else
 typedef uint32_t okey_t;
 #define CRH_KEY_MISS 0xFFFFFFFFu
-#define CRH_MAKE_KEY(BITS, K) (((uint32_t)(BITS) & ~3u) | (uint32_t)(K))
+#define CRH_MAKE_KEY(BITS, K) (((uint32_t)(BITS) & 0x7FFFFFFCu) | (uint32_t)(K))
 #endif
 #define CRH_CE(a, b) { const okey_t lo_ = min(a, b); const okey_t hi_ = max(a, b); a = lo_; b = hi_; }
 
@@ -352,6 +352,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (f32x2){-gy, gy});
       const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ddz, ddz}, (f32x2){iz, iz}, (f32x2){-gz, gz});
       okey_t key[4];
+      bool hitk[4];
 #define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))      /* v_cvt_f32_ubyteK */
 #define CRH_CHILD(K)                                                                                         \
       {                                                                                                     \
@@ -360,8 +361,10 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         const f32x2 tz = __builtin_elementwise_fma((f32x2){CRH_QB(lz, K), CRH_QB(hz, K)}, az2, bz2);      \
         const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
         const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), prune);                                   \
-        const int bits = max(__float_as_int(tmin), 0);                                                     \
-        key[K] = ((uint32_t)K < nch && tmin <= tmx) ? CRH_MAKE_KEY(bits, K) : CRH_KEY_MISS;                   \
+        /* tmin = max(.., 0) is >= 0 or -0 (never a negative number, and a NaN never passes the test below): clearing the sign bit IS max(bits, 0) */ \
+        const uint32_t bits = __float_as_uint(tmin);                                                       \
+        hitk[K] = (uint32_t)K < nch && tmin <= tmx;                                                        \
+        key[K] = hitk[K] ? CRH_MAKE_KEY(bits, K) : CRH_KEY_MISS;                                           \
       }
       CRH_CHILD(0)
       CRH_CHILD(1)
@@ -369,6 +372,33 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       CRH_CHILD(3)
 #undef CRH_CHILD
 #undef CRH_QB
+      if (ANY && CRH_SPEC_ANYHIT_SLOT_ORDER) {
+        // crh_spec.h #8: an occlusion query needs no near-to-far order -- the hit children are taken in SLOT order (no sort, no keys): the
+        // lowest hit slot continues, the others go onto the stack so that they pop in slot order; three unconditional stores, the ones of
+        // children that were not hit (and of the one that continues) land in dead slots at / above the new top
+        const uint32_t rs0 = (0u < ni ? base_inner : base_leaf) + 0u, rs1 = (1u < ni ? base_inner : base_leaf) + 1u,
+                       rs2 = (2u < ni ? base_inner : base_leaf) + 2u, rs3 = (3u < ni ? base_inner : base_leaf) + 3u;
+        const int f0 = hitk[0] ? 1 : 0, f1 = hitk[1] ? 1 : 0, f2 = hitk[2] ? 1 : 0, f3 = hitk[3] ? 1 : 0;
+        const int a2 = f3, a1 = f3 + f2, nh = (a1 + f1) + f0;                   // hits in higher slots = position above the old top
+        if (__builtin_expect(sp <= kLdsStack - 4, 1)) {
+          uint32_t* top = lds + sp * kBlock;
+          top[(f3 ? 0 : nh) * kBlock] = rs3; top[(f2 ? a2 : nh) * kBlock] = rs2; top[(f1 ? a1 : nh) * kBlock] = rs1;
+          // the lowest hit slot sits at the top (position nh - 1) if it was stored at all: it continues in registers, its slot is dead
+          sp += max(nh, 1) - 1;
+        } else {
+#define CRH_PUSH(V)                                                          \
+          { const uint32_t v_ = (V);                                           \
+            if (sp < kLdsStack) lds[sp * kBlock] = v_; else ovf[sp - kLdsStack] = v_; \
+            ++sp; }
+          const int first = f0 ? 0 : (f1 ? 1 : (f2 ? 2 : 3));
+          if (f3 && first != 3) CRH_PUSH(rs3)
+          if (f2 && first != 2) CRH_PUSH(rs2)
+          if (f1 && first != 1) CRH_PUSH(rs1)
+#undef CRH_PUSH
+        }
+        if (nh >= 1) cur = f0 ? rs0 : (f1 ? rs1 : (f2 ? rs2 : rs3)); else pop();
+        return;
+      }
       CRH_CE(key[0], key[1]) CRH_CE(key[2], key[3]) CRH_CE(key[0], key[2]) CRH_CE(key[1], key[3]) CRH_CE(key[1], key[2])
       // The sorted keys put the nh hit children first (miss keys have bit 31 set).  Far .. near go onto the
       // stack, the nearest continues in registers.  Common case (room for three entries in the LDS part of
@@ -404,9 +434,11 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float4* tp = tris + kTriStride * ti;
       const float4 a = tp[0], b = tp[1], c = tp[2];
       if (COUNT) ++n_tris;
-      const v3 v0 = xyz(a), v1 = xyz(b), v2 = xyz(c);
-      const v3 e0 = crh_sub3(v1, v0), e1 = crh_sub3(v0, v2);
-      const v3 nrm = crh_cross3(e1, e0);
+      // record = {v0 | n.x}, {e0 = v1 - v0 | n.y}, {e1 = v0 - v2 | n.z}: the two edges and n = e1 x e0 are evaluated ONCE per triangle on the host
+      // with the inline arithmetic this function used to apply per test (crh_sub3 / crh_cross3, same bits) -- 15 VALU instructions per test
+      // fewer in a kernel that runs at the VALU issue limit
+      const v3 v0 = xyz(a), e0 = xyz(b), e1 = xyz(c);
+      const v3 nrm = crh_mk3(a.w, b.w, c.w);
       const v3 to = crh_sub3(v0, o);
       const float inv = 1.0f / crh_dot3(nrm, d);
       const v3 vc = crh_cross3(d, to);
@@ -549,7 +581,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict
       if (ANY) out_vis[tag] = f ? 0u : 1u;
       else {
         const int k = __float_as_int(h.w);
-        if (k >= 0) h.w = S.tris[kTriStride * (uint32_t)k].w;   // leaf order -> caller's triangle index
+        if (k >= 0) h.w = S.tris[kTriStride * (uint32_t)k + 3u].x;   // leaf order -> caller's triangle index (fourth quarter of the 64-B record)
         out_hit[tag] = h;
       }
     }, nn, nt);
@@ -1066,7 +1098,7 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
         // two-level scenes: s1.w = the object of a triangle that lives in an object tree (-1: a triangle of the static world-space tree)
         const bool in_object = S.two_level && __float_as_int(s1.w) >= 0;
         if (in_object) {                                     // object -> world through the instance's forward transform
-          const float4* tp = S.tris + kTriStride * (uint32_t)hk;
+          const float4* tp = S.verts + 3u * (uint32_t)hk;       // the three object-space vertices (the traversal record holds edges, not vertices)
           const float4 a = tp[0], b4 = tp[1], c4 = tp[2];
           const float4* ip = S.inst + 8u * (uint32_t)__float_as_int(s1.w);
           const float4 f0 = ip[3], f1 = ip[4], f2 = ip[5];

@@ -170,6 +170,7 @@ CRH_API int crh_set_params(crh_ctx* ctx, const crh_params* p);
 CRH_API int crh_set_spec(crh_ctx* ctx, const crh_spec* spec);
 CRH_API int crh_get_spec(crh_ctx* ctx, crh_spec* spec_out);
 CRH_API int crh_spec_order_exact(void);
+CRH_API int crh_spec_anyhit_slot_order(void);      /* the other build-time switch, CRH_SPEC_ANYHIT_SLOT_ORDER */
 /* == OCCT updateRaytraceGeometry + uploadRaytraceData on a changed scene: BVH build,
  * QBVH collapse, upload.  Invalidates the accumulator. */
 CRH_API int crh_build(crh_ctx* ctx);

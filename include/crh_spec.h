@@ -52,4 +52,11 @@ typedef struct crh_spec {
 #define CRH_SPEC_ORDER_EXACT 0
 #endif
 
+/* #8: build-time.  Child order of ANY-HIT (shadow-ray) traversal: 0 = near to far like nearest-hit rays (default; what OCCT's
+ * SceneAnyHit is recollected to do, it shares the ordered walk), 1 = slot order -- an occlusion query needs no order, and the walk
+ * then needs no sort (round-2 verdict item 3).  Changes the any-hit visit counters only: visibility is order-independent. */
+#ifndef CRH_SPEC_ANYHIT_SLOT_ORDER
+#define CRH_SPEC_ANYHIT_SLOT_ORDER 0
+#endif
+
 #endif /* CRH_SPEC_H */

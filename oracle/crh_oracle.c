@@ -558,6 +558,7 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
 #else
           uint32_t ky = ((uint32_t)bits & ~3u) | (uint32_t)k;
 #endif
+          if (any_hit && CRH_SPEC_ANYHIT_SLOT_ORDER) ky = (uint32_t)k;      /* crh_spec.h #8: occlusion queries take the hit children in slot order */
           int j = nh++;
           while (j > 0 && key[j - 1] > ky) { key[j] = key[j - 1]; rf[j] = rf[j - 1]; --j; }
           key[j] = ky; rf[j] = r;
@@ -1250,6 +1251,7 @@ ORC_API int orc_set_spec(orc_ctx* c, const crh_spec* sp)
 }
 ORC_API int orc_get_spec(orc_ctx* c, crh_spec* out) { if (!c || !out) return CRH_E_INVALID; *out = c->spec; out->size = (uint32_t)sizeof(crh_spec); return 0; }
 ORC_API int orc_spec_order_exact(void) { return CRH_SPEC_ORDER_EXACT; }
+ORC_API int orc_spec_anyhit_slot_order(void) { return CRH_SPEC_ANYHIT_SLOT_ORDER; }
 ORC_API int orc_build(orc_ctx* c)
 {
   if (!c) return CRH_E_INVALID;

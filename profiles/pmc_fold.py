@@ -46,8 +46,8 @@ def main():
     data["hash_of"] = list(bench.pmc_hash_files())
     for cfg in cfgs:
         vals = {}
-        for grp in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum"):
-            v, n = counters(os.path.join(out, cfg, "pmc_" + grp))
+        for d in sorted(glob.glob(os.path.join(out, cfg, "pmc_*"))):
+            v, n = counters(d)
             vals.update(v)
         if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
             print(f"{cfg}: counters missing ({sorted(vals)})"); continue
@@ -69,7 +69,10 @@ def main():
                "hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
                "tcc_miss_x128_bytes_per_launch": vals["TCC_MISS_sum"] * 128 if "TCC_MISS_sum" in vals else None,
                "avg_launch_ms": avg_ms, "from": os.path.basename(os.path.normpath(out)),
-               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes of `bench.py --config %s --steps 2 --warmup 1 --no-cpu --no-interactive` (profiles/pmc_collect.sh); bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 x2 read-side correction); memory-side counter, Infinity-Cache hits included" % cfg}
+               # everything else that was collected, per launch of the timed instantiation (SQ_* activity counters are in quad-cycles summed over
+               # the SIMDs; see bench.roofline_ceilings for what is derived from them)
+               "counters_per_launch": {k: vals[k] for k in sorted(vals) if k not in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum")},
+               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum / TCC_REQ_sum TCC_READ_sum / SQ groups in separate passes of `bench.py --config %s --steps 2 --warmup 1 --no-cpu --no-interactive --no-parity` (profiles/pmc_collect.sh); bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 x2 read-side correction); memory-side counter, Infinity-Cache hits included" % cfg}
         data["configs"][cfg] = ent
         print(cfg, json.dumps(ent))
     json.dump(data, open(path, "w"), indent=1)

@@ -139,20 +139,22 @@ def test_random_scenes_with_random_switches(hip_lib, oracle_lib, seed):
 
 
 @pytest.mark.gpu
-def test_exact_child_order_build_matches_its_oracle(hip_lib, tmp_path):
-    """crh_spec.h #4 is a build-time switch (it sits in the traversal loop): `make -C cadrays_amd/csrc spec-exact` and `make -C oracle
-    spec-exact` build both sides with CRH_SPEC_ORDER_EXACT=1; a child process loads the pair and compares images, hits and counters.
-    The two builds of the PRODUCT must also agree on every hit distance (the order only decides visits and ties)."""
+@pytest.mark.parametrize("variant", ["exact", "anyslot"])
+def test_build_time_switch_matches_its_oracle(hip_lib, tmp_path, variant):
+    """crh_spec.h #4 and #8 are build-time switches (they sit in the traversal loop): `make -C cadrays_amd/csrc spec-exact spec-anyslot` and
+    `make -C oracle spec-exact spec-anyslot` build both sides with CRH_SPEC_ORDER_EXACT=1 / CRH_SPEC_ANYHIT_SLOT_ORDER=1; a child process loads
+    the pair and compares images, hits and counters.  The builds of the PRODUCT must also agree on every hit distance (the order only
+    decides visits and ties) and, for #8, on the whole image (visibility does not depend on the order)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "cadrays_amd", "variants", "spec_exact.so")
-    orc = os.path.join(root, "oracle", "variants", "libcrh_oracle_spec_exact.so")
+    lib = os.path.join(root, "cadrays_amd", "variants", f"spec_{variant}.so")
+    orc = os.path.join(root, "oracle", "variants", f"libcrh_oracle_spec_{variant}.so")
     if not (os.path.exists(lib) and os.path.exists(orc)):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "cadrays_amd", "csrc"), "spec-exact"])
-        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "spec-exact"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "cadrays_amd", "csrc"), f"spec-{variant}"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), f"spec-{variant}"])
     code = r"""
 import json, sys, numpy as np, torch
 sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -168,7 +170,7 @@ r = np.random.default_rng(1); n = 50000
 rays = np.zeros((n, 8), np.float32); rays[:, :3] = r.random((n, 3)); rays[:, 3] = 1e15
 d = r.normal(size=(n, 3)); rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
 h = v.trace_nearest(rays); ho = o.trace_nearest(rays)
-print(json.dumps({"exact": [v.spec_order_exact(), o.spec_order_exact()], "image": bool(np.array_equal(bits(v.read_hdr()), bits(o.read_hdr()))),
+print(json.dumps({"exact": [v.spec_order_exact(), o.spec_order_exact()], "anyslot": [v.spec_anyhit_slot_order(), o.spec_anyhit_slot_order()], "sha": __import__("hashlib").sha256(v.read_hdr().tobytes()).hexdigest(), "nodes_any": v.stats()["nodes_any"], "image": bool(np.array_equal(bits(v.read_hdr()), bits(o.read_hdr()))),
                   "counters": all(v.stats()[k] == o.stats()[k] for k in ("nodes_nearest", "tris_nearest", "nodes_any", "tris_any", "rays_any")),
                   "hits": bool(np.array_equal(bits(h), bits(ho))), "t": h[:, 0].tolist()[:2000], "nodes": v.stats()["nodes_nearest"]}))
 """ % (root, os.path.join(root, "tests"))
@@ -178,7 +180,10 @@ print(json.dumps({"exact": [v.spec_order_exact(), o.spec_order_exact()], "image"
         assert p.returncode == 0, p.stderr[-3000:]
         return json.loads(p.stdout.strip().splitlines()[-1])
     ex = run({"CRH_LIB_PATH": lib, "CRH_ORACLE_LIB": orc})
-    assert ex["exact"] == [1, 1] and ex["image"] and ex["counters"] and ex["hits"]
+    assert ex["exact"] == ([1, 1] if variant == "exact" else [0, 0]) and ex["anyslot"] == ([1, 1] if variant == "anyslot" else [0, 0])
+    assert ex["image"] and ex["counters"] and ex["hits"]
     de = run({})
-    assert de["exact"] == [0, 0] and de["image"] and de["counters"] and de["hits"]
+    assert de["exact"] == [0, 0] and de["anyslot"] == [0, 0] and de["image"] and de["counters"] and de["hits"]
     assert np.array_equal(np.float32(ex["t"]), np.float32(de["t"]))          # same nearest distances under either order
+    if variant == "anyslot":
+        assert ex["sha"] == de["sha"] and ex["nodes_any"] != de["nodes_any"]  # the same image bit for bit; only the shadow rays' visits differ
