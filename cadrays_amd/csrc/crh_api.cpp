@@ -1243,6 +1243,15 @@ int crh_build(crh_ctx* c)
   if (c->two_level) {
     // what the FIRST crh_set_transforms would otherwise allocate while the user is dragging: the staging of the triangle patches of the largest object
     uint32_t biggest = 0; for (const crh_ctx::Obj& o : c->objs) biggest = std::max(biggest, o.ntri);
+    // ... and the pinned staging buffers the records of one object travel through (stage_copy grows them lazily: four hipHostMalloc of a few
+    // milliseconds each would otherwise land in the first dragged frame)
+    const size_t want_stage = std::min<size_t>(4u << 20, (size_t)biggest * 64 + (size_t)c->nO * 160 + 65536);
+    for (crh_ctx::Stage& st : c->stage)
+      if (st.cap < want_stage) {
+        if (st.used) CRH_HIP(hipEventSynchronize(st.ev));
+        if (st.p) { CRH_HIP(hipHostFree(st.p)); st.p = nullptr; st.cap = 0; }
+        CRH_HIP(hipHostMalloc(&st.p, want_stage, hipHostMallocDefault)); st.cap = want_stage;
+      }
     const size_t want_patch = 2 * ((size_t)biggest * 52 + 512);
     if (c->cap_patch < want_patch) {
       if (c->d_patch) { CRH_HIP(hipFree(c->d_patch)); c->d_patch = nullptr; c->cap_patch = 0; }
@@ -1250,6 +1259,22 @@ int crh_build(crh_ctx* c)
     }
   }
   c->built = true;
+  if (c->two_level && c->inst.empty()) {
+    // Every object sits at the identity: the single-level kernels render this scene.  The first crh_set_transforms (the user has just grabbed the
+    // gizmo) switches to the two-level instantiations and the record scatter -- launch each of them once now, on empty queues, so that their
+    // first-launch cost (function lookup, code upload: ~20 ms for the set) is paid while the scene loads and not in the first dragged frame.
+    if ((rc = ensure_paths(c, 4096))) return rc;
+    CRH_HIP(hipMemsetAsync(c->queues.counts, 0, 8 * sizeof(uint32_t), cstream(c)));
+    DScene S; fill_scene(c, S); S.two_level = 1;
+    for (int don = 0; don < 2; ++don) {
+      Launch LT{cstream(c), 64, false, 0, don != 0};
+      launch_trace_nearest(LT, S, c->paths, c->queues, 0, c->d_counters);
+      launch_trace_any(LT, S, c->paths, c->queues, c->d_counters);
+    }
+    Launch L{cstream(c), 64, false};
+    launch_scatter_tris(L, c->d_tris, (const uint32_t*)c->d_patch, (const float4*)c->d_patch, 0);
+    CRH_HIP(hipGetLastError());
+  }
   rc = do_reset(c); if (rc) return rc;
   CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;

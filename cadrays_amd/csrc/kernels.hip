@@ -117,6 +117,8 @@ typedef uint32_t okey_t;
 #define CRH_MAKE_KEY(BITS, K) (((uint32_t)(BITS) & 0x7FFFFFFCu) | (uint32_t)(K))
 #endif
 #define CRH_CE(a, b) { const okey_t lo_ = min(a, b); const okey_t hi_ = max(a, b); a = lo_; b = hi_; }
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{ uint32_t r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // Persistent-wave traversal engine shared by every tracing kernel.
 //
@@ -334,8 +336,10 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       // multiplication: fma(origin, inv_d, -o * inv_d) cancels catastrophically when |o * inv_d| >> t (a ray grazing a box
       // corner was culled by 2e-5 of t); the guard is the per-ray constant above.
       const uint32_t ew = __float_as_uint(n0.w);
-      const float ax = __uint_as_float((ew & 0xffu) << 23) * ix, ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * iy,
-                  az = __uint_as_float(((ew >> 16) & 0xffu) << 23) * iz;
+      // step * inv_d: the step is 2^k with k a signed byte of the node -- v_bfe_i32 + v_ldexp_f32, the same value as the product (a scaling by a
+      // power of two is exact, and both round the same way where the result is subnormal)
+      const float ax = __builtin_amdgcn_ldexpf(ix, (int)(ew << 24) >> 24), ay = __builtin_amdgcn_ldexpf(iy, (int)(ew << 16) >> 24),
+                  az = __builtin_amdgcn_ldexpf(iz, (int)(ew << 8) >> 24);
       const float ddx = n0.x - o.x, ddy = n0.y - o.y, ddz = n0.z - o.z;
       // child references are implicit: slots < ni are the consecutive inner nodes from child_base, the others the leaves
       // with consecutive references from leaf_base (crh_bvh_format.h): ref(slot) = (slot < ni ? child_base : leaf_base - ni) + slot
@@ -399,7 +403,18 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         if (nh >= 1) cur = f0 ? rs0 : (f1 ? rs1 : (f2 ? rs2 : rs3)); else pop();
         return;
       }
+#if CRH_SPEC_ORDER_EXACT
       CRH_CE(key[0], key[1]) CRH_CE(key[2], key[3]) CRH_CE(key[0], key[2]) CRH_CE(key[1], key[3]) CRH_CE(key[1], key[2])
+#else
+      {
+        // four unique 32-bit keys in eight three-input operations (a five-comparator network is ten): sort three (v_min3 / v_med3 / v_max3), then the
+        // fourth goes in -- the smallest and the largest of all are one min / max, the middle pair is {mid, med3(lo, hi, d)} in order
+        const uint32_t lo = min(min(key[0], key[1]), key[2]), hi = max(max(key[0], key[1]), key[2]);
+        const uint32_t mid = umed3(key[0], key[1], key[2]), d = key[3];
+        const uint32_t m = umed3(lo, hi, d);
+        key[0] = min(lo, d); key[3] = max(hi, d); key[1] = min(mid, m); key[2] = max(mid, m);
+      }
+#endif
       // The sorted keys put the nh hit children first (miss keys have bit 31 set).  Far .. near go onto the
       // stack, the nearest continues in registers.  Common case (room for three entries in the LDS part of
       // the stack): three UNCONDITIONAL stores -- hit children land at sp + (nh-1-j), the others in the dead
@@ -1586,7 +1601,7 @@ void launch_hdr(const Launch& L, const float4* accum, float* out, uint32_t n)
 }
 void launch_scatter_tris(const Launch& L, float4* tris, const uint32_t* pos, const float4* recs, uint32_t n)
 {
-  hipLaunchKernelGGL(k_scatter_tris, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, L.stream, tris, pos, recs, n);
+  hipLaunchKernelGGL(k_scatter_tris, dim3(n ? (n + kBlock - 1) / kBlock : 1u), dim3(kBlock), 0, L.stream, tris, pos, recs, n);
 }
 void launch_add4(const Launch& L, float4* dst, const float4* src, uint32_t n)
 {

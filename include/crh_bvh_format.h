@@ -7,8 +7,10 @@
  * fetched): packed at 48 B half of them straddle two 64-B sectors, which costs more HBM traffic than the smaller array
  * saves (measured, Mrays/s at 64-B / 48-B stride: C3 2890 / 2836, C5 -- 10 M triangles, HBM-bound -- 2104 / 1955).
  *   [0..2]  origin.xyz (float)            minimum corner of the union of the child boxes
- *   [3]     ex | ey<<8 | ez<<16 | n_inner<<24 | n_children<<28
- *                                          biased exponent bytes of the per-axis grid step 2^(e-127); child counts
+ *   [3]     kx | ky<<8 | kz<<16 | n_inner<<24 | n_children<<28
+ *                                          per-axis grid step 2^k, k a SIGNED byte (two's complement, -126 .. 126): the traversal kernel scales
+ *                                          the ray's reciprocal direction with one v_bfe_i32 + one v_ldexp_f32 per axis (it runs at the VALU issue
+ *                                          limit; shift + mask + multiply for a biased exponent byte was three); child counts
  *   [4..6]  qlo_x, qlo_y, qlo_z            byte k = child k's lower bound on the grid:  origin + q * step
  *   [7..9]  qhi_x, qhi_y, qhi_z            byte k = child k's upper bound
  *   [10]    child_base                     slots 0 .. n_inner-1 are inner nodes child_base + slot (consecutive indices); 0 if n_inner = 0
@@ -26,6 +28,7 @@
 #ifndef CRH_BVH_FORMAT_H
 #define CRH_BVH_FORMAT_H
 
+#include <stdint.h>
 #include "crh_math.h"
 
 #ifndef CRH_NODE_DWORDS
@@ -39,6 +42,9 @@
 #define CRH_LEAF_TAG      0x80000000u
 #define CRH_NODE_NINNER(w3)    (((w3) >> 24) & 7u)
 #define CRH_NODE_NCHILDREN(w3) (((w3) >> 28) & 7u)
+/* grid step exponent of axis a (0..2) as stored (signed byte) and as the biased exponent e = k + 127 the quantiser works with */
+#define CRH_NODE_STEP_K(w3, a) ((int)(int8_t)(((w3) >> (8 * (a))) & 0xffu))
+#define CRH_NODE_STEP_E(w3, a) ((uint32_t)(CRH_NODE_STEP_K(w3, a) + 127))
 
 /* biased exponent byte E of the smallest power-of-two step with 255 * 2^(E-127) >= ext */
 CRH_HD uint32_t crh_quant_exp(float ext)
@@ -84,7 +90,7 @@ CRH_HD void crh_pack_node(const float cmin[4][3], const float cmax[4][3], int n_
     org[a] = lo; ext[a] = hi - lo; e[a] = crh_quant_exp(ext[a]);
   }
   out[0] = crh_f2u(org[0]); out[1] = crh_f2u(org[1]); out[2] = crh_f2u(org[2]);
-  out[3] = e[0] | (e[1] << 8) | (e[2] << 16) | ((uint32_t)n_inner << 24) | ((uint32_t)n_children << 28);
+  out[3] = ((e[0] - 127u) & 0xffu) | (((e[1] - 127u) & 0xffu) << 8) | (((e[2] - 127u) & 0xffu) << 16) | ((uint32_t)n_inner << 24) | ((uint32_t)n_children << 28);
   for (int a = 0; a < 3; ++a) {
     uint32_t lo = 0u, hi = 0u;
     for (int k = 0; k < n_children; ++k) {

@@ -525,7 +525,7 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
       const qnode* q = &c->nodes[cur]; ORC_COUNT(any_hit ? cn->nodes_any++ : cn->nodes++);
       /* decode the per-node grid: face t = fma(q, step * inv, fma(origin - o, inv, -+ guard)) */
       const uint32_t ew = q->w[3];
-      const float ax = crh_quant_step(ew & 0xffu) * ix, ay = crh_quant_step((ew >> 8) & 0xffu) * iy, az = crh_quant_step((ew >> 16) & 0xffu) * iz;
+      const float ax = crh_quant_step(CRH_NODE_STEP_E(ew, 0)) * ix, ay = crh_quant_step(CRH_NODE_STEP_E(ew, 1)) * iy, az = crh_quant_step(CRH_NODE_STEP_E(ew, 2)) * iz;
       const float ddx = crh_u2f(q->w[0]) - o.x, ddy = crh_u2f(q->w[1]) - o.y, ddz = crh_u2f(q->w[2]) - o.z;
       const float bix = CRH_FMA(ddx, ix, -gx), box = CRH_FMA(ddx, ix, gx);
       const float biy = CRH_FMA(ddy, iy, -gy), boy = CRH_FMA(ddy, iy, gy);

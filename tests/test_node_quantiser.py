@@ -13,8 +13,10 @@ from cadrays_amd.materials import BSDF
 def decode(w):
     """packed node (16 dwords) -> origin[3], step[3], n_inner, n_children, qlo[4, 3], qhi[4, 3], child_base, leaf_base"""
     org = w[0:3].view(np.float32).astype(np.float64)
-    e = np.array([w[3] & 0xff, (w[3] >> 8) & 0xff, (w[3] >> 16) & 0xff], np.int64)
-    step = np.ldexp(1.0, (e - 127).astype(int))
+    k = np.array([w[3] & 0xff, (w[3] >> 8) & 0xff, (w[3] >> 16) & 0xff], np.int64)
+    k = np.where(k >= 128, k - 256, k)                   # signed bytes: step = 2^k (include/crh_bvh_format.h)
+    e = k + 127
+    step = np.ldexp(1.0, k.astype(int))
     ni, nc = int((w[3] >> 24) & 7), int((w[3] >> 28) & 7)
     qlo = np.array([[(int(w[4 + a]) >> (8 * k)) & 0xff for a in range(3)] for k in range(4)], np.float64)
     qhi = np.array([[(int(w[7 + a]) >> (8 * k)) & 0xff for a in range(3)] for k in range(4)], np.float64)
