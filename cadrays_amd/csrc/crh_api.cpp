@@ -1222,6 +1222,12 @@ int crh_build(crh_ctx* c)
   c->h_tris.clear();
   fill_records(c, 0, c->n_pos, tr, sh, uvr, c->two_level ? &vt : nullptr);
   c->cap_pos = (size_t)std::max(c->n_pos, 1u) + (c->two_level ? c->n_static : 0u);
+  if (c->two_level) {
+    // host arrays that grow when an object tree is built later: reserve now -- the first growth of a 33 MB node vector or a 48 MB record vector is a
+    // reallocation + copy of 10-20 ms, which used to land in the first dragged frame
+    c->bvh.nodes.reserve(c->bvh.nodes.size() + 2 * (size_t)c->n_static + 4 * (size_t)c->nO + 64);
+    c->h_tris.reserve(12 * c->cap_pos); c->bvh.prim_order.reserve(c->cap_pos); c->pos_obj.reserve(c->cap_pos);
+  }
   int rc;
   // head-room behind the node array: object trees built later by crh_set_transforms (<= ~1.5 nodes per triangle incl. alignment holes) and the top-level tree
   if ((rc = dev_put(c, c->d_nodes, c->cap_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode),
@@ -1267,7 +1273,7 @@ int crh_build(crh_ctx* c)
     CRH_HIP(hipMemsetAsync(c->queues.counts, 0, 8 * sizeof(uint32_t), cstream(c)));
     DScene S; fill_scene(c, S); S.two_level = 1;
     for (int don = 0; don < 2; ++don) {
-      Launch LT{cstream(c), 64, false, 0, don != 0};
+      Launch LT{cstream(c), 64, false, c->clamp_grid ? c->cus : 0, don != 0};      // with the occupancy query of resident_grid<>
       launch_trace_nearest(LT, S, c->paths, c->queues, 0, c->d_counters);
       launch_trace_any(LT, S, c->paths, c->queues, c->d_counters);
     }

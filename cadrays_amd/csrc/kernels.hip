@@ -338,8 +338,14 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const uint32_t ew = __float_as_uint(n0.w);
       // step * inv_d: the step is 2^k with k a signed byte of the node -- v_bfe_i32 + v_ldexp_f32, the same value as the product (a scaling by a
       // power of two is exact, and both round the same way where the result is subnormal)
+#ifndef CRH_EXP_MUL
       const float ax = __builtin_amdgcn_ldexpf(ix, (int)(ew << 24) >> 24), ay = __builtin_amdgcn_ldexpf(iy, (int)(ew << 16) >> 24),
                   az = __builtin_amdgcn_ldexpf(iz, (int)(ew << 8) >> 24);
+#else   /* A/B: the same value as a product with the step rebuilt from the signed byte (bfe + shift-add + multiply) */
+      const float ax = __uint_as_float((uint32_t)(((int)(ew << 24) >> 24) << 23) + 0x3f800000u) * ix,
+                  ay = __uint_as_float((uint32_t)(((int)(ew << 16) >> 24) << 23) + 0x3f800000u) * iy,
+                  az = __uint_as_float((uint32_t)(((int)(ew << 8) >> 24) << 23) + 0x3f800000u) * iz;
+#endif
       const float ddx = n0.x - o.x, ddy = n0.y - o.y, ddz = n0.z - o.z;
       // child references are implicit: slots < ni are the consecutive inner nodes from child_base, the others the leaves
       // with consecutive references from leaf_base (crh_bvh_format.h): ref(slot) = (slot < ni ? child_base : leaf_base - ni) + slot

@@ -69,6 +69,9 @@ if "split" in KINDS or len(sys.argv) == 1:
     v = View(0).load_scene(dataclasses.replace(sc, tri_object=inv.astype(np.int32), obj_xform=ident))
     flat = rate(v)
     print(json.dumps({"scene": f"split: {len(ids)} objects, none moved", "mrays_per_s": round(flat, 1)}), flush=True)
+    for _ in range(3):                                               # an interactive session has been issuing Redraw()s all along: the small-batch
+        v.Redraw()                                                   # streams exist (their one-time creation is not part of a move)
+    v.sync(); v.reset()
     r = np.random.default_rng(7)
     picks = r.permutation(len(ids))[:10]
     for n_moved in (1, 10):
