@@ -140,34 +140,46 @@ N_SIMDS = 256 * 4                 # 256 CUs x 4 SIMDs
 
 
 def roofline_ceilings(ent, avg_ms):
-    """Which roof the dominant kernel is under, from the committed SQ / TCC counter passes of THIS build (profiles/pmc_collect.sh):
+    """Which roof the dominant kernel is under, from the committed SQ / TCC counter passes of THIS build (profiles/pmc_collect.sh).  Units as
+    calibrated on gfx950 (profiles/r3/counter_units.md): GRBM_GUI_ACTIVE is summed over the 8 XCDs (/ 8 = shader cycles of the launch, 2.34 GHz);
+    SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES are in quad-cycles summed over all waves; a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles.
       hbm         memory-side bytes / time against the 8 TB/s peak
       l2          requests that reached the L2s x 128-B line / time against the ~34.5 TB/s the guide measures for the L2s -- an UPPER estimate of
                   the L2-side load (a divergent 16-B lane request occupies a line slot but moves less)
-      valu_issue  SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES per SIMD: share of the kernel's time a SIMD's VALU is issuing (both in the SQ's cycle unit;
-                  ACTIVE counts are summed over the 4 SIMDs of a CU -> / 4)
-      lane_util   SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU x 4): active lanes per issued VALU instruction cycle
-    `bound` = the largest of hbm / l2 / valu_issue (lane_util is a multiplier on valu_issue, not a ceiling of its own)."""
+      valu_issue  4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles): the share of all SIMD issue cycles of the launch spent issuing VALU instructions
+      lane_util   SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): active lanes per issued VALU instruction -- a multiplier on what the issue
+                  slots achieve, not a ceiling of its own
+    `binding` = the largest of hbm / l2 / valu_issue."""
     c = ent.get("counters_per_launch") or {}
-    out = {}
     t = avg_ms * 1e-3
     if t <= 0:
         return None
-    out["hbm"] = round(float(ent["hbm_bytes_per_launch"]) / t / 1e9 / HBM_PEAK_GBPS, 4)
+    out = {"hbm": round(float(ent["hbm_bytes_per_launch"]) / t / 1e9 / HBM_PEAK_GBPS, 4)}
     if c.get("TCC_REQ_sum"):
         out["l2"] = round(c["TCC_REQ_sum"] * 128.0 / t / 1e9 / L2_PEAK_GBPS, 4)
         out["l2_requests_per_launch"] = c["TCC_REQ_sum"]
-    if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_BUSY_CYCLES"):
-        # SQ_BUSY_CYCLES is tallied per SQ (one per CU... per shader engine on some parts): report the ratio AND the raw pair so that the unit can be checked
-        out["valu_issue"] = round(c["SQ_ACTIVE_INST_VALU"] / 4.0 / c["SQ_BUSY_CYCLES"], 4)
-        out["valu_issue_raw"] = {"SQ_ACTIVE_INST_VALU": c["SQ_ACTIVE_INST_VALU"], "SQ_BUSY_CYCLES": c["SQ_BUSY_CYCLES"], "SQ_WAVE_CYCLES": c.get("SQ_WAVE_CYCLES"),
-                                 "SQ_WAVES": c.get("SQ_WAVES")}
+    cycles = c["GRBM_GUI_ACTIVE"] / 8.0 if c.get("GRBM_GUI_ACTIVE") else None
+    pmc_ms = ent.get("avg_launch_ms") or avg_ms                      # the counters belong to the profiled launches
+    if cycles is None:
+        cycles = pmc_ms * 1e-3 * 2.34e9
+    else:
+        out["shader_clock_ghz"] = round(cycles / (pmc_ms * 1e-3) / 1e9, 3)
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAVES"):
+        # same-pass, clock-free form: the persistent waves live for the whole launch, SQ_WAVES / 1024 of them share a SIMD, so a SIMD's time is
+        # SQ_WAVE_CYCLES / (waves per SIMD) and its VALU is issuing for SQ_ACTIVE_INST_VALU of it (both quad-cycles).  Comes out at 1.00-1.05 on the
+        # cache-resident configs (the waves' ramp-up / drain is not in SQ_WAVE_CYCLES): saturated.  The clock-based form 4 x ACTIVE / (1024 x cycles)
+        # with cycles from another pass agrees within the pass-to-pass spread of the launch time.
+        out["valu_issue"] = round(c["SQ_ACTIVE_INST_VALU"] * (c["SQ_WAVES"] / float(N_SIMDS)) / c["SQ_WAVE_CYCLES"], 4)
+        out["valu_issue_clock_based"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMDS * cycles), 4)
+    elif c.get("SQ_ACTIVE_INST_VALU"):
+        out["valu_issue"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMDS * cycles), 4)
     if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
-        out["lane_util"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * 4.0 * c["SQ_ACTIVE_INST_VALU"]), 4)
+        out["lane_util"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4)
     if c.get("SQ_INSTS_VALU"):
         out["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
-        # issue floor: every wave-level VALU instruction takes >= 1 issue cycle of its SIMD (4 cycles for a 64-wide op on a 16-lane SIMD)
-        out["valu_issue_floor_ms"] = round(c["SQ_INSTS_VALU"] * 4.0 / N_SIMDS / 2.4e9 * 1e3, 3)
+        out["valu_issue_floor_ms"] = round(c["SQ_INSTS_VALU"] * 4.0 / N_SIMDS / (cycles / (pmc_ms * 1e-3)) * 1e3, 3)     # every instruction issued back to back
+    if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_ANY") is not None:
+        out["wave_time_split"] = {k: round(c[n] / c["SQ_WAVE_CYCLES"], 3) for k, n in (("waiting", "SQ_WAIT_ANY"), ("issue_stalled", "SQ_WAIT_INST_ANY"), ("issuing", "SQ_ACTIVE_INST_ANY")) if c.get(n) is not None}
     if c.get("SQ_INSTS_VMEM_RD"):
         out["vmem_rd_insts_per_launch"] = c["SQ_INSTS_VMEM_RD"]
     cands = {k: out[k] for k in ("hbm", "l2", "valu_issue") if k in out}
