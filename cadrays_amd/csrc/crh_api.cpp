@@ -58,6 +58,8 @@ struct crh_ctx {
   uint32_t root2 = 0xFFFFFFFFu; float tlas_lo[3] = {0, 0, 0}, tlas_hi[3] = {0, 0, 0};
   size_t cap_pos = 0;                     // leaf positions the triangle / shading / uv arrays have room for
   void* d_patch = nullptr; size_t cap_patch = 0;
+  int split_passes = -1;                  // CRH_SPLIT_PASSES: -1 auto, 0 one walk, 1 two passes
+  float4* d_ibox = nullptr;               // world boxes of the instances when there are at most kMaxIBox (the "does the ray touch a moved object" test)
   float4* d_inst = nullptr;
   // ---- built scene
   QBvh bvh;
@@ -255,14 +257,14 @@ int ensure_paths(crh_ctx* c, uint32_t need)
   void** ptrs[] = {(void**)&c->paths.ray_o[0], (void**)&c->paths.ray_d[0], (void**)&c->paths.hit, (void**)&c->paths.thr[0], (void**)&c->paths.rad,
                    (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c,
                    (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh,
-                   (void**)&c->paths.ray_o[1], (void**)&c->paths.ray_d[1], (void**)&c->paths.thr[1]};
-  const size_t sz[] = {16, 16, 16, 16, 16, 16, 16, 16, 4, 4, 4, 16, 16, 16};
+                   (void**)&c->paths.ray_o[1], (void**)&c->paths.ray_d[1], (void**)&c->paths.thr[1], (void**)&c->queues.q2, (void**)&c->queues.q2_sh};
+  const size_t sz[] = {16, 16, 16, 16, 16, 16, 16, 16, 4, 4, 4, 16, 16, 16, 4, 4};
   c->path_cap = 0;                                          // stays 0 if an allocation below fails
-  for (int i = 0; i < 14; ++i) {
+  for (int i = 0; i < 16; ++i) {
     if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
     CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
   }
-  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, 8 * sizeof(uint32_t))); CRH_HIP(hipMemsetAsync(c->queues.counts, 0, 8 * sizeof(uint32_t), cstream(c))); }
+  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, kCounts * sizeof(uint32_t))); CRH_HIP(hipMemsetAsync(c->queues.counts, 0, kCounts * sizeof(uint32_t), cstream(c))); }
   c->path_cap = need;
   return CRH_OK;
 }
@@ -282,7 +284,12 @@ void fill_scene(const crh_ctx* c, DScene& S)
   S.nodes = c->d_nodes; S.tris = c->d_tris; S.verts = c->d_verts; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = (c->envW && c->envH) ? c->d_env : nullptr;
   S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * (size_t)c->nO : nullptr; S.root = c->root; S.two_level = c->inst.empty() ? 0 : 1;
   S.root2 = c->inst.empty() ? kQEmpty : c->root2;
+  // render path of a split scene: with at most kMaxIBox moved objects the producers can tell precisely which rays come near one -- two traversal passes
+  // (the plain single-level kernels over everything, the two-level ones over the few flagged rays); with more, most rays would be flagged: one walk
+  // "static tree, then top level" in the two-level kernels, like the API-level tracers.  Same hits, same counters either way (CRH_SPLIT_PASSES=0/1 forces one).
+  S.split = (S.root2 != kQEmpty && (c->split_passes < 0 ? c->inst.size() <= kMaxIBox : c->split_passes != 0)) ? 1 : 0;
   for (int a = 0; a < 3; ++a) { S.tlas_lo[a] = c->tlas_lo[a]; S.tlas_hi[a] = c->tlas_hi[a]; }
+  S.ibox = c->d_ibox; S.n_ibox = (c->d_ibox && c->inst.size() <= kMaxIBox) ? (uint32_t)c->inst.size() : 0u;
   {
     const float* lo = c->bvh.bbmin; const float* hi = c->bvh.bbmax;      // bounds of the tree the walk starts in (the world box of a two-level scene)
     S.guard_box = make_float4((lo[0] + hi[0]) * 0.5f, (lo[1] + hi[1]) * 0.5f, (lo[2] + hi[2]) * 0.5f, (((hi[0] - lo[0]) + (hi[1] - lo[1])) + (hi[2] - lo[2])) * 0.5f);
@@ -380,6 +387,12 @@ int build_tlas(crh_ctx* c)
   } else {
     c->root = troot;
     for (int a = 0; a < 3; ++a) { c->bvh.bbmin[a] = c->tlas_lo[a]; c->bvh.bbmax[a] = c->tlas_hi[a]; }
+  }
+  if (!c->d_ibox) CRH_HIP(hipMalloc((void**)&c->d_ibox, sizeof(float4) * 2 * kMaxIBox));
+  if (n <= kMaxIBox) {
+    float ib[8 * kMaxIBox] = {0};
+    for (uint32_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { ib[8 * i + a] = boxes[6 * (size_t)i + a]; ib[8 * i + 4 + a] = boxes[6 * (size_t)i + 3 + a]; }
+    int rc_b = stage_copy(c, c->d_ibox, ib, sizeof(float) * 8 * n); if (rc_b) return rc_b;
   }
   return dev_put(c, c->d_inst, c->cap_inst, table.data(), table.size() * sizeof(float), 32 * sizeof(float) * ((size_t)c->nO + 64));
 }
@@ -507,10 +520,10 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     if (ln.timed && c->timing_on) {
       hipEvent_t e0 = get_event(c), e1 = get_event(c);
       hipEventRecord(e0, ln.stream);
-      launch_trace_nearest(T, S, ln.P, ln.Q, qin, c->d_counters);
+      launch_trace_nearest(T, S, ln.P, ln.Q, qin, b, c->d_counters);
       hipEventRecord(e1, ln.stream);
       c->trace_ev.emplace_back(e0, e1);
-    } else launch_trace_nearest(T, S, ln.P, ln.Q, qin, c->d_counters);
+    } else launch_trace_nearest(T, S, ln.P, ln.Q, qin, b, c->d_counters);
     launch_shade(L, S, ln.P, ln.Q, qin, b, c->d_counters);
     if (S.n_lights > 0) launch_trace_any(T, S, ln.P, ln.Q, c->d_counters);
     qin = 1 - qin;
@@ -531,8 +544,8 @@ int ensure_lanes(crh_ctx* c)
   }
   CRH_HIP(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
   CRH_HIP(hipMalloc((void**)&c->d_pipe_seeds, 4 * 16 * sizeof(uint32_t)));
-  CRH_HIP(hipMalloc((void**)&c->d_lane_counts, 8 * sizeof(uint32_t) * 8));
-  CRH_HIP(hipMemsetAsync(c->d_lane_counts, 0, 8 * sizeof(uint32_t) * 8, cstream(c)));
+  CRH_HIP(hipMalloc((void**)&c->d_lane_counts, kCounts * sizeof(uint32_t) * 8));
+  CRH_HIP(hipMemsetAsync(c->d_lane_counts, 0, kCounts * sizeof(uint32_t) * 8, cstream(c)));
   return CRH_OK;
 }
 
@@ -571,7 +584,7 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
     ln.P.thr[0] = P.thr[0] + base; ln.P.thr[1] = P.thr[1] + base; ln.P.hit = P.hit + base; ln.P.rad = P.rad + base;
     ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base;
-    ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.counts = c->d_lane_counts + 8 * k;
+    ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.q2 = Q.q2 + base; ln.Q.q2_sh = Q.q2_sh + base; ln.Q.counts = c->d_lane_counts + kCounts * k;
     CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
     rc = run_lane(c, ln, S, d_tiles + t0, t1 - t0, seed_per_tile ? d_seeds + t0 : d_seeds, ns, seed_per_tile, true); if (rc) return rc;
     CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
@@ -640,7 +653,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
     ln.P.thr[0] = P.thr[0] + base; ln.P.thr[1] = P.thr[1] + base; ln.P.hit = P.hit + base; ln.P.rad = P.rad + base;
     ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base;
-    ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.counts = c->d_lane_counts + 8 * k;
+    ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.q2 = Q.q2 + base; ln.Q.q2_sh = Q.q2_sh + base; ln.Q.counts = c->d_lane_counts + kCounts * k;
     CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
     // the frames in flight own path-state slices [k * total, (k + 1) * total): a batch of ANOTHER size (crh_render_tiles with another
     // sample count or tile list) would lay its slice across theirs -- it starts only when they are all done
@@ -892,6 +905,7 @@ crh_ctx* crh_create(int device_ordinal)
   if (const char* e = getenv("CRH_GRID_TRACE")) { int v = atoi(e); if (v > 0) c->grid_trace = v; }
   if (const char* e = getenv("CRH_CLAMP_GRID")) c->clamp_grid = atoi(e) != 0;
   if (const char* e = getenv("CRH_DONATE")) c->donate = atoi(e) != 0;
+  if (const char* e = getenv("CRH_SPLIT_PASSES")) c->split_passes = atoi(e);
   if (const char* e = getenv("CRH_PIPELINE")) c->pipeline = atoi(e) != 0;
   if (const char* e = getenv("CRH_PIPE_DEPTH")) { int v = atoi(e); if (v >= 2 && v <= 4) c->pipe_depth = (uint32_t)v; }
   if (const char* e = getenv("CRH_PIPE_DIV")) { int v = atoi(e); if (v > 0) c->pipe_div = v; }
@@ -916,7 +930,7 @@ void crh_destroy(crh_ctx* c)
   void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o[0], c->paths.ray_d[0], c->paths.ray_o[1], c->paths.ray_d[1], c->paths.thr[1],
                   c->paths.hit, c->paths.thr[0], c->paths.rad, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
                   c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
-                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst, c->d_patch, c->d_verts};
+                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst, c->d_patch, c->d_verts, c->d_ibox, c->queues.q2, c->queues.q2_sh};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->d_assembled) hipFree(c->d_assembled);
   if (c->d_peer_stage) hipFree(c->d_peer_stage);
@@ -1270,12 +1284,12 @@ int crh_build(crh_ctx* c)
     // gizmo) switches to the two-level instantiations and the record scatter -- launch each of them once now, on empty queues, so that their
     // first-launch cost (function lookup, code upload: ~20 ms for the set) is paid while the scene loads and not in the first dragged frame.
     if ((rc = ensure_paths(c, 4096))) return rc;
-    CRH_HIP(hipMemsetAsync(c->queues.counts, 0, 8 * sizeof(uint32_t), cstream(c)));
-    DScene S; fill_scene(c, S); S.two_level = 1;
+    CRH_HIP(hipMemsetAsync(c->queues.counts, 0, kCounts * sizeof(uint32_t), cstream(c)));
+    DScene S; fill_scene(c, S); S.two_level = 1; S.root2 = 0;
     for (int don = 0; don < 2; ++don) {
       Launch LT{cstream(c), 64, false, c->clamp_grid ? c->cus : 0, don != 0};      // with the occupancy query of resident_grid<>
-      launch_trace_nearest(LT, S, c->paths, c->queues, 0, c->d_counters);
-      launch_trace_any(LT, S, c->paths, c->queues, c->d_counters);
+      S.split = 0; launch_trace_nearest(LT, S, c->paths, c->queues, 0, 0, c->d_counters); launch_trace_any(LT, S, c->paths, c->queues, c->d_counters);      // the instantiations of an all-moved scene
+      S.split = 1; launch_trace_nearest(LT, S, c->paths, c->queues, 0, 0, c->d_counters); launch_trace_any(LT, S, c->paths, c->queues, c->d_counters);      // and the second-pass ones
     }
     Launch L{cstream(c), 64, false};
     launch_scatter_tris(L, c->d_tris, (const uint32_t*)c->d_patch, (const float4*)c->d_patch, 0);
@@ -1394,7 +1408,7 @@ int crh_set_path_budget(crh_ctx* c, uint64_t max_paths)
     CRH_HIP(hipStreamSynchronize(cstream(c)));
     void** ptrs[] = {(void**)&c->paths.ray_o[0], (void**)&c->paths.ray_d[0], (void**)&c->paths.hit, (void**)&c->paths.thr[0], (void**)&c->paths.rad,
                      (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c, (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh,
-                     (void**)&c->paths.ray_o[1], (void**)&c->paths.ray_d[1], (void**)&c->paths.thr[1]};
+                     (void**)&c->paths.ray_o[1], (void**)&c->paths.ray_d[1], (void**)&c->paths.thr[1], (void**)&c->queues.q2, (void**)&c->queues.q2_sh};
     for (void** q : ptrs) if (*q) { CRH_HIP(hipFree(*q)); *q = nullptr; }
     c->path_cap = 0;
   }

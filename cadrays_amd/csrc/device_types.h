@@ -23,6 +23,8 @@ constexpr uint32_t kQLeafBit      = 0x80000000u;
 static_assert(CRH_TRI_STRIDE == 4, "the fourth float4 of a triangle record holds the caller's triangle id");
 constexpr uint32_t kTriStride = CRH_TRI_STRIDE;   // float4 between consecutive triangle records on the device (3 are fetched by the traversal): on a 64-B stride no
                                                   // record straddles two 64-B sectors (packed at 48 B half of them do): +2.8 % C3, +4 % C5
+constexpr uint32_t kMaxIBox = 4;   // instances whose world boxes the "does this ray touch a moved object at all" test looks at one by one (spec constant)
+constexpr int kCounts     = 16;    // words per queue-counter block (DQueues::counts)
 constexpr int kBlock      = 256;   // threads per workgroup (4 waves)
 constexpr int kLdsStack   = 16;    // traversal stack entries per lane kept in LDS
 constexpr int kOvfStack   = 112;   // spill entries per lane (scratch, rarely touched); 16 + 112 = 128 >= 63 (top-level tree: binary depth <= 40
@@ -47,8 +49,12 @@ struct DScene {
   float4 guard_box;       // {centre.xyz, L1 half-extent} of the tree traversal starts in: scales the slab test's guard band (kSlabGuard)
   uint32_t root;          // node index traversal starts at: the (static) world-space tree; the top-level root when no static triangle is live
   uint32_t root2;         // static / moved split: top-level root walked AFTER the static tree (kQEmpty: none) ...
-  float tlas_lo[3], tlas_hi[3];   // ... if the ray touches the bounds of all instances
+  float tlas_lo[3], tlas_hi[3];   // ... if the ray touches the bounds of all instances ...
+  const float4* ibox;     // ... and, when there are at most kMaxIBox of them (n_ibox > 0), the world box of at least one: 2 x float4 {lo, hi} per instance
+  uint32_t n_ibox;
   int two_level;          // some object is rendered as an instance right now (object trees + top level exist)
+  int split;              // render path of a split scene (root2 valid): two traversal passes -- the single-level kernels over the static tree, then the
+                          // two-level ones over the top level for the rays their producers flagged (DQueues::q2 / q2_sh)
   uint32_t n_mats, n_lights, env_w, env_h;
   float bg[3]; int env_as_bg;
   // camera frame
@@ -86,7 +92,10 @@ struct DCounters {          // device-side mirror of crh_stats
 struct DQueues {
   uint32_t* q[2];           // active path ids, ping-pong
   uint32_t* q_sh;           // path ids with a pending shadow ray
-  uint32_t* counts;         // [0],[1]: active counts (ping-pong), [2]: shadow count, [4..6]: work cursors (nearest, shade, any)
+  uint32_t* q2;             // static / moved split: the entries of the current nearest-hit queue whose rays touch a moved object (second pass over the top level)
+  uint32_t* q2_sh;          // ... and of the shadow queue
+  uint32_t* counts;         // kCounts words: [0],[1] active counts (ping-pong), [2] shadow count, [4..6] work cursors (nearest, shade, any),
+                            // [3],[10] second-pass nearest counts (ping-pong by bounce parity), [7] second-pass shadow count, [8],[9] second-pass cursors
 };
 
 }  // namespace crh

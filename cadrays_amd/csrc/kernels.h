@@ -17,7 +17,7 @@ void launch_raygen(const Launch&, const DScene&, const DPaths&, const DQueues&, 
                    const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_frame_seeds, uint32_t n_samples,
                    int seed_per_tile = 0, const uint32_t* d_n_tiles = nullptr /* tile count in HBM (device-drawn tile list) */);
 // nearest-hit traversal of queue `qin`; also zeroes the other queue's count and the shadow count
-void launch_trace_nearest(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, DCounters*);
+void launch_trace_nearest(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, uint32_t bounce, DCounters*);
 // emission, NEE, BSDF sampling, Russian roulette; survivors -> queue 1-qin, shadow rays -> q_sh
 void launch_shade(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, uint32_t bounce, DCounters*);
 // any-hit traversal of the shadow queue; unoccluded contributions are added to the path radiance

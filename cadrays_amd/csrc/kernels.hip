@@ -164,9 +164,31 @@ constexpr uint32_t kNoLane = 64u;
 // never donate.
 // Static / moved split of a two-level scene: the walk starts in the static world-space tree (`root`) and the top-level
 // tree over the moved objects (`root2`) waits at the bottom of the stack -- pushed only when the ray touches the instances' bounds.
-struct Top2 { uint32_t root2; float lo[3], hi[3]; };
+struct Top2 { uint32_t root2; float lo[3], hi[3]; const float4* ibox; uint32_t n_ibox; };
 __device__ __forceinline__ Top2 top2_of(const DScene& S)
-{ Top2 t; t.root2 = S.root2; for (int a = 0; a < 3; ++a) { t.lo[a] = S.tlas_lo[a]; t.hi[a] = S.tlas_hi[a]; } return t; }
+{ Top2 t; t.root2 = S.root2; for (int a = 0; a < 3; ++a) { t.lo[a] = S.tlas_lo[a]; t.hi[a] = S.tlas_hi[a]; } t.ibox = S.ibox; t.n_ibox = S.n_ibox; return t; }
+
+// Does the ray touch a moved object at all?  (spec; the oracle's traverse() has the twin.)  The planes of a box with the ray's
+// guard band, like a node's child test: first the bounds of ALL instances, then -- when there are at most kMaxIBox of them -- the world box of at
+// least one.  ix.. = reciprocal direction, gx.. = guard band of the world-space ray.
+__device__ __forceinline__ bool touches_instances(const Top2& t2, v3 o, float ix, float iy, float iz, float gx, float gy, float gz, float tmax)
+{
+  auto slab = [&](float lx, float ly, float lz, float hx, float hy, float hz) {
+    const float ax_ = (lx - o.x) * ix, bx_ = (hx - o.x) * ix, ay_ = (ly - o.y) * iy, by_ = (hy - o.y) * iy, az_ = (lz - o.z) * iz, bz_ = (hz - o.z) * iz;
+    const float tn_ = fmaxf(fmaxf(fmaxf(fminf(ax_, bx_) - gx, fminf(ay_, by_) - gy), fminf(az_, bz_) - gz), 0.f);
+    const float tf_ = fminf(fminf(fminf(fmaxf(ax_, bx_) + gx, fmaxf(ay_, by_) + gy), fmaxf(az_, bz_) + gz), tmax);
+    return tn_ <= tf_;
+  };
+  if (!slab(t2.lo[0], t2.lo[1], t2.lo[2], t2.hi[0], t2.hi[1], t2.hi[2])) return false;
+  if (t2.n_ibox == 0u) return true;
+  for (uint32_t i = 0; i < t2.n_ibox; ++i) {
+    const float4 lo = t2.ibox[2u * i], hi = t2.ibox[2u * i + 1u];
+    if (slab(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z)) return true;
+  }
+  return false;
+}
+// the same for a ray whose reciprocals and guard band are not at hand (the kernels that PRODUCE rays flag the ones of the second pass)
+__device__ __forceinline__ bool ray_touches_instances(const DScene& S, v3 o, v3 d, float tmax);
 
 template <bool ANY, bool COUNT, bool TWO, bool DON, class Load, class Store>
 __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, const float4* __restrict__ tris,
@@ -245,14 +267,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           set_guard(gbox);
           if (TWO) save_world();
           best = tmax; found = false; sp = 0; cur = root; have = true;
-          if (TWO && t2.root2 != kQEmpty) {
-            // same planes + guard band as a node's child test, against the bounds of all instances (the oracle's traverse() has the twin)
-            const float ax_ = (t2.lo[0] - o.x) * ix, bx_ = (t2.hi[0] - o.x) * ix, ay_ = (t2.lo[1] - o.y) * iy, by_ = (t2.hi[1] - o.y) * iy;
-            const float az_ = (t2.lo[2] - o.z) * iz, bz_ = (t2.hi[2] - o.z) * iz;
-            const float tn_ = fmaxf(fmaxf(fmaxf(fminf(ax_, bx_) - gx, fminf(ay_, by_) - gy), fminf(az_, bz_) - gz), 0.f);
-            const float tf_ = fminf(fminf(fminf(fmaxf(ax_, bx_) + gx, fmaxf(ay_, by_) + gy), fmaxf(az_, bz_) + gz), tmax);
-            if (tn_ <= tf_) { lds[0] = t2.root2; sp = 1; }
-          }
+          if (ANY && tmax < 0.f) cur = kDone;                      // second any-hit pass of a split scene: already occluded in the first (no visit, no test)
+          if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, ix, iy, iz, gx, gy, gz, tmax)) { lds[0] = t2.root2; sp = 1; }
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
           if (DON) { sbase = 0; is_child = false; cfound = false; next = kNoLane; head = lane; bound[lane] = __float_as_uint(tmax); }
         }
@@ -527,50 +543,67 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   }
 }
 
-template <bool COUNT, bool TWO, bool DON>
+// P2: the SECOND pass of a split scene (static tree + moved objects).  The first pass is the single-level instantiation over the
+// whole queue, walking the static tree only; the kernels that produced the rays listed the ones that touch a moved object in `q` of this launch
+// (DQueues::q2); this pass walks the top-level tree for them, from the distance the first pass found, and overwrites the hit when it finds a nearer
+// one.  Same visits, same hits as one walk "static tree, then top level" -- the rays that never come near a moved object run the plain kernel.
+template <bool COUNT, bool TWO, bool DON, bool P2 = false>
 __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, int cur, const uint32_t* __restrict__ q,
                                                   const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors,
-                                                  uint32_t* zero_a, uint32_t* zero_b, DCounters* C)
+                                                  uint32_t* zero_a, uint32_t* zero_b, uint32_t* zero_c, uint32_t* zero_d, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   __shared__ uint32_t s_bound[DON ? kBlock : 1];
   const uint32_t n = *count;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *zero_a = 0u; *zero_b = 0u;
-    cursors[1] = 0u; cursors[2] = 0u;            // shade / any-hit cursors for the launches that follow
+  if (!P2 && blockIdx.x == 0 && threadIdx.x == 0) {
+    *zero_a = 0u; *zero_b = 0u; *zero_c = 0u; *zero_d = 0u;      // the other queue's count, the shadow count, the second-pass counts shading will fill
+    cursors[1] = 0u; cursors[2] = 0u; cursors[5] = 0u;            // shade / any-hit / second-pass any-hit cursors for the launches that follow
     atomicAdd(&C->rays_nearest, (unsigned long long)n);
   }
   uint32_t nn = 0, nt = 0;
   const float4* __restrict__ ray_o = P.ray_o[cur]; const float4* __restrict__ ray_d = P.ray_d[cur];
-  trace_engine<false, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, top2_of(S), cursors + 0, n, &stk[threadIdx.x],
+  Top2 t2 = top2_of(S); if (P2) t2.root2 = kQEmpty;             // the second pass starts AT the top level
+  trace_engine<false, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, P2 ? S.root2 : S.root, S.guard_box, t2, cursors + (P2 ? 4 : 0), n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = ld_stream(&ray_o[tag]), d4 = ld_stream(&ray_d[tag]);      // .w lanes carry the path's rng state / slot + flags, not ray data
-      o = xyz(o4); d = xyz(d4); tmax = CRH_MAXFLOAT;
+      o = xyz(o4); d = xyz(d4); tmax = P2 ? P.hit[tag].x : CRH_MAXFLOAT;           // first-pass distance (its miss record holds the ray's tmax)
     },
-    [&](uint32_t tag, float4 h, bool) { st_stream(&P.hit[tag], h); }, nn, nt, DON ? &s_bound[threadIdx.x & ~63u] : nullptr);
+    [&](uint32_t tag, float4 h, bool f) { if (!P2 || f) st_stream(&P.hit[tag], h); }, nn, nt, DON ? &s_bound[threadIdx.x & ~63u] : nullptr);
   if (COUNT) {
     nn = wave_sum(nn); nt = wave_sum(nt);
     if (lane_id() == 0) { atomicAdd(&C->nodes_nearest, (unsigned long long)nn); atomicAdd(&C->tris_nearest, (unsigned long long)nt); }
   }
 }
 
-template <bool COUNT, bool TWO, bool DON>
+// P2 / S.split: shadow rays of a split scene.  First pass (single-level instantiation, static tree): a ray the producer flagged (sh_d.w != 0: it touches a
+// moved object) does not add its contribution yet -- if the static tree occludes it, its pending contribution is zeroed instead; the second pass walks
+// the top level for the flagged rays and adds what is left when that does not occlude either.
+template <bool COUNT, bool TWO, bool DON, bool P2 = false>
 __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t* __restrict__ q,
                                               const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors, DCounters* C)
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   __shared__ uint32_t s_bound[DON ? kBlock : 1];
   const uint32_t n = *count;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
+  if (!P2 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays_any, (unsigned long long)n);
   uint32_t nn = 0, nt = 0;
-  trace_engine<true, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, top2_of(S), cursors + 2, n, &stk[threadIdx.x],
+  Top2 t2 = top2_of(S); if (P2) t2.root2 = kQEmpty;
+  const bool split = !P2 && S.split != 0;
+  trace_engine<true, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, P2 ? S.root2 : S.root, S.guard_box, t2, cursors + (P2 ? 5 : 2), n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = P.sh_o[tag], d4 = P.sh_d[tag];
       o = xyz(o4); d = xyz(d4); tmax = o4.w;
     },
     [&](uint32_t tag, float4, bool occluded) {
+      if (split && P.sh_d[tag].w != 0.f) {                    // flagged: the second pass decides; an occluder found here cancels the contribution
+        if (occluded) {                                       // nothing left to add, and nothing left to walk: the second pass retires it on sight
+          P.sh_c[tag] = make_float4(0.f, 0.f, 0.f, P.sh_c[tag].w);
+          float4 so = P.sh_o[tag]; so.w = -1.0f; P.sh_o[tag] = so;
+        }
+        return;
+      }
       if (!occluded) {
         const float4 c = P.sh_c[tag];
         const uint32_t slot = __float_as_uint(c.w);
@@ -614,6 +647,14 @@ __global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict
       atomicAdd(ANY ? &C->tris_any : &C->tris_nearest, (unsigned long long)nt);
     }
   }
+}
+
+__device__ __forceinline__ bool ray_touches_instances(const DScene& S, v3 o, v3 d, float tmax)
+{
+  const float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
+  const float4 gb = S.guard_box;
+  const float R = CRH_FMA(gb.w, 3.0f, (crh_abs(o.x - gb.x) + crh_abs(o.y - gb.y)) + crh_abs(o.z - gb.z)) * kSlabGuard;      // trace_engine's set_guard
+  return touches_instances(top2_of(S), o, ix, iy, iz, crh_abs(ix) * R, crh_abs(iy) * R, crh_abs(iz) * R, tmax);
 }
 
 // ================================================================== BSDF
@@ -964,7 +1005,10 @@ __device__ __forceinline__ uint32_t pixel_sample_to_slot(uint32_t local, uint32_
   return B * 64u * ns + (((c << lg) + b) << 6) + (CRH_SLOT_SAMPLE_MAJOR ? si * P + pi_ : (pi_ << lg) + si);
 }
 
+// SPLIT: the instantiation for split scenes (static tree + moved objects) also lists the rays that touch a moved object; the plain one carries none of it
+template <bool SPLIT>
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t* __restrict__ q, uint32_t* __restrict__ count,
+                                                    uint32_t* __restrict__ q2, uint32_t* __restrict__ count2,
                                                     uint32_t* __restrict__ cursors,
                                                     const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
                                                     const uint32_t* __restrict__ seeds, uint32_t n_samples, int seed_per_tile,
@@ -976,7 +1020,11 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
   // their ids at exclusive-scan offsets.  (Per-workgroup appends were atomic-rate bound: 261 K atomics per 67 M paths.)
   __shared__ uint32_t s_cnt[kGenIters * 4];
   __shared__ uint32_t s_base;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { cursors[0] = 0u; cursors[1] = 0u; cursors[2] = 0u; }
+  // split scenes: the camera rays that touch a moved object are listed for the second traversal pass (collected per chunk, one atomic per chunk)
+  __shared__ uint32_t s_q2[SPLIT ? kGenIters * kBlock : 1];
+  __shared__ uint32_t s_n2, s_b2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { cursors[0] = 0u; cursors[1] = 0u; cursors[2] = 0u; cursors[4] = 0u; cursors[5] = 0u; }
+  if (threadIdx.x == 0) s_n2 = 0u;
   const uint32_t per_sample = n_tiles * S.tile_size * S.tile_size;
   const uint32_t total = per_sample * n_samples;
   const uint32_t chunk = kGenIters * kBlock;
@@ -1002,7 +1050,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
     __syncthreads();
     for (uint32_t it = 0; it < kGenIters; ++it) {
     const uint32_t pid = cbase + it * kBlock + threadIdx.x;
-    bool valid = pid < total;
+    bool valid = pid < total, flagged = false;
     uint32_t px = 0, py = 0, s = 0, local = 0;
     if (valid) { slot_to_pixel_sample(pid, n_samples, local, s); valid = slot_pixel(S, tile_ids, local, px, py); }
     if (valid) {
@@ -1033,13 +1081,22 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
       }
       P.ray_o[0][pid] = mk4(o, __uint_as_float(rng));           // .w = rng state; position = path slot at bounce 0
       P.ray_d[0][pid] = mk4(d, __uint_as_float(pid << 1));      // .w = (path slot << 1) | inside-a-medium flag
+      if (SPLIT) flagged = ray_touches_instances(S, o, d, CRH_MAXFLOAT);
       // throughput (1,1,1 | no pending pdf) and radiance (0) are NOT written here: every generated path goes through
       // the bounce-0 k_shade, which takes them as constants and writes the radiance record unconditionally
     }
     const unsigned long long m = __ballot(valid);
     if (valid) q[s_base + s_cnt[it * 4u + wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pid;
+    if (SPLIT) lds_append(flagged, pid, s_q2, &s_n2);
     }
     __syncthreads();
+    if (SPLIT) {
+      if (threadIdx.x == 0) { s_b2 = s_n2 ? atomicAdd(count2, s_n2) : 0u; }
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < s_n2; j += kBlock) q2[s_b2 + j] = s_q2[j];
+      __syncthreads();
+      if (threadIdx.x == 0) s_n2 = 0u;
+    }
   }
 }
 
@@ -1056,17 +1113,22 @@ constexpr int kLdsMats = 64;   // materials staged in LDS (8 KB); larger tables 
 #else
 #define CRH_SHADE_BOUNDS __launch_bounds__(kBlock)
 #endif
+template <bool SPLIT>
 __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t bounce,
                                                    const uint32_t* __restrict__ q_in, const uint32_t* __restrict__ count_in,
                                                    uint32_t* __restrict__ q_out, uint32_t* __restrict__ count_out,
                                                    uint32_t* __restrict__ q_sh, uint32_t* __restrict__ count_sh,
+                                                   uint32_t* __restrict__ q2, uint32_t* __restrict__ count2,
+                                                   uint32_t* __restrict__ q2_sh, uint32_t* __restrict__ count2_sh,
                                                    uint32_t* __restrict__ cursors, DCounters* C)
 {
   __shared__ float4 s_mats[kLdsMats * 8];
   // survivors / shadow rays of kShadeIters x 256 paths are collected in LDS and appended with ONE global atomic each
   __shared__ uint32_t s_qc[kShadeIters * kBlock], s_qs[kShadeIters * kBlock];
-  __shared__ uint32_t s_base, s_nc, s_ns, s_gc, s_gs;
-  if (blockIdx.x == 0 && threadIdx.x == 0) cursors[0] = 0u;     // nearest-hit cursor of the next bounce
+  // split scenes: those of them that touch a moved object, for the second traversal pass
+  __shared__ uint32_t s_q2c[SPLIT ? kShadeIters * kBlock : 1], s_q2s[SPLIT ? kShadeIters * kBlock : 1];
+  __shared__ uint32_t s_base, s_nc, s_ns, s_gc, s_gs, s_n2c, s_n2s, s_g2c, s_g2s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { cursors[0] = 0u; cursors[4] = 0u; }     // nearest-hit cursors (both passes) of the next bounce
   const bool mats_in_lds = S.n_mats <= (uint32_t)kLdsMats;
   if (mats_in_lds) {
     for (uint32_t i = threadIdx.x; i < S.n_mats * 8u; i += kBlock) s_mats[i] = S.mats[i];
@@ -1081,7 +1143,7 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
   uint32_t n_shaded = 0;
   for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) { s_base = atomicAdd(cursors + 1, kShadeIters * (uint32_t)kBlock); s_nc = 0u; s_ns = 0u; }
+    if (threadIdx.x == 0) { s_base = atomicAdd(cursors + 1, kShadeIters * (uint32_t)kBlock); s_nc = 0u; s_ns = 0u; s_n2c = 0u; s_n2s = 0u; }
     __syncthreads();
     const uint32_t base = s_base;
     if (base >= n) break;
@@ -1192,7 +1254,8 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
             if (contrib.x > kMinContrib || contrib.y > kMinContrib || contrib.z > kMinContrib) {
               shadow = true;
               s_o = mk4(offset_origin(p, ld, ng, S.eps), dist);
-              s_d = mk4(ld, 0.f);
+              // split scenes: .w != 0 marks a shadow ray that touches a moved object (the first any-hit pass leaves its contribution to the second)
+              s_d = mk4(ld, (SPLIT && ray_touches_instances(S, xyz(s_o), ld, dist)) ? 1.0f : 0.f);
               s_c = mk4(wc, __uint_as_float(pid));
             }
           }
@@ -1221,18 +1284,29 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
     // survivors): positions stay packed in runs, no two chunks ever share one, and no global atomic is needed to find them.
     if (S.n_lights > 0u) {
       const uint32_t r = lds_rank(shadow, &s_ns);
-      if (shadow) { const uint32_t ps = q_in[base + r]; s_qs[r] = ps; P.sh_o[ps] = s_o; P.sh_d[ps] = s_d; P.sh_c[ps] = s_c; }
+      uint32_t ps = 0u;
+      if (shadow) { ps = q_in[base + r]; s_qs[r] = ps; P.sh_o[ps] = s_o; P.sh_d[ps] = s_d; P.sh_c[ps] = s_c; }
+      if (SPLIT) lds_append(shadow && s_d.w != 0.f, ps, s_q2s, &s_n2s);
     }
     {
       const uint32_t r = lds_rank(cont, &s_nc);
-      if (cont) { const uint32_t pn = q_in[base + r]; s_qc[r] = pn; out_o[pn] = n_o; out_d[pn] = n_d; out_t[pn] = n_t; }
+      uint32_t pn = 0u;
+      if (cont) { pn = q_in[base + r]; s_qc[r] = pn; out_o[pn] = n_o; out_d[pn] = n_d; out_t[pn] = n_t; }
+      if (SPLIT) lds_append(cont && ray_touches_instances(S, xyz(n_o), xyz(n_d), CRH_MAXFLOAT), pn, s_q2c, &s_n2c);
     }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { s_gc = s_nc ? atomicAdd(count_out, s_nc) : 0u; s_gs = s_ns ? atomicAdd(count_sh, s_ns) : 0u; }
+    if (threadIdx.x == 0) {
+      s_gc = s_nc ? atomicAdd(count_out, s_nc) : 0u; s_gs = s_ns ? atomicAdd(count_sh, s_ns) : 0u;
+      if (SPLIT) { s_g2c = s_n2c ? atomicAdd(count2, s_n2c) : 0u; s_g2s = s_n2s ? atomicAdd(count2_sh, s_n2s) : 0u; }
+    }
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < s_nc; j += kBlock) q_out[s_gc + j] = s_qc[j];
     for (uint32_t j = threadIdx.x; j < s_ns; j += kBlock) q_sh[s_gs + j] = s_qs[j];
+    if (SPLIT) {
+      for (uint32_t j = threadIdx.x; j < s_n2c; j += kBlock) q2[s_g2c + j] = s_q2c[j];
+      for (uint32_t j = threadIdx.x; j < s_n2s; j += kBlock) q2_sh[s_g2s + j] = s_q2s[j];
+    }
   }
   n_shaded = wave_sum(n_shaded);
   if (lane_id() == 0 && n_shaded) atomicAdd(&C->shaded_hits, (unsigned long long)n_shaded);
@@ -1549,7 +1623,9 @@ void launch_raygen(const Launch& L, const DScene& S, const DPaths& P, const DQue
                    const uint32_t* d_n_tiles)
 {
   hipMemsetAsync(Q.counts + qsel, 0, sizeof(uint32_t), L.stream);
-  hipLaunchKernelGGL(k_raygen, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile, d_n_tiles);
+  if (S.split) hipMemsetAsync(Q.counts + 3, 0, sizeof(uint32_t), L.stream);                 // second-pass count of bounce 0 (even parity)
+  if (S.split) hipLaunchKernelGGL(k_raygen<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.q2, Q.counts + 3, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile, d_n_tiles);
+  else         hipLaunchKernelGGL(k_raygen<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.q2, Q.counts + 3, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile, d_n_tiles);
 }
 // A persistent traversal grid larger than what the register budget keeps resident leaves workgroups queued behind the first
 // wave of them, i.e. a second, nearly empty round at the end of every launch: clamp the grid to occupancy x compute units.
@@ -1561,24 +1637,38 @@ template <auto Kernel> static int resident_grid(const Launch& L)
   return per_cu > 0 ? min(L.grid, per_cu * L.cus) : L.grid;
 }
 
-void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, DCounters* C)
+// second-pass counts ping-pong by bounce parity: bounce b's list is counted in counts[3] (b even) / counts[10] (b odd)
+static inline int count2_slot(uint32_t bounce) { return (bounce & 1u) ? 10 : 3; }
+
+void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, uint32_t bounce, DCounters* C)
 {
-#define CRH_LAUNCH_TN(CNT, TWO, DON) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO, DON>), dim3(resident_grid<k_trace_nearest<CNT, TWO, DON>>(L)), dim3(kBlock), 0, L.stream, S, P, qin, Q.q[qin], \
-                                                   Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, C)
-  if (S.two_level) { if (L.counters) CRH_LAUNCH_TN(true, true, false); else if (L.donate) CRH_LAUNCH_TN(false, true, true); else CRH_LAUNCH_TN(false, true, false); }
-  else             { if (L.counters) CRH_LAUNCH_TN(true, false, false); else if (L.donate) CRH_LAUNCH_TN(false, false, true); else CRH_LAUNCH_TN(false, false, false); }
+  // first pass (or the only one): a split scene walks its static tree with the SINGLE-LEVEL instantiation
+  const bool two = S.two_level && !S.split;
+#define CRH_LAUNCH_TN(CNT, TWO, DON, P2, QQ, CC) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO, DON, P2>), dim3(resident_grid<k_trace_nearest<CNT, TWO, DON, P2>>(L)), dim3(kBlock), 0, L.stream, S, P, qin, QQ, \
+                                                   CC, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, Q.counts + count2_slot(bounce + 1u), Q.counts + 7, C)
+  if (two) { if (L.counters) CRH_LAUNCH_TN(true, true, false, false, Q.q[qin], Q.counts + qin); else if (L.donate) CRH_LAUNCH_TN(false, true, true, false, Q.q[qin], Q.counts + qin); else CRH_LAUNCH_TN(false, true, false, false, Q.q[qin], Q.counts + qin); }
+  else     { if (L.counters) CRH_LAUNCH_TN(true, false, false, false, Q.q[qin], Q.counts + qin); else if (L.donate) CRH_LAUNCH_TN(false, false, true, false, Q.q[qin], Q.counts + qin); else CRH_LAUNCH_TN(false, false, false, false, Q.q[qin], Q.counts + qin); }
+  if (S.split) {     // second pass: the top level, for the rays listed by their producer
+    if (L.counters) CRH_LAUNCH_TN(true, true, false, true, Q.q2, Q.counts + count2_slot(bounce)); else if (L.donate) CRH_LAUNCH_TN(false, true, true, true, Q.q2, Q.counts + count2_slot(bounce)); else CRH_LAUNCH_TN(false, true, false, true, Q.q2, Q.counts + count2_slot(bounce));
+  }
 #undef CRH_LAUNCH_TN
 }
 void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, uint32_t bounce, DCounters* C)
 {
-  hipLaunchKernelGGL(k_shade, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, qin, bounce, Q.q[qin], Q.counts + qin,
-                     Q.q[1 - qin], Q.counts + (1 - qin), Q.q_sh, Q.counts + 2, Q.counts + 4, C);
+  if (S.split) hipLaunchKernelGGL(k_shade<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, qin, bounce, Q.q[qin], Q.counts + qin,
+                     Q.q[1 - qin], Q.counts + (1 - qin), Q.q_sh, Q.counts + 2, Q.q2, Q.counts + count2_slot(bounce + 1u), Q.q2_sh, Q.counts + 7, Q.counts + 4, C);
+  else         hipLaunchKernelGGL(k_shade<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, qin, bounce, Q.q[qin], Q.counts + qin,
+                     Q.q[1 - qin], Q.counts + (1 - qin), Q.q_sh, Q.counts + 2, Q.q2, Q.counts + count2_slot(bounce + 1u), Q.q2_sh, Q.counts + 7, Q.counts + 4, C);
 }
 void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, DCounters* C)
 {
-#define CRH_LAUNCH_TA(CNT, TWO, DON) hipLaunchKernelGGL((k_trace_any<CNT, TWO, DON>), dim3(resident_grid<k_trace_any<CNT, TWO, DON>>(L)), dim3(kBlock), 0, L.stream, S, P, Q.q_sh, Q.counts + 2, Q.counts + 4, C)
-  if (S.two_level) { if (L.counters) CRH_LAUNCH_TA(true, true, false); else if (L.donate) CRH_LAUNCH_TA(false, true, true); else CRH_LAUNCH_TA(false, true, false); }
-  else             { if (L.counters) CRH_LAUNCH_TA(true, false, false); else if (L.donate) CRH_LAUNCH_TA(false, false, true); else CRH_LAUNCH_TA(false, false, false); }
+  const bool two = S.two_level && !S.split;
+#define CRH_LAUNCH_TA(CNT, TWO, DON, P2, QQ, CC) hipLaunchKernelGGL((k_trace_any<CNT, TWO, DON, P2>), dim3(resident_grid<k_trace_any<CNT, TWO, DON, P2>>(L)), dim3(kBlock), 0, L.stream, S, P, QQ, CC, Q.counts + 4, C)
+  if (two) { if (L.counters) CRH_LAUNCH_TA(true, true, false, false, Q.q_sh, Q.counts + 2); else if (L.donate) CRH_LAUNCH_TA(false, true, true, false, Q.q_sh, Q.counts + 2); else CRH_LAUNCH_TA(false, true, false, false, Q.q_sh, Q.counts + 2); }
+  else     { if (L.counters) CRH_LAUNCH_TA(true, false, false, false, Q.q_sh, Q.counts + 2); else if (L.donate) CRH_LAUNCH_TA(false, false, true, false, Q.q_sh, Q.counts + 2); else CRH_LAUNCH_TA(false, false, false, false, Q.q_sh, Q.counts + 2); }
+  if (S.split) {
+    if (L.counters) CRH_LAUNCH_TA(true, true, false, true, Q.q2_sh, Q.counts + 7); else if (L.donate) CRH_LAUNCH_TA(false, true, true, true, Q.q2_sh, Q.counts + 7); else CRH_LAUNCH_TA(false, true, false, true, Q.q2_sh, Q.counts + 7);
+  }
 #undef CRH_LAUNCH_TA
 }
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,

@@ -64,7 +64,8 @@ typedef struct { uint64_t nodes, tris, nodes_any, tris_any; } trav_counters;
 #else
 #define ORC_COUNT(x) (x)
 #endif
-typedef struct orc_instance { float fwd[12], inv[12]; float bmin[3], bmax[3]; uint32_t root, obj; } orc_instance;
+typedef struct orc_instance { float fwd[12], inv[12]; float bmin[3], bmax[3]; float wmin[3], wmax[3]; uint32_t root, obj; } orc_instance;
+#define MAX_IBOX 4u       /* instances whose world boxes the "does the ray touch a moved object at all" test looks at one by one (kMaxIBox of the product) */
 /* per object of a two-level scene ("static / moved split"): static0 = at the identity when the scene was built (its
  * triangles are in the static world-space tree); is_inst = rendered through its own object tree + the top level right now (static0 objects:
  * while they are off the identity -- their triangles in the static tree are disabled meanwhile); the object tree is built the first time
@@ -342,6 +343,7 @@ static void build_tlas(orc_ctx* c)
     memcpy(in->fwd, &c->xf[12 * ob], sizeof in->fwd);
     if (!crh_xform_inverse(in->fwd, in->inv)) memset(in->inv, 0, sizeof in->inv);
     crh_xform_box(in->fwd, in->bmin, in->bmax, pb[i].mn, pb[i].mx);
+    for (int a = 0; a < 3; ++a) { in->wmin[a] = pb[i].mn[a]; in->wmax[a] = pb[i].mx[a]; }
     aabb_grow(&sb, &pb[i]);
     ++i;
   }
@@ -493,14 +495,22 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
   const v3 wo = o, wd = d;                       /* the world-space ray (restored when an object is left) */
   uint32_t cur = c->root;
   if (c->root2 != QBVH_EMPTY) {
-    /* static tree first; the top-level tree over the moved objects waits at the bottom of the stack -- if the ray touches their bounds at
-     * all (same planes + guard band as a node's child test) */
-    const float ax_ = (c->tlas_lo[0] - o.x) * ix, bx_ = (c->tlas_hi[0] - o.x) * ix;
-    const float ay_ = (c->tlas_lo[1] - o.y) * iy, by_ = (c->tlas_hi[1] - o.y) * iy;
-    const float az_ = (c->tlas_lo[2] - o.z) * iz, bz_ = (c->tlas_hi[2] - o.z) * iz;
-    const float tn_ = crh_max(crh_max(crh_max(crh_min(ax_, bx_) - gx, crh_min(ay_, by_) - gy), crh_min(az_, bz_) - gz), 0.f);
-    const float tf_ = crh_min(crh_min(crh_min(crh_max(ax_, bx_) + gx, crh_max(ay_, by_) + gy), crh_max(az_, bz_) + gz), tmax);
-    if (tn_ <= tf_) stack[sp++] = c->root2;
+    /* static tree first; the top-level tree over the moved objects waits at the bottom of the stack -- if the ray touches a moved object at all:
+     * the bounds of ALL instances and, when there are at most MAX_IBOX of them, the world box of at least one (same planes + guard band as a
+     * node's child test) */
+#define SLAB_HIT(LO, HI, OUT) do { \
+      const float ax_ = ((LO)[0] - o.x) * ix, bx_ = ((HI)[0] - o.x) * ix, ay_ = ((LO)[1] - o.y) * iy, by_ = ((HI)[1] - o.y) * iy; \
+      const float az_ = ((LO)[2] - o.z) * iz, bz_ = ((HI)[2] - o.z) * iz; \
+      const float tn_ = crh_max(crh_max(crh_max(crh_min(ax_, bx_) - gx, crh_min(ay_, by_) - gy), crh_min(az_, bz_) - gz), 0.f); \
+      const float tf_ = crh_min(crh_min(crh_min(crh_max(ax_, bx_) + gx, crh_max(ay_, by_) + gy), crh_max(az_, bz_) + gz), tmax); \
+      (OUT) = tn_ <= tf_; } while (0)
+    int touch; SLAB_HIT(c->tlas_lo, c->tlas_hi, touch);
+    if (touch && c->nInst <= MAX_IBOX) {
+      touch = 0;
+      for (uint32_t i = 0; i < c->nInst && !touch; ++i) SLAB_HIT(c->inst[i].wmin, c->inst[i].wmax, touch);
+    }
+    if (touch) stack[sp++] = c->root2;
+#undef SLAB_HIT
   }
   for (;;) {
     if ((cur & 0xF0000000u) == CRH_REF_INSTANCE_TAG) {

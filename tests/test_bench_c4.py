@@ -13,10 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_c4_code_path_runs_on_one_gpu(hip_lib):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C4", "--spp", "64", "--gpus", "1", "--steps", "1", "--warmup", "0",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C4", "--spp", "64", "--gpus", "1", "--steps", "1", "--warmup", "1",
                         "--no-cpu", "--no-interactive", "--parity-seconds", "3"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 1000
+    assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 500
     assert out["config"]["workload"].startswith("C4: 1000000") and out["config"]["spp_per_step_per_rank"] == 64
     assert out["parity"]["bit_exact"] is True and out["parity"]["spp"] == 64

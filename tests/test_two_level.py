@@ -286,3 +286,31 @@ def test_translated_only_instances_and_signed_zero_directions(hip_lib, oracle_li
         a = View(0).load_scene(s2); b = oracle_lib.Oracle().load_scene(s2)
         a.render(2); b.render(2)
         assert np.array_equal(a.read_hdr().view(np.uint32), b.read_hdr().view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_moved", [1, 3, 6])
+def test_split_scene_two_passes_equal_one_walk(hip_lib, oracle_lib, monkeypatch, n_moved):
+    """A split scene (static tree + moved objects) is rendered either by one walk "static tree, then top level" in the two-level kernels, or -- when at
+    most kMaxIBox = 4 objects are off the identity, so that the kernels that PRODUCE rays can tell which of them come near one -- in two passes: the plain
+    single-level kernels over every ray, then the two-level ones over the flagged rays only (the dragged-object case runs at the single-level rate).  Both
+    are the same spec: same image, same hits, same eight counters as the oracle, with lights (shadow rays take the two passes too)."""
+    from cadrays_amd.view import View
+    sc = object_scene(None, 160, 120)
+    xf = np.tile(rigid(), (7, 1))
+    for k, ob in enumerate([3, 5, 6, 1, 4, 2][:n_moved]):
+        xf[ob] = rigid(15.0 * k, (0, 0, 1), (0.03 * (k + 1), -0.02 * k, 0.01 * k))
+    o = oracle_lib.Oracle().load_scene(sc); o.set_transforms(xf); o.render(3)
+    ref, ost = o.read_hdr(), o.stats()
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CRH_SPLIT_PASSES", mode)
+        for counters in (True, False):
+            v = View(0).load_scene(sc); v.enable_counters(counters); v.set_transforms(xf)
+            assert v.get_tlas()["n_instances"] == n_moved
+            v.render(3)
+            assert np.array_equal(v.read_hdr().view(np.uint32), ref.view(np.uint32)), (mode, counters)
+            st = v.stats()
+            keys = ("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "nodes_any", "tris_any", "shaded_hits", "samples") if counters else ("rays_nearest", "rays_any", "shaded_hits", "samples")
+            for key in keys:
+                assert st[key] == ost[key], (mode, counters, key, st[key], ost[key])
+            v.close()

@@ -12,9 +12,9 @@ import torch  # noqa: F401
 from cadrays_amd import scenes
 from cadrays_amd.view import View
 
-KINDS = [k for k in sys.argv[1:] if not k.isdigit()] or ["identity", "translated", "rotated"]
+KINDS = [k for k in sys.argv[1:] if not k.isdigit() and not k.startswith("spp")] or ["identity", "translated", "rotated"]
 Gs = [int(x) for x in sys.argv[1:] if x.isdigit()] or [1, 4, 10]
-SPP = 32
+SPP = next((int(k[3:]) for k in sys.argv[1:] if k.startswith("spp")), 32)      # samples per batch: `spp128` = the batch bench.py times
 sc = scenes.baseline_config("C3")
 cen = sc.pos.reshape(-1, 3, 3).mean(1)
 
@@ -61,6 +61,7 @@ for G in Gs:
 # object (src/ImGui/ImRaytraceControls.cxx:64,88).  1000 objects at the identity; 1, then 10 of them translated a little: throughput against the flat
 # rate, latency of the first move (the object's tree is built, its triangles in the static tree disabled) and of the following ones.
 if "split" in KINDS or len(sys.argv) == 1:
+    print(json.dumps({"spp_per_batch": SPP}), flush=True)
     G = 10
     cell = np.clip(((cen + 1.0) * 0.5 * G).astype(np.int32), 0, G - 1)
     obj = (cell[:, 0] * G + cell[:, 1]) * G + cell[:, 2]
