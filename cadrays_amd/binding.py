@@ -248,6 +248,17 @@ class Backend:
         self._call("read_ldr_end", out.ctypes.data_as(_u8p))
         return out
 
+    def read_hdr_begin(self):
+        """queue the HDR read-back of the frame as submitted so far; returns at once (crh_read_hdr_begin)"""
+        self._call("read_hdr_begin")
+        self._rbh_shapes = getattr(self, "_rbh_shapes", []) + [(self.height, self.width, 3)]
+
+    def read_hdr_end(self):
+        shape = self._rbh_shapes.pop(0) if getattr(self, "_rbh_shapes", None) else (self.height, self.width, 3)
+        out = np.empty(shape, np.float32)
+        self._call("read_hdr_end", _fp(out))
+        return out
+
     def stats(self):
         s = abi.crh_stats()
         self._call("get_stats", C.byref(s))

@@ -384,6 +384,9 @@ static int usable_cpus()
     if (q > 0 && per > 0) quota = q / per;
   }
   if (quota > 0.0) { const int qn = (int)(quota + 0.999); if (qn >= 1 && qn < n) n = qn; }
+  // one process per GPU on one host (torchrun sets LOCAL_WORLD_SIZE): every rank builds the same tree at the same time -- each takes its share of the
+  // CPUs instead of all of them (8 ranks x all threads on the 16 usable CPUs of a GPU box was an 8-fold oversubscription)
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) { const int w = atoi(e); if (w > 1) n = n / w > 1 ? n / w : 1; }
   return n;
 }
 

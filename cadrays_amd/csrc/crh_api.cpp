@@ -115,7 +115,7 @@ struct crh_ctx {
   // own stream into one of two device / pinned-host buffer pairs while the next Redraw()s are already rendering; only the NEXT
   // accumulate waits (for the tone map, which reads the accumulator), nothing else does
   hipStream_t rb_stream = nullptr; hipEvent_t rb_fork = nullptr, rb_tm[2] = {nullptr, nullptr}, rb_done[2] = {nullptr, nullptr};
-  uint8_t* d_rb[2] = {nullptr, nullptr}; uint8_t* h_rb[2] = {nullptr, nullptr}; size_t rb_cap = 0, rb_bytes[2] = {0, 0};
+  uint8_t* d_rb[2] = {nullptr, nullptr}; uint8_t* h_rb[2] = {nullptr, nullptr}; size_t rb_cap = 0, rb_bytes[2] = {0, 0}; bool rb_hdr[2] = {false, false};
   uint32_t rb_head = 0, rb_outstanding = 0; bool rb_guard_pending = false; hipEvent_t rb_guard = nullptr;
   bool read_since_render = true;   // a host that looks at every frame (read-back / sync between Redraws) gets the two-range schedule instead
   bool counters_on = false, timing_on = false;
@@ -1460,13 +1460,16 @@ int crh_read_ldr(crh_ctx* c, uint8_t* out)
   return CRH_OK;
 }
 
-int crh_read_ldr_begin(crh_ctx* c)
+// Asynchronous read-back of the frame as submitted so far, LDR (tone-mapped RGB8) or HDR (linear float RGB): tone map / unpack + device-to-host copy
+// run on a stream of their own into one of two device / pinned-host buffer pairs while the next Redraw()s are already rendering; only the NEXT
+// accumulate waits (for the kernel that reads the accumulator), nothing else does.
+static int read_begin(crh_ctx* c, bool hdr)
 {
   if (!c || !c->d_accum) return fail(c, CRH_E_INVALID, "no accumulator");
-  if (c->rb_outstanding >= 2) return fail(c, CRH_E_INVALID, "two read-backs are already in flight (crh_read_ldr_end first)");
+  if (c->rb_outstanding >= 2) return fail(c, CRH_E_INVALID, "two read-backs are already in flight (crh_read_ldr_end / crh_read_hdr_end first)");
   CRH_HIP(hipSetDevice(c->device));
   const uint32_t n = c->par.width * c->par.height;
-  const size_t bytes = 3 * (size_t)n;
+  const size_t bytes = (hdr ? 12 : 3) * (size_t)n;
   if (!c->rb_stream) {
     CRH_HIP(hipStreamCreateWithFlags(&c->rb_stream, hipStreamNonBlocking));
     CRH_HIP(hipEventCreateWithFlags(&c->rb_fork, hipEventDisableTiming));
@@ -1474,7 +1477,7 @@ int crh_read_ldr_begin(crh_ctx* c)
   }
   if (bytes > c->rb_cap) {
     CRH_HIP(hipStreamSynchronize(c->rb_stream));
-    if (c->rb_outstanding) return fail(c, CRH_E_INVALID, "the image grew while a read-back was in flight (crh_read_ldr_end first)");
+    if (c->rb_outstanding) return fail(c, CRH_E_INVALID, "the read-back buffers must grow while a read-back is in flight (crh_read_*_end first)");
     for (int k = 0; k < 2; ++k) { if (c->d_rb[k]) CRH_HIP(hipFree(c->d_rb[k])); if (c->h_rb[k]) CRH_HIP(hipHostFree(c->h_rb[k])); c->d_rb[k] = nullptr; c->h_rb[k] = nullptr; }
     for (int k = 0; k < 2; ++k) { CRH_HIP(hipMalloc((void**)&c->d_rb[k], bytes)); CRH_HIP(hipHostMalloc((void**)&c->h_rb[k], bytes, hipHostMallocDefault)); }
     c->rb_cap = bytes;
@@ -1485,32 +1488,41 @@ int crh_read_ldr_begin(crh_ctx* c)
   for (int k = 0; k < 4; ++k) if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(c->rb_stream, c->lane_join[k], 0));
   CRH_HIP(hipEventRecord(c->rb_fork, c->stream_));
   CRH_HIP(hipStreamWaitEvent(c->rb_stream, c->rb_fork, 0));
-  const uint32_t ts = c->par.tile_size, n_tiles = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
-  const bool overlay = c->show_tiles && c->adaptive && c->picked_valid && c->d_picked && c->tile_stat_cap >= n_tiles;
   Launch L{c->rb_stream, c->grid, false};
-  launch_tonemap(L, c->assembled_valid ? c->d_assembled : c->d_accum, c->d_rb[slot], n, c->par.tonemap_mode, c->par.exposure, c->par.white_point,
-                 overlay ? c->d_picked : nullptr, c->par.width, ts);
+  const float4* src = c->assembled_valid ? c->d_assembled : c->d_accum;
+  if (hdr) launch_hdr(L, src, (float*)c->d_rb[slot], n);
+  else {
+    const uint32_t ts = c->par.tile_size, n_tiles = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
+    const bool overlay = c->show_tiles && c->adaptive && c->picked_valid && c->d_picked && c->tile_stat_cap >= n_tiles;
+    launch_tonemap(L, src, c->d_rb[slot], n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, overlay ? c->d_picked : nullptr, c->par.width, ts);
+  }
   CRH_HIP(hipGetLastError());
   CRH_HIP(hipEventRecord(c->rb_tm[slot], c->rb_stream));
   CRH_HIP(hipMemcpyAsync(c->h_rb[slot], c->d_rb[slot], bytes, hipMemcpyDeviceToHost, c->rb_stream));
   CRH_HIP(hipEventRecord(c->rb_done[slot], c->rb_stream));
-  c->rb_bytes[slot] = bytes;
+  c->rb_bytes[slot] = bytes; c->rb_hdr[slot] = hdr;
   c->rb_guard = c->rb_tm[slot]; c->rb_guard_pending = true;
   ++c->rb_head; ++c->rb_outstanding;
   return CRH_OK;
 }
 
-int crh_read_ldr_end(crh_ctx* c, uint8_t* out)
+static int read_end(crh_ctx* c, void* out, bool hdr)
 {
   if (!c || !out) return fail(c, CRH_E_INVALID, "null output");
-  if (!c->rb_outstanding) return fail(c, CRH_E_INVALID, "no read-back in flight (crh_read_ldr_begin first)");
+  if (!c->rb_outstanding) return fail(c, CRH_E_INVALID, "no read-back in flight (crh_read_*_begin first)");
   CRH_HIP(hipSetDevice(c->device));
   const uint32_t slot = (c->rb_head - c->rb_outstanding) & 1u;          // the oldest one
+  if (c->rb_hdr[slot] != hdr) return fail(c, CRH_E_INVALID, "the oldest read-back in flight is of the other kind (LDR / HDR): end it with its own call");
   CRH_HIP(hipEventSynchronize(c->rb_done[slot]));
   std::memcpy(out, c->h_rb[slot], c->rb_bytes[slot]);
   --c->rb_outstanding;
   return CRH_OK;
 }
+
+int crh_read_ldr_begin(crh_ctx* c) { return read_begin(c, false); }
+int crh_read_ldr_end(crh_ctx* c, uint8_t* out) { return read_end(c, out, false); }
+int crh_read_hdr_begin(crh_ctx* c) { return read_begin(c, true); }
+int crh_read_hdr_end(crh_ctx* c, float* out) { return read_end(c, out, true); }
 
 int crh_save_accum(crh_ctx* c, float* out, uint32_t* frames_done)
 {

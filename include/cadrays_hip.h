@@ -235,6 +235,11 @@ CRH_API int crh_read_ldr(crh_ctx* ctx, uint8_t* rgb_out);
  * would have returned at the moment of crh_read_ldr_begin(). */
 CRH_API int crh_read_ldr_begin(crh_ctx* ctx);
 CRH_API int crh_read_ldr_end(crh_ctx* ctx, uint8_t* rgb_out);
+/* The same for the linear HDR image == BufferDump(Graphic3d_BT_RGB_RayTraceHdrLeft) (AppGui.cxx:345-349) without stalling the render loop: W*H*3 floats as
+ * crh_read_hdr would have returned them at the moment of crh_read_hdr_begin().  LDR and HDR read-backs share the two slots in flight and complete in
+ * the order they were begun: the oldest one must be ended with the call of its own kind. */
+CRH_API int crh_read_hdr_begin(crh_ctx* ctx);
+CRH_API int crh_read_hdr_end(crh_ctx* ctx, float* rgb_out);
 /* Accumulator checkpoint / resume (SURVEY.md section 5 "checkpoint / resume", 8f rank 4; the reference only keeps the
  * image while paused, AppViewer.cxx:916-920,1045): copy out / restore the float4 accumulator (rgb running mean + per-pixel
  * sample count) together with the whole-frame iteration counter that selects the next frame seed. */

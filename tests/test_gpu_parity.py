@@ -612,6 +612,28 @@ def test_async_ldr_readback_returns_the_frame_of_its_begin(view_cls, Oracle, mon
     assert np.array_equal(v.read_ldr(), want[-1]) and np.array_equal(bits(v.read_hdr()), bits(twin.read_hdr()))
 
 
+def test_async_hdr_readback_returns_the_frame_of_its_begin(view_cls):
+    """crh_read_hdr_begin / _end: the asynchronous twin of BufferDump(Graphic3d_BT_RGB_RayTraceHdrLeft) (AppGui.cxx:345-349); LDR and HDR read-backs share the
+    two slots in flight, complete in order, and each must be ended by the call of its own kind."""
+    from cadrays_amd.binding import BackendError
+    sc = scenes.cornell_box(True, 1280, 960)
+    v = view_cls(0).load_scene(sc); twin = view_cls(0).load_scene(sc)
+    want_h, want_l = [], []
+    got = []
+    for i in range(6):
+        v.Redraw(); twin.Redraw()
+        want_h.append(twin.read_hdr()); want_l.append(twin.read_ldr())
+        if i >= 2:
+            got.append(v.read_hdr_end() if (i - 2) % 2 == 0 else v.read_ldr_end())
+        (v.read_hdr_begin if i % 2 == 0 else v.read_ldr_begin)()
+    for i, g in enumerate(got):
+        assert np.array_equal(bits(g), bits(want_h[i])) if i % 2 == 0 else np.array_equal(g, want_l[i]), i
+    with pytest.raises(BackendError):
+        v.read_ldr_end()                                             # the oldest one in flight is an HDR read-back
+    assert np.array_equal(bits(v.read_hdr_end()), bits(want_h[4])) and np.array_equal(v.read_ldr_end(), want_l[5])
+    assert np.array_equal(bits(v.read_hdr()), bits(twin.read_hdr()))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_sequences_with_async_readbacks_in_flight(view_cls, monkeypatch, seed):
     """crh_read_ldr_begin / _end under arbitrary call orders: read-backs begun between bursts of Redraw()s, setters without and with
