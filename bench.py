@@ -123,6 +123,20 @@ def roofline_report(config, spp, modified, alg_bytes_per_launch, avg_ms, scene_b
             r["achieved"] = round(alg_gbps, 1)
             r["achieved_basis"] = "algorithmic bytes / kernel time (traffic_over_alg > 1 = over-fetch)"
         r["frac"] = round(r["achieved"] / HBM_PEAK_GBPS, 4)
+        # the same counter passes of THIS build for the other single-GPU configs (profiles/pmc_traffic.json), so that the line of the cache-resident
+        # headline config also shows the HBM-resident one: C5 (10 M triangles, 0.97 GB of nodes + triangles) is where the path meets the memory roof
+        others = {}
+        try:
+            pmc = json.load(open(PMC_FILE))
+            for cfg, e in (pmc.get("configs") or {}).items():
+                if cfg != config and e.get("source_hash") == kernel_source_hash() and e.get("avg_launch_ms"):
+                    c2 = roofline_ceilings(e, e["avg_launch_ms"]) or {}
+                    others[cfg] = {"workload": e.get("workload"), "avg_launch_ms": round(e["avg_launch_ms"], 3),
+                                   "hbm_frac_memory_side": c2.get("hbm"), "valu_issue": c2.get("valu_issue"), "l2": c2.get("l2"), "binding": c2.get("binding")}
+        except (OSError, ValueError, KeyError):
+            pass
+        if others:
+            r["other_configs_same_build"] = others
     else:
         r.update({"traffic": None, "traffic_reason": reason, "l2_hit_rate": None})
         r["achieved"] = round(alg_gbps, 1)

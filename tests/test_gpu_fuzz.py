@@ -282,3 +282,66 @@ def test_random_sequences_between_one_tree_and_object_trees(view_cls, Oracle, se
         gs, cs = v.stats(), o.stats()
         for k in ("rays_nearest", "nodes_nearest", "tris_nearest", "rays_any", "nodes_any", "shaded_hits"):
             assert gs[k] == cs[k], k
+
+
+def _random_rigid(r, scale):
+    a = r.random() * 6.28; ax = r.normal(size=3); ax /= np.linalg.norm(ax); s = float(r.choice([1.0, 1.0, 0.7, 1.4]))
+    x, y, z = ax; c, sn = np.cos(a), np.sin(a)
+    R = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * sn, x * z * (1 - c) + y * sn],
+                  [y * x * (1 - c) + z * sn, c + y * y * (1 - c), y * z * (1 - c) - x * sn],
+                  [z * x * (1 - c) - y * sn, z * y * (1 - c) + x * sn, c + z * z * (1 - c)]]) * s
+    if r.random() < 0.4:
+        R = np.eye(3)                                                # translation only (the instance keeps the world ray's reciprocals)
+    return np.concatenate([R, (0.15 * scale * r.normal(size=3))[:, None]], 1).astype(np.float32).reshape(12)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_walks_over_the_static_moved_split(view_cls, Oracle, seed):
+    """Static / moved split under random call sequences: 2 .. 12 objects, some of them off the identity when the scene is built
+    (instances for good), then single objects dragged away (translated, rotated, scaled), put back, everything put back, renders, resets -- at most four
+    moved objects take the two-pass traversal, more the one-walk kernels, and the walk crosses that boundary.  After every call: image, top-level info,
+    node and triangle-record bytes equal the oracle's; at the end all eight counters (odd seeds run the counting kernels)."""
+    import dataclasses
+    r = np.random.default_rng(9100 + seed)
+    base = None
+    for s_ in range(seed * 7, seed * 7 + 300):
+        cand = random_scene(s_)
+        if len(cand.tri) >= 60:
+            base = cand; break
+    n = len(base.tri); scale = float(np.abs(base.pos).max())
+    nO = int(r.integers(2, 13))
+    tri_obj = (np.arange(n) * nO // n).astype(np.int32) if r.random() < 0.5 else (np.arange(n) % nO).astype(np.int32)
+    ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (nO, 1))
+    xf0 = ident.copy()
+    for k in range(nO):
+        if r.random() < 0.25: xf0[k] = _random_rigid(r, scale)      # never part of the static tree
+    sc = dataclasses.replace(base, tri_object=tri_obj, obj_xform=xf0.copy(),
+                             params=dataclasses.replace(base.params, max_depth=min(base.params.max_depth, 4), width=48, height=32, tile_size=8))
+    counted = bool(seed % 2)
+    v = view_cls(0).load_scene(sc); v.enable_counters(counted); v.reset(); o = Oracle().load_scene(sc)
+    xf = xf0.copy()
+    seen_modes = set()
+    for step in range(14):
+        op = int(r.integers(0, 7))
+        if op <= 1:
+            k = int(r.integers(1, 3)); v.render(k); o.render(k)
+        elif op == 2 or op == 3:
+            xf = xf.copy(); xf[int(r.integers(0, nO))] = _random_rigid(r, scale); v.set_transforms(xf); o.set_transforms(xf)
+        elif op == 4:
+            xf = xf.copy(); xf[int(r.integers(0, nO))] = ident[0]; v.set_transforms(xf); o.set_transforms(xf)      # one object back in place
+        elif op == 5:
+            xf = ident.copy() if r.random() < 0.5 else xf0.copy(); v.set_transforms(xf); o.set_transforms(xf)
+        else:
+            v.reset(); o.reset()
+        info = v.get_tlas()
+        seen_modes.add(min(info["n_instances"], 5))
+        assert info == o.get_tlas(), (seed, step, op)
+        assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), (seed, step, op, info)
+        gn, gt = v.get_bvh(); on, ot = o.get_bvh()
+        assert np.array_equal(gn.view(np.uint32), on.view(np.uint32)) and np.array_equal(gt.view(np.uint32), ot.view(np.uint32)), (seed, step, op)
+    v.render(2); o.render(2)
+    assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), seed
+    assert np.array_equal(v.read_ldr(), o.read_ldr())
+    gs, cs = v.stats(), o.stats()
+    for k in (("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "nodes_any", "tris_any", "shaded_hits", "samples") if counted else ("rays_nearest", "rays_any", "shaded_hits", "samples")):
+        assert gs[k] == cs[k], (seed, k, gs[k], cs[k])
