@@ -46,12 +46,13 @@ struct crh_ctx {
   // ---- two-level mode (per-object transforms)
   bool two_level = false; uint32_t nO = 0;
   std::vector<float> xf; std::vector<int32_t> tri_obj;
+  std::vector<float> xf0, pos_w, nrm_w;   // the transforms the scene was built with; per vertex: position / unit normal under its object's build-time transform (what the static tree holds)
   struct Inst { float fwd[12], inv[12], bmin[3], bmax[3]; uint32_t root, obj; };
   std::vector<Inst> inst;                 // the objects rendered as instances RIGHT NOW, ascending object index (empty: the scene is one world-space tree)
   uint32_t n_blas_nodes = 0, root = 0;    // nodes of the static tree + the object trees built so far (the top-level tree follows them); entry point of the walk
-  // static / moved split (reference: the gizmo moves ONE object per drag, ImRaytraceControls.cxx:64,88): the objects that sat at
-  // the identity when the scene was built share one world-space tree; an object that leaves the identity has its triangles there disabled and gets an
-  // object tree of its own (built on first need, kept); nothing else is ever rebuilt by crh_set_transforms but the top-level tree
+  // static / moved split (reference: the gizmo moves ONE object per drag, ImRaytraceControls.cxx:64,88): every object is baked into
+  // one world-space tree with the transform it has when the scene is built; an object that is moved away from that placement has its triangles there
+  // disabled and gets an object tree of its own (built on first need, kept); nothing else is ever rebuilt by crh_set_transforms but the top-level tree
   struct Obj { bool static0 = false, built = false, is_inst = false; uint32_t root = 0, first = 0, ntri = 0; float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}; };
   std::vector<Obj> objs; std::vector<uint32_t> obj_tris, static_pos, pos_obj;   // pos_obj: object of the triangle at a leaf position >= n_static
   uint32_t n_static = 0, n_static_live = 0, n_pos = 0; float sbmin[3] = {0, 0, 0}, sbmax[3] = {0, 0, 0};
@@ -123,7 +124,7 @@ struct crh_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> render_ev, trace_ev;
   std::vector<hipEvent_t> ev_pool;
   double seconds_acc = 0.0, trace_ms_acc = 0.0, all_ms_acc = 0.0; uint64_t trace_launches = 0;
-  // path slots per batch (188 B each = 50 GB of the 288 GB; allocated on demand, so small renders stay small).  Every launch of
+  // path slots per batch (196 B each = 53 GB of the 288 GB; allocated on demand, so small renders stay small).  Every launch of
   // the wavefront schedule ends in a drain phase whose length does not depend on the launch's size (~0.24 ms per launch on C3), so
   // the batch is made as wide as the memory comfortably allows: 32 M / 64 M / 128 M / 256 M / 512 M slots -> 2745 / 2960 / 3114 /
   // 3205 / 3243 Mrays/s on C3
@@ -439,9 +440,12 @@ void fill_records(crh_ctx* c, uint32_t p0, uint32_t p1, std::vector<float>& tr, 
   for (uint32_t p = p0; p < p1; ++p) {
     const uint32_t t = c->bvh.prim_order[p]; const size_t i = p - p0;
     float* q = &c->h_tris[12 * (size_t)p]; float* s_ = &sh[16 * i];
+    // a position of the static tree of a two-level scene holds the BAKED vertex (its object's build-time transform applied); an object tree the object-space one
+    const bool baked = c->two_level && p < c->n_static;
+    const float* VP = baked ? c->pos_w.data() : c->pos.data(); const float* VN = baked ? c->nrm_w.data() : c->nrm.data();
     for (int k = 0; k < 3; ++k) {
       const int32_t vi = c->tri[4 * t + k];
-      for (int a = 0; a < 3; ++a) { q[4 * k + a] = c->pos[3 * vi + a]; s_[4 * k + a] = c->nrm[3 * vi + a]; }
+      for (int a = 0; a < 3; ++a) { q[4 * k + a] = VP[3 * vi + a]; s_[4 * k + a] = VN[3 * vi + a]; }
       q[4 * k + 3] = 0.f;
       if (!uvr.empty()) { uvr[8 * i + 2 * k] = c->uv[2 * vi]; uvr[8 * i + 2 * k + 1] = c->uv[2 * vi + 1]; }
     }
@@ -999,7 +1003,7 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
   for (uint32_t ob = 0; ob < nO; ++ob) {
     crh_ctx::Obj& o = c->objs[ob];
     if (!o.ntri) continue;
-    const bool want = !(o.static0 && is_identity(&xf[12 * (size_t)ob]));
+    const bool want = std::memcmp(&xf[12 * (size_t)ob], &c->xf0[12 * (size_t)ob], 12 * sizeof(float)) != 0;      // off its build-time placement: an instance
     if (want == o.is_inst) continue;
     // static0 object changing sides: its records in the static tree die / come back
     for (uint32_t i = 0; i < o.ntri; ++i) {
@@ -1007,7 +1011,7 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
       float* q = &c->h_tris[12 * (size_t)p];
       if (want) { std::memset(q, 0, 48); std::memcpy(&q[3], &t, 4); }
       else {
-        for (int k = 0; k < 3; ++k) { const int32_t vi = c->tri[4 * t + k]; for (int a = 0; a < 3; ++a) q[4 * k + a] = c->pos[3 * vi + a]; q[4 * k + 3] = 0.f; }
+        for (int k = 0; k < 3; ++k) { const int32_t vi = c->tri[4 * t + k]; for (int a = 0; a < 3; ++a) q[4 * k + a] = c->pos_w[3 * vi + a]; q[4 * k + 3] = 0.f; }
         std::memcpy(&q[3], &t, 4);
       }
       float d[16]; device_tri_record(q, d);
@@ -1191,8 +1195,28 @@ int crh_build(crh_ctx* c)
     // order); every other non-empty object gets an object-space tree (triangles in input order); then the top-level tree over the instances
     c->objs.assign(c->nO, crh_ctx::Obj{}); c->obj_tris.resize(nT ? nT : 1); c->static_pos.assign(nT ? nT : 1, 0u);
     for (uint32_t t = 0; t < nT; ++t) c->objs[c->tri_obj[t]].ntri++;
-    { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { crh_ctx::Obj& o = c->objs[ob]; o.first = acc; acc += o.ntri; o.ntri = 0; o.static0 = is_identity(&c->xf[12 * (size_t)ob]); } }
+    { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { crh_ctx::Obj& o = c->objs[ob]; o.first = acc; acc += o.ntri; o.ntri = 0; o.static0 = true; } }
     for (uint32_t t = 0; t < nT; ++t) { crh_ctx::Obj& o = c->objs[c->tri_obj[t]]; c->obj_tris[o.first + o.ntri++] = t; }
+    // bake: every vertex under the transform its object has NOW (each vertex belongs to one object; an object at the identity keeps its bits) -- a
+    // loaded scene whose objects all carry a location (vlocation lines of model.tcl) renders as ONE tree at the single-level rate until one is dragged
+    c->xf0 = c->xf; c->pos_w = c->pos; c->nrm_w = c->nrm;
+    {
+      std::vector<uint8_t> done(c->pos.size() / 3 + 1, 0);
+      for (uint32_t t = 0; t < nT; ++t) {
+        const float* M = &c->xf0[12 * (size_t)c->tri_obj[t]];
+        if (is_identity(M)) continue;
+        for (int k = 0; k < 3; ++k) {
+          const int32_t vi = c->tri[4 * t + k];
+          if (done[vi]) continue;
+          done[vi] = 1;
+          const crh_v3 pw = crh_xform_point(M, crh_mk3(c->pos[3 * vi], c->pos[3 * vi + 1], c->pos[3 * vi + 2]));
+          crh_v3 nn = crh_norm3(crh_xform_vector(M, crh_mk3(c->nrm[3 * vi], c->nrm[3 * vi + 1], c->nrm[3 * vi + 2])));
+          if (!(crh_dot3(nn, nn) > 0.f)) nn = crh_mk3(c->nrm[3 * vi], c->nrm[3 * vi + 1], c->nrm[3 * vi + 2]);
+          c->pos_w[3 * vi] = pw.x; c->pos_w[3 * vi + 1] = pw.y; c->pos_w[3 * vi + 2] = pw.z;
+          c->nrm_w[3 * vi] = nn.x; c->nrm_w[3 * vi + 1] = nn.y; c->nrm_w[3 * vi + 2] = nn.z;
+        }
+      }
+    }
     std::vector<uint32_t> list; list.reserve(nT);
     for (uint32_t t = 0; t < nT; ++t) if (c->objs[c->tri_obj[t]].static0) list.push_back(t);
     const uint32_t nS = (uint32_t)list.size();
@@ -1202,7 +1226,7 @@ int crh_build(crh_ctx* c)
       for (uint32_t i = 0; i < nS; ++i)
         for (int a = 0; a < 3; ++a) {
           const uint32_t t = list[i];
-          const float v0 = c->pos[3 * c->tri[4 * t + 0] + a], v1 = c->pos[3 * c->tri[4 * t + 1] + a], v2 = c->pos[3 * c->tri[4 * t + 2] + a];
+          const float v0 = c->pos_w[3 * c->tri[4 * t + 0] + a], v1 = c->pos_w[3 * c->tri[4 * t + 1] + a], v2 = c->pos_w[3 * c->tri[4 * t + 2] + a];
           boxes[6 * (size_t)i + a] = std::min(v0, std::min(v1, v2)); boxes[6 * (size_t)i + 3 + a] = std::max(v0, std::max(v1, v2));
         }
       c->bvh.nodes.reserve(nS / 2 + 16);

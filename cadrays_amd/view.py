@@ -58,7 +58,7 @@ class View(Backend):
         self._call("set_lookahead", C.c_uint32(int(frames)))
 
     def set_path_budget(self, max_paths):
-        """crh_set_path_budget: at most this many path slots (188 B each) in flight per batch; images do not depend on it"""
+        """crh_set_path_budget: at most this many path slots (196 B each) in flight per batch; images do not depend on it"""
         self._call("set_path_budget", C.c_uint64(int(max_paths)))
 
     def set_schedule(self, mode):

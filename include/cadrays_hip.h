@@ -132,10 +132,11 @@ CRH_API const char* crh_last_error(crh_ctx* ctx);
  * (AisMesh.cxx:357-423), per-object 3x4 row-major transforms (DataNode.cxx:239-242).
  * With tri_object + obj_xform the scene is a TWO-LEVEL BVH like OCCT's: vertices are in object space (each vertex must belong to one
  * object), an object with a transform gets its own tree and a top-level tree over the instances' world boxes carries the transforms.
- * Without them the arrays are world space and one tree is built.  STATIC / MOVED SPLIT: the objects whose obj_xform is exactly the
- * identity at crh_build (imported meshes and shapes sit where their vertices say until something is dragged) share ONE world-space tree;
- * a scene in which every object is at the identity is that tree alone -- same images, counters and speed as without objects.  Rays walk the
- * static tree first and then the top-level tree of the moved objects (skipped when the ray misses their bounds). */
+ * Without them the arrays are world space and one tree is built.  STATIC / MOVED SPLIT: at crh_build EVERY object is baked into ONE world-space
+ * tree with the transform it has at that moment (each vertex is transformed once, on the host; an object at the identity keeps its bits, so a
+ * scene whose objects all sit at the identity is bit for bit the scene without objects) -- a loaded scene renders at the single-level rate
+ * whatever locations its objects carry.  Only an object whose transform is CHANGED afterwards (crh_set_transforms) is rendered as an instance:
+ * rays walk the static tree first and then the top-level tree of the moved objects (skipped when the ray misses their bounds). */
 CRH_API int crh_set_geometry(crh_ctx* ctx,
                      const float* pos, const float* nrm, const float* uv, uint32_t n_vertices,
                      const int32_t* tri /* 4*nT: i0,i1,i2,material */, uint32_t n_triangles,
@@ -143,10 +144,10 @@ CRH_API int crh_set_geometry(crh_ctx* ctx,
                      const float* obj_xform /* 12*nO or NULL */, uint32_t n_objects);
 /* == AIS_InteractiveObject::SetLocalTransformation / the manipulator moving an object (ImRaytraceControls.cxx:58-89,
  * DataNode.cxx:239-242): new 3x4 transforms for the n_objects of the two-level scene.  Only the top-level tree is rebuilt; restarts
- * accumulation.  The static tree is never rebuilt: when an object in it leaves the identity, its triangles there are disabled in place
- * (their leaves stay, the test rejects) and the object gets a tree of its own -- built the first time, a few hundred microseconds per
- * thousand triangles, and kept; when it returns to the identity its triangles are restored and the instance is dropped.  The result
- * depends on the transforms given to crh_build (which objects share the static tree) and on the current ones, not on the calls in between. */
+ * accumulation.  The static tree is never rebuilt: when an object's transform differs from the one it was built with, its triangles there are
+ * disabled in place (their leaves stay, the test rejects) and the object gets an object-space tree of its own -- built the first time, about a
+ * millisecond per thousand triangles, and kept; when it returns to its build-time transform its triangles are restored and the instance is
+ * dropped.  The result depends on the transforms given to crh_build and on the current ones, not on the calls in between. */
 CRH_API int crh_set_transforms(crh_ctx* ctx, const float* obj_xform /* 12*nO */, uint32_t n_objects);
 /* == Graphic3d_MaterialAspect::SetBSDF + SynchronizeAspects (MaterialEditor.cxx:331-337, Utils.cxx:57-93) */
 CRH_API int crh_set_materials(crh_ctx* ctx, const crh_bsdf* m, uint32_t n);
@@ -208,8 +209,8 @@ CRH_API int crh_set_lookahead(crh_ctx* ctx, uint32_t frames);
 #define CRH_SCHEDULE_WIDE  1
 #define CRH_SCHEDULE_SMALL 2
 CRH_API int crh_set_schedule(crh_ctx* ctx, int mode);
-/* Device-memory budget of the wavefront path state: at most `max_paths` path slots (188 B each) are in flight per batch; a render
- * that needs more is cut into tile groups / sample batches (same image, bit for bit).  Default 2^28 slots = 50 GB of the
+/* Device-memory budget of the wavefront path state: at most `max_paths` path slots (196 B each) are in flight per batch; a render
+ * that needs more is cut into tile groups / sample batches (same image, bit for bit).  Default 2^28 slots = 53 GB of the
  * 288 GB, allocated on demand (a 1080p Redraw() takes 0.4 GB): every launch of the schedule ends in a drain phase of fixed
  * length, so wide batches are faster -- 32 M / 64 M / 128 M / 256 M slots reach 80 / 86 / 91 / 93 % of the 512 M-slot rate on
  * the 1 M-triangle benchmark.  A host that shares the GPU with other consumers lowers it here (the environment variable

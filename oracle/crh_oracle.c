@@ -66,10 +66,10 @@ typedef struct { uint64_t nodes, tris, nodes_any, tris_any; } trav_counters;
 #endif
 typedef struct orc_instance { float fwd[12], inv[12]; float bmin[3], bmax[3]; float wmin[3], wmax[3]; uint32_t root, obj; } orc_instance;
 #define MAX_IBOX 4u       /* instances whose world boxes the "does the ray touch a moved object at all" test looks at one by one (kMaxIBox of the product) */
-/* per object of a two-level scene ("static / moved split"): static0 = at the identity when the scene was built (its
- * triangles are in the static world-space tree); is_inst = rendered through its own object tree + the top level right now (static0 objects:
- * while they are off the identity -- their triangles in the static tree are disabled meanwhile); the object tree is built the first time
- * it is needed and kept */
+/* per object of a two-level scene ("static / moved split"): every object is BAKED into the static world-space tree with
+ * the transform it has when the scene is built (static0 = 1 for every non-empty object); is_inst = rendered through its own object tree + the
+ * top level right now, i.e. while its transform differs from the build-time one -- its triangles in the static tree are disabled meanwhile;
+ * the object tree is built the first time it is needed and kept */
 typedef struct orc_object { uint8_t static0, built, is_inst; uint32_t root, first, ntri; float bmin[3], bmax[3]; } orc_object;
 
 typedef struct orc_ctx {
@@ -89,7 +89,9 @@ typedef struct orc_ctx {
   struct orc_instance* inst; uint32_t nInst; uint32_t nBlasNodes; uint32_t root;
   uint32_t* tlas_order;          /* instance at top-level leaf position i */
   orc_object* obj; uint32_t* obj_tris;   /* per object; its triangles (input order) at obj_tris[first .. first + ntri) */
-  uint32_t* static_pos;          /* leaf position of triangle t in the static tree (objects with static0) */
+  uint32_t* static_pos;          /* leaf position of triangle t in the static tree */
+  float* xf0;                    /* the transforms the scene was built with (12 * nO) */
+  float* pos_w; float* nrm_w;    /* per vertex: position / unit normal under its object's build-time transform = what the static tree holds */
   uint32_t n_static, n_static_live; float sbmin[3], sbmax[3];   /* triangles in the static tree, those not disabled; its bounds */
   uint32_t root2;                /* top-level root to walk AFTER the static tree (QBVH_EMPTY: none) and the bounds of the instances */
   float tlas_lo[3], tlas_hi[3];
@@ -119,6 +121,8 @@ static uint32_t frame_seed(uint32_t seed, uint32_t n)
   for (uint32_t i = 0; i <= n; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; r = hi; }
   return r >> 2;
 }
+
+static void* dup_mem(const void* p, size_t n) { void* r = malloc(n ? n : 1); if (p && n) memcpy(r, p, n); return r; }
 
 /* ================================================================== BVH build */
 typedef struct { float mn[3], mx[3]; } aabb;
@@ -296,22 +300,25 @@ static uint32_t build_tree(collapser* C, const aabb* pb, uint32_t n, uint32_t le
   return root;
 }
 
-static void tri_box(const orc_ctx* c, uint32_t t, aabb* b)
+static void tri_box_of(const orc_ctx* c, const float* pos, uint32_t t, aabb* b)
 {
   aabb_empty(b);
   for (int k = 0; k < 3; ++k) {
-    const float* p = &c->pos[3 * c->tri[4 * t + k]];
+    const float* p = &pos[3 * c->tri[4 * t + k]];
     for (int a = 0; a < 3; ++a) { if (p[a] < b->mn[a]) b->mn[a] = p[a]; if (p[a] > b->mx[a]) b->mx[a] = p[a]; }
   }
 }
-static void emit_tri(const orc_ctx* c, qtri* q, uint32_t t)
+static void tri_box(const orc_ctx* c, uint32_t t, aabb* b) { tri_box_of(c, c->pos, t, b); }
+static void emit_tri_of(const orc_ctx* c, const float* pos, qtri* q, uint32_t t)
 {
   for (int k = 0; k < 3; ++k) {
-    const float* p = &c->pos[3 * c->tri[4 * t + k]];
+    const float* p = &pos[3 * c->tri[4 * t + k]];
     q->f[4 * k + 0] = p[0]; q->f[4 * k + 1] = p[1]; q->f[4 * k + 2] = p[2]; q->f[4 * k + 3] = 0.f;
   }
   q->f[3] = crh_u2f(t);
 }
+
+static void emit_tri(const orc_ctx* c, qtri* q, uint32_t t) { emit_tri_of(c, c->pos, q, t); }
 
 /* every object at the identity: the scene is one world-space tree -- no top level, no ray transforms (spec: same result as the same
  * triangles handed over without objects) */
@@ -394,7 +401,7 @@ static void set_static_triangles(orc_ctx* c, uint32_t ob, int live)
   for (uint32_t i = 0; i < o->ntri; ++i) {
     const uint32_t t = c->obj_tris[o->first + i];
     qtri* q = &c->qtris[c->static_pos[t]];
-    if (live) emit_tri(c, q, t);
+    if (live) emit_tri_of(c, c->pos_w, q, t);
     else { memset(q->f, 0, sizeof q->f); q->f[3] = crh_u2f(t); }
   }
   if (live) c->n_static_live += o->ntri; else c->n_static_live -= o->ntri;
@@ -426,8 +433,30 @@ static int do_build(orc_ctx* c)
   c->obj_tris = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
   c->static_pos = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
   for (uint32_t t = 0; t < n; ++t) c->obj[c->tri_obj[t]].ntri++;
-  { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { c->obj[ob].first = acc; acc += c->obj[ob].ntri; c->obj[ob].ntri = 0; c->obj[ob].static0 = (uint8_t)is_identity(&c->xf[12 * ob]); } }
+  { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { c->obj[ob].first = acc; acc += c->obj[ob].ntri; c->obj[ob].ntri = 0; c->obj[ob].static0 = 1; } }
   for (uint32_t t = 0; t < n; ++t) { orc_object* o = &c->obj[c->tri_obj[t]]; c->obj_tris[o->first + o->ntri++] = t; }
+  /* bake: every vertex under the transform its object has NOW (each vertex belongs to one object); an object at the identity keeps its bits */
+  free(c->xf0); free(c->pos_w); free(c->nrm_w);
+  c->xf0 = (float*)dup_mem(c->xf, sizeof(float) * 12 * c->nO);
+  c->pos_w = (float*)dup_mem(c->pos, sizeof(float) * 3 * c->nV); c->nrm_w = (float*)dup_mem(c->nrm, sizeof(float) * 3 * c->nV);
+  {
+    uint8_t* done = (uint8_t*)calloc(c->nV ? c->nV : 1, 1);
+    for (uint32_t t = 0; t < n; ++t) {
+      const float* M = &c->xf0[12 * c->tri_obj[t]];
+      if (is_identity(M)) continue;
+      for (int k = 0; k < 3; ++k) {
+        const int32_t vi = c->tri[4 * t + k];
+        if (done[vi]) continue;
+        done[vi] = 1;
+        const v3 p = crh_xform_point(M, crh_mk3(c->pos[3 * vi], c->pos[3 * vi + 1], c->pos[3 * vi + 2]));
+        v3 nn = crh_norm3(crh_xform_vector(M, crh_mk3(c->nrm[3 * vi], c->nrm[3 * vi + 1], c->nrm[3 * vi + 2])));
+        if (!(crh_dot3(nn, nn) > 0.f)) nn = crh_mk3(c->nrm[3 * vi], c->nrm[3 * vi + 1], c->nrm[3 * vi + 2]);
+        c->pos_w[3 * vi] = p.x; c->pos_w[3 * vi + 1] = p.y; c->pos_w[3 * vi + 2] = p.z;
+        c->nrm_w[3 * vi] = nn.x; c->nrm_w[3 * vi + 1] = nn.y; c->nrm_w[3 * vi + 2] = nn.z;
+      }
+    }
+    free(done);
+  }
   uint32_t nS = 0;
   for (uint32_t t = 0; t < n; ++t) if (c->obj[c->tri_obj[t]].static0) ++nS;
   c->n_static = c->n_static_live = nS; c->nQT = 0;
@@ -435,10 +464,10 @@ static int do_build(orc_ctx* c)
     aabb* pb = (aabb*)malloc(sizeof(aabb) * nS);
     uint32_t* list = (uint32_t*)malloc(sizeof(uint32_t) * nS); uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * nS);
     uint32_t k = 0;
-    for (uint32_t t = 0; t < n; ++t) if (c->obj[c->tri_obj[t]].static0) { tri_box(c, t, &pb[k]); list[k++] = t; }
+    for (uint32_t t = 0; t < n; ++t) if (c->obj[c->tri_obj[t]].static0) { tri_box_of(c, c->pos_w, t, &pb[k]); list[k++] = t; }
     aabb sb;
     build_tree(&C, pb, nS, BVH_LEAF, 0, 0, order, &sb);
-    for (uint32_t i = 0; i < nS; ++i) { emit_tri(c, &c->qtris[i], list[order[i]]); c->static_pos[list[order[i]]] = i; }
+    for (uint32_t i = 0; i < nS; ++i) { emit_tri_of(c, c->pos_w, &c->qtris[i], list[order[i]]); c->static_pos[list[order[i]]] = i; }
     for (int a = 0; a < 3; ++a) { c->sbmin[a] = sb.mn[a]; c->sbmax[a] = sb.mx[a]; }
     c->nQT = nS;
     free(pb); free(list); free(order);
@@ -958,14 +987,16 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
     }
     st->shaded_hits++;
     const int32_t* ti = &c->tri[4 * h.prim];
-    v3 p0 = crh_mk3(c->pos[3 * ti[0]], c->pos[3 * ti[0] + 1], c->pos[3 * ti[0] + 2]);
-    v3 p1 = crh_mk3(c->pos[3 * ti[1]], c->pos[3 * ti[1] + 1], c->pos[3 * ti[1] + 2]);
-    v3 p2 = crh_mk3(c->pos[3 * ti[2]], c->pos[3 * ti[2] + 1], c->pos[3 * ti[2] + 2]);
     const float* M = (c->two_level && c->obj[c->tri_obj[h.prim]].is_inst) ? &c->xf[12 * c->tri_obj[h.prim]] : NULL;      /* object -> world (an object in the static tree is in world space) */
+    /* a hit in the static tree of a two-level scene sees the BAKED vertices and normals (build-time transform applied per vertex) */
+    const float* VP = (c->two_level && !M) ? c->pos_w : c->pos; const float* VN = (c->two_level && !M) ? c->nrm_w : c->nrm;
+    v3 p0 = crh_mk3(VP[3 * ti[0]], VP[3 * ti[0] + 1], VP[3 * ti[0] + 2]);
+    v3 p1 = crh_mk3(VP[3 * ti[1]], VP[3 * ti[1] + 1], VP[3 * ti[1] + 2]);
+    v3 p2 = crh_mk3(VP[3 * ti[2]], VP[3 * ti[2] + 1], VP[3 * ti[2] + 2]);
     if (M) { p0 = crh_xform_point(M, p0); p1 = crh_xform_point(M, p1); p2 = crh_xform_point(M, p2); }
     v3 ng = crh_norm3(crh_cross3(crh_sub3(p0, p2), crh_sub3(p1, p0)));
     float w0 = (1.0f - h.u) - h.v;
-    const float* n0 = &c->nrm[3 * ti[0]]; const float* n1 = &c->nrm[3 * ti[1]]; const float* n2 = &c->nrm[3 * ti[2]];
+    const float* n0 = &VN[3 * ti[0]]; const float* n1 = &VN[3 * ti[1]]; const float* n2 = &VN[3 * ti[2]];
     v3 ns = crh_norm3(crh_mk3(CRH_FMA(n2[0], h.v, CRH_FMA(n1[0], h.u, n0[0] * w0)),
                                CRH_FMA(n2[1], h.v, CRH_FMA(n1[1], h.u, n0[1] * w0)),
                                CRH_FMA(n2[2], h.v, CRH_FMA(n1[2], h.u, n0[2] * w0))));
@@ -1147,7 +1178,7 @@ ORC_API void orc_destroy(orc_ctx* c)
 {
   if (!c) return;
   free(c->pos); free(c->nrm); free(c->uv); free(c->tri); free(c->mats); free(c->lights); free(c->env);
-  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->last_picked); free(c->xf); free(c->tri_obj); free(c->inst); free(c->tlas_order); free(c->obj); free(c->obj_tris); free(c->static_pos); free(c);
+  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->last_picked); free(c->xf); free(c->tri_obj); free(c->inst); free(c->tlas_order); free(c->obj); free(c->obj_tris); free(c->static_pos); free(c->xf0); free(c->pos_w); free(c->nrm_w); free(c);
 }
 ORC_API const char* orc_last_error(orc_ctx* c) { return c ? c->err : "null ctx"; }
 
@@ -1157,7 +1188,6 @@ static int all_finite(const float* v, size_t n, float limit)
   for (size_t i = 0; i < n; ++i) if (!(v[i] >= -limit && v[i] <= limit)) return 0;
   return 1;
 }
-static void* dup_mem(const void* p, size_t n) { void* r = malloc(n ? n : 1); if (p && n) memcpy(r, p, n); return r; }
 
 ORC_API int orc_set_geometry(orc_ctx* c, const float* pos, const float* nrm, const float* uv, uint32_t nV,
                              const int32_t* tri, uint32_t nT, const int32_t* tri_obj, const float* xf, uint32_t nO)
@@ -1192,7 +1222,7 @@ ORC_API int orc_set_transforms(orc_ctx* c, const float* xf, uint32_t nO)
     for (uint32_t ob = 0; ob < nO; ++ob) {
       orc_object* o = &c->obj[ob];
       if (!o->ntri) continue;
-      const int want = !(o->static0 && is_identity(&xf[12 * ob]));
+      const int want = memcmp(&xf[12 * ob], &c->xf0[12 * ob], 12 * sizeof(float)) != 0;      /* off its build-time placement: an instance */
       if (want && !o->is_inst) { set_static_triangles(c, ob, 0); if (!o->built) build_object_tree(c, &C, ob); o->is_inst = 1; }
       else if (!want && o->is_inst) { set_static_triangles(c, ob, 1); o->is_inst = 0; }
     }

@@ -123,6 +123,19 @@ def test_random_scene_bit_exact(view_cls, Oracle, seed):
     gs, cs = v.stats(), o.stats()
     for k in ("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "nodes_any", "tris_any", "shaded_hits", "samples"):
         assert gs[k] == cs[k], (seed, k, gs[k], cs[k])
+    if sc.tri_object is not None:
+        # objects placed at build time are baked into one tree; dragging them afterwards makes them instances: a random subset (or all) moved on
+        r = np.random.default_rng(seed)
+        xf = sc.obj_xform.copy()
+        for ob in range(len(xf)):
+            if r.random() < 0.6: xf[ob, 3::4] += (0.1 * float(np.abs(sc.pos).max()) * r.normal(size=3)).astype(np.float32)
+        v.set_transforms(xf); o.set_transforms(xf)
+        v.render(spp); o.render(spp)
+        assert v.get_tlas() == o.get_tlas()
+        assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), (seed, "after set_transforms", v.get_tlas())
+        gs, cs = v.stats(), o.stats()
+        for k in ("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "nodes_any", "tris_any", "shaded_hits", "samples"):
+            assert gs[k] == cs[k], (seed, k, gs[k], cs[k])
 
 
 @pytest.mark.parametrize("seed", range(1, 49))
@@ -199,7 +212,7 @@ def test_random_sequences_two_level_adaptive_checkpoint(view_cls, Oracle, seed):
             v.set_adaptive(adaptive, 6); o.set_adaptive(adaptive, 6)
         elif op == 4 and not adaptive:
             acc, frames = v.save_accum()
-            w = view_cls(0).load_scene(dataclasses.replace(sc, obj_xform=xf)); w.load_accum(acc, frames)
+            w = view_cls(0).load_scene(sc); w.set_transforms(xf); w.load_accum(acc, frames)      # the same build-time placement, then the same moves (a fresh build with xf would bake other trees)
             w.set_lookahead(int(r.choice([1, 4])))
             v = w                                                     # carry on in the restored context
         else:

@@ -130,9 +130,10 @@ def test_oracle_static_moved_split(oracle_lib):
     assert len(tris) == n_tri + moved_tris                                   # object-tree copies of the moved objects' triangles
     dead = ~np.any(tris[:n_tri, [0, 1, 2, 4, 5, 6, 8, 9, 10]] != 0, axis=1)
     assert dead.sum() == moved_tris
-    # the same placement built from scratch has other trees (its static tree holds four objects only) but the same surfaces and the same estimator
+    # the same placement built from scratch is ONE tree again (every object is baked with the transform it has at build time): other trees, the same
+    # surfaces (up to the rounding of transforming vertices instead of rays) and the same estimator
     c = oracle_lib.Oracle().load_scene(dataclasses.replace(sc, obj_xform=moved)); c.render(3)
-    assert c.get_tlas()["n_instances"] == 3
+    assert c.get_tlas()["n_instances"] == 0 and len(c.get_bvh()[1]) == n_tri
     same_surfaces(a, c, probe_rays())
     ia, ic = a.read_hdr(), c.read_hdr()
     assert abs(ia.mean() - ic.mean()) / ic.mean() < 0.02
@@ -154,22 +155,29 @@ def test_oracle_static_moved_split(oracle_lib):
     assert np.array_equal(a.get_bvh()[1][:n_tri].view(np.uint32), b.get_bvh()[1].view(np.uint32))
 
 
-def test_oracle_objects_off_the_identity_at_build_are_instances_for_good(oracle_lib):
-    start = np.tile(rigid(), (7, 1)); start[2] = rigid(0.0, (0, 0, 1), (0.0, 0.0, 0.001))       # one object off the identity when the scene is built
-    base = object_scene(start)
-    a = oracle_lib.Oracle().load_scene(base); a.render(2)
-    assert a.get_tlas()["n_instances"] == 1
-    before = a.get_bvh()[0][:a.get_tlas()["n_blas_nodes"]].view(np.uint32).copy()
-    a.set_transforms(moved_xforms(7)); a.render(3)               # object 2 is at the identity now -- but it was never part of the static tree
-    assert a.get_tlas()["n_instances"] == 4
-    assert np.array_equal(a.get_bvh()[0].view(np.uint32)[:len(before)], before)              # static tree and object 2's tree untouched
-    b = oracle_lib.Oracle().load_scene(dataclasses.replace(base, obj_xform=moved_xforms(7))); b.render(3)
-    same_surfaces(a, b, probe_rays())
-    # all objects off the identity at build: no static tree at all, the walk starts at the top level (the structure of rounds 1-2)
-    allm = np.stack([rigid(0.0, (0, 0, 1), (0.001 * (i + 1), 0, 0)) for i in range(7)])
-    c = oracle_lib.Oracle().load_scene(object_scene(allm))
-    info = c.get_tlas()
-    assert info["n_instances"] == 7 and info["root"] == info["n_blas_nodes"] and len(c.get_bvh()[1]) == len(base.tri)
+def test_oracle_objects_are_baked_with_their_build_time_placement(oracle_lib):
+    """A scene whose objects carry locations when it is built (the `vlocation` lines of a saved CADRays scene, ImportExport.cxx:276-305) is ONE world-space
+    tree: every vertex is transformed once, on the host.  An object becomes an instance when its transform differs from the BUILD-TIME one, and part of
+    the static tree again when it returns to it."""
+    placed = moved_xforms(7)
+    sc = object_scene(placed)
+    a = oracle_lib.Oracle().load_scene(sc); a.render(3)
+    assert a.get_tlas()["n_instances"] == 0 and len(a.get_bvh()[1]) == len(sc.tri)
+    f = oracle_lib.Oracle().load_scene(flattened(sc)); f.render(3)                  # the same placement applied by the test, in float64, then rounded
+    same_surfaces(a, f, probe_rays())
+    assert abs(a.read_hdr().mean() - f.read_hdr().mean()) / f.read_hdr().mean() < 0.02
+    base_img = a.read_hdr().copy()
+    nodes0 = a.get_bvh()[0].view(np.uint32).copy()
+    xf = placed.copy(); xf[3] = rigid(70.0, (0, 0, 1), (-0.3, 0.1, 0.05))            # the yellow box dragged on from where it was placed
+    a.set_transforms(xf); a.render(3)
+    assert a.get_tlas()["n_instances"] == 1 and np.array_equal(a.get_bvh()[0].view(np.uint32)[:len(nodes0)], nodes0)
+    g = oracle_lib.Oracle().load_scene(dataclasses.replace(sc, obj_xform=xf)); g.render(3)
+    same_surfaces(a, g, probe_rays())
+    a.set_transforms(placed); a.render(3)                                            # back where it was when the scene was built: one tree, the same bits
+    assert a.get_tlas()["n_instances"] == 0 and np.array_equal(a.read_hdr().view(np.uint32), base_img.view(np.uint32))
+    ident = np.tile(rigid(), (7, 1))
+    a.set_transforms(ident)                                                          # the identity is NOT special: three objects are off their placement now
+    assert a.get_tlas()["n_instances"] == 3
 
 
 @pytest.mark.gpu
@@ -211,9 +219,13 @@ def test_hip_identity_objects_are_one_tree(hip_lib, oracle_lib):
 @pytest.mark.gpu
 def test_hip_two_level_matches_oracle_bit_exact(hip_lib, oracle_lib):
     from cadrays_amd.view import View
-    sc = object_scene(moved_xforms(7), 128, 96)
+    sc = object_scene(None, 128, 96)
     v = View(0).load_scene(sc); v.enable_counters(True); v.reset()
     o = oracle_lib.Oracle().load_scene(sc)
+    allm = moved_xforms(7)
+    for k in (0, 1, 2, 4): allm[k] = rigid(3.0 * (k + 1), (0, 1, 0), (0.002 * k, 0.001, -0.003 * k))      # EVERY object off its build-time placement: no live static triangle,
+    v.set_transforms(allm); o.set_transforms(allm)                                                        # the walk starts at the top level (more than four instances: one-walk kernels)
+    assert v.get_tlas()["n_instances"] == 7
     assert np.array_equal(v.get_bvh()[0].view(np.uint32), o.get_bvh()[0].view(np.uint32)) and v.get_tlas() == o.get_tlas()
     r = np.random.default_rng(9)
     n = 100000
@@ -244,14 +256,18 @@ def test_hip_set_transforms_rebuilds_only_the_top_level(hip_lib, oracle_lib):
     # a scene of 64 objects x 4096 triangles: moving them costs a top-level rebuild, not 262 k triangles of BVH build
     pos, nrm, tri = scenes.gen_scene(64 * 4096, 5, 1)
     tri_obj = (np.arange(len(tri)) // 4096).astype(np.int32)
-    xf = np.stack([rigid(0.0, (0, 0, 1), (0.001 * (i + 1), 0, 0)) for i in range(64)])       # off the identity: object trees + top level from the start
+    xf = np.stack([rigid(0.0, (0, 0, 1), (0.001 * (i + 1), 0, 0)) for i in range(64)])       # placed objects: baked into one tree at build time
     big = scenes.Scene(pos, nrm, tri, [scenes.BSDF.CreateDiffuse(0.7)], tri_object=tri_obj, obj_xform=xf,
                        params=scenes.Params(width=64, height=64, background=(1, 1, 1)))
     t0 = time.time(); w = View(0).load_scene(big); t_build = time.time() - t0
+    assert w.get_tlas()["n_instances"] == 0
     xf2 = np.stack([rigid(10.0 * i, (0, 0, 1), (0.01 * i, 0, 0)) for i in range(64)])
-    t0 = time.time(); w.set_transforms(xf2); t_move = time.time() - t0
+    w.set_transforms(xf2)                                                                     # all 64 dragged once: their object trees are built now (and kept)
+    assert w.get_tlas()["n_instances"] == 64
+    xf3 = np.stack([rigid(10.0 * i + 5.0, (0, 0, 1), (0.01 * i, 0.02, 0)) for i in range(64)])
+    t0 = time.time(); w.set_transforms(xf3); t_move = time.time() - t0
     w.render(1)
-    assert np.isfinite(w.read_hdr()).all() and t_move < t_build
+    assert np.isfinite(w.read_hdr()).all() and t_move < 0.1 * t_build
 
 
 @pytest.mark.gpu
@@ -265,8 +281,9 @@ def test_translated_only_instances_and_signed_zero_directions(hip_lib, oracle_li
     xf = np.tile(rigid(), (n, 1))
     for k in range(n):
         xf[k] = rigid(0.0, (0, 0, 1), (0.01 * k, -0.02 * k, 0.005 * k))
-    sc = dataclasses.replace(sc, obj_xform=xf)
     v = View(0).load_scene(sc); o = oracle_lib.Oracle().load_scene(sc)
+    v.set_transforms(xf); o.set_transforms(xf)               # dragged after the build: instances (objects placed AT build time are baked into the static tree)
+    assert v.get_tlas()["n_instances"] == n
     r = np.random.default_rng(3)
     m = 20000
     rays = np.zeros((m, 8), np.float32)
@@ -284,6 +301,7 @@ def test_translated_only_instances_and_signed_zero_directions(hip_lib, oracle_li
     for cam_dir in ((0.0, 1.0, 0.0), (-0.0, 1.0, -0.0)):
         s2 = dataclasses.replace(sc, camera=dataclasses.replace(sc.camera, dir=cam_dir, is_ortho=True, ortho_scale=0.6))
         a = View(0).load_scene(s2); b = oracle_lib.Oracle().load_scene(s2)
+        a.set_transforms(xf); b.set_transforms(xf)
         a.render(2); b.render(2)
         assert np.array_equal(a.read_hdr().view(np.uint32), b.read_hdr().view(np.uint32))
 

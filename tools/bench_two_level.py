@@ -53,9 +53,14 @@ for G in Gs:
             nrm = np.einsum("tij,tvj->tvi", Rt[inv], nrm).astype(np.float32)
             xf = np.concatenate([R, t[:, :, None]], 2).reshape(len(ids), 12).astype(np.float32)
         two = dataclasses.replace(sc, pos=pos.reshape(-1, 3), nrm=nrm.reshape(-1, 3), tri_object=inv.astype(np.int32), obj_xform=xf)
-        v = View(0).load_scene(two)
-        print(json.dumps({"scene": f"two-level, {len(ids)} objects, {kind}", "mrays_per_s": round(rate(v), 1)}), flush=True)
+        v = View(0).load_scene(two)                                  # placed at build time: baked into one tree (round 3)
+        print(json.dumps({"scene": f"two-level, {len(ids)} objects, {kind}, as built (baked)", "mrays_per_s": round(rate(v), 1), "instances": v.get_tlas()["n_instances"]}), flush=True)
         v.close()
+        if kind != "identity":                                       # the same world, every object an INSTANCE: built at the identity, then all moved into place
+            ident_all = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(ids), 1))
+            v = View(0).load_scene(dataclasses.replace(two, obj_xform=ident_all)); v.set_transforms(xf)
+            print(json.dumps({"scene": f"two-level, {len(ids)} objects, {kind}, every object an instance", "mrays_per_s": round(rate(v), 1), "instances": v.get_tlas()["n_instances"]}), flush=True)
+            v.close()
 
 # ---- static / moved split: what a CADRays session does -- the scene is loaded with every object where its vertices say, then the gizmo drags ONE
 # object (src/ImGui/ImRaytraceControls.cxx:64,88).  1000 objects at the identity; 1, then 10 of them translated a little: throughput against the flat
