@@ -402,7 +402,21 @@ def main():
                 v.Redraw()
             v.sync()
             interactive[f"redraw_per_s_lookahead_{k}"] = round(n_fr / (time.perf_counter() - t1), 1)
-        v.set_lookahead(1); v.reset()
+        v.set_lookahead(1)
+        # crh_set_lookahead_auto(16): FROM a restart -- one sample, then batches of 4, 16, 16, ... -- 64 Redraw()s, three sessions
+        v.set_lookahead_auto(16); v.reset(); v.sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            v.reset()
+            for _ in range(64):
+                v.Redraw()
+        v.sync()
+        interactive["redraw_per_s_lookahead_auto_16_first_64_frames_after_a_restart"] = round(3 * 64 / (time.perf_counter() - t1), 1)
+        v.reset(); v.sync()
+        t1 = time.perf_counter()
+        v.Redraw(); v.sync()
+        interactive["first_frame_after_a_restart_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+        v.set_lookahead_auto(0); v.reset()
         interactive["note"] = "one crh_render(1) per call over the whole frame, no read-back; NOT part of `value`"
 
     # ---- parity gate ("parity gate accompanying every number"; the reference's own gate is pixel-exact,

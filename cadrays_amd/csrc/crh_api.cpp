@@ -82,6 +82,7 @@ struct crh_ctx {
   // speculative look-ahead for the +1-spp-per-Redraw boundary: frames [pending_first, pending_first + pending_n) are traced
   // and wait in the path buffer (batch sample index pending_off ...) to be folded in by the next crh_render calls
   uint32_t lookahead = 1, pending_first = 0, pending_n = 0, pending_off = 0, pending_tiles = 0;
+  uint32_t lookahead_auto = 0, ramp_k = 1;               // crh_set_lookahead_auto: the batch grows 1, 4, 16, ... after every restart of the accumulation
   DPaths paths{}; DQueues queues{}; uint32_t path_cap = 0;
   uint32_t* d_tile_ids = nullptr; uint32_t tile_cap = 0;
   uint32_t* d_seeds = nullptr; uint32_t seed_cap = 0;
@@ -500,7 +501,7 @@ int do_reset(crh_ctx* c)
   int rc = alloc_accum(c); if (rc) return rc;
   CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, cstream(c)));
   CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, cstream(c)));
-  c->adaptive_picks = 0; c->pending_n = 0; c->picked_valid = false; c->assembled_valid = false;
+  c->adaptive_picks = 0; c->pending_n = 0; c->ramp_k = 1; c->picked_valid = false; c->assembled_valid = false;
   CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), cstream(c)));
   discard_events(c);
   c->seconds_acc = c->trace_ms_acc = c->all_ms_acc = 0.0; c->trace_launches = 0; c->frames_done = 0;
@@ -1341,13 +1342,25 @@ int crh_render(crh_ctx* c, uint32_t n)
   const uint32_t nt = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
   std::vector<uint32_t> all(nt);
   for (uint32_t i = 0; i < nt; ++i) all[i] = i;
-  if (c->lookahead > 1 && (uint64_t)nt * ts * ts * c->lookahead <= c->max_paths) {
+  // crh_set_lookahead_auto: the first frame after a restart is ONE sample (what the user sees while dragging), then batches of 4, 16, ... max
+  const bool ramp = c->lookahead_auto > 1;
+  const uint32_t k_max = ramp ? c->lookahead_auto : c->lookahead;
+  if (k_max > 1 && (uint64_t)nt * ts * ts * k_max <= c->max_paths) {
     // look-ahead: one wide batch of `lookahead` frames is traced at once; each call folds in only the samples it asked for
     CRH_HIP(hipSetDevice(c->device));
     while (n > 0) {
       if (c->pending_n == 0 || c->pending_first != c->frames_done || c->pending_tiles != nt) {
+        uint32_t k = c->lookahead;
+        if (ramp) {
+          k = std::min(std::max(c->ramp_k, std::min(n, k_max)), k_max);      // a call that asks for n samples at once is not cut finer than that
+          c->ramp_k = std::min(4u * k, k_max);
+          if (k == 1) {                                                       // nothing to speculate on yet: a plain frame
+            int rc1 = render_impl(c, all.data(), nt, c->frames_done, 1); if (rc1) return rc1;
+            c->frames_done += 1; n -= 1;
+            continue;
+          }
+        }
         int rc_t = upload_textures(c); if (rc_t) return rc_t;
-        const uint32_t k = c->lookahead;
         if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; }
         if (k > c->seed_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_seeds) CRH_HIP(hipFree(c->d_seeds)); CRH_HIP(hipMalloc((void**)&c->d_seeds, sizeof(uint32_t) * k)); c->seed_cap = k; }
         std::vector<uint32_t> seeds(k);
@@ -1406,6 +1419,13 @@ int crh_set_lookahead(crh_ctx* c, uint32_t frames)
 {
   if (!c || frames == 0) return fail(c, CRH_E_INVALID, "lookahead must be >= 1");
   c->lookahead = frames; c->pending_n = 0;
+  return CRH_OK;
+}
+
+int crh_set_lookahead_auto(crh_ctx* c, uint32_t max_frames)
+{
+  if (!c) return CRH_E_INVALID;
+  c->lookahead_auto = max_frames; c->ramp_k = 1; c->pending_n = 0;
   return CRH_OK;
 }
 

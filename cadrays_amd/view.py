@@ -57,6 +57,10 @@ class View(Backend):
         """trace `frames` Redraw()s ahead in one wide batch; images after every Redraw stay bit-identical"""
         self._call("set_lookahead", C.c_uint32(int(frames)))
 
+    def set_lookahead_auto(self, max_frames):
+        """crh_set_lookahead_auto: one sample right after a restart, then batches of 4, 16, ... max_frames; 0 / 1 = off"""
+        self._call("set_lookahead_auto", C.c_uint32(int(max_frames)))
+
     def set_path_budget(self, max_paths):
         """crh_set_path_budget: at most this many path slots (196 B each) in flight per batch; images do not depend on it"""
         self._call("set_path_budget", C.c_uint64(int(max_paths)))

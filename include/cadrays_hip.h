@@ -199,6 +199,13 @@ CRH_API int crh_set_show_tiles(crh_ctx* ctx, int on);
  * change of scene / camera / parameters, crh_reset, crh_render_tiles or adaptive mode discards what is pending.  Ray
  * counters include the speculative samples.  frames = 1 (default) disables it. */
 CRH_API int crh_set_lookahead(crh_ctx* ctx, uint32_t frames);
+/* Look-ahead that follows the session (AppViewer.cxx:979-984 restarts the accumulation on every camera change, :1045-1047 then issues one
+ * Redraw() per GUI frame): the first crh_render(1) after a restart traces ONE sample -- the frame the user sees while dragging costs what it
+ * always did -- the next batch holds 4, then 16, ... up to max_frames samples, so a view left alone converges at the rate of the wide schedule
+ * (a speculative batch costs ~1.3 ms per sample at 1080p on C3 where a lone frame costs 2.5).  Every restart (crh_reset and all that imply it)
+ * starts again at one; what was traced ahead is dropped as with crh_set_lookahead.  Images are the same bit for bit.  max_frames <= 1 switches
+ * it off (default); while on, it takes the place of crh_set_lookahead's fixed batch. */
+CRH_API int crh_set_lookahead_auto(crh_ctx* ctx, uint32_t max_frames);
 /* Which of the two wavefront schedules a batch takes.  CRH_SCHEDULE_AUTO (default): batches above ~12 M paths run the WIDE schedule
  * (one stream, full persistent grids, the plain traversal kernels); smaller ones -- one Redraw(), adaptive iterations, tile subsets --
  * run the SMALL one (two tile ranges on two streams or pipelined frames, grids that follow the batch, the work-donating traversal

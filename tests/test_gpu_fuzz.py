@@ -149,6 +149,7 @@ def test_random_call_sequences_keep_both_sides_in_step(view_cls, Oracle, seed):
     sc = dataclasses.replace(sc, tri_object=None, obj_xform=None, params=dataclasses.replace(sc.params, max_depth=min(sc.params.max_depth, 6)))
     v = view_cls(0).load_scene(sc); o = Oracle().load_scene(sc)
     v.set_lookahead(int(r.choice([1, 3, 8])))
+    if seed % 3 == 0: v.set_lookahead_auto(int(r.choice([2, 8, 16])))     # the ramping look-ahead takes the fixed one's place
     par, cam = sc.params, sc.camera
     done = 0                                             # whole-frame iterations since the last restart (what crh_render continues from)
     for step in range(14):

@@ -432,6 +432,36 @@ def test_lookahead_keeps_every_redraw_bit_identical(view_cls):
     assert v.stats()["samples"] == ref.stats()["samples"]
 
 
+def test_auto_lookahead_ramps_from_one_sample_and_keeps_every_redraw_bit_identical(view_cls):
+    """crh_set_lookahead_auto: one sample right after a restart, then batches of 4 and 8; every Redraw() still reveals exactly +1 spp, a restart
+    in the middle of a batch drops what was traced ahead, and the ray counters show how far ahead the context is."""
+    import dataclasses
+    sc = scenes.cornell_box(True, 96, 80)
+    ref = view_cls(0).load_scene(sc)
+    v = view_cls(0).load_scene(sc); v.set_lookahead_auto(8)
+    one = None
+    for i in range(1, 24):
+        ref.Redraw(); v.Redraw()
+        assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr())), i
+        if i == 1:
+            one = v.stats()["rays_nearest"]
+            assert one == ref.stats()["rays_nearest"]                  # the first frame after a restart speculates on nothing
+        if i == 2:
+            assert v.stats()["rays_nearest"] > ref.stats()["rays_nearest"]        # frames 2 .. 5 were traced together
+        if i in (9, 12):                                               # 1 + 4 consumed, inside the batch of 8: restart -> one sample again
+            cam = dataclasses.replace(sc.camera, eye=(0.45, -1.5 + 0.01 * i, 0.55))
+            ref.set_camera(cam); ref.reset(); v.set_camera(cam); v.reset()
+            ref.Redraw(); v.Redraw()
+            assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr()))
+            assert v.stats()["rays_nearest"] == ref.stats()["rays_nearest"]
+    v.render(11); ref.render(11)                                       # a request larger than the current batch is traced in one piece
+    assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr()))
+    assert v.stats()["samples"] == ref.stats()["samples"]
+    v.set_lookahead_auto(0); v.reset(); ref.reset()
+    v.render(3); ref.render(3)
+    assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr())) and v.stats()["rays_nearest"] == ref.stats()["rays_nearest"]
+
+
 def test_crh_reduce_assembles_tile_shards(view_cls, monkeypatch):
     """C-ABI exchange step: three contexts render interleaved tiles, crh_reduce assembles the frame on the root
     bit-identically to a one-context render; own accumulators stay untouched and rendering continues afterwards."""
