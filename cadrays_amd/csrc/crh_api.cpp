@@ -1352,9 +1352,14 @@ int crh_render(crh_ctx* c, uint32_t n)
       if (c->pending_n == 0 || c->pending_first != c->frames_done || c->pending_tiles != nt) {
         uint32_t k = c->lookahead;
         if (ramp) {
-          k = std::min(std::max(c->ramp_k, std::min(n, k_max)), k_max);      // a call that asks for n samples at once is not cut finer than that
+          if (n >= k_max) {                                                   // the caller asks for a whole batch itself: nothing to speculate on,
+            int rcn = render_impl(c, all.data(), nt, c->frames_done, n); if (rcn) return rcn;      // and render_impl cuts it into the widest batches that fit
+            c->frames_done += n; n = 0; c->ramp_k = k_max;
+            break;
+          }
+          k = std::max(c->ramp_k, n);                                         // a call that asks for n samples at once is not cut finer than that
           c->ramp_k = std::min(4u * k, k_max);
-          if (k == 1) {                                                       // nothing to speculate on yet: a plain frame
+          if (k == 1) {                                                       // right after a restart: a plain frame
             int rc1 = render_impl(c, all.data(), nt, c->frames_done, 1); if (rc1) return rc1;
             c->frames_done += 1; n -= 1;
             continue;

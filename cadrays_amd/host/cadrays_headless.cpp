@@ -42,7 +42,7 @@ int main(int argc, char** argv)
   const std::string path = argv[1];
   const int n_frames = atoi(argv[2]);
   const int device = argc > 3 ? atoi(argv[3]) : 0;
-  const int lookahead = argc > 4 ? atoi(argv[4]) : 1;      // crh_set_lookahead: frames traced ahead per wide batch
+  const int lookahead = argc > 4 ? atoi(argv[4]) : 1;      // k > 1: crh_set_lookahead(k), frames traced ahead per wide batch; -k: crh_set_lookahead_auto(k)
   const int n_gpus = argc > 5 ? atoi(argv[5]) : 1;
   if (n_frames <= 0 || n_gpus <= 0) { fprintf(stderr, "nFrames and gpus must be > 0\n"); return 2; }
 
@@ -111,6 +111,7 @@ int main(int argc, char** argv)
     if ((rc = crh_set_params(c, &par))) return die_all(c, "crh_set_params", rc);
     if ((rc = crh_build(c))) return die_all(c, "crh_build", rc);
     if (n_gpus == 1 && lookahead > 1 && (rc = crh_set_lookahead(c, (uint32_t)lookahead))) return die_all(c, "crh_set_lookahead", rc);
+    if (n_gpus == 1 && lookahead < -1 && (rc = crh_set_lookahead_auto(c, (uint32_t)-lookahead))) return die_all(c, "crh_set_lookahead_auto", rc);
   }
   crh_ctx* c = ctx[0];
 
