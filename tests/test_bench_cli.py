@@ -64,7 +64,7 @@ def test_stale_counter_traffic_is_refused(tmp_path, monkeypatch):
     got, why = bench.pmc_entry("C3", 128, False)
     assert got is None and why.startswith("stale")
     r = bench.roofline_report("C3", 128, False, 1.2e11, 16.0, 81 << 20, {})
-    assert r["traffic"] is None and r["frac"] is None and r["bound"].startswith("l2-miss")          # cache-resident, no counters: no HBM fraction
+    assert r["traffic"] is None and r["frac"] is None and r["bound"] == "hbm" and r["limited_by"].startswith("l2-miss")          # cache-resident, no counters: no HBM fraction
     r = bench.roofline_report("C5", 32, False, 1.5e11, 28.0, 1 << 30, {})
     assert r["bound"] == "hbm" and r["traffic"] is None and 0 < r["frac"] < 1
     # a matching entry is used, and a cache-resident scene can then never report more than what crossed the memory side
