@@ -60,7 +60,8 @@ struct crh_ctx {
   size_t cap_pos = 0;                     // leaf positions the triangle / shading / uv arrays have room for
   void* d_patch = nullptr; size_t cap_patch = 0;
   int split_passes = -1;                  // CRH_SPLIT_PASSES: -1 auto, 0 one walk, 1 two passes
-  float4* d_ibox = nullptr;               // world boxes of the instances when there are at most kMaxIBox (the "does the ray touch a moved object" test)
+  float4* d_ibox = nullptr;               // spheres around the instances' world boxes when there are at most kMaxIBox (the "does the ray come near a moved object" test)
+  float usph[4] = {0.f, 0.f, 0.f, 0.f};  // ... and around the bounds of all of them
   float4* d_inst = nullptr;
   // ---- built scene
   QBvh bvh;
@@ -292,6 +293,7 @@ void fill_scene(const crh_ctx* c, DScene& S)
   S.split = (S.root2 != kQEmpty && (c->split_passes < 0 ? c->inst.size() <= kMaxIBox : c->split_passes != 0)) ? 1 : 0;
   for (int a = 0; a < 3; ++a) { S.tlas_lo[a] = c->tlas_lo[a]; S.tlas_hi[a] = c->tlas_hi[a]; }
   S.ibox = c->d_ibox; S.n_ibox = (c->d_ibox && c->inst.size() <= kMaxIBox) ? (uint32_t)c->inst.size() : 0u;
+  S.usph = make_float4(c->usph[0], c->usph[1], c->usph[2], c->usph[3]);
   {
     const float* lo = c->bvh.bbmin; const float* hi = c->bvh.bbmax;      // bounds of the tree the walk starts in (the world box of a two-level scene)
     S.guard_box = make_float4((lo[0] + hi[0]) * 0.5f, (lo[1] + hi[1]) * 0.5f, (lo[2] + hi[2]) * 0.5f, (((hi[0] - lo[0]) + (hi[1] - lo[1])) + (hi[2] - lo[2])) * 0.5f);
@@ -390,11 +392,12 @@ int build_tlas(crh_ctx* c)
     c->root = troot;
     for (int a = 0; a < 3; ++a) { c->bvh.bbmin[a] = c->tlas_lo[a]; c->bvh.bbmax[a] = c->tlas_hi[a]; }
   }
-  if (!c->d_ibox) CRH_HIP(hipMalloc((void**)&c->d_ibox, sizeof(float4) * 2 * kMaxIBox));
+  if (!c->d_ibox) CRH_HIP(hipMalloc((void**)&c->d_ibox, sizeof(float4) * kMaxIBox));
+  crh_box_sphere(c->tlas_lo, c->tlas_hi, c->usph);
   if (n <= kMaxIBox) {
-    float ib[8 * kMaxIBox] = {0};
-    for (uint32_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { ib[8 * i + a] = boxes[6 * (size_t)i + a]; ib[8 * i + 4 + a] = boxes[6 * (size_t)i + 3 + a]; }
-    int rc_b = stage_copy(c, c->d_ibox, ib, sizeof(float) * 8 * n); if (rc_b) return rc_b;
+    float ib[4 * kMaxIBox] = {0};
+    for (uint32_t i = 0; i < n; ++i) crh_box_sphere(&boxes[6 * (size_t)i], &boxes[6 * (size_t)i + 3], &ib[4 * i]);
+    int rc_b = stage_copy(c, c->d_ibox, ib, sizeof(float) * 4 * n); if (rc_b) return rc_b;
   }
   return dev_put(c, c->d_inst, c->cap_inst, table.data(), table.size() * sizeof(float), 32 * sizeof(float) * ((size_t)c->nO + 64));
 }

@@ -23,7 +23,7 @@ constexpr uint32_t kQLeafBit      = 0x80000000u;
 static_assert(CRH_TRI_STRIDE == 4, "the fourth float4 of a triangle record holds the caller's triangle id");
 constexpr uint32_t kTriStride = CRH_TRI_STRIDE;   // float4 between consecutive triangle records on the device (3 are fetched by the traversal): on a 64-B stride no
                                                   // record straddles two 64-B sectors (packed at 48 B half of them do): +2.8 % C3, +4 % C5
-constexpr uint32_t kMaxIBox = 4;   // instances whose world boxes the "does this ray touch a moved object at all" test looks at one by one (spec constant)
+constexpr uint32_t kMaxIBox = 12;  // moved objects whose spheres the "does this ray come near a moved object at all" test looks at one by one (spec constant)
 constexpr int kCounts     = 16;    // words per queue-counter block (DQueues::counts)
 constexpr int kBlock      = 256;   // threads per workgroup (4 waves)
 constexpr int kLdsStack   = 16;    // traversal stack entries per lane kept in LDS
@@ -50,8 +50,9 @@ struct DScene {
   uint32_t root;          // node index traversal starts at: the (static) world-space tree; the top-level root when no static triangle is live
   uint32_t root2;         // static / moved split: top-level root walked AFTER the static tree (kQEmpty: none) ...
   float tlas_lo[3], tlas_hi[3];   // ... if the ray touches the bounds of all instances ...
-  const float4* ibox;     // ... and, when there are at most kMaxIBox of them (n_ibox > 0), the world box of at least one: 2 x float4 {lo, hi} per instance
+  const float4* ibox;     // ... and, when there are at most kMaxIBox of them (n_ibox > 0), the sphere {centre, padded radius} around each one's world box (crh_box_sphere)
   uint32_t n_ibox;
+  float4 usph;            // the sphere around the bounds of ALL instances
   int two_level;          // some object is rendered as an instance right now (object trees + top level exist)
   int split;              // render path of a split scene (root2 valid): two traversal passes -- the single-level kernels over the static tree, then the
                           // two-level ones over the top level for the rays their producers flagged (DQueues::q2 / q2_sh)

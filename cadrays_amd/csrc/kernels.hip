@@ -164,31 +164,26 @@ constexpr uint32_t kNoLane = 64u;
 // never donate.
 // Static / moved split of a two-level scene: the walk starts in the static world-space tree (`root`) and the top-level
 // tree over the moved objects (`root2`) waits at the bottom of the stack -- pushed only when the ray touches the instances' bounds.
-struct Top2 { uint32_t root2; float lo[3], hi[3]; const float4* ibox; uint32_t n_ibox; };
-__device__ __forceinline__ Top2 top2_of(const DScene& S)
-{ Top2 t; t.root2 = S.root2; for (int a = 0; a < 3; ++a) { t.lo[a] = S.tlas_lo[a]; t.hi[a] = S.tlas_hi[a]; } t.ibox = S.ibox; t.n_ibox = S.n_ibox; return t; }
+struct Top2 { uint32_t root2; float4 usph; const float4* isph; uint32_t n_isph; bool ask; };
+__device__ __forceinline__ Top2 top2_of(const DScene& S, bool ask = true)
+{ Top2 t; t.root2 = S.root2; t.usph = S.usph; t.isph = S.ibox; t.n_isph = S.n_ibox; t.ask = ask; return t; }
 
-// Does the ray touch a moved object at all?  (spec; the oracle's traverse() has the twin.)  The planes of a box with the ray's
-// guard band, like a node's child test: first the bounds of ALL instances, then -- when there are at most kMaxIBox of them -- the world box of at
-// least one.  ix.. = reciprocal direction, gx.. = guard band of the world-space ray.
-__device__ __forceinline__ bool touches_instances(const Top2& t2, v3 o, float ix, float iy, float iz, float gx, float gy, float gz, float tmax)
+// Does the ray come near a moved object at all?  (spec: include/crh_math.h, crh_ray_near_sphere; the oracle's traverse() asks the same function.)
+// The sphere around the bounds of ALL instances first, then -- when there are at most kMaxIBox of them -- the sphere of at least one.  ONE moved
+// object (the gizmo drags one, ImRaytraceControls.cxx:64,88): the two spheres are the same numbers, one test.  Rays handed in through the API
+// (any direction length) are not asked: they always walk the top level.
+__device__ __forceinline__ bool touches_instances(const Top2& t2, v3 o, v3 d, float tmax)
 {
-  auto slab = [&](float lx, float ly, float lz, float hx, float hy, float hz) {
-    const float ax_ = (lx - o.x) * ix, bx_ = (hx - o.x) * ix, ay_ = (ly - o.y) * iy, by_ = (hy - o.y) * iy, az_ = (lz - o.z) * iz, bz_ = (hz - o.z) * iz;
-    const float tn_ = fmaxf(fmaxf(fmaxf(fminf(ax_, bx_) - gx, fminf(ay_, by_) - gy), fminf(az_, bz_) - gz), 0.f);
-    const float tf_ = fminf(fminf(fminf(fmaxf(ax_, bx_) + gx, fmaxf(ay_, by_) + gy), fmaxf(az_, bz_) + gz), tmax);
-    return tn_ <= tf_;
-  };
-  if (!slab(t2.lo[0], t2.lo[1], t2.lo[2], t2.hi[0], t2.hi[1], t2.hi[2])) return false;
-  if (t2.n_ibox == 0u) return true;
-  for (uint32_t i = 0; i < t2.n_ibox; ++i) {
-    const float4 lo = t2.ibox[2u * i], hi = t2.ibox[2u * i + 1u];
-    if (slab(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z)) return true;
+  if (!t2.ask) return true;
+  if (t2.n_isph != 1u && !crh_ray_near_sphere(o, d, tmax, t2.usph.x, t2.usph.y, t2.usph.z, t2.usph.w)) return false;
+  if (t2.n_isph == 0u) return true;
+  for (uint32_t i = 0; i < t2.n_isph; ++i) {
+    const float4 sp = t2.isph[i];
+    if (crh_ray_near_sphere(o, d, tmax, sp.x, sp.y, sp.z, sp.w)) return true;
   }
   return false;
 }
-// the same for a ray whose reciprocals and guard band are not at hand (the kernels that PRODUCE rays flag the ones of the second pass)
-__device__ __forceinline__ bool ray_touches_instances(const DScene& S, v3 o, v3 d, float tmax);
+__device__ __forceinline__ bool ray_touches_instances(const DScene& S, v3 o, v3 d, float tmax) { return touches_instances(top2_of(S), o, d, tmax); }
 
 template <bool ANY, bool COUNT, bool TWO, bool DON, class Load, class Store>
 __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, const float4* __restrict__ tris,
@@ -268,7 +263,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           if (TWO) save_world();
           best = tmax; found = false; sp = 0; cur = root; have = true;
           if (ANY && tmax < 0.f) cur = kDone;                      // second any-hit pass of a split scene: already occluded in the first (no visit, no test)
-          if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, ix, iy, iz, gx, gy, gz, tmax)) { lds[0] = t2.root2; sp = 1; }
+          if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, d, tmax)) { lds[0] = t2.root2; sp = 1; }
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
           if (DON) { sbase = 0; is_child = false; cfound = false; next = kNoLane; head = lane; bound[lane] = __float_as_uint(tmax); }
         }
@@ -653,7 +648,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict
 {
   __shared__ uint32_t stk[kLdsStack * kBlock];
   uint32_t nn = 0, nt = 0;
-  trace_engine<ANY, COUNT, TWO, false>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, top2_of(S), cursor, n, &stk[threadIdx.x],
+  trace_engine<ANY, COUNT, TWO, false>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, top2_of(S, false), cursor, n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = idx;
       const float4 o4 = rays[2u * idx], d4 = rays[2u * idx + 1u];
@@ -677,13 +672,6 @@ __global__ CRH_TRACE_BOUNDS void k_trace_rays(DScene S, const float4* __restrict
   }
 }
 
-__device__ __forceinline__ bool ray_touches_instances(const DScene& S, v3 o, v3 d, float tmax)
-{
-  const float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
-  const float4 gb = S.guard_box;
-  const float R = CRH_FMA(gb.w, 3.0f, (crh_abs(o.x - gb.x) + crh_abs(o.y - gb.y)) + crh_abs(o.z - gb.z)) * kSlabGuard;      // trace_engine's set_guard
-  return touches_instances(top2_of(S), o, ix, iy, iz, crh_abs(ix) * R, crh_abs(iy) * R, crh_abs(iz) * R, tmax);
-}
 
 // ================================================================== BSDF
 struct Bsdf {

@@ -136,7 +136,7 @@ CRH_API const char* crh_last_error(crh_ctx* ctx);
  * tree with the transform it has at that moment (each vertex is transformed once, on the host; an object at the identity keeps its bits, so a
  * scene whose objects all sit at the identity is bit for bit the scene without objects) -- a loaded scene renders at the single-level rate
  * whatever locations its objects carry.  Only an object whose transform is CHANGED afterwards (crh_set_transforms) is rendered as an instance:
- * rays walk the static tree first and then the top-level tree of the moved objects (skipped when the ray misses their bounds). */
+ * rays walk the static tree first and then the top-level tree of the moved objects (skipped when the ray does not come near one: crh_ray_near_sphere, crh_math.h). */
 CRH_API int crh_set_geometry(crh_ctx* ctx,
                      const float* pos, const float* nrm, const float* uv, uint32_t n_vertices,
                      const int32_t* tri /* 4*nT: i0,i1,i2,material */, uint32_t n_triangles,

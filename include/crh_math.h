@@ -76,6 +76,31 @@ CRH_HD crh_v3 crh_norm3(crh_v3 a)
 }
 CRH_HD float crh_maxcomp3(crh_v3 a) { return crh_max(a.x, crh_max(a.y, a.z)); }
 
+/* ---- split scenes (static tree + moved objects): "does the ray come near a moved object at all?"  (spec)
+ * Every moved object's world box is wrapped in a sphere {centre, padded radius}; a ray is sent through the top-level tree only if the part
+ * [0, tmax] of it comes within the sphere of at least one of them (first: within the sphere around ALL of them).  No reciprocal direction, no
+ * division: the kernels that PRODUCE rays ask this for every ray they write.  The direction must be of unit length (path rays are; rays handed in
+ * through the API are not asked).  Conservative by construction: triangles of a moved object lie inside its world box, the box inside the sphere;
+ * the radius is padded for the rounding of the box itself and of the ray's transformation into object space (both scale with the coordinates'
+ * magnitude), the comparison for the rounding of the closest-point evaluation (scales with the distance to the centre). */
+CRH_HD void crh_box_sphere(const float* lo, const float* hi, float* s4)
+{
+  const float hx = (hi[0] - lo[0]) * 0.5f, hy = (hi[1] - lo[1]) * 0.5f, hz = (hi[2] - lo[2]) * 0.5f;
+  const float far_ = crh_max(crh_max(crh_max(crh_abs(lo[0]), crh_abs(hi[0])), crh_max(crh_abs(lo[1]), crh_abs(hi[1]))), crh_max(crh_abs(lo[2]), crh_abs(hi[2])));
+  const float r = crh_sqrt(CRH_FMA(hz, hz, CRH_FMA(hy, hy, hx * hx)));
+  s4[0] = (lo[0] + hi[0]) * 0.5f; s4[1] = (lo[1] + hi[1]) * 0.5f; s4[2] = (lo[2] + hi[2]) * 0.5f;
+  s4[3] = CRH_FMA(far_, 7.62939453125e-06f, r * 1.00000762939453125f);          /* r (1 + 2^-17) + 2^-17 * largest |coordinate| */
+}
+CRH_HD int crh_ray_near_sphere(crh_v3 o, crh_v3 d, float tmax, float cx, float cy, float cz, float r)
+{
+  const crh_v3 v = crh_mk3(cx - o.x, cy - o.y, cz - o.z);
+  const float t = crh_min(crh_max(crh_dot3(v, d), 0.f), tmax);                  /* parameter of the point of [0, tmax] closest to the centre */
+  const crh_v3 q = crh_mk3(CRH_FMA(-d.x, t, v.x), CRH_FMA(-d.y, t, v.y), CRH_FMA(-d.z, t, v.z));
+  const float m = crh_max(crh_max(crh_abs(v.x), crh_abs(v.y)), crh_abs(v.z));
+  const float rr = CRH_FMA(m, 3.814697265625e-06f, r);                          /* + 2^-18 of the distance to the centre */
+  return crh_dot3(q, q) <= rr * rr;
+}
+
 /* ------------------------------------------------------------------ sin/cos */
 /* core polynomials on [-pi/4, pi/4] */
 CRH_HD float crh__sin_poly(float a)

@@ -64,8 +64,8 @@ typedef struct { uint64_t nodes, tris, nodes_any, tris_any; } trav_counters;
 #else
 #define ORC_COUNT(x) (x)
 #endif
-typedef struct orc_instance { float fwd[12], inv[12]; float bmin[3], bmax[3]; float wmin[3], wmax[3]; uint32_t root, obj; } orc_instance;
-#define MAX_IBOX 4u       /* instances whose world boxes the "does the ray touch a moved object at all" test looks at one by one (kMaxIBox of the product) */
+typedef struct orc_instance { float fwd[12], inv[12]; float bmin[3], bmax[3]; float wmin[3], wmax[3]; float sph[4]; uint32_t root, obj; } orc_instance;
+#define MAX_IBOX 12u      /* moved objects whose spheres the "does the ray come near a moved object at all" test looks at one by one (kMaxIBox of the product) */
 /* per object of a two-level scene ("static / moved split"): every object is BAKED into the static world-space tree with
  * the transform it has when the scene is built (static0 = 1 for every non-empty object); is_inst = rendered through its own object tree + the
  * top level right now, i.e. while its transform differs from the build-time one -- its triangles in the static tree are disabled meanwhile;
@@ -94,7 +94,7 @@ typedef struct orc_ctx {
   float* pos_w; float* nrm_w;    /* per vertex: position / unit normal under its object's build-time transform = what the static tree holds */
   uint32_t n_static, n_static_live; float sbmin[3], sbmax[3];   /* triangles in the static tree, those not disabled; its bounds */
   uint32_t root2;                /* top-level root to walk AFTER the static tree (QBVH_EMPTY: none) and the bounds of the instances */
-  float tlas_lo[3], tlas_hi[3];
+  float tlas_lo[3], tlas_hi[3], usph[4];      /* bounds of all instances, and the sphere around them (crh_box_sphere) */
   uint32_t capNodes, capQT;
   float bbmin[3], bbmax[3]; float eps;
   int built;
@@ -351,6 +351,7 @@ static void build_tlas(orc_ctx* c)
     if (!crh_xform_inverse(in->fwd, in->inv)) memset(in->inv, 0, sizeof in->inv);
     crh_xform_box(in->fwd, in->bmin, in->bmax, pb[i].mn, pb[i].mx);
     for (int a = 0; a < 3; ++a) { in->wmin[a] = pb[i].mn[a]; in->wmax[a] = pb[i].mx[a]; }
+    crh_box_sphere(in->wmin, in->wmax, in->sph);
     aabb_grow(&sb, &pb[i]);
     ++i;
   }
@@ -366,6 +367,7 @@ static void build_tlas(orc_ctx* c)
   const uint32_t troot = build_tree(&C, pb, n, 1, 1, 0, order, NULL);
   c->nodes = C.qn; c->nNodes = C.nq; c->capNodes = C.capq;
   for (int a = 0; a < 3; ++a) { c->tlas_lo[a] = sb.mn[a]; c->tlas_hi[a] = sb.mx[a]; }
+  crh_box_sphere(c->tlas_lo, c->tlas_hi, c->usph);
   if (c->n_static_live) {
     c->root = 0; c->root2 = troot;
     for (int a = 0; a < 3; ++a) { c->bbmin[a] = crh_min(sb.mn[a], c->sbmin[a]); c->bbmax[a] = crh_max(sb.mx[a], c->sbmax[a]); }
@@ -506,7 +508,9 @@ static inline int tri_test(const qtri* q, v3 o, v3 d, float tmax, float* t, floa
 }
 
 /* Ordered stack traversal of the 4-wide BVH.  any_hit: stop at the first accepted triangle. */
-static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t* h, trav_counters* cn)
+static int traverse_ex(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t* h, trav_counters* cn, int ask);
+static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t* h, trav_counters* cn) { return traverse_ex(c, o, d, tmax, any_hit, h, cn, 1); }
+static int traverse_ex(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t* h, trav_counters* cn, int ask)
 {
   uint32_t stack[STACK_MAX]; int sp = 0;
   float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
@@ -524,22 +528,18 @@ static int traverse(const orc_ctx* c, v3 o, v3 d, float tmax, int any_hit, hit_t
   const v3 wo = o, wd = d;                       /* the world-space ray (restored when an object is left) */
   uint32_t cur = c->root;
   if (c->root2 != QBVH_EMPTY) {
-    /* static tree first; the top-level tree over the moved objects waits at the bottom of the stack -- if the ray touches a moved object at all:
-     * the bounds of ALL instances and, when there are at most MAX_IBOX of them, the world box of at least one (same planes + guard band as a
-     * node's child test) */
-#define SLAB_HIT(LO, HI, OUT) do { \
-      const float ax_ = ((LO)[0] - o.x) * ix, bx_ = ((HI)[0] - o.x) * ix, ay_ = ((LO)[1] - o.y) * iy, by_ = ((HI)[1] - o.y) * iy; \
-      const float az_ = ((LO)[2] - o.z) * iz, bz_ = ((HI)[2] - o.z) * iz; \
-      const float tn_ = crh_max(crh_max(crh_max(crh_min(ax_, bx_) - gx, crh_min(ay_, by_) - gy), crh_min(az_, bz_) - gz), 0.f); \
-      const float tf_ = crh_min(crh_min(crh_min(crh_max(ax_, bx_) + gx, crh_max(ay_, by_) + gy), crh_max(az_, bz_) + gz), tmax); \
-      (OUT) = tn_ <= tf_; } while (0)
-    int touch; SLAB_HIT(c->tlas_lo, c->tlas_hi, touch);
-    if (touch && c->nInst <= MAX_IBOX) {
-      touch = 0;
-      for (uint32_t i = 0; i < c->nInst && !touch; ++i) SLAB_HIT(c->inst[i].wmin, c->inst[i].wmax, touch);
+    /* static tree first; the top-level tree over the moved objects waits at the bottom of the stack -- if the ray comes near a moved object at all
+     * (include/crh_math.h, crh_ray_near_sphere): the sphere around the bounds of ALL instances, then, when there are at most MAX_IBOX of them, the
+     * sphere of at least one (ONE instance: the two are the same numbers, one test).  Rays handed in through the API are not asked. */
+    int touch = 1;
+    if (ask) {
+      if (c->nInst != 1u) touch = crh_ray_near_sphere(o, d, tmax, c->usph[0], c->usph[1], c->usph[2], c->usph[3]);
+      if (touch && c->nInst <= MAX_IBOX) {
+        touch = 0;
+        for (uint32_t i = 0; i < c->nInst && !touch; ++i) touch = crh_ray_near_sphere(o, d, tmax, c->inst[i].sph[0], c->inst[i].sph[1], c->inst[i].sph[2], c->inst[i].sph[3]);
+      }
     }
     if (touch) stack[sp++] = c->root2;
-#undef SLAB_HIT
   }
   for (;;) {
     if ((cur & 0xF0000000u) == CRH_REF_INSTANCE_TAG) {
@@ -1430,7 +1430,7 @@ ORC_API int orc_trace_nearest(orc_ctx* c, const float* rays, uint32_t n, float* 
 #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : nn, tt)
   for (uint32_t i = 0; i < n; ++i) {
     const float* r = &rays[8 * i]; hit_t h; trav_counters cn = {0, 0, 0, 0};
-    traverse(c, crh_mk3(r[0], r[1], r[2]), crh_mk3(r[4], r[5], r[6]), r[3], 0, &h, &cn);
+    traverse_ex(c, crh_mk3(r[0], r[1], r[2]), crh_mk3(r[4], r[5], r[6]), r[3], 0, &h, &cn, 0);
     out[4 * i] = h.t; out[4 * i + 1] = h.u; out[4 * i + 2] = h.v; out[4 * i + 3] = crh_u2f((uint32_t)h.prim);
     nn += cn.nodes; tt += cn.tris;
   }
@@ -1444,7 +1444,7 @@ ORC_API int orc_trace_any(orc_ctx* c, const float* rays, uint32_t n, uint32_t* v
 #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : nn, tt)
   for (uint32_t i = 0; i < n; ++i) {
     const float* r = &rays[8 * i]; hit_t h; trav_counters cn = {0, 0, 0, 0};
-    vis[i] = traverse(c, crh_mk3(r[0], r[1], r[2]), crh_mk3(r[4], r[5], r[6]), r[3], 1, &h, &cn) ? 0u : 1u;
+    vis[i] = traverse_ex(c, crh_mk3(r[0], r[1], r[2]), crh_mk3(r[4], r[5], r[6]), r[3], 1, &h, &cn, 0) ? 0u : 1u;
     nn += cn.nodes_any; tt += cn.tris_any;
   }
   c->st.rays_any += n; c->st.nodes_any += nn; c->st.tris_any += tt;
@@ -1501,4 +1501,8 @@ ORC_API void orc_rng_stream(uint32_t pixel, uint32_t fseed, float* out, uint32_t
 { uint32_t s = crh_rng_seed(pixel, fseed); for (uint32_t i = 0; i < n; ++i) out[i] = crh_rng_next(&s); }
 ORC_API uint32_t orc_frame_seed(uint32_t seed, uint32_t n) { return frame_seed(seed, n); }
 /* the uniform drawn from xorshift state `s_after` under either setting of crh_spec.uniform_32bit (the conversion crh_rng_next_mode applies) */
+/* test hooks for the split-scene pre-test (include/crh_math.h): the padded sphere around a box, and "does [0, tmax] of the ray come within it" */
+ORC_API void orc_box_sphere(const float* lo, const float* hi, float* s4) { crh_box_sphere(lo, hi, s4); }
+ORC_API int orc_ray_near_sphere(const float* o, const float* d, float tmax, const float* s4)
+{ return crh_ray_near_sphere(crh_mk3(o[0], o[1], o[2]), crh_mk3(d[0], d[1], d[2]), tmax, s4[0], s4[1], s4[2], s4[3]); }
 ORC_API float orc_rng_float(uint32_t s_after, int full32) { return full32 ? (float)s_after * 2.3283064365386963e-10f : (float)(s_after >> 8) * 5.9604644775390625e-8f; }

@@ -224,7 +224,7 @@ def test_hip_two_level_matches_oracle_bit_exact(hip_lib, oracle_lib):
     o = oracle_lib.Oracle().load_scene(sc)
     allm = moved_xforms(7)
     for k in (0, 1, 2, 4): allm[k] = rigid(3.0 * (k + 1), (0, 1, 0), (0.002 * k, 0.001, -0.003 * k))      # EVERY object off its build-time placement: no live static triangle,
-    v.set_transforms(allm); o.set_transforms(allm)                                                        # the walk starts at the top level (more than four instances: one-walk kernels)
+    v.set_transforms(allm); o.set_transforms(allm)                                                        # the walk starts at the top level (no live static triangle: one-walk kernels)
     assert v.get_tlas()["n_instances"] == 7
     assert np.array_equal(v.get_bvh()[0].view(np.uint32), o.get_bvh()[0].view(np.uint32)) and v.get_tlas() == o.get_tlas()
     r = np.random.default_rng(9)
@@ -310,7 +310,7 @@ def test_translated_only_instances_and_signed_zero_directions(hip_lib, oracle_li
 @pytest.mark.parametrize("n_moved", [1, 3, 6])
 def test_split_scene_two_passes_equal_one_walk(hip_lib, oracle_lib, monkeypatch, n_moved):
     """A split scene (static tree + moved objects) is rendered either by one walk "static tree, then top level" in the two-level kernels, or -- when at
-    most kMaxIBox = 4 objects are off the identity, so that the kernels that PRODUCE rays can tell which of them come near one -- in two passes: the plain
+    most kMaxIBox = 12 objects are off the identity, so that the kernels that PRODUCE rays can tell which of them come near one -- in two passes: the plain
     single-level kernels over every ray, then the two-level ones over the flagged rays only (the dragged-object case runs at the single-level rate).  Both
     are the same spec: same image, same hits, same eight counters as the oracle, with lights (shadow rays take the two passes too)."""
     from cadrays_amd.view import View
@@ -332,3 +332,88 @@ def test_split_scene_two_passes_equal_one_walk(hip_lib, oracle_lib, monkeypatch,
             for key in keys:
                 assert st[key] == ost[key], (mode, counters, key, st[key], ost[key])
             v.close()
+
+
+def test_sphere_pretest_never_misses_a_ray_that_enters_the_box(oracle_lib):
+    """The split-scene pre-test (include/crh_math.h: crh_box_sphere + crh_ray_near_sphere) may flag too many rays, never too few: every ray whose part
+    [0, tmax] enters a box -- decided in float64 with the box grown by 1e-6 of its size -- must come out as "near" its sphere; boxes anywhere from the
+    origin to 1e4 box sizes away from it, ray origins inside, next to and far from the box, unit directions as the kernels produce them (float32
+    normalisation), finite and "infinite" tmax.  And the test is not vacuous: rays that pass the sphere by more than its radius are rejected."""
+    import ctypes as C
+    L = oracle_lib.lib()
+    L.orc_box_sphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; L.orc_box_sphere.restype = None
+    L.orc_ray_near_sphere.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]; L.orc_ray_near_sphere.restype = C.c_int
+    r = np.random.default_rng(11)
+    missed = rejected = entered = 0
+    for trial in range(400):
+        size = np.float32(10.0 ** r.uniform(-3, 2))
+        centre = (r.normal(size=3) * size * 10.0 ** r.uniform(-1, 4)).astype(np.float32)
+        half = (r.uniform(0.05, 1.0, 3) * size).astype(np.float32)
+        lo, hi = (centre - half).astype(np.float32), (centre + half).astype(np.float32)
+        s4 = np.zeros(4, np.float32); L.orc_box_sphere(lo.ctypes.data, hi.ctypes.data, s4.ctypes.data)
+        assert s4[3] >= np.linalg.norm((hi.astype(np.float64) - lo) * 0.5)                                   # the padded radius covers the half diagonal
+        for k in range(60):
+            o = (centre + r.normal(size=3) * size * 10.0 ** r.uniform(-1, 3)).astype(np.float32)
+            target = lo + (hi - lo) * r.uniform(-0.6, 1.6, 3)                                                 # aim at / next to the box
+            d = (target - o).astype(np.float32); n = np.float32(np.sqrt(np.float32(d @ d)))
+            if not n > 0: continue
+            d = (d / n).astype(np.float32)
+            tmax = np.float32(1e15) if k % 3 else np.float32(abs(r.normal()) * np.linalg.norm(target - o))
+            near = L.orc_ray_near_sphere(o.ctypes.data, d.ctypes.data, tmax, s4.ctypes.data)
+            # float64 slab test against the box grown by 1e-6 of its size
+            o64, d64 = o.astype(np.float64), d.astype(np.float64); g = 1e-6 * float(size)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t0, t1 = (lo - g - o64) / d64, (hi + g - o64) / d64
+            tn, tf = np.nanmax(np.minimum(t0, t1)), np.nanmin(np.maximum(t0, t1))
+            if max(tn, 0.0) <= min(tf, float(tmax)):
+                entered += 1; missed += 0 if near else 1
+            else:
+                v = s4[:3].astype(np.float64) - o64; t = min(max(v @ d64, 0.0), float(tmax))
+                if np.linalg.norm(v - d64 * t) > 2.0 * s4[3]:
+                    rejected += 0 if near else 1; assert not near
+    assert missed == 0 and entered > 3000 and rejected > 1000, (missed, entered, rejected)
+
+
+@pytest.mark.gpu
+def test_split_scene_with_more_moved_objects_than_the_pretest_looks_at(hip_lib, oracle_lib, monkeypatch):
+    """More than kMaxIBox = 12 moved objects: the pre-test asks only the sphere around ALL of them and the scene renders in ONE walk (two-level kernels);
+    14 of 27 small objects dragged -- image, hits and counters as the oracle, whichever traversal mode is forced; then 10 of them put back (two passes)."""
+    from cadrays_amd.view import View
+    r = np.random.default_rng(5)
+    base = scenes.cornell_box(True, 144, 108)
+    # 27 small tetrahedra on a 3 x 3 x 3 grid inside the room, one object each, next to the room itself (object 27)
+    P, N, T = [], [], []
+    for k in range(27):
+        c = np.array([0.2 + 0.3 * (k % 3), 0.2 + 0.3 * ((k // 3) % 3), 0.2 + 0.3 * (k // 9)], np.float32)
+        v = (c + 0.06 * r.normal(size=(4, 3))).astype(np.float32)
+        for f in ((0, 1, 2), (0, 3, 1), (0, 2, 3), (1, 3, 2)):
+            i0 = len(P)
+            nrm = np.cross(v[f[1]] - v[f[0]], v[f[2]] - v[f[0]]); nrm = (nrm / np.linalg.norm(nrm)).astype(np.float32)
+            P += [v[f[0]], v[f[1]], v[f[2]]]; N += [nrm] * 3; T.append((i0, i0 + 1, i0 + 2, k % len(base.materials), k))
+    nV = len(base.pos)
+    pos = np.concatenate([base.pos, np.array(P, np.float32)]); nrm = np.concatenate([base.nrm, np.array(N, np.float32)])
+    tri = np.concatenate([base.tri, np.array([(a + nV, b + nV, c_ + nV, m) for a, b, c_, m, _ in T], np.int32)])
+    tri_obj = np.concatenate([np.full(len(base.tri), 27, np.int32), np.array([t[4] for t in T], np.int32)])
+    ident = np.tile(rigid(), (28, 1))
+    sc = dataclasses.replace(base, pos=pos, nrm=nrm, tri=tri, tri_object=tri_obj, obj_xform=ident, uv=None)
+    xf = ident.copy()
+    for k in r.permutation(27)[:14]:
+        xf[k] = rigid(float(r.uniform(0, 60)), (0, 0, 1), tuple(0.05 * r.normal(size=3)))
+    back = xf.copy()
+    for k in np.flatnonzero((xf != ident).any(1))[:10]: back[k] = ident[k]
+    o = oracle_lib.Oracle().load_scene(sc); o.set_transforms(xf); o.render(2); ref1, st1 = o.read_hdr(), o.stats()
+    o.set_transforms(back); o.render(2); ref2, st2 = o.read_hdr(), o.stats()
+    keys = ("rays_nearest", "nodes_nearest", "tris_nearest", "rays_any", "nodes_any", "tris_any", "shaded_hits")
+    for mode in ("-1", "1", "0"):
+        monkeypatch.setenv("CRH_SPLIT_PASSES", mode)
+        v = View(0).load_scene(sc); v.enable_counters(True); v.set_transforms(xf)
+        assert v.get_tlas()["n_instances"] == 14
+        v.render(2)
+        assert np.array_equal(v.read_hdr().view(np.uint32), ref1.view(np.uint32)), mode
+        assert all(v.stats()[k] == st1[k] for k in keys), (mode, v.stats(), st1)
+        v.set_transforms(back)
+        assert v.get_tlas()["n_instances"] == 4
+        v.render(2)
+        assert np.array_equal(v.read_hdr().view(np.uint32), ref2.view(np.uint32)), mode
+        assert all(v.stats()[k] == st2[k] for k in keys), mode
+        v.close()
