@@ -287,6 +287,9 @@ def main():
         dist.destroy_process_group()
         return
 
+    # before anything initialises HIP: free-running Redraw()s keep eight frames in flight, one stream each, and the runtime maps streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4; cadrays_amd/__init__.py, crh_set_pipeline_depth) -- only the `interactive` figures depend on it
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import numpy as np
     import torch
     dist = None
@@ -395,10 +398,10 @@ def main():
         interactive = {}
         for k in (1, 16):
             v.set_lookahead(k); v.reset()
-            for _ in range(2 * k):
+            for _ in range(max(8, 2 * k)):              # the frame pipeline (up to eight in flight) is full before the clock starts
                 v.Redraw()
             v.sync()
-            n_fr = max(32, 4 * k)
+            n_fr = max(64, 4 * k)
             t1 = time.perf_counter()
             for _ in range(n_fr):
                 v.Redraw()

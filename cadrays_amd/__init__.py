@@ -3,9 +3,32 @@
 Only what the hot path needs: csrc/ (hand-written gfx950 kernels + the C ABI), the ctypes binding,
 the host mirror of the reference's View / BSDF / light interface, scene inputs and tile sharding.
 """
-from . import abi, materials, scenes  # noqa: F401
-from .materials import BSDF, Fresnel  # noqa: F401
-from .scenes import Camera, Light, Params, Scene  # noqa: F401
+import os as _os
+import sys as _sys
+
+
+def _want_hw_queues():
+    """Free-running Redraw()s keep up to eight frames in flight, one HIP stream each; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+    queues (default 4) and reads that variable when it initialises -- so it is set here, at import, IF nothing in the process has touched the GPU
+    yet (torch initialises HIP lazily; torch.cuda.is_initialized() tells).  Returns whether a deep pipeline is safe to ask for."""
+    have = _os.environ.get("GPU_MAX_HW_QUEUES")
+    if have is not None:
+        try:
+            return int(have) >= 10
+        except ValueError:
+            return False
+    torch = _sys.modules.get("torch")
+    if torch is not None and getattr(torch, "cuda", None) is not None and torch.cuda.is_initialized():
+        return False                                  # too late for this process: three frames in flight, as ever
+    _os.environ["GPU_MAX_HW_QUEUES"] = "16"
+    return True
+
+
+deep_pipeline_ok = _want_hw_queues()
+
+from . import abi, materials, scenes  # noqa: E402,F401
+from .materials import BSDF, Fresnel  # noqa: E402,F401
+from .scenes import Camera, Light, Params, Scene  # noqa: E402,F401
 
 
 def View(*a, **k):

@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>     // types only: the library is loaded with dlopen on the first multi-device crh_reduce
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -111,8 +112,10 @@ struct crh_ctx {
   // frame pipelining: consecutive small whole batches (one Redraw() each) run on alternating streams and path-state halves, so
   // the drain-bound late bounces of frame n overlap the throughput-bound first bounces of frame n + 1; accumulation stays in
   // frame order (an event between the two accumulate launches)
-  bool pipeline = true; bool pipe_pending[4] = {false, false, false, false}; uint32_t pipe_seq = 0; uint32_t* d_pipe_seeds = nullptr; int pipe_div = 4096;
+  bool pipeline = true; bool pipe_pending[8] = {false, false, false, false, false, false, false, false}; uint32_t pipe_seq = 0; uint32_t* d_pipe_seeds = nullptr; int pipe_div = 4096;
   uint64_t pipe_total = 0;         // batch size of the frames in flight (their path-state slices are laid out by it)
+  std::chrono::steady_clock::time_point pipe_last_submit{};      // when the previous pipelined frame was submitted
+  int pipe_grid_min = 192, pipe_grid_min_shade = 512;      // floors of a pipelined frame's traversal / streaming grids
   uint32_t pipe_depth = 3;         // frames in flight: 2 / 3 / 4 -> 323 / 391 / 312 Redraw/s on C3, 448 / 558 / 453 on C2
   // asynchronous LDR read-back (crh_read_ldr_begin / _end): tone map + device-to-host copy of the frame as submitted so far run on their
   // own stream into one of two device / pinned-host buffer pairs while the next Redraw()s are already rendering; only the NEXT
@@ -138,7 +141,7 @@ struct crh_ctx {
 // whoever wants to enqueue on, or wait for, the context's stream first makes it wait for the frames still in flight.
 static inline hipStream_t cstream(crh_ctx* c)
 {
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 8; ++k)
     if (c->pipe_pending[k]) { hipStreamWaitEvent(c->stream_, c->lane_join[k], 0); c->pipe_pending[k] = false; }
   if (c->rb_guard_pending) { hipStreamWaitEvent(c->stream_, c->rb_guard, 0); c->rb_guard_pending = false; }      // an asynchronous read-back still tone-maps the accumulator
   c->read_since_render = true;      // something other than the next frame used the stream (render_impl clears this when it is done)
@@ -546,12 +549,12 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
 int ensure_lanes(crh_ctx* c)
 {
   if (c->d_lane_counts) return CRH_OK;
-  for (uint32_t k = 0; k < std::max(c->n_lanes, 4u); ++k) {      // tile ranges of one batch, or frames in flight (pipe_depth <= 4)
+  for (uint32_t k = 0; k < 8u; ++k) {      // tile ranges of one batch (n_lanes <= 8), or frames in flight (pipe_depth <= 8)
     CRH_HIP(hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
     CRH_HIP(hipEventCreateWithFlags(&c->lane_join[k], hipEventDisableTiming));
   }
   CRH_HIP(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
-  CRH_HIP(hipMalloc((void**)&c->d_pipe_seeds, 4 * 16 * sizeof(uint32_t)));
+  CRH_HIP(hipMalloc((void**)&c->d_pipe_seeds, 8 * 16 * sizeof(uint32_t)));
   CRH_HIP(hipMalloc((void**)&c->d_lane_counts, kCounts * sizeof(uint32_t) * 8));
   CRH_HIP(hipMemsetAsync(c->d_lane_counts, 0, kCounts * sizeof(uint32_t) * 8, cstream(c)));
   return CRH_OK;
@@ -654,8 +657,21 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     DScene S; fill_scene(c, S);
     CRH_HIP(hipEventRecord(c->lane_fork, cs));
     Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false; ln.donate = c->donate;
-    ln.grid = (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>(512u, total / 2048u));
-    ln.grid_trace = (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(512u, total / (uint64_t)c->pipe_div));
+    ln.grid = (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>((uint64_t)c->pipe_grid_min_shade, total / 2048u));
+    // traversal grid of this frame: the chip's resident workgroups (6 per CU) shared among the frames that are in flight RIGHT NOW -- a host that runs far
+    // ahead has pipe_depth of them (eight: 192 workgroups each), one that waits for every other frame's read-back has two or three (512 each); measured
+    // optima at 3 / 4 / 6 / 8 frames in flight: 512 / 384 / 256 / 192-256 (profiles/r3/interactive_counters.txt)
+    uint32_t in_flight = 1u;
+    for (uint32_t j = 0; j < 8u; ++j) if (j != k && c->pipe_pending[j] && hipEventQuery(c->lane_join[j]) == hipErrorNotReady) ++in_flight;
+    {
+      // a host that submitted the previous frame a moment ago is not waiting for anything: the pipeline is about to fill (counting what is in flight NOW
+      // would give the first frames of a burst grids for a nearly empty chip: eight of them, 2900 workgroups)
+      const auto now = std::chrono::steady_clock::now();
+      if (c->pipe_last_submit.time_since_epoch().count() != 0 && now - c->pipe_last_submit < std::chrono::microseconds(300)) in_flight = std::max(in_flight, c->pipe_depth);
+      c->pipe_last_submit = now;
+    }
+    const uint64_t share = std::min<uint64_t>(512u, std::max<uint64_t>((uint64_t)c->pipe_grid_min, (uint64_t)c->grid_trace / in_flight));
+    ln.grid_trace = (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(share, total / (uint64_t)c->pipe_div));
     const size_t base = (size_t)k * total;
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
@@ -666,7 +682,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     // the frames in flight own path-state slices [k * total, (k + 1) * total): a batch of ANOTHER size (crh_render_tiles with another
     // sample count or tile list) would lay its slice across theirs -- it starts only when they are all done
     if (total != c->pipe_total) {
-      for (int j = 0; j < 4; ++j) if (c->pipe_pending[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));
+      for (int j = 0; j < 8; ++j) if (c->pipe_pending[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));
       c->pipe_total = total;
     }
     c->pending_n = 0;
@@ -915,8 +931,10 @@ crh_ctx* crh_create(int device_ordinal)
   if (const char* e = getenv("CRH_DONATE")) c->donate = atoi(e) != 0;
   if (const char* e = getenv("CRH_SPLIT_PASSES")) c->split_passes = atoi(e);
   if (const char* e = getenv("CRH_PIPELINE")) c->pipeline = atoi(e) != 0;
-  if (const char* e = getenv("CRH_PIPE_DEPTH")) { int v = atoi(e); if (v >= 2 && v <= 4) c->pipe_depth = (uint32_t)v; }
+  if (const char* e = getenv("CRH_PIPE_DEPTH")) { int v = atoi(e); if (v >= 2 && v <= 8) c->pipe_depth = (uint32_t)v; }
   if (const char* e = getenv("CRH_PIPE_DIV")) { int v = atoi(e); if (v > 0) c->pipe_div = v; }
+  if (const char* e = getenv("CRH_PIPE_GRID_MIN")) { int v = atoi(e); if (v > 0) c->pipe_grid_min = v; }
+  if (const char* e = getenv("CRH_PIPE_GRID_MIN_SHADE")) { int v = atoi(e); if (v > 0) c->pipe_grid_min_shade = v; }
   if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }
   if (const char* e = getenv("CRH_LANE_MAX_PATHS")) { long v = atol(e); if (v >= 0) c->lane_max_paths = (uint32_t)std::min<long>(v, 1l << 30); }
   if (const char* e = getenv("CRH_LANE_GRID")) { int v = atoi(e); if (v > 0) c->lane_grid = v; }
@@ -1451,6 +1469,15 @@ int crh_set_schedule(crh_ctx* c, int mode)
   return CRH_OK;
 }
 
+int crh_set_pipeline_depth(crh_ctx* c, uint32_t frames)
+{
+  if (!c || frames < 2u || frames > 8u) return fail(c, CRH_E_INVALID, "pipeline depth must be in 2 .. 8 frames");
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));            // the frames in flight own slices of the path state laid out for the old depth
+  c->pipe_depth = frames; c->pipe_seq = 0; c->pipe_total = 0;
+  return CRH_OK;
+}
+
 int crh_set_path_budget(crh_ctx* c, uint64_t max_paths)
 {
   if (!c || max_paths < 1024u || max_paths > (1ull << 30)) return fail(c, CRH_E_INVALID, "path budget must be in 1024 .. 2^30 slots");
@@ -1537,7 +1564,7 @@ static int read_begin(crh_ctx* c, bool hdr)
   const uint32_t slot = c->rb_head & 1u;
   // everything submitted so far comes first: the frames in flight on the pipeline streams (not joined, they stay in flight) and
   // whatever sits on the context's stream
-  for (int k = 0; k < 4; ++k) if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(c->rb_stream, c->lane_join[k], 0));
+  for (int k = 0; k < 8; ++k) if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(c->rb_stream, c->lane_join[k], 0));
   CRH_HIP(hipEventRecord(c->rb_fork, c->stream_));
   CRH_HIP(hipStreamWaitEvent(c->rb_stream, c->rb_fork, 0));
   Launch L{c->rb_stream, c->grid, false};

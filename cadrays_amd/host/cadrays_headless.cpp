@@ -38,6 +38,8 @@ template <class T> bool read_vec(FILE* f, std::vector<T>& v, size_t n)
 
 int main(int argc, char** argv)
 {
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);      // before the first HIP call: eight frames in flight need more hardware queues than the runtime's default four (crh_set_pipeline_depth)
+
   if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene | model.tcl> <nFrames> [device] [lookahead] [gpus] [WxH]\n", argv[0]); return 2; }
   const std::string path = argv[1];
   const int n_frames = atoi(argv[2]);
@@ -110,6 +112,7 @@ int main(int argc, char** argv)
     if ((rc = crh_set_camera(c, &cam))) return die_all(c, "crh_set_camera", rc);
     if ((rc = crh_set_params(c, &par))) return die_all(c, "crh_set_params", rc);
     if ((rc = crh_build(c))) return die_all(c, "crh_build", rc);
+    { const char* q = getenv("GPU_MAX_HW_QUEUES"); if (q && atoi(q) >= 10 && !getenv("CRH_PIPE_DEPTH") && (rc = crh_set_pipeline_depth(c, 8))) return die_all(c, "crh_set_pipeline_depth", rc); }
     if (n_gpus == 1 && lookahead > 1 && (rc = crh_set_lookahead(c, (uint32_t)lookahead))) return die_all(c, "crh_set_lookahead", rc);
     if (n_gpus == 1 && lookahead < -1 && (rc = crh_set_lookahead_auto(c, (uint32_t)-lookahead))) return die_all(c, "crh_set_lookahead_auto", rc);
   }

@@ -26,6 +26,10 @@ class View(Backend):
         super().__init__(load_library(), "crh_", (C.c_int(int(device)),))
         self.device = int(device)
         self._params = None
+        import os
+        from . import deep_pipeline_ok
+        if deep_pipeline_ok and "CRH_PIPE_DEPTH" not in os.environ:      # enough hardware queues for eight frames in flight (cadrays_amd/__init__.py)
+            self.set_pipeline_depth(8)
 
     # ---- V3d_View vocabulary ----------------------------------------------------------------
     def Redraw(self):
@@ -60,6 +64,10 @@ class View(Backend):
     def set_lookahead_auto(self, max_frames):
         """crh_set_lookahead_auto: one sample right after a restart, then batches of 4, 16, ... max_frames; 0 / 1 = off"""
         self._call("set_lookahead_auto", C.c_uint32(int(max_frames)))
+
+    def set_pipeline_depth(self, frames):
+        """crh_set_pipeline_depth: frames in flight of free-running Redraw()s (2 .. 8); more than 3 needs GPU_MAX_HW_QUEUES (cadrays_amd.deep_pipeline_ok)"""
+        self._call("set_pipeline_depth", C.c_uint32(int(frames)))
 
     def set_path_budget(self, max_paths):
         """crh_set_path_budget: at most this many path slots (196 B each) in flight per batch; images do not depend on it"""

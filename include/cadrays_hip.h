@@ -222,6 +222,13 @@ CRH_API int crh_set_schedule(crh_ctx* ctx, int mode);
  * length, so wide batches are faster -- 32 M / 64 M / 128 M / 256 M slots reach 80 / 86 / 91 / 93 % of the 512 M-slot rate on
  * the 1 M-triangle benchmark.  A host that shares the GPU with other consumers lowers it here (the environment variable
  * CRH_MAX_PATHS sets the initial value).  1024 <= max_paths <= 2^30; buffers already larger are released. */
+/* Frames in flight of free-running crh_render(ctx, 1) calls (the application's loop, AppViewer.cxx:1045-1047, when it does not read every frame
+ * back): each call only enqueues, frame i runs on stream i mod `frames` with its own slice of the path state and is folded into the accumulator
+ * after frame i - 1.  2 .. 8, default 3 (CRH_PIPE_DEPTH in the environment sets the default).  MORE THAN 3 NEEDS MORE HARDWARE QUEUES than the
+ * HIP runtime creates by default (4): export GPU_MAX_HW_QUEUES >= frames + 2 (16 is fine) before the process's first HIP call -- with it, C3 at
+ * 1080p renders 385 / 400 / 442 / 455 Redraw()/s at 3 / 4 / 6 / 8 frames in flight; without it streams share queues and 4 frames are SLOWER than 3
+ * (320).  Images do not depend on it.  Waits for the frames in flight. */
+CRH_API int crh_set_pipeline_depth(crh_ctx* ctx, uint32_t frames);
 CRH_API int crh_set_path_budget(crh_ctx* ctx, uint64_t max_paths);
 /* Per-tile error estimate (mean standard error of the pixel luminance) and per-tile sample count; pass NULL
  * arrays to query n_tiles.  Needs adaptive mode for a meaningful error. */

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before HIP initialises: the eight-frame pipeline of free-running Redraw()s (cadrays_amd/__init__.py)
+
 import pytest
 import torch  # noqa: F401 -- must be imported BEFORE libcadrays_hip.so initialises HIP: torch bundles its own HIP runtime and
               # finds no GPU when it is loaded into a process where the system runtime is already up (seen on the GPU box)

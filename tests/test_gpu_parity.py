@@ -462,6 +462,33 @@ def test_auto_lookahead_ramps_from_one_sample_and_keeps_every_redraw_bit_identic
     assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr())) and v.stats()["rays_nearest"] == ref.stats()["rays_nearest"]
 
 
+@pytest.mark.parametrize("depth", [2, 5, 8])
+def test_pipeline_depth_does_not_change_the_image(view_cls, depth):
+    """crh_set_pipeline_depth: free-running Redraw()s (no read-back in between) keep `depth` frames in flight, each on its own stream and slice of the
+    path state, folded into the accumulator in frame order -- the image after 19 of them, a restart in the middle and a change of depth with
+    frames in flight is the image of the same samples rendered in one call.  (Frames are pipelined from 2^20 paths per frame on: 1184 x 928.)"""
+    import dataclasses
+    sc = scenes.cornell_box(True, 1184, 928)
+    sc = dataclasses.replace(sc, params=dataclasses.replace(sc.params, max_depth=4))
+    ref = view_cls(0).load_scene(sc); ref.render(7)
+    v = view_cls(0).load_scene(sc); v.set_pipeline_depth(depth)
+    for _ in range(12):
+        v.Redraw()
+    v.reset()                                              # with frames in flight
+    for _ in range(7):
+        v.Redraw()
+    assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr()))
+    v.Redraw(); v.Redraw()
+    v.set_pipeline_depth(3 if depth != 3 else 4)           # waits for the two in flight
+    for _ in range(4):
+        v.Redraw()
+    ref.render(6)
+    assert np.array_equal(bits(v.read_hdr()), bits(ref.read_hdr()))
+    assert v.stats()["samples"] == ref.stats()["samples"]
+    with pytest.raises(Exception):
+        v.set_pipeline_depth(9)
+
+
 def test_crh_reduce_assembles_tile_shards(view_cls, monkeypatch):
     """C-ABI exchange step: three contexts render interleaved tiles, crh_reduce assembles the frame on the root
     bit-identically to a one-context render; own accumulators stay untouched and rendering continues afterwards."""

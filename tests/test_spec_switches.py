@@ -152,8 +152,13 @@ def test_build_time_switch_matches_its_oracle(hip_lib, tmp_path, variant):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "cadrays_amd", "variants", f"spec_{variant}.so")
     orc = os.path.join(root, "oracle", "variants", f"libcrh_oracle_spec_{variant}.so")
-    if not (os.path.exists(lib) and os.path.exists(orc)):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "cadrays_amd", "csrc"), f"spec-{variant}"])
+    def stale(path):                                   # a variant left over from an older ABI (built before an entry point was added)
+        from cadrays_amd import abi
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+        have = {line.split()[-1] for line in out.splitlines() if line.strip()}
+        return not all(name in have for name in abi.EXPORTS)
+    if not (os.path.exists(lib) and os.path.exists(orc)) or stale(lib):
+        subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(root, "cadrays_amd", "csrc"), f"spec-{variant}"])
         subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), f"spec-{variant}"])
     code = r"""
 import json, sys, numpy as np, torch
