@@ -197,3 +197,19 @@ def test_scene_generators_are_deterministic():
     assert len(scenes.cornell_box(False).tri) == 34            # BASELINE C1: "~36 tris"
     sky = scenes.procedural_sky(512, 256, 1)     # the 1-degree sun disc needs texels finer than ~1 degree
     assert sky.shape == (256, 512, 3) and sky.max() >= 4e4 and sky.min() > 0
+
+
+def test_hardware_queue_request_follows_the_environment(monkeypatch):
+    """cadrays_amd asks the HIP runtime for more hardware queues (eight frames in flight, one stream each) only when that can still take effect, and
+    respects what the user exported: GPU_MAX_HW_QUEUES >= 10 in the environment -> deep pipeline; a smaller value -> three frames, as ever."""
+    import cadrays_amd
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    assert cadrays_amd._want_hw_queues() is False
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert cadrays_amd._want_hw_queues() is True
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "many")
+    assert cadrays_amd._want_hw_queues() is False
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    import torch
+    if not torch.cuda.is_initialized():                     # nothing has touched the GPU in this process: the request is made
+        assert cadrays_amd._want_hw_queues() is True and __import__("os").environ["GPU_MAX_HW_QUEUES"] == "16"
