@@ -333,11 +333,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    assembled = [None]
+
     def step(i):
         v.render_tiles(tiles, i * spp_step, spp_step)
         if dist is not None:
             v.sync()                                          # the accumulator is written on the context's own stream
-            sharding.reduce_framebuffer(fb.tensor, 0)         # RCCL reduce of a staging copy; returns synchronised
+            assembled[0] = sharding.reduce_framebuffer(fb.tensor, 0)         # RCCL reduce of a staging copy; returns synchronised
 
     rccl_ranks = 1
     if dist is not None:                                      # RCCL builds its rings / channels on first use: keep that out of the
@@ -359,6 +361,9 @@ def main():
     st = v.stats()
     # what the TIMED steps themselves accumulated (rank 0, N = 1): the parity gate below compares exactly these pixels with the oracle
     timed_hdr = v.read_hdr() if (rank == 0 and world == 1 and not args.no_parity) else None
+    if rank == 0 and world > 1 and not args.no_parity and assembled[0] is not None:
+        # N > 1: the frame the LAST timed step's reduce assembled on rank 0 (every rank's tiles, the same samples) goes through the same gate
+        timed_hdr = assembled[0][..., :3].contiguous().cpu().numpy()
     timed_first, timed_n = args.warmup * spp_step, args.steps * spp_step
     if dist is not None:
         dev = torch.device(f"cuda:{local}") if backend == "nccl" else torch.device("cpu")
