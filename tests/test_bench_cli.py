@@ -101,6 +101,7 @@ def test_two_ranks_on_one_gpu_report_two(hip_lib):
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["value"] > 0
     assert out["config"]["tiles_per_rank"] * 2 >= 256 - 1            # 512 x 512 in 32 x 32 tiles, interleaved
+    assert out["parity"]["bit_exact"] and out["parity"]["pixels"] > 0   # the ASSEMBLED frame of the timed step goes through the oracle gate
 
 
 @pytest.mark.gpu
