@@ -35,4 +35,8 @@ void build_qbvh(const float* pos, const int32_t* tri, uint32_t n_tris, QBvh& out
 uint32_t build_tree(const float* boxes, uint32_t n, bool instance_leaves, uint32_t leaf0,
                     std::vector<QNode>& nodes, std::vector<uint32_t>& order, float bmin[3], float bmax[3], int threads = 0);
 
+// threads the builder takes when asked for `threads <= 0`: the CPUs this process may run on at once (affinity mask, cgroup quota), its share of them
+// when torchrun started several ranks on one host
+int build_threads(int threads);
+
 }  // namespace crh
