@@ -349,14 +349,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const uint32_t ew = __float_as_uint(n0.w);
       // step * inv_d: the step is 2^k with k a signed byte of the node -- v_bfe_i32 + v_ldexp_f32, the same value as the product (a scaling by a
       // power of two is exact, and both round the same way where the result is subnormal)
-#ifndef CRH_EXP_MUL
       const float ax = __builtin_amdgcn_ldexpf(ix, (int)(ew << 24) >> 24), ay = __builtin_amdgcn_ldexpf(iy, (int)(ew << 16) >> 24),
                   az = __builtin_amdgcn_ldexpf(iz, (int)(ew << 8) >> 24);
-#else   /* A/B: the same value as a product with the step rebuilt from the signed byte (bfe + shift-add + multiply) */
-      const float ax = __uint_as_float((uint32_t)(((int)(ew << 24) >> 24) << 23) + 0x3f800000u) * ix,
-                  ay = __uint_as_float((uint32_t)(((int)(ew << 16) >> 24) << 23) + 0x3f800000u) * iy,
-                  az = __uint_as_float((uint32_t)(((int)(ew << 8) >> 24) << 23) + 0x3f800000u) * iz;
-#endif
       const float ddx = n0.x - o.x, ddy = n0.y - o.y, ddz = n0.z - o.z;
       // child references are implicit: slots < ni are the consecutive inner nodes from child_base, the others the leaves
       // with consecutive references from leaf_base (crh_bvh_format.h): ref(slot) = (slot < ni ? child_base : leaf_base - ni) + slot
@@ -393,35 +387,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       CRH_CHILD(3)
 #undef CRH_CHILD
 #undef CRH_QB
-#ifndef CRH_EXP_ORDER
-#define CRH_EXP_ORDER 0      // A/B experiments on the NEAREST-hit child order (round-2 verdict item 3; images stay bit-identical, only visits change -- no oracle twin):
-#endif                       //   1: hit children in slot order, no sort at all;  2: the nearest hit child continues, the others pop in slot order
-      if (!ANY && CRH_EXP_ORDER == 2) {
-        const uint32_t kmin = min(min((uint32_t)key[0], (uint32_t)key[1]), min((uint32_t)key[2], (uint32_t)key[3])), s0 = kmin & 3u;
-        const uint32_t rs0 = (0u < ni ? base_inner : base_leaf) + 0u, rs1 = (1u < ni ? base_inner : base_leaf) + 1u,
-                       rs2 = (2u < ni ? base_inner : base_leaf) + 2u, rs3 = (3u < ni ? base_inner : base_leaf) + 3u;
-        const int f0 = hitk[0] ? 1 : 0, f1 = hitk[1] ? 1 : 0, f2 = hitk[2] ? 1 : 0, f3 = hitk[3] ? 1 : 0;
-        const int a2 = f3, a1 = f3 + f2, nh = (a1 + f1) + f0;
-        const uint32_t refL = f0 ? rs0 : (f1 ? rs1 : (f2 ? rs2 : rs3));          // the lowest hit slot takes the nearest one's place on the stack
-        if (__builtin_expect(sp <= kLdsStack - 4, 1)) {
-          uint32_t* top = lds + sp * kBlock;
-          top[(f3 ? 0 : nh) * kBlock] = s0 == 3u ? refL : rs3; top[(f2 ? a2 : nh) * kBlock] = s0 == 2u ? refL : rs2; top[(f1 ? a1 : nh) * kBlock] = s0 == 1u ? refL : rs1;
-          sp += max(nh, 1) - 1;
-        } else {
-#define CRH_PUSH(V)                                                          \
-          { const uint32_t v_ = (V);                                           \
-            if (sp < kLdsStack) lds[sp * kBlock] = v_; else ovf[sp - kLdsStack] = v_; \
-            ++sp; }
-          const int first = f0 ? 0 : (f1 ? 1 : (f2 ? 2 : 3));
-          if (f3 && first != 3) CRH_PUSH(s0 == 3u ? refL : rs3)
-          if (f2 && first != 2) CRH_PUSH(s0 == 2u ? refL : rs2)
-          if (f1 && first != 1) CRH_PUSH(s0 == 1u ? refL : rs1)
-#undef CRH_PUSH
-        }
-        if (nh >= 1) cur = s0 == 0u ? rs0 : (s0 == 1u ? rs1 : (s0 == 2u ? rs2 : rs3)); else pop();
-        return;
-      }
-      if ((ANY && CRH_SPEC_ANYHIT_SLOT_ORDER) || (!ANY && CRH_EXP_ORDER == 1)) {
+      if (ANY && CRH_SPEC_ANYHIT_SLOT_ORDER) {
         // crh_spec.h #8: an occlusion query needs no near-to-far order -- the hit children are taken in SLOT order (no sort, no keys): the
         // lowest hit slot continues, the others go onto the stack so that they pop in slot order; three unconditional stores, the ones of
         // children that were not hit (and of the one that continues) land in dead slots at / above the new top

@@ -80,37 +80,50 @@ class Scene:
 
 
 # ---------------------------------------------------------------------------------------------
-def splitmix64_uniform(seed, n):
-    """n doubles in [0,1) from the splitmix64 stream of `seed` (vectorised)."""
+def splitmix64_uniform(seed, n, first=0):
+    """n doubles in [0,1) from the splitmix64 stream of `seed`, starting at its element `first` (vectorised, in cache-sized chunks: at 90 M
+    elements -- the 10 M-triangle scene -- whole-array temporaries made this 27 s instead of 1.3 s)."""
+    n = int(n)
+    out = np.empty(n, np.float64)
+    chunk = 1 << 18
     with np.errstate(over="ignore"):
-        k = np.arange(1, n + 1, dtype=np.uint64)
-        z = np.uint64(seed) + k * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            z = np.arange(first + a + 1, first + b + 1, dtype=np.uint64)
+            z *= np.uint64(0x9E3779B97F4A7C15); z += np.uint64(seed)
+            t = z >> np.uint64(30); z ^= t; z *= np.uint64(0xBF58476D1CE4E5B9)
+            np.right_shift(z, np.uint64(27), out=t); z ^= t; z *= np.uint64(0x94D049BB133111EB)
+            np.right_shift(z, np.uint64(31), out=t); z ^= t
+            z >>= np.uint64(11)                                       # < 2^53: the conversion to double below is exact
+            np.multiply(z, 1.0 / 9007199254740992.0, out=out[a:b])
+    return out
 
 
 def gen_scene(n_tris, seed=1, n_materials=1):
     """SURVEY.md section 8(d) generator: centre ~ U([-1,1]^3); two edges ~ U([-1,1]^3) * r with
     r = 1.5 * N^(-1/3); flat normals; material = i mod M.  Returns pos, nrm, tri."""
     n = int(n_tris)
-    u = splitmix64_uniform(seed, 9 * n).reshape(n, 9) * 2.0 - 1.0
     r = 1.5 * float(n) ** (-1.0 / 3.0)
-    c = u[:, 0:3]
-    e1 = u[:, 3:6] * r
-    e2 = u[:, 6:9] * r
-    v = np.stack([c, c + e1, c + e2], axis=1).astype(np.float32)          # (n, 3, 3)
-    fn = np.cross((v[:, 1] - v[:, 0]).astype(np.float64), (v[:, 2] - v[:, 0]).astype(np.float64))
-    ln = np.linalg.norm(fn, axis=1, keepdims=True)
-    fn = np.where(ln > 0, fn / np.maximum(ln, 1e-300), np.array([0.0, 0.0, 1.0]))
-    pos = v.reshape(3 * n, 3)
-    nrm = np.repeat(fn.astype(np.float32), 3, axis=0)
+    pos = np.empty((3 * n, 3), np.float32)
+    nrm = np.empty((3 * n, 3), np.float32)
+    chunk = 1 << 17                                    # triangles per pass: the float64 temporaries stay in the caches
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        u = splitmix64_uniform(seed, 9 * (b - a), 9 * a).reshape(b - a, 9) * 2.0 - 1.0
+        c = u[:, 0:3]
+        e1 = u[:, 3:6] * r
+        e2 = u[:, 6:9] * r
+        v = np.stack([c, c + e1, c + e2], axis=1).astype(np.float32)          # (m, 3, 3)
+        fn = np.cross((v[:, 1] - v[:, 0]).astype(np.float64), (v[:, 2] - v[:, 0]).astype(np.float64))
+        ln = np.linalg.norm(fn, axis=1, keepdims=True)
+        fn = np.where(ln > 0, fn / np.maximum(ln, 1e-300), np.array([0.0, 0.0, 1.0]))
+        pos[3 * a:3 * b] = v.reshape(3 * (b - a), 3)
+        nrm[3 * a:3 * b] = np.repeat(fn.astype(np.float32), 3, axis=0)
     tri = np.empty((n, 4), np.int32)
     base = np.arange(n, dtype=np.int32) * 3
     tri[:, 0], tri[:, 1], tri[:, 2] = base, base + 1, base + 2
     tri[:, 3] = np.arange(n, dtype=np.int32) % max(int(n_materials), 1)
-    return np.ascontiguousarray(pos), np.ascontiguousarray(nrm), tri
+    return pos, nrm, tri
 
 
 def procedural_sky(w=2048, h=1024, seed=1, sun=5.0e4):
