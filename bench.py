@@ -103,6 +103,9 @@ def roofline_report(config, spp, modified, alg_bytes_per_launch, avg_ms, scene_b
         t_gbps = traffic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         hit, miss = ent.get("tcc_hit_per_launch"), ent.get("tcc_miss_per_launch")
         r.update({"traffic": traffic, "traffic_source": ent.get("how", "profiles/pmc_traffic.json"),
+                  "traffic_measured": (f"NOT in this run: committed counter passes (profiles/pmc_traffic.json, collected by profiles/pmc_collect.sh on kernel build "
+                                       f"{ent.get('source_hash')} = the sources of this library, hash re-checked at run time); this run supplies avg_launch_ms only, so "
+                                       "traffic_gbps / frac = committed bytes per launch / THIS run's launch time"),
                   "traffic_gbps": round(t_gbps, 1), "traffic_frac_of_peak": round(t_gbps / HBM_PEAK_GBPS, 4),
                   "traffic_frac_of_achievable": round(t_gbps / HBM_ACHIEVABLE_GBPS, 4),
                   "traffic_over_alg": round(traffic / max(alg_bytes_per_launch, 1.0), 3),
@@ -248,10 +251,18 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (the oracle re-renders sampled tiles of the TIMED frames)")
-    ap.add_argument("--parity-seconds", type=float, default=8.0, help="CPU budget of the parity gate")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity gates (the oracle re-renders sampled tiles of the TIMED frames)")
+    ap.add_argument("--parity-seconds", type=float, default=8.0, help="CPU budget of the whole-timed-region parity gate")
+    ap.add_argument("--step0-seconds", type=float, default=6.0, help="CPU budget of the first-timed-step parity gate (at least 32 tiles whatever it costs)")
     ap.add_argument("--no-interactive", action="store_true", help="skip the 1-spp-per-Redraw figure")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--other-configs", default=None,
+                    help="comma list of further single-GPU configs timed AFTER the headline as short legs, each with its own parity gates and roofline "
+                         "(config.other_configs_timed); default C5,C2,C1 for the default headline run at N = 1, none otherwise; 'none' switches them off")
+    ap.add_argument("--other-steps", type=int, default=4)
+    ap.add_argument("--assemble", default="auto", choices=["auto", "reduce", "gather"],
+                    help="N > 1 exchange step: full-frame RCCL reduce, gather of owned tiles, or whichever is faster on this fabric (timed before the run)")
+    ap.add_argument("--no-shared-build", action="store_true", help="N > 1: every rank builds its own BVH (default: rank 0 builds, the others take its tree)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -259,6 +270,13 @@ def parse_args(argv=None):
         args.scaling = "strong" if args.config == "C4" else "weak"
     if args.steps is None:
         args.steps = 1 if args.config == "C4" else 4
+    if args.other_configs is None:
+        plain = args.gpus == 1 and args.config == "C3" and not (args.tris or args.width or args.height or args.spp)
+        args.other_configs = "C5,C2,C1" if plain else "none"
+    args.other_list = [c for c in args.other_configs.split(",") if c and c != "none"]
+    for c in args.other_list:
+        if c not in ("C1", "C2", "C3", "C5"):
+            ap.error(f"--other-configs: unknown config {c}")
     return args
 
 
@@ -288,9 +306,9 @@ def main():
         return
 
     # before anything initialises HIP: free-running Redraw()s keep eight frames in flight, one stream each, and the runtime maps streams onto
-    # GPU_MAX_HW_QUEUES hardware queues (default 4; cadrays_amd/__init__.py, crh_set_pipeline_depth) -- only the `interactive` figures depend on it
+    # GPU_MAX_HW_QUEUES hardware queues (default 4).  bench.py is the HOST here and exports the variable itself -- the library never touches the
+    # environment (crh_query_pipeline_capacity reports what it found); only the `interactive` figures depend on it
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-    import numpy as np
     import torch
     dist = None
     backend = None
@@ -304,27 +322,96 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend)
-    n_gpus = world
 
+    # N ranks on one host share its CPUs.  With the shared build (default) rank 0 builds the tree with every thread and the others wait; without it every
+    # rank builds the same BVH with its share of the threads (8 ranks x all threads oversubscribed the 16 usable CPUs of a GPU box 8-fold)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > 1 and args.no_shared_build and not os.environ.get("CRH_BUILD_THREADS"):
+        os.environ["CRH_BUILD_THREADS"] = str(max(1, usable_cpus() // local_world))
+    if local_world > 1 and not args.no_shared_build:
+        os.environ.pop("LOCAL_WORLD_SIZE", None)                  # the builder would take 1 / LOCAL_WORLD_SIZE of the CPUs (bvh_builder.cpp): one rank builds here
+
+    ctxt = {"world": world, "rank": rank, "local": local, "dist": dist, "backend": backend, "torch": torch}
+    out, failed, errors = run_leg(args, ctxt, args.config, args.steps, args.warmup, args.spp, headline=True)
+
+    # ---- the other single-GPU configs of BASELINE.json, driver-timed in the same run (verdict r3 item 1): short legs, own parity gates, own roofline.
+    # `value` stays the headline config; C5 (10 M triangles, 4K) is the one whose scene does not fit the caches, i.e. where HBM is the roof.
+    if rank == 0 and world == 1 and args.other_list:
+        others = {}
+        for cfg in args.other_list:
+            t0 = time.time()
+            try:
+                o, f, e = run_leg(args, ctxt, cfg, args.other_steps, 1, 0, headline=False)
+                others[cfg] = compact_leg(o)
+                others[cfg]["leg_wall_s"] = round(time.time() - t0, 1)
+                failed = failed or f
+                errors += e
+            except Exception as e:                              # a leg that cannot run must not lose the headline
+                others[cfg] = {"error": f"{type(e).__name__}: {e}"}
+                errors.append(f"{cfg}: {type(e).__name__}: {e}")
+        out["config"]["other_configs_timed"] = others
+        out["config"]["other_configs_note"] = ("timed in this very run after the headline, inputs resident in HBM, 1 warm-up + %d timed steps each, same kernels and schedule; "
+                                               "NOT part of `value`" % args.other_steps)
+    if rank == 0:
+        if errors:
+            out["checker_errors"] = errors
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()                                       # rank 0 may still be in its counting pass
+        dist.destroy_process_group()
+    if failed:
+        sys.exit("bench.py: PARITY GATE FAILED -- timed frames differ from the oracle (see \"parity\" / \"parity_step0\" in the JSON line)")
+    if errors:
+        print("bench.py: a checker leg could not run (the measurement stands; see \"checker_errors\" in the JSON line): " + "; ".join(errors), file=sys.stderr)
+
+
+def compact_leg(o):
+    """What config.other_configs_timed keeps of a leg's full line."""
+    r = o.get("roofline") or {}
+    ceil = r.get("ceilings") or {}
+    keep = lambda p: None if p is None else {k: p.get(k) for k in ("bit_exact", "rel_l2", "tiles", "pixels", "spp", "first_sample", "schedule", "error") if k in p}
+    return {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+            "spp_per_step": o["config"]["spp_per_step_per_rank"], "msamples_per_s": o["config"]["msamples_per_s"], "build_upload_s": o["config"]["build_upload_s"],
+            "parity": keep(o.get("parity")), "parity_step0": keep(o.get("parity_step0")),
+            "roofline": {"kernel": r.get("kernel"), "avg_launch_ms": r.get("avg_launch_ms"), "launches": r.get("launches"), "kernel_time_share": r.get("kernel_time_share"),
+                         "scene_bytes": r.get("scene_bytes"), "alg_gbps": r.get("alg_gbps"), "alg_frac": r.get("alg_frac_of_hbm_peak"),
+                         "traffic_gbps": r.get("traffic_gbps"), "traffic_frac": r.get("traffic_frac_of_peak"), "traffic_measured": r.get("traffic_measured"),
+                         "traffic_reason": r.get("traffic_reason"), "frac": r.get("frac"), "achieved_basis": r.get("achieved_basis"),
+                         "nodes_per_ray": r.get("nodes_per_ray"), "tris_per_ray": r.get("tris_per_ray"),
+                         "ceilings": {k: ceil.get(k) for k in ("hbm", "l2", "valu_issue", "lane_util", "binding") if k in ceil} or None,
+                         "limited_by": r.get("limited_by")}}
+
+
+def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
+    """One workload, measured: scene hand-over, warm-up, EXACTLY `steps` timed steps between barriers, counting pass, parity gates, roofline.
+    Returns (json dict on rank 0 | None, parity_failed, checker_errors)."""
+    import numpy as np
+    world, rank, local, dist, backend, torch = (ctxt[k] for k in ("world", "rank", "local", "dist", "backend", "torch"))
     from cadrays_amd import scenes, sharding
     from cadrays_amd.view import View
+    n_gpus = world
+    scaling = args.scaling if headline else "weak"
+    errors = []
 
-    # N ranks on one host share its CPUs: every rank builds the same BVH, each with its share of the threads (8 ranks x all threads
-    # oversubscribed the 16 usable CPUs of a GPU box 8-fold)
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if local_world > 1 and not os.environ.get("CRH_BUILD_THREADS"):
-        os.environ["CRH_BUILD_THREADS"] = str(max(1, usable_cpus() // local_world))
-
-    scene_cfg = "C3" if args.config == "C4" else args.config
-    sc = scenes.baseline_config(scene_cfg, args.width or None, args.height or None, args.tris or None)
+    scene_cfg = "C3" if config == "C4" else config
+    ov = headline                                            # command-line overrides of the workload apply to the headline leg only
     t0 = time.time()
-    v = View(local).load_scene(sc)
+    sc = scenes.baseline_config(scene_cfg, (args.width or None) if ov else None, (args.height or None) if ov else None, (args.tris or None) if ov else None)
+    gen_s = time.time() - t0
+    t0 = time.time()
+    v = View(local)
+    dev = torch.device(f"cuda:{local}") if backend == "nccl" else torch.device("cpu")
+    if world > 1 and not args.no_shared_build:
+        share = sharding.load_scene_shared(v, sc, dist, dev)
+    else:
+        v.load_scene(sc); share = None
     build_s = time.time() - t0
     fb = sharding.DeviceFramebuffer(v) if world > 1 else None
     tiles = sharding.tiles_for_rank(v.n_tiles(), rank, world, sharding.tiles_x_of(v))       # Morton-interleaved across the ranks
-    if args.spp <= 0:                     # one full path batch per step: 2^28 slots / (tiles x 32 x 32 pixels); C4: the named 4096 spp
-        args.spp = 4096 if args.config == "C4" else max(1, (256 << 20) // (v.n_tiles() * sc.params.tile_size ** 2))
-    spp_step = args.spp * world if args.scaling == "weak" else args.spp      # samples per pixel each rank renders per step
+    spp = spp_arg
+    if spp <= 0:                          # one full path batch per step: 2^28 slots / (tiles x 32 x 32 pixels); C4: the named 4096 spp
+        spp = 4096 if config == "C4" else max(1, (256 << 20) // (v.n_tiles() * sc.params.tile_size ** 2))
+    spp_step = spp * world if scaling == "weak" else spp      # samples per pixel each rank renders per step
 
     def barrier():
         v.sync()
@@ -333,27 +420,61 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # ---- N > 1: the exchange step.  Full-frame reduce (sum of disjoint supports) or gather of owned tiles (1 / N of the bytes): timed on THIS fabric, the
+    # faster one is used in the timed steps (--assemble forces one); both assemble the same bits
     assembled = [None]
+    assemble_info = None
+    gather = sharding.TileGather(v.width, v.height, v.tile_size, world, fb.tensor.device) if world > 1 else None
+
+    def assemble_reduce():
+        return sharding.reduce_framebuffer(fb.tensor, 0)
+
+    def assemble_gather():
+        return gather.assemble(fb.tensor, rank, 0)
+
+    assemble = assemble_reduce
+    rccl_ranks = 1
+    if dist is not None:                                      # RCCL builds its rings / channels on first use: keep that out of the timed steps
+        timing = {}
+        for name, fn in (("reduce", assemble_reduce), ("gather", assemble_gather)):
+            fn(); barrier()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            barrier()
+            tt = torch.tensor([(time.perf_counter() - t1) / 3 * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            timing[name] = round(float(tt.item()), 3)
+        mode = args.assemble if args.assemble != "auto" else ("gather" if timing["gather"] < timing["reduce"] else "reduce")
+        assemble = assemble_gather if mode == "gather" else assemble_reduce
+        assemble_info = {"mode": mode, "chosen_by": "--assemble" if args.assemble != "auto" else "measurement before the timed steps (3 calls each, max over ranks)",
+                         "reduce_ms": timing["reduce"], "gather_ms": timing["gather"],
+                         "reduce_bytes_per_rank": int(v.width * v.height * 16), "gather_bytes_per_rank": int(gather.bytes_per_rank)}
+        rccl_ranks = dist.get_world_size()                    # as seen after the first collectives
+
+    t_render = [0.0]; t_assemble = [0.0]
 
     def step(i):
+        if dist is None:
+            v.render_tiles(tiles, i * spp_step, spp_step)
+            return
+        t1 = time.perf_counter()
         v.render_tiles(tiles, i * spp_step, spp_step)
-        if dist is not None:
-            v.sync()                                          # the accumulator is written on the context's own stream
-            assembled[0] = sharding.reduce_framebuffer(fb.tensor, 0)         # RCCL reduce of a staging copy; returns synchronised
+        v.sync()                                          # the accumulator is written on the context's own stream
+        t2 = time.perf_counter()
+        assembled[0] = assemble()                         # returns synchronised
+        t_render[0] += t2 - t1; t_assemble[0] += time.perf_counter() - t2
 
-    rccl_ranks = 1
-    if dist is not None:                                      # RCCL builds its rings / channels on first use: keep that out of the
-        sharding.reduce_framebuffer(fb.tensor, 0)             # timed steps even when the caller asks for --warmup 0
-        rccl_ranks = dist.get_world_size()                    # as seen after the first reduce
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     barrier()
     v.reset()
     v.enable_kernel_timing(True)
+    t_render[0] = t_assemble[0] = 0.0
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     v.enable_kernel_timing(False)
@@ -362,17 +483,23 @@ def main():
     # what the TIMED steps themselves accumulated (rank 0, N = 1): the parity gate below compares exactly these pixels with the oracle
     timed_hdr = v.read_hdr() if (rank == 0 and world == 1 and not args.no_parity) else None
     if rank == 0 and world > 1 and not args.no_parity and assembled[0] is not None:
-        # N > 1: the frame the LAST timed step's reduce assembled on rank 0 (every rank's tiles, the same samples) goes through the same gate
+        # N > 1: the frame the LAST timed step's exchange assembled on rank 0 (every rank's tiles, the same samples) goes through the same gate
         timed_hdr = assembled[0][..., :3].contiguous().cpu().numpy()
-    timed_first, timed_n = args.warmup * spp_step, args.steps * spp_step
+    timed_first, timed_n = warmup * spp_step, steps * spp_step
+    per_rank = None
     if dist is not None:
-        dev = torch.device(f"cuda:{local}") if backend == "nccl" else torch.device("cpu")
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         cnt = torch.tensor([st["rays_nearest"], st["rays_any"], st["samples"]], dtype=torch.float64, device=dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         rays_n, rays_a, samples = (float(x) for x in cnt.tolist())
+        mine = torch.tensor([t_render[0] * 1e3 / steps, t_assemble[0] * 1e3 / steps, float(st["rays_nearest"] + st["rays_any"]), float(len(tiles)),
+                             (share or {}).get("seconds", {}).get("load_scene", 0.0) + (share or {}).get("seconds", {}).get("load_prebuilt", 0.0), build_s], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "ms_render": round(float(a[0]), 3), "ms_reduce": round(float(a[1]), 3), "rays": int(a[2]), "tiles": int(a[3]),
+                     "scene_hand_over_s": round(float(a[5]), 2)} for r, a in enumerate(x.tolist() for x in allr)]
     else:
         rays_n, rays_a, samples = float(st["rays_nearest"]), float(st["rays_any"]), float(st["samples"])
 
@@ -380,8 +507,8 @@ def main():
     roof = None
     if rank == 0:
         v.reset(); v.enable_counters(True)
-        for i in range(args.steps):
-            v.render_tiles(tiles, (args.warmup + i) * spp_step, spp_step)
+        for i in range(steps):
+            v.render_tiles(tiles, (warmup + i) * spp_step, spp_step)
         cs = v.stats()
         v.enable_counters(False)
         assert cs["rays_nearest"] == st["rays_nearest"], "counting pass traced different rays"
@@ -389,7 +516,7 @@ def main():
         alg_bytes = float(NODE_BYTES_FETCHED) * cs["nodes_nearest"] + 48.0 * cs["tris_nearest"] + 48.0 * cs["rays_nearest"]
         avg_ms = kt["trace_nearest_ms_total"] / launches
         mem = v.scene_bytes()
-        roof = roofline_report(args.config if world == 1 else f"{args.config}@{world}", spp_step, bool(args.tris or args.width or args.height),
+        roof = roofline_report(config if world == 1 else f"{config}@{world}", spp_step, bool(ov and (args.tris or args.width or args.height)),
                                alg_bytes / launches, avg_ms, mem["nodes"] + mem["triangles"], {
             "launches": int(launches),
             "kernel_time_share": round(kt["trace_nearest_ms_total"] / max(kt["render_ms_total"], 1e-9), 3),
@@ -397,83 +524,119 @@ def main():
             "tris_per_ray": round(cs["tris_nearest"] / max(cs["rays_nearest"], 1), 2),
             "scene_bytes_detail": mem})
 
+    # ---- first-timed-step replay (verdict r3 item 4a): the samples of the FIRST timed step again, untimed, same schedule (one wide batch), counters off;
+    # the oracle checks >= 32 tiles of it whatever --steps is -- the whole-region gate below covers fewer tiles the more samples the timed region holds
+    step0_hdr = None
+    if rank == 0 and world == 1 and not args.no_parity:
+        v.reset()
+        v.render_tiles(tiles, warmup * spp_step, spp_step)
+        step0_hdr = v.read_hdr()
+
     # ---- the reference's interactive regime (one Redraw() = +1 spp per call, AppViewer.cxx:1045-1047), reported beside `value`
     interactive = None
-    if rank == 0 and world == 1 and not args.no_interactive:
-        interactive = {}
-        for k in (1, 16):
-            v.set_lookahead(k); v.reset()
-            for _ in range(max(8, 2 * k)):              # the frame pipeline (up to eight in flight) is full before the clock starts
-                v.Redraw()
-            v.sync()
-            n_fr = max(64, 4 * k)
-            t1 = time.perf_counter()
-            for _ in range(n_fr):
-                v.Redraw()
-            v.sync()
-            interactive[f"redraw_per_s_lookahead_{k}"] = round(n_fr / (time.perf_counter() - t1), 1)
-        v.set_lookahead(1)
-        # crh_set_lookahead_auto(16): FROM a restart -- one sample, then batches of 4, 16, 16, ... -- 64 Redraw()s, three sessions
-        v.set_lookahead_auto(16); v.reset(); v.sync()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            v.reset()
-            for _ in range(64):
-                v.Redraw()
-        v.sync()
-        interactive["redraw_per_s_lookahead_auto_16_first_64_frames_after_a_restart"] = round(3 * 64 / (time.perf_counter() - t1), 1)
-        v.reset(); v.sync()
-        t1 = time.perf_counter()
-        v.Redraw(); v.sync()
-        interactive["first_frame_after_a_restart_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
-        v.set_lookahead_auto(0); v.reset()
-        interactive["note"] = "one crh_render(1) per call over the whole frame, no read-back; NOT part of `value`"
+    if headline and rank == 0 and world == 1 and not args.no_interactive:
+        interactive = interactive_figures(v)
 
-    # ---- parity gate ("parity gate accompanying every number"; the reference's own gate is pixel-exact,
+    v.close()                                                 # the path state (up to 53 GB) and the scene go before the next leg / the CPU legs
+
+    # ---- parity gates ("parity gate accompanying every number"; the reference's own gate is pixel-exact,
     # testing/CADRays_Testing.py:226-230): the oracle renders the SAME samples the timed steps rendered on sampled tiles; those pixels of
     # the accumulator the timed region left behind must be bit-identical (rel L2 <= 1e-4 is north_star's bar)
-    parity = None
-    if timed_hdr is not None:
+    parity = parity0 = None
+    failed = False
+    wide = (spp_step * len(tiles) * sc.params.tile_size ** 2) > (12 << 20)
+    sched = ("big-batch (wide), counters off" if wide else "small-batch, counters off")
+    if rank == 0 and (timed_hdr is not None or step0_hdr is not None):
         try:
-            parity = parity_gate(sc, timed_hdr, timed_first, timed_n, args.parity_seconds)
-            parity["schedule"] = ("big-batch (wide), counters off" if (spp_step * len(tiles) * sc.params.tile_size ** 2) > (12 << 20)
-                                  else "small-batch, counters off") + " -- the timed steps' own output"
-        except Exception as e:                                  # a broken checker must not lose the measurement
-            parity = {"error": f"{type(e).__name__}: {e}"}
+            gate = ParityOracle(sc)
+            if timed_hdr is not None:
+                parity = gate.check(timed_hdr, timed_first, timed_n, args.parity_seconds, 4)
+                parity["schedule"] = sched + " -- the timed steps' own output"
+            if step0_hdr is not None:
+                parity0 = gate.check(step0_hdr, timed_first, spp_step, args.step0_seconds, 32)
+                parity0["schedule"] = sched + " -- the FIRST timed step's samples replayed untimed after the timed region"
+            gate.close()
+        except Exception as e:                                  # a broken checker is its own state, not a failed gate: the measurement stands
+            errors.append(f"{config} parity checker: {type(e).__name__}: {e}")
+            if parity is None and timed_hdr is not None:
+                parity = {"error": f"{type(e).__name__}: {e}"}
+            if parity0 is None and step0_hdr is not None:
+                parity0 = {"error": f"{type(e).__name__}: {e}"}
+        for p in (parity, parity0):
+            if p is not None and "error" not in p and not (p["pixels"] > 0 and p["rel_l2"] <= 1e-4):
+                failed = True                                   # differing pixels -- or no pixel compared at all
 
     # ---- CPU baseline: the oracle (a port, not the reference: OCCT has no CPU path tracer) on this box's cores
     cpu = None
-    if rank == 0 and not args.no_cpu and world == 1:          # reported on rank 0 at N = 1 only
+    if headline and rank == 0 and not args.no_cpu and world == 1:          # reported on rank 0 at N = 1 only
         try:
             cpu = cpu_baseline(sc, args.cpu_seconds)
         except Exception as e:
             cpu = {"value": None, "error": f"{type(e).__name__}: {e}"}
 
-    failed = False
+    out = None
     if rank == 0:
         mrays = (rays_n + rays_a) / dt / 1e6
+        cfgd = {"workload": f"{config}: {len(sc.tri)} random triangles, {len(sc.materials)} BSDF(s), "
+                            f"{'HDR sky env' if sc.env is not None else 'constant env'}, {len(sc.lights)} light(s), "
+                            f"{sc.params.width}x{sc.params.height}, depth {sc.params.max_depth}",
+                "spp_per_step_per_rank": spp_step, "spp_per_step_whole_frame": spp_step if scaling == "strong" or world == 1 else spp,
+                "tiles_per_rank": int(len(tiles)), "parallelism": f"tiles x{n_gpus} + {assemble_info['mode'] if assemble_info else 'RCCL reduce'}" if n_gpus > 1 else "single GPU",
+                "rccl_ranks": int(rccl_ranks), "backend": backend,
+                "msamples_per_s": round(samples / dt / 1e6, 3), "rays_nearest": int(rays_n), "rays_any": int(rays_a),
+                "build_upload_s": round(build_s, 2), "scene_generation_s": round(gen_s, 2), "host_cores": os.cpu_count(), "host_usable_cpus": usable_cpus(), "interactive": interactive}
+        if n_gpus > 1:
+            rr = [p["rays"] for p in per_rank]
+            cfgd.update({"per_rank": per_rank, "reduce_ms_per_step": max(p["ms_reduce"] for p in per_rank),
+                         "render_ms_per_step_max": max(p["ms_render"] for p in per_rank),
+                         "shard_rays_max_over_mean": round(max(rr) / max(sum(rr) / len(rr), 1.0), 4),
+                         "assemble": assemble_info, "scene_hand_over": share,
+                         "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                         "per_rank_note": "ms_render = crh_render_tiles + sync per timed step on that rank, ms_reduce = the exchange step as that rank saw it (it includes waiting for slower ranks)"})
         out = {
-            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {len(sc.tri)} random triangles, {len(sc.materials)} BSDF(s), "
-                                   f"{'HDR sky env' if sc.env is not None else 'constant env'}, {len(sc.lights)} light(s), "
-                                   f"{sc.params.width}x{sc.params.height}, depth {sc.params.max_depth}",
-                       "spp_per_step_per_rank": spp_step, "spp_per_step_whole_frame": spp_step if args.scaling == "strong" or world == 1 else args.spp,
-                       "tiles_per_rank": int(len(tiles)), "parallelism": f"tiles x{n_gpus} + RCCL reduce" if n_gpus > 1 else "single GPU",
-                       "rccl_ranks": int(rccl_ranks), "backend": backend,
-                       "msamples_per_s": round(samples / dt / 1e6, 3), "rays_nearest": int(rays_n), "rays_any": int(rays_a),
-                       "build_upload_s": round(build_s, 2), "host_cores": os.cpu_count(), "host_usable_cpus": usable_cpus(), "interactive": interactive},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "config": cfgd,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "parity_step0": parity0,
         }
-        print(json.dumps(out), flush=True)
-        if parity is not None and not (parity.get("rel_l2") is not None and parity["rel_l2"] <= 1e-4):
-            failed = True
-    if dist is not None:
-        dist.barrier()                                       # rank 0 may still be in its counting pass
-        dist.destroy_process_group()
-    if failed:
-        sys.exit("bench.py: PARITY GATE FAILED -- the timed frames differ from the oracle (see \"parity\" in the JSON line)")
+    return out, failed, errors
+
+
+def interactive_figures(v):
+    interactive = {}
+    for k in (1, 16):
+        v.set_lookahead(k); v.reset()
+        for _ in range(max(8, 2 * k)):              # the frame pipeline (up to eight in flight) is full before the clock starts
+            v.Redraw()
+        v.sync()
+        n_fr = max(64, 4 * k)
+        t1 = time.perf_counter()
+        for _ in range(n_fr):
+            v.Redraw()
+        v.sync()
+        interactive[f"redraw_per_s_lookahead_{k}"] = round(n_fr / (time.perf_counter() - t1), 1)
+    v.set_lookahead(1)
+    # crh_set_lookahead_auto(16): FROM a restart -- one sample, then batches of 4, 16, 16, ... -- 64 Redraw()s, three sessions
+    v.set_lookahead_auto(16); v.reset(); v.sync()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        v.reset()
+        for _ in range(64):
+            v.Redraw()
+    v.sync()
+    interactive["redraw_per_s_lookahead_auto_16_first_64_frames_after_a_restart"] = round(3 * 64 / (time.perf_counter() - t1), 1)
+    v.reset(); v.sync()
+    t1 = time.perf_counter()
+    v.Redraw(); v.sync()
+    interactive["first_frame_after_a_restart_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+    v.set_lookahead_auto(0); v.reset()
+    import cadrays_amd
+    frames, queues = cadrays_amd.pipeline_capacity()
+    interactive["frames_in_flight"] = frames
+    interactive["hw_queues"] = queues
+    interactive["note"] = ("one crh_render(1) per call over the whole frame, no read-back; NOT part of `value`; bench.py (the host) exported GPU_MAX_HW_QUEUES before "
+                           "the first HIP call -- the library itself never writes the environment (crh_query_pipeline_capacity)")
+    return interactive
 
 
 def cpu_model():
@@ -532,36 +695,47 @@ def cpu_baseline(sc, seconds):
     return out
 
 
-def parity_gate(sc, gpu_hdr, first_sample, n_samples, seconds):
-    """The CPU oracle (parity build: -O2, no contraction) renders samples [first_sample, first_sample + n_samples) of a bounded tile
-    sample of the same workload -- the samples the timed steps rendered -- and the timed accumulator must hold the same bits there."""
-    import numpy as np
-    from oracle import pyoracle
-    Or = pyoracle.oracle_class("parity")
-    Or.set_threads(usable_cpus())
-    o = Or().load_scene(sc)
-    nt = o.n_tiles()
-    probe = np.unique(np.linspace(0, nt - 1, 16).astype(np.uint32))
-    o.render_tiles(probe, first_sample, 1)                       # calibration: rays per tile-sample and the rate on this host
-    s0 = o.stats()
-    per_tile_sample = (s0["rays_nearest"] + s0["rays_any"]) / len(probe)
-    rate = (s0["rays_nearest"] + s0["rays_any"]) / max(s0["seconds"], 1e-9)
-    want = int(max(4, min(64, nt, rate * seconds / max(per_tile_sample * n_samples, 1))))
-    sample = np.unique(np.linspace(0, nt - 1, want).astype(np.uint32))
-    o.reset()
-    t0 = time.perf_counter()
-    o.render_tiles(sample, first_sample, n_samples)
-    dt = time.perf_counter() - t0
-    ref = o.read_accum()
-    o.close()
-    mask = ref[..., 3] == n_samples
-    g = np.ascontiguousarray(gpu_hdr[mask], np.float32)
-    r = np.ascontiguousarray(ref[..., :3][mask], np.float32)
-    rel = float(np.linalg.norm(g.astype(np.float64) - r) / max(np.linalg.norm(r.astype(np.float64)), 1e-300))
-    diff = int((g.view(np.uint32) != r.view(np.uint32)).sum())
-    return {"rel_l2": rel, "bit_exact": diff == 0, "words_differing": diff, "tiles": int(len(sample)), "pixels": int(mask.sum()),
-            "spp": int(n_samples), "first_sample": int(first_sample), "tolerance_rel_l2": 1e-4,
-            "oracle": f"CPU oracle, parity build, {usable_cpus()} threads, {dt:.1f} s"}
+class ParityOracle:
+    """The CPU oracle (parity build: -O2, no contraction) loaded once per leg.  check() renders samples [first_sample, first_sample + n_samples) of a
+    bounded, evenly spread tile sample of the same workload -- the samples the timed steps rendered -- and the GPU frame must hold the same bits there."""
+
+    def __init__(self, sc):
+        from oracle import pyoracle
+        Or = pyoracle.oracle_class("parity")
+        Or.set_threads(usable_cpus())
+        t0 = time.perf_counter()
+        self.o = Or().load_scene(sc)
+        self.load_s = time.perf_counter() - t0
+        self.rate = None
+
+    def close(self):
+        self.o.close()
+
+    def check(self, gpu_hdr, first_sample, n_samples, seconds, min_tiles):
+        import numpy as np
+        o = self.o
+        nt = o.n_tiles()
+        if self.rate is None:
+            probe = np.unique(np.linspace(0, nt - 1, 16).astype(np.uint32))
+            o.reset(); o.render_tiles(probe, first_sample, 1)          # calibration: rays per tile-sample and the rate on this host
+            s0 = o.stats()
+            self.per_tile_sample = (s0["rays_nearest"] + s0["rays_any"]) / len(probe)
+            self.rate = (s0["rays_nearest"] + s0["rays_any"]) / max(s0["seconds"], 1e-9)
+        want = int(max(min_tiles, min(256, nt, self.rate * seconds / max(self.per_tile_sample * n_samples, 1))))
+        sample = np.unique(np.linspace(0, nt - 1, min(want, nt)).astype(np.uint32))
+        o.reset()
+        t0 = time.perf_counter()
+        o.render_tiles(sample, first_sample, n_samples)
+        dt = time.perf_counter() - t0
+        ref = o.read_accum()
+        mask = ref[..., 3] == n_samples
+        g = np.ascontiguousarray(gpu_hdr[mask], np.float32)
+        r = np.ascontiguousarray(ref[..., :3][mask], np.float32)
+        rel = float(np.linalg.norm(g.astype(np.float64) - r) / max(np.linalg.norm(r.astype(np.float64)), 1e-300))
+        diff = int((g.view(np.uint32) != r.view(np.uint32)).sum())
+        return {"rel_l2": rel, "bit_exact": diff == 0 and int(mask.sum()) > 0, "words_differing": diff, "tiles": int(len(sample)), "pixels": int(mask.sum()),
+                "spp": int(n_samples), "first_sample": int(first_sample), "tolerance_rel_l2": 1e-4,
+                "oracle": f"CPU oracle, parity build, {usable_cpus()} threads, {dt:.1f} s (scene hand-over {self.load_s:.1f} s)"}
 
 
 if __name__ == "__main__":

@@ -178,7 +178,8 @@ class Backend:
         f = self._fn("spec_anyhit_slot_order"); f.restype = C.c_int
         return int(f())
 
-    def load_scene(self, scene):
+    def load_scene(self, scene, prebuilt=None):
+        """prebuilt = (nodes, prim_order) of another context's tree over the same geometry (crh_build_prebuilt) instead of building one here"""
         self.set_geometry(scene.pos, scene.nrm, scene.tri, scene.uv, getattr(scene, "tri_object", None), getattr(scene, "obj_xform", None))
         self.set_materials(scene.materials)
         self.set_lights(scene.lights)
@@ -189,12 +190,26 @@ class Backend:
             self.set_texture(slot, img)
         if getattr(scene, "spec", None):
             self.set_spec(**scene.spec)
-        self.build()
+        if prebuilt is not None:
+            self.build_prebuilt(*prebuilt)
+        else:
+            self.build()
         return self
 
     # -- rendering -----------------------------------------------------------------------
     def build(self):
         self._call("build")
+
+    def build_prebuilt(self, nodes, prim_order):
+        """crh_build_prebuilt: this context takes the tree another one built for the same geometry (export_tree)"""
+        nodes = np.ascontiguousarray(nodes).view(np.float32).reshape(-1, abi.NODE_DWORDS)
+        order = np.ascontiguousarray(prim_order, np.uint32)
+        self._call("build_prebuilt", _fp(nodes), C.c_uint32(len(nodes)), order.ctypes.data_as(_u32p), C.c_uint32(len(order)))
+
+    def export_tree(self):
+        """(nodes, prim_order) for build_prebuilt of another context: the node array and the leaf order (dword 3 of the leaf-ordered triangle records)"""
+        nodes, tris = self.get_bvh()
+        return nodes, np.ascontiguousarray(tris[:, 3]).view(np.uint32).copy()
 
     def reset(self):
         self._call("reset")

@@ -1,0 +1,263 @@
+// crh_context.cpp -- context life cycle, device-memory / event helpers, accumulator, the CRH_* environment table
+// (one of the translation units behind include/cadrays_hip.h; the context, the shared helpers and the map of the files: crh_context.h)
+#include "crh_context.h"
+
+using namespace crh;
+using namespace crh::api;
+
+namespace crh {
+namespace api {
+
+int fail(crh_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
+
+// The boundary takes finite numbers only (coordinates additionally |x| <= 1e30, so that box centres and extents stay finite):
+// NaN / Inf would otherwise reach the BVH builder's binning and the kernels' float -> int conversions.
+bool all_finite(const float* v, size_t n, float limit)
+{
+  for (size_t i = 0; i < n; ++i) if (!(v[i] >= -limit && v[i] <= limit)) return false;
+  return true;
+}
+
+// Stream-ordered copy of a small host block: staged through one of four pinned buffers, so the call returns at once and `src`
+// can be reused; a slot is waited for only when the copy issued four uploads earlier has not finished yet.
+int stage_copy(crh_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t on)
+{
+  if (!bytes) return CRH_OK;
+  const hipStream_t stream = on ? on : cstream(c);
+  BuiltScene::Stage& st = c->stage[c->stage_next++ & 3u];
+  if (st.used) CRH_HIP(hipEventSynchronize(st.ev));
+  if (st.cap < bytes) {
+    if (st.p) { CRH_HIP(hipHostFree(st.p)); st.p = nullptr; st.cap = 0; }
+    const size_t want = bytes + bytes / 2 + 4096;
+    CRH_HIP(hipHostMalloc(&st.p, want, hipHostMallocDefault));
+    st.cap = want;
+  }
+  if (!st.ev) CRH_HIP(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+  std::memcpy(st.p, src, bytes);
+  CRH_HIP(hipMemcpyAsync(dst, st.p, bytes, hipMemcpyHostToDevice, stream));
+  CRH_HIP(hipEventRecord(st.ev, stream));
+  st.used = true;
+  return CRH_OK;
+}
+
+hipEvent_t get_event(crh_ctx* c)
+{
+  if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr; hipEventCreate(&e); return e;
+}
+
+// Fold finished event pairs into the accumulated times (stream must be idle).
+void drain_events(crh_ctx* c)
+{
+  for (auto& p : c->render_ev) { float ms = 0.f; if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { c->seconds_acc += 1e-3 * ms; c->all_ms_acc += ms; } c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second); }
+  c->render_ev.clear();
+  for (auto& p : c->trace_ev) { float ms = 0.f; if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { c->trace_ms_acc += ms; c->trace_launches++; } c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second); }
+  c->trace_ev.clear();
+}
+
+// Event pairs wait in the context until someone asks for the times; an interactive loop that never does (one crh_render(1)
+// per GUI frame, adaptive or look-ahead) must not grow the lists without bound: fold them in every 4096 pairs.
+int trim_events(crh_ctx* c)
+{
+  if (c->render_ev.size() + c->trace_ev.size() > 4096) { CRH_HIP(hipStreamSynchronize(cstream(c))); drain_events(c); }
+  return CRH_OK;
+}
+
+// A restart does not need the old epoch's times: hand the events back without waiting for them (no stream synchronisation).
+void discard_events(crh_ctx* c)
+{
+  for (auto& p : c->render_ev) { c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second); }
+  for (auto& p : c->trace_ev) { c->ev_pool.push_back(p.first); c->ev_pool.push_back(p.second); }
+  c->render_ev.clear(); c->trace_ev.clear();
+}
+
+int ensure_paths(crh_ctx* c, uint32_t need)
+{
+  if (need <= c->path_cap) return CRH_OK;
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
+  void** ptrs[] = {(void**)&c->paths.ray_o[0], (void**)&c->paths.ray_d[0], (void**)&c->paths.hit, (void**)&c->paths.thr[0], (void**)&c->paths.rad,
+                   (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c,
+                   (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh,
+                   (void**)&c->paths.ray_o[1], (void**)&c->paths.ray_d[1], (void**)&c->paths.thr[1], (void**)&c->queues.q2, (void**)&c->queues.q2_sh};
+  const size_t sz[] = {16, 16, 16, 16, 16, 16, 16, 16, 4, 4, 4, 16, 16, 16, 4, 4};
+  c->path_cap = 0;                                          // stays 0 if an allocation below fails
+  for (int i = 0; i < 16; ++i) {
+    if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
+    CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
+  }
+  if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, kCounts * sizeof(uint32_t))); CRH_HIP(hipMemsetAsync(c->queues.counts, 0, kCounts * sizeof(uint32_t), cstream(c))); }
+  c->path_cap = need;
+  return CRH_OK;
+}
+
+int ensure_scratch(crh_ctx* c, size_t bytes)
+{
+  if (bytes <= c->scratch_bytes) return CRH_OK;
+  if (c->d_scratch) { CRH_HIP(hipFree(c->d_scratch)); c->d_scratch = nullptr; }
+  CRH_HIP(hipMalloc(&c->d_scratch, bytes));
+  c->scratch_bytes = bytes;
+  return CRH_OK;
+}
+
+int alloc_accum(crh_ctx* c)
+{
+  if (c->d_accum && c->accumW == c->par.width && c->accumH == c->par.height) return CRH_OK;
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
+  if (c->d_accum) { CRH_HIP(hipFree(c->d_accum)); c->d_accum = nullptr; }
+  CRH_HIP(hipMalloc((void**)&c->d_accum, sizeof(float4) * (size_t)c->par.width * c->par.height));
+  if (c->d_m2) { CRH_HIP(hipFree(c->d_m2)); c->d_m2 = nullptr; }
+  CRH_HIP(hipMalloc((void**)&c->d_m2, sizeof(float) * (size_t)c->par.width * c->par.height));
+  c->accumW = c->par.width; c->accumH = c->par.height;
+  return CRH_OK;
+}
+
+int do_reset(crh_ctx* c)
+{
+  // stream-ordered: kernels still in flight finish into the old accumulator contents first, nothing is waited for
+  CRH_HIP(hipSetDevice(c->device));
+  int rc = alloc_accum(c); if (rc) return rc;
+  CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, cstream(c)));
+  CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, cstream(c)));
+  c->adaptive_picks = 0; c->pending_n = 0; c->ramp_k = 1; c->picked_valid = false; c->assembled_valid = false;
+  CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), cstream(c)));
+  discard_events(c);
+  c->seconds_acc = c->trace_ms_acc = c->all_ms_acc = 0.0; c->trace_launches = 0; c->frames_done = 0;
+  return CRH_OK;
+}
+
+// ---- every environment variable the library reads, in ONE table (crh_env_table() hands it to the host; tests/test_cpu_host.py checks that no other
+// getenv("CRH_...") exists in the sources).  These are reference-schedule selectors for tests and diagnostics, never needed for correct output: images
+// do not depend on any of them.  Tuning knobs whose A/B is settled (grid sizes, pipeline grid floors, lane sizes) are gone -- their values are constants
+// with their measurements beside them in crh_context.h.
+struct EnvKnob { const char* name; const char* what; };
+static const EnvKnob kEnvKnobs[] = {
+  {"CRH_BUILD_THREADS",      "threads of the host BVH builder and the record fill (default: the CPUs this process may use; bench.py gives each of N ranks its share)"},
+  {"CRH_BUILD_VERBOSE",      "crh_build prints its phases and their times on stderr"},
+  {"CRH_MAX_PATHS",          "path slots per batch, 1024 .. 2^30 (default 2^28); the same knob as crh_set_path_budget"},
+  {"CRH_DONATE",             "0: small batches use the plain traversal kernels instead of the work-donating ones (reference schedule of the sequence tests)"},
+  {"CRH_PIPELINE",           "0: free-running Redraw()s are not pipelined across streams (reference schedule of the sequence tests)"},
+  {"CRH_PIPE_DEPTH",         "frames in flight of free-running Redraw()s, 2 .. 8; the same knob as crh_set_pipeline_depth (crh_query_pipeline_capacity says what the process supports)"},
+  {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
+  {"CRH_SPLIT_PASSES",       "split scenes (static tree + moved objects): 0 one walk in the two-level kernels, 1 two traversal passes, unset: by the number of moved objects"},
+  {"CRH_REDUCE_RCCL_SINGLE", "crh_reduce sends even a one-context group through RCCL (exercises the library binding on a 1-GPU box)"},
+};
+
+// Hardware queues the HIP runtime of this process maps streams onto: GPU_MAX_HW_QUEUES as it stands at this library's FIRST use (crh_create or
+// crh_query_pipeline_capacity, whichever comes first), default 4.  The runtime reads the variable at its own initialisation -- the process's first HIP
+// call, which a host without another HIP user makes through crh_create -- so a host exports it before that; a value exported later changes nothing in
+// the runtime and is not seen here either.  A pipelined frame needs a queue of its own beside the context's stream and the read-back stream.
+int hw_queues()
+{
+  static const int n = [] { const char* e = getenv("GPU_MAX_HW_QUEUES"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();
+  return n;
+}
+uint32_t pipeline_capacity() { return (uint32_t)std::min(8, std::max(3, hw_queues() - 2)); }
+
+int build_threads_env() { if (const char* e = getenv("CRH_BUILD_THREADS")) return atoi(e); return 0; }
+
+static void read_env(crh_ctx* c)
+{
+  if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)std::min<long>(v, 1l << 30); }   // a path slot travels in 31 bits
+  if (const char* e = getenv("CRH_DONATE")) c->donate = atoi(e) != 0;
+  if (const char* e = getenv("CRH_SPLIT_PASSES")) c->split_passes = atoi(e);
+  if (const char* e = getenv("CRH_PIPELINE")) c->pipeline = atoi(e) != 0;
+  if (const char* e = getenv("CRH_PIPE_DEPTH")) { int v = atoi(e); if (v >= 2 && v <= (int)pipeline_capacity()) c->pipe_depth = (uint32_t)v; }
+  if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }
+}
+
+}  // namespace api
+}  // namespace crh
+
+extern "C" {
+
+crh_ctx* crh_create(int device_ordinal)
+{
+  (void)api::hw_queues();      // what the HIP runtime is about to read, if this is the process's first HIP call
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) {
+    fprintf(stderr, "crh_create: no HIP device %d (device count %d) -- this backend has no CPU fallback\n", device_ordinal, n);
+    return nullptr;
+  }
+  crh_ctx* c = new crh_ctx();
+  c->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&c->d_counters, sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), cstream(c)) != hipSuccess ||
+      hipStreamSynchronize(cstream(c)) != hipSuccess) {
+    fprintf(stderr, "crh_create: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
+    delete c; return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->cus = prop.multiProcessorCount; c->grid = prop.multiProcessorCount * 4; c->grid_trace = prop.multiProcessorCount * 6; }
+  api::read_env(c);
+  // reference defaults: GI on, depth as vrenderparams default, two-sided (SettingsWidget.cxx:65-90)
+  c->par.width = 64; c->par.height = 64; c->par.max_depth = 5; c->par.two_sided = 1; c->par.seed = 1; c->par.tile_size = 32;
+  c->par.white_point = 1.0f; c->par.russian_roulette = 1; c->par.env_as_background = 1;
+  c->cam.dir[1] = 1.0f; c->cam.up[2] = 1.0f; c->cam.fovy_deg = 45.0f;
+  return c;
+}
+
+void crh_destroy(crh_ctx* c)
+{
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(cstream(c));
+  drain_events(c);
+  for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  void* ptrs[] = {c->d_nodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o[0], c->paths.ray_d[0], c->paths.ray_o[1], c->paths.ray_d[1], c->paths.thr[1],
+                  c->paths.hit, c->paths.thr[0], c->paths.rad, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
+                  c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
+                  c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst, c->d_patch, c->d_verts, c->d_ibox, c->queues.q2, c->queues.q2_sh};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (c->d_assembled) hipFree(c->d_assembled);
+  if (c->d_peer_stage) hipFree(c->d_peer_stage);
+  for (BuiltScene::Stage& st : c->stage) { if (st.p) hipHostFree(st.p); if (st.ev) hipEventDestroy(st.ev); }
+  for (int k = 0; k < 8; ++k) { if (c->lane_stream[k]) { hipStreamSynchronize(c->lane_stream[k]); hipStreamDestroy(c->lane_stream[k]); } if (c->lane_join[k]) hipEventDestroy(c->lane_join[k]); }
+  if (c->lane_fork) hipEventDestroy(c->lane_fork);
+  if (c->d_lane_counts) hipFree(c->d_lane_counts);
+  if (c->d_pipe_seeds) hipFree(c->d_pipe_seeds);
+  if (c->rb_stream) { hipStreamSynchronize(c->rb_stream); hipStreamDestroy(c->rb_stream); }
+  for (int k = 0; k < 2; ++k) { if (c->d_rb[k]) hipFree(c->d_rb[k]); if (c->h_rb[k]) hipHostFree(c->h_rb[k]); if (c->rb_tm[k]) hipEventDestroy(c->rb_tm[k]); if (c->rb_done[k]) hipEventDestroy(c->rb_done[k]); }
+  if (c->rb_fork) hipEventDestroy(c->rb_fork);
+  for (void* q : {(void*)c->d_tile_cdf, (void*)c->d_picked, (void*)c->d_adapt_n}) if (q) hipFree(q);
+  release_comms(c);
+  hipStreamDestroy(c->stream_);
+  delete c;
+}
+
+const char* crh_last_error(crh_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int crh_reset(crh_ctx* c) { if (!c) return CRH_E_INVALID; return do_reset(c); }
+
+int crh_sync(crh_ctx* c) { if (!c) return CRH_E_INVALID; c->read_since_render = true; CRH_HIP(hipSetDevice(c->device)); CRH_HIP(hipStreamSynchronize(cstream(c))); return CRH_OK; }
+
+int crh_set_path_budget(crh_ctx* c, uint64_t max_paths)
+{
+  if (!c || max_paths < 1024u || max_paths > (1ull << 30)) return fail(c, CRH_E_INVALID, "path budget must be in 1024 .. 2^30 slots");
+  CRH_HIP(hipSetDevice(c->device));
+  c->max_paths = (uint32_t)max_paths; c->pending_n = 0;
+  if (c->path_cap > c->max_paths) {                      // give the memory back now; the next render allocates what it needs
+    CRH_HIP(hipStreamSynchronize(cstream(c)));
+    void** ptrs[] = {(void**)&c->paths.ray_o[0], (void**)&c->paths.ray_d[0], (void**)&c->paths.hit, (void**)&c->paths.thr[0], (void**)&c->paths.rad,
+                     (void**)&c->paths.sh_o, (void**)&c->paths.sh_d, (void**)&c->paths.sh_c, (void**)&c->queues.q[0], (void**)&c->queues.q[1], (void**)&c->queues.q_sh,
+                     (void**)&c->paths.ray_o[1], (void**)&c->paths.ray_d[1], (void**)&c->paths.thr[1], (void**)&c->queues.q2, (void**)&c->queues.q2_sh};
+    for (void** q : ptrs) if (*q) { CRH_HIP(hipFree(*q)); *q = nullptr; }
+    c->path_cap = 0;
+  }
+  return CRH_OK;
+}
+
+int crh_query_pipeline_capacity(uint32_t* max_frames, int* hw_queues)
+{
+  if (max_frames) *max_frames = api::pipeline_capacity();
+  if (hw_queues) *hw_queues = api::hw_queues();
+  return CRH_OK;
+}
+
+const char* crh_env_table(void)
+{
+  static std::string t;
+  if (t.empty()) for (const api::EnvKnob& k : api::kEnvKnobs) { t += k.name; t += "\t"; t += k.what; t += "\n"; }
+  return t.c_str();
+}
+
+}  // extern "C"

@@ -112,7 +112,8 @@ int main(int argc, char** argv)
     if ((rc = crh_set_camera(c, &cam))) return die_all(c, "crh_set_camera", rc);
     if ((rc = crh_set_params(c, &par))) return die_all(c, "crh_set_params", rc);
     if ((rc = crh_build(c))) return die_all(c, "crh_build", rc);
-    { const char* q = getenv("GPU_MAX_HW_QUEUES"); if (q && atoi(q) >= 10 && !getenv("CRH_PIPE_DEPTH") && (rc = crh_set_pipeline_depth(c, 8))) return die_all(c, "crh_set_pipeline_depth", rc); }
+    { uint32_t frames = 3; crh_query_pipeline_capacity(&frames, nullptr);      // what the hardware queues of this process carry (main exported GPU_MAX_HW_QUEUES before the first HIP call)
+      if (frames > 3 && !getenv("CRH_PIPE_DEPTH") && (rc = crh_set_pipeline_depth(c, frames))) return die_all(c, "crh_set_pipeline_depth", rc); }
     if (n_gpus == 1 && lookahead > 1 && (rc = crh_set_lookahead(c, (uint32_t)lookahead))) return die_all(c, "crh_set_lookahead", rc);
     if (n_gpus == 1 && lookahead < -1 && (rc = crh_set_lookahead_auto(c, (uint32_t)-lookahead))) return die_all(c, "crh_set_lookahead_auto", rc);
   }

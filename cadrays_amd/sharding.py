@@ -71,6 +71,100 @@ def reduce_framebuffer(accum, dst=0):
     return out
 
 
+def load_scene_shared(view, scene, dist=None, device=None, src=0):
+    """One BVH build per job instead of one per rank (the scene is replicated): rank `src` builds (all of the host's build threads are
+    its own -- the other ranks wait), exports its tree (crh_get_bvh) and broadcasts node array + leaf order; every other rank hands them to
+    crh_build_prebuilt.  At 10 M triangles: 350 MB of nodes + 40 MB of order over xGMI / shared memory against 8 builds on 2 threads each.  Two-level
+    scenes and single-rank jobs build locally.  Returns {"built_here": bool, "tree_bytes": n, "seconds": {...}}."""
+    import time
+    t0 = time.perf_counter()
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if world == 1 or getattr(scene, "tri_object", None) is not None:
+        view.load_scene(scene)
+        return {"built_here": True, "tree_bytes": 0, "seconds": {"load_scene": round(time.perf_counter() - t0, 3)}}
+    import torch
+    rank = dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    hdr = torch.zeros(2, dtype=torch.int64, device=dev)
+    if rank == src:
+        view.load_scene(scene)
+        t1 = time.perf_counter()
+        nodes, order = view.export_tree()
+        hdr[0], hdr[1] = nodes.shape[0], order.shape[0]
+        dist.broadcast(hdr, src=src)
+        tn = torch.from_numpy(nodes.view(np.uint8).reshape(-1)).to(dev)
+        to = torch.from_numpy(order.view(np.uint8).reshape(-1)).to(dev)
+        dist.broadcast(tn, src=src); dist.broadcast(to, src=src)
+        if tn.is_cuda:
+            torch.cuda.synchronize(tn.device)
+        return {"built_here": True, "tree_bytes": int(tn.numel() + to.numel()),
+                "seconds": {"load_scene": round(t1 - t0, 3), "export_and_broadcast": round(time.perf_counter() - t1, 3)}}
+    dist.broadcast(hdr, src=src)
+    n_nodes, n_tris = int(hdr[0].item()), int(hdr[1].item())
+    t1 = time.perf_counter()
+    from . import abi
+    tn = torch.empty(n_nodes * abi.NODE_DWORDS * 4, dtype=torch.uint8, device=dev)
+    to = torch.empty(n_tris * 4, dtype=torch.uint8, device=dev)
+    dist.broadcast(tn, src=src); dist.broadcast(to, src=src)
+    nodes = tn.cpu().numpy().view(np.float32).reshape(n_nodes, abi.NODE_DWORDS)
+    order = to.cpu().numpy().view(np.uint32)
+    t2 = time.perf_counter()
+    view.load_scene(scene, prebuilt=(nodes, order))
+    return {"built_here": False, "tree_bytes": int(tn.numel() + to.numel()),
+            "seconds": {"wait_for_builder": round(t1 - t0, 3), "receive": round(t2 - t1, 3), "load_prebuilt": round(time.perf_counter() - t2, 3)}}
+
+
+class TileGather:
+    """The cheaper exchange step of SURVEY.md 8e: every rank owns a disjoint set of tiles, so instead of summing whole frames (33 MB at 1080p, 133 MB at
+    4K per rank) each rank sends ONLY its tiles' pixels -- W*H*16/N bytes -- and the root scatters them into the frame.  Pixel lists are built once per
+    (frame shape, world size): rank r's pixels in tile order, rows inside a tile, clipped to the image, padded to the longest list with repeats of the
+    rank's last pixel (a repeated pixel is written twice with the same value).  Values are copied, not summed: bit-exact by construction."""
+
+    def __init__(self, width, height, tile_size, world, device):
+        import torch
+        self.world, self.shape = world, (height, width, 4)
+        tx, ty = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
+        lists = []
+        for r in range(world):
+            tiles = tiles_for_rank(tx * ty, r, world, tx)
+            px = []
+            yy, xx = np.mgrid[0:tile_size, 0:tile_size]
+            for t in tiles:
+                x = (int(t) % tx) * tile_size + xx; y = (int(t) // tx) * tile_size + yy
+                ok = (x < width) & (y < height)
+                px.append((y[ok].astype(np.int64) * width + x[ok]).reshape(-1))
+            lists.append(np.concatenate(px) if px else np.zeros(0, np.int64))
+        self.n_max = max(1, max(len(l) for l in lists))
+        pad = [np.concatenate([l, np.full(self.n_max - len(l), l[-1] if len(l) else 0, np.int64)]) for l in lists]
+        self.idx = [torch.from_numpy(p).to(device) for p in pad]
+        self.bytes_per_rank = self.n_max * 16
+        self._out = None
+
+    def assemble(self, accum, rank, dst=0):
+        """gather the owned tiles of every rank's accumulator into a persistent frame on rank `dst` (returned there; None elsewhere)"""
+        import torch
+        import torch.distributed as dist
+        send = accum.view(-1, 4).index_select(0, self.idx[rank])
+        via_cpu = send.is_cuda and dist.get_backend() == "gloo"        # rehearsal on one GPU: gloo has no device-side gather
+        if via_cpu:
+            send = send.cpu()
+        if rank == dst:
+            recv = [torch.empty_like(send) for _ in range(self.world)]
+            dist.gather(send, recv, dst=dst)
+            if self._out is None:
+                self._out = torch.zeros(self.shape, dtype=accum.dtype, device=accum.device)
+            flat = self._out.view(-1, 4)
+            for r in range(self.world):
+                flat.index_copy_(0, self.idx[r], recv[r].to(accum.device))
+            if accum.is_cuda:
+                torch.cuda.current_stream(accum.device).synchronize()
+            return self._out
+        dist.gather(send, None, dst=dst)
+        if accum.is_cuda:
+            torch.cuda.current_stream(accum.device).synchronize()
+        return None
+
+
 class DeviceFramebuffer:
     """Zero-copy torch view of a backend's device accumulator (crh_accum_device_ptr)."""
 

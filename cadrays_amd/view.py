@@ -27,9 +27,10 @@ class View(Backend):
         self.device = int(device)
         self._params = None
         import os
-        from . import deep_pipeline_ok
-        if deep_pipeline_ok and "CRH_PIPE_DEPTH" not in os.environ:      # enough hardware queues for eight frames in flight (cadrays_amd/__init__.py)
-            self.set_pipeline_depth(8)
+        from . import pipeline_capacity
+        frames, _ = pipeline_capacity()
+        if frames > 3 and "CRH_PIPE_DEPTH" not in os.environ:      # the process has the hardware queues for a deeper frame pipeline (crh_query_pipeline_capacity)
+            self.set_pipeline_depth(frames)
 
     # ---- V3d_View vocabulary ----------------------------------------------------------------
     def Redraw(self):
@@ -66,7 +67,7 @@ class View(Backend):
         self._call("set_lookahead_auto", C.c_uint32(int(max_frames)))
 
     def set_pipeline_depth(self, frames):
-        """crh_set_pipeline_depth: frames in flight of free-running Redraw()s (2 .. 8); more than 3 needs GPU_MAX_HW_QUEUES (cadrays_amd.deep_pipeline_ok)"""
+        """crh_set_pipeline_depth: frames in flight of free-running Redraw()s, 2 .. cadrays_amd.pipeline_capacity()[0] (3 on the runtime's default four hardware queues)"""
         self._call("set_pipeline_depth", C.c_uint32(int(frames)))
 
     def set_path_budget(self, max_paths):

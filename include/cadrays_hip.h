@@ -175,6 +175,14 @@ CRH_API int crh_spec_anyhit_slot_order(void);      /* the other build-time switc
 /* == OCCT updateRaytraceGeometry + uploadRaytraceData on a changed scene: BVH build,
  * QBVH collapse, upload.  Invalidates the accumulator. */
 CRH_API int crh_build(crh_ctx* ctx);
+/* crh_build with the tree handed over instead of built: `nodes` (n_nodes x 16 dwords) as crh_get_bvh / crh_build_bvh_host returned them for the SAME
+ * geometry in another context or process, prim_order[leaf position] = triangle (the dword 3 of crh_get_bvh's leaf-ordered triangle records).  One
+ * process per GPU on one host (the scene is replicated): local rank 0 builds once, the other ranks take its tree -- at 10 M triangles
+ * the build is 4.5 s on 16 threads, and 8 ranks building at once get 2 threads each (bench.py --gpus N, cadrays_amd/sharding.py share_tree).  The
+ * builder is deterministic, so the bytes are the ones crh_build would produce here.  Single-level scenes only; the array is validated (every child
+ * reference inside it, the leaf order a permutation): CRH_E_INVALID otherwise.  Replaces OCCT's per-context BVH build behind
+ * AIS_InteractiveContext::Display (AisMesh.cxx:357-423). */
+CRH_API int crh_build_prebuilt(crh_ctx* ctx, const float* nodes, uint32_t n_nodes, const uint32_t* prim_order, uint32_t n_tris);
 /* == accumulation restart (camera/scene/param change, AppViewer.cxx:979-984) */
 CRH_API int crh_reset(crh_ctx* ctx);
 /* == n x V3d_View::Redraw() (AppViewer.cxx:1047): +n samples per pixel over the whole target */
@@ -227,8 +235,14 @@ CRH_API int crh_set_schedule(crh_ctx* ctx, int mode);
  * after frame i - 1.  2 .. 8, default 3 (CRH_PIPE_DEPTH in the environment sets the default).  MORE THAN 3 NEEDS MORE HARDWARE QUEUES than the
  * HIP runtime creates by default (4): export GPU_MAX_HW_QUEUES >= frames + 2 (16 is fine) before the process's first HIP call -- with it, C3 at
  * 1080p renders 385 / 400 / 442 / 455 Redraw()/s at 3 / 4 / 6 / 8 frames in flight; without it streams share queues and 4 frames are SLOWER than 3
- * (320).  Images do not depend on it.  Waits for the frames in flight. */
+ * (320).  The library never touches the environment: it reads GPU_MAX_HW_QUEUES at its first use (crh_create / this query), crh_query_pipeline_capacity reports what this
+ * process supports (max_frames = min(8, max(3, hw_queues - 2)); 3 on the runtime's default four queues) and a deeper request is refused with
+ * CRH_E_INVALID and a message that names the variable.  Images do not depend on the depth.  Waits for the frames in flight. */
 CRH_API int crh_set_pipeline_depth(crh_ctx* ctx, uint32_t frames);
+CRH_API int crh_query_pipeline_capacity(uint32_t* max_frames, int* hw_queues);
+/* Every environment variable the library reads, one "NAME<TAB>what it does" line each (reference-schedule selectors for tests and diagnostics;
+ * images never depend on them).  INTEGRATION.md carries the same table. */
+CRH_API const char* crh_env_table(void);
 CRH_API int crh_set_path_budget(crh_ctx* ctx, uint64_t max_paths);
 /* Per-tile error estimate (mean standard error of the pixel luminance) and per-tile sample count; pass NULL
  * arrays to query n_tiles.  Needs adaptive mode for a meaningful error. */

@@ -154,11 +154,9 @@ static int keyidx_cmp(const void* a, const void* b)
   return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0);
 }
 
-static uint32_t bn_new(builder* B)
-{
-  if (B->nbn == B->cap) { B->cap *= 2; B->bn = (bnode*)realloc(B->bn, sizeof(bnode) * B->cap); }
-  return B->nbn++;
-}
+/* the node array is allocated once (a binary tree over n primitives has at most 2n - 1 nodes): big subtrees are built by OpenMP tasks, and the
+ * numbering of the BINARY nodes -- the only thing that depends on who allocates first -- does not reach the output (the collapse follows links) */
+static uint32_t bn_new(builder* B) { return __atomic_fetch_add(&B->nbn, 1u, __ATOMIC_RELAXED); }
 
 static uint32_t build_rec(builder* B, uint32_t lo, uint32_t hi, int depth)
 {
@@ -213,9 +211,9 @@ static uint32_t build_rec(builder* B, uint32_t lo, uint32_t hi, int depth)
         uint32_t p = B->idx[i];
         int b = (int)(((B->cen[3 * p + baxis] - cmn[baxis]) / ext) * (float)BVH_NBINS);
         if (b > BVH_NBINS - 1) b = BVH_NBINS - 1;
-        if (b <= bsplit) B->idx[lo + nl++] = p; else B->tmp[nr++] = p;
+        if (b <= bsplit) B->idx[lo + nl++] = p; else B->tmp[lo + nr++] = p;      /* scratch range [lo, hi): private to this subtree */
       }
-      memcpy(&B->idx[lo + nl], B->tmp, sizeof(uint32_t) * nr);
+      memcpy(&B->idx[lo + nl], B->tmp + lo, sizeof(uint32_t) * nr);
       mid = lo + nl; done = 1;
     }
   }
@@ -232,8 +230,16 @@ static uint32_t build_rec(builder* B, uint32_t lo, uint32_t hi, int depth)
     }
     mid = lo + n / 2;
   }
-  uint32_t l = build_rec(B, lo, mid, depth + 1);
-  uint32_t r = build_rec(B, mid, hi, depth + 1);
+  uint32_t l, r;
+  if (n >= 32768u) {            /* the two halves own disjoint ranges of idx / tmp: same tree whoever builds them */
+#pragma omp task shared(l) firstprivate(B, lo, mid, depth)
+    l = build_rec(B, lo, mid, depth + 1);
+    r = build_rec(B, mid, hi, depth + 1);
+#pragma omp taskwait
+  } else {
+    l = build_rec(B, lo, mid, depth + 1);
+    r = build_rec(B, mid, hi, depth + 1);
+  }
   B->bn[me].left = (int32_t)l; B->bn[me].right = (int32_t)r;
   return me;
 }
@@ -289,8 +295,12 @@ static uint32_t build_tree(collapser* C, const aabb* pb, uint32_t n, uint32_t le
   builder B; B.pb = pb; B.cen = cen; B.leaf_max = leaf_max;
   B.idx = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1)); B.tmp = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
   for (uint32_t t = 0; t < n; ++t) B.idx[t] = t;
-  B.cap = 1024; B.nbn = 0; B.bn = (bnode*)malloc(sizeof(bnode) * B.cap);
-  build_rec(&B, 0, n, 0);
+  B.cap = 2 * (n ? n : 1) + 1; B.nbn = 0; B.bn = (bnode*)malloc(sizeof(bnode) * B.cap);
+  if (n >= 32768u) {
+#pragma omp parallel
+#pragma omp single
+    build_rec(&B, 0, n, 0);
+  } else build_rec(&B, 0, n, 0);
   if (rootbox) *rootbox = B.bn[0].box;
   C->bn = B.bn; C->instances = instances; C->next_leaf = leaf0; C->leaf0 = leaf0; C->idx = B.idx; C->order = order;
   if (C->nq == C->capq) { C->capq *= 2; C->qn = (qnode*)realloc(C->qn, sizeof(qnode) * C->capq); }

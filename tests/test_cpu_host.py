@@ -4,6 +4,7 @@ mirror of the reference's material interface behaves like MaterialEditor::setBSD
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -199,17 +200,41 @@ def test_scene_generators_are_deterministic():
     assert sky.shape == (256, 512, 3) and sky.max() >= 4e4 and sky.min() > 0
 
 
-def test_hardware_queue_request_follows_the_environment(monkeypatch):
-    """cadrays_amd asks the HIP runtime for more hardware queues (eight frames in flight, one stream each) only when that can still take effect, and
-    respects what the user exported: GPU_MAX_HW_QUEUES >= 10 in the environment -> deep pipeline; a smaller value -> three frames, as ever."""
-    import cadrays_amd
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
-    assert cadrays_amd._want_hw_queues() is False
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
-    assert cadrays_amd._want_hw_queues() is True
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "many")
-    assert cadrays_amd._want_hw_queues() is False
-    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
-    import torch
-    if not torch.cuda.is_initialized():                     # nothing has touched the GPU in this process: the request is made
-        assert cadrays_amd._want_hw_queues() is True and __import__("os").environ["GPU_MAX_HW_QUEUES"] == "16"
+def _capacity_in_fresh_process(env_value):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    if env_value is not None:
+        env["GPU_MAX_HW_QUEUES"] = env_value
+    code = ("import os, cadrays_amd\n"
+            "before = os.environ.get('GPU_MAX_HW_QUEUES')\n"
+            "print(cadrays_amd.pipeline_capacity(), before == os.environ.get('GPU_MAX_HW_QUEUES'))\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return p.stdout.strip()
+
+
+def test_pipeline_capacity_follows_the_environment_and_the_package_never_writes_it():
+    """crh_query_pipeline_capacity (verdict r3 item 8): frames in flight = min(8, max(3, GPU_MAX_HW_QUEUES - 2)) with the variable as the HOST exported it;
+    importing the package and asking leaves os.environ alone (round 3 set the variable at import)."""
+    assert _capacity_in_fresh_process(None) == "(3, 4) True"
+    assert _capacity_in_fresh_process("4") == "(3, 4) True"
+    assert _capacity_in_fresh_process("16") == "(8, 16) True"
+    assert _capacity_in_fresh_process("7") == "(5, 7) True"
+    assert _capacity_in_fresh_process("many") == "(3, 4) True"
+
+
+def test_every_environment_variable_the_library_reads_is_in_its_table(hip_lib):
+    """crh_env_table() (verdict r3 item 9): one documented table; no other getenv("CRH_...") in the library's sources, and INTEGRATION.md carries the names."""
+    import ctypes as C
+    import glob
+    import re
+    hip_lib.crh_env_table.restype = C.c_char_p
+    table = dict(l.split("\t", 1) for l in hip_lib.crh_env_table().decode().splitlines())
+    assert all(len(v) > 20 for v in table.values())
+    read = set()
+    for f in glob.glob(os.path.join(ROOT, "cadrays_amd", "csrc", "*")):
+        if f.endswith((".cpp", ".hip", ".h")):
+            read |= set(re.findall(r'getenv\("(CRH_[A-Z0-9_]+)"\)', open(f).read()))
+    assert read == set(table), (sorted(read - set(table)), sorted(set(table) - read))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert all(name in doc for name in table), [n for n in table if n not in doc]

@@ -34,8 +34,19 @@ def _worker(rank, world, port, spp, out_path):
         acc = torch.from_numpy(o.read_accum().copy())
         total = sharding.reduce_framebuffer(acc, 0)
         assert torch.equal(acc, torch.from_numpy(o.read_accum()))      # the rank's own buffer is left untouched
+        # the cheaper exchange step: gather of owned tiles -- 1 / world of the bytes, the same frame on the root
+        g = sharding.TileGather(o.width, o.height, o.tile_size, world, acc.device)
+        assert g.bytes_per_rank * world < 16 * o.width * o.height * 1.6      # 12 tiles (96 x 72, the last row 8 pixels high) over 2 / 3 ranks, padded to the longest list
+        frame = g.assemble(acc, rank, 0)
+        assert torch.equal(acc, torch.from_numpy(o.read_accum()))
         if rank == 0:
+            assert torch.equal(frame, total), "tile gather and full-frame reduce assemble different frames"
+            frame2 = g.assemble(acc, rank, 0)                            # persistent output buffer, second call
+            assert torch.equal(frame2, total)
             np.save(out_path, total.numpy())
+        else:
+            assert frame is None
+            g.assemble(acc, rank, 0)
     finally:
         dist.destroy_process_group()
 
