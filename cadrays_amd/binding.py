@@ -156,11 +156,15 @@ class Backend:
         self.width, self.height, self.tile_size = int(p.width), int(p.height), int(p.tile_size)
 
     def set_spec(self, **switches):
-        """crh_set_spec: flip switches of include/crh_spec.h (uniform_32bit, texel_gamma2, mis_single_lobe, eps_rule,
-        eta_no_dielectric); the ones not named return to their defaults.  Restarts accumulation."""
+        """crh_set_spec: flip switches of include/crh_spec.h (abi.SPEC_DEFAULTS names them all); the ones not named return to their defaults.
+        An unknown name is an error, not a silently ignored switch.  Restarts accumulation."""
+        unknown = sorted(set(switches) - set(abi.SPEC_DEFAULTS))
+        if unknown:
+            raise ValueError(f"set_spec: no such switch {unknown}; include/crh_spec.h has {sorted(abi.SPEC_DEFAULTS)}")
         vals = dict(abi.SPEC_DEFAULTS); vals.update(switches)
-        sp = abi.crh_spec(C.sizeof(abi.crh_spec), int(vals["uniform_32bit"]), int(vals["texel_gamma2"]), int(vals["mis_single_lobe"]),
-                          int(vals["eps_rule"]), float(vals["eta_no_dielectric"]))
+        sp = abi.crh_spec(size=C.sizeof(abi.crh_spec))
+        for name, ctype in abi.crh_spec._fields_[1:]:
+            setattr(sp, name, float(vals[name]) if ctype is C.c_float else int(vals[name]))
         self._call("set_spec", C.byref(sp))
 
     def get_spec(self):

@@ -44,6 +44,10 @@ void fill_scene(const crh_ctx* c, DScene& S)
         : (c->spec.eps_rule ? crh_max(1.0e-6f, 1.0e-4f * (crh_len3(dg) * 0.5f)) : crh_max(1.0e-6f, 1.0e-5f * crh_len3(dg)));      // crh_spec.h #6
   S.two_sided = c->par.two_sided; S.coherent = c->par.coherent_rng; S.rr = c->par.russian_roulette;
   S.spec_u32 = c->spec.uniform_32bit; S.spec_gamma2 = c->spec.texel_gamma2; S.spec_mis1 = c->spec.mis_single_lobe; S.spec_eta_nd = c->spec.eta_no_dielectric;
+  S.spec_rr_start = (uint32_t)c->spec.rr_start_bounce; S.spec_rr_cap = c->spec.rr_survival_cap; S.spec_min_contrib = c->spec.min_contribution;
+  S.spec_min_thr = c->spec.min_throughput; S.spec_raygen = c->spec.raygen_bilinear; S.spec_env_orient = c->spec.env_orientation;
+  for (int k = 0; k < 4; ++k)      // crh_spec.h #13: frustum-corner directions LB, RB, LT, RT
+    S.corner[k] = crh_frustum_corner(S.fwd, S.right, S.up, S.tan_half, S.aspect, (k & 1) ? 1.0f : -1.0f, (k & 2) ? 1.0f : -1.0f, c->spec.raygen_bilinear == 2);
 }
 
 int upload_textures(crh_ctx* c)
@@ -436,12 +440,10 @@ int crh_set_params(crh_ctx* c, const crh_params* p)
 
 int crh_set_spec(crh_ctx* c, const crh_spec* sp)
 {
-  if (!c || !sp) return fail(c, CRH_E_INVALID, "null spec");
-  if (sp->size != sizeof(crh_spec)) return fail(c, CRH_E_INVALID, "crh_spec.size does not match this library's struct");
-  if (!(sp->eta_no_dielectric >= 1.0e-2f && sp->eta_no_dielectric <= 1.0e3f)) return fail(c, CRH_E_INVALID, "eta_no_dielectric must be in 1e-2 .. 1e3");
-  c->spec = *sp;
-  c->spec.uniform_32bit = sp->uniform_32bit != 0; c->spec.texel_gamma2 = sp->texel_gamma2 != 0; c->spec.mis_single_lobe = sp->mis_single_lobe != 0;
-  c->spec.eps_rule = sp->eps_rule != 0;
+  if (!c) return CRH_E_INVALID;
+  crh_spec n; const char* why = "";
+  if (crh_spec_normalise(sp, &n, &why)) return fail(c, CRH_E_INVALID, why);      // an older, shorter struct is accepted: the fields it lacks take their defaults
+  c->spec = n;
   return do_reset(c);                                     // like every rendering-parameter change (pending look-ahead samples are dropped there)
 }
 

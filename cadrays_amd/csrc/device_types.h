@@ -12,8 +12,6 @@ namespace crh {
 constexpr float    kDirEps        = 1.0e-15f;
 constexpr float    kSlabGuard     = 4.76837158203125e-7f;   // 2^-21: guard band of the slab test per unit of |1/d| x reach
 constexpr float    kBsdfEps       = 1.0e-5f;
-constexpr float    kMinThroughput = 1.0e-3f;
-constexpr float    kMinContrib    = 1.0e-2f;
 constexpr uint32_t kQEmpty        = 0xFFFFFFFFu;
 constexpr uint32_t kQLeafBit      = 0x80000000u;
 
@@ -68,6 +66,9 @@ struct DScene {
   int two_sided, coherent, rr;
   // crh_spec.h switches (wave-uniform; the defaults 0 / 0 / 0 / 1.0f are the frozen spec)
   int spec_u32, spec_gamma2, spec_mis1; float spec_eta_nd;
+  // round 4 (#9 - #14; defaults 3 / 0.95 / 1e-2 / 1e-3 / 0 / 0)
+  uint32_t spec_rr_start; float spec_rr_cap, spec_min_contrib, spec_min_thr; int spec_raygen, spec_env_orient;
+  crh_v3 corner[4];       // #13: frustum-corner directions LB, RB, LT, RT (crh_frustum_corner; unit vectors when spec_raygen == 2)
 };
 
 // Wavefront path state, structure-of-arrays.  A queue entry is a POSITION in these arrays, not a pixel slot: k_raygen puts

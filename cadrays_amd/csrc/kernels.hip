@@ -844,8 +844,9 @@ __device__ __forceinline__ float lerpf(float a, float b, float t) { return CRH_F
 __device__ v3 env_lookup(const DScene& S, v3 d)
 {
   if (!S.env) return crh_mk3(S.bg[0], S.bg[1], S.bg[2]);
-  const float u = (crh_atan2(d.y, d.x) + CRH_PI) * CRH_INV_TWOPI;
-  const float v = crh_acos(d.z) * CRH_INV_PI;
+  float u = (crh_atan2(d.y, d.x) + CRH_PI) * CRH_INV_TWOPI;
+  float v = crh_acos(d.z) * CRH_INV_PI;
+  if (S.spec_env_orient) { u = crh_atan2(d.y, d.x) * CRH_INV_TWOPI; v = crh_acos(-d.z) * CRH_INV_PI; }      // crh_spec.h #14
   const float x = CRH_FMA(u, (float)S.env_w, -0.5f), y = CRH_FMA(v, (float)S.env_h, -0.5f);
   float xf = (float)(int)x; if (xf > x) xf -= 1.0f;
   float yf = (float)(int)y; if (yf > y) yf -= 1.0f;
@@ -1048,6 +1049,11 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
         const float sx = (nx * S.ortho_scale) * S.aspect, sy = ny * S.ortho_scale;
         o = crh_madd3(crh_madd3(S.eye, S.right, sx), S.up, sy);
         d = S.fwd;
+      } else if (S.spec_raygen) {
+        // crh_spec.h #13 (SURVEY a2, Appendix A GenerateRay): blend of the four frustum-corner directions by the pixel's position in [0,1]^2
+        const float u = ((float)px + jx) / (float)S.width, v = 1.0f - ((float)py + jy) / (float)S.height;
+        o = S.eye;
+        d = crh_norm3(crh_lerp3(crh_lerp3(S.corner[0], S.corner[1], u), crh_lerp3(S.corner[2], S.corner[3], u), v));
       } else {
         const float sx = (nx * S.tan_half) * S.aspect, sy = ny * S.tan_half;
         o = S.eye;
@@ -1233,7 +1239,7 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
             const float mis = (e_pdf == CRH_MAXFLOAT) ? 1.0f : e_pdf / CRH_FMA(e_pdf, e_pdf, i_pdf * i_pdf);
             const v3 contrib = crh_scale3(crh_mul3(xyz(l1), eval_layered(bs, wi, wo, S.two_sided)), mis);
             const v3 wc = crh_mul3(W, contrib);
-            if (contrib.x > kMinContrib || contrib.y > kMinContrib || contrib.z > kMinContrib) {
+            if (contrib.x > S.spec_min_contrib || contrib.y > S.spec_min_contrib || contrib.z > S.spec_min_contrib) {      // crh_spec.h #11
               shadow = true;
               s_o = mk4(offset_origin(p, ld, ng, S.eps), dist);
               // split scenes: .w != 0 marks a shadow ray that touches a moved object (the first any-hit pass leaves its contribution to the second)
@@ -1247,12 +1253,13 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
           v3 wi; bool delta; const v3 Wsel = W; int lobe;
           const bool alive = sample_layered(bs, wo, wi, W, inside, delta, rng, S.two_sided, SpecB{S.spec_u32, S.spec_eta_nd}, lobe);
           if (alive) imp_pdf = delta ? CRH_MAXFLOAT : pdf_layered(bs, wo, wi, Wsel, S.two_sided, S.spec_mis1 ? lobe : -1);
-          float survive = (W.x > kMinThroughput || W.y > kMinThroughput || W.z > kMinThroughput) ? 1.0f : 0.f;
-          if (S.rr && bounce >= 3u)
-            survive = crh_min(CRH_FMA(0.0722f, W.z, CRH_FMA(0.7152f, W.y, 0.2126f * W.x)), 0.95f) * survive;
+          const bool roulette = S.rr && bounce >= S.spec_rr_start;      // crh_spec.h #9, #10, #12
+          float survive = (W.x > S.spec_min_thr || W.y > S.spec_min_thr || W.z > S.spec_min_thr) ? 1.0f : 0.f;
+          if (roulette)
+            survive = crh_min(CRH_FMA(0.0722f, W.z, CRH_FMA(0.7152f, W.y, 0.2126f * W.x)), S.spec_rr_cap) * survive;
           const float kr = crh_rng_next_mode(&rng, S.spec_u32);
           if (alive && kr < survive) {
-            if (S.rr && bounce >= 3u) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
+            if (roulette) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
             const v3 nd2 = crh_norm3(from_local(fr, wi));
             n_o = mk4(offset_origin(p, nd2, ng, S.eps), __uint_as_float(rng));
             n_d = mk4(nd2, __uint_as_float((pid << 1) | (inside ? 1u : 0u)));

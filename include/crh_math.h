@@ -75,6 +75,15 @@ CRH_HD crh_v3 crh_norm3(crh_v3 a)
   return crh_scale3(a, inv);
 }
 CRH_HD float crh_maxcomp3(crh_v3 a) { return crh_max(a.x, crh_max(a.y, a.z)); }
+/* a + (b - a) * t, one subtraction and one fma per component */
+CRH_HD crh_v3 crh_lerp3(crh_v3 a, crh_v3 b, float t) { return crh_madd3(a, crh_sub3(b, a), t); }
+/* crh_spec.h #13: direction through the frustum corner (sx, sy) in {-1, +1}^2 -- the expression the tan form of ray generation evaluates at ndc = (sx, sy);
+ * unit != 0: normalised (what a host uploads when it hands the shader unit vectors) */
+CRH_HD crh_v3 crh_frustum_corner(crh_v3 fwd, crh_v3 right, crh_v3 up, float tan_half, float aspect, float sx, float sy, int unit)
+{
+  const crh_v3 d = crh_madd3(crh_madd3(fwd, right, (sx * tan_half) * aspect), up, sy * tan_half);
+  return unit ? crh_norm3(d) : d;
+}
 
 /* ---- split scenes (static tree + moved objects): "does the ray come near a moved object at all?"  (spec)
  * Every moved object's world box is wrapped in a sphere {centre, padded radius}; a ray is sent through the top-level tree only if the part

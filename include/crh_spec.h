@@ -26,6 +26,20 @@
  *                                     (crh_params.scene_epsilon > 0 overrides both)
  *  7  crh_spec.eta_no_dielectric     specular transmission under a coat that is    any other index for that case (e.g. 1.5, the material editor's
  *                                     NOT a dielectric is index-matched: eta = 1     default glass index, MaterialEditor.cxx:789-806)
+ *  -- round 4: the Appendix-A "(?)" choices that were constants, so that the kit spans every recollected choice (round-3 verdict item 5) --
+ *  9  crh_spec.rr_start_bounce       Russian roulette from bounce 3 on             any other first bounce (0 = from the camera ray's first hit on)
+ * 10  crh_spec.rr_survival_cap       survival probability min(luma(W), 0.95)       any other cap in (0, 1]  (1 = no cap)
+ * 11  crh_spec.min_contribution      an NEE sample is traced when a channel of     any other threshold >= 0 (Appendix A: MIN_CONTRIBUTION = vec3(1e-2) "(?)")
+ *                                     its MIS-weighted contribution exceeds 1e-2
+ * 12  crh_spec.min_throughput        a path goes on while a channel of its         any other threshold >= 0 (Appendix A: MIN_THROUGHPUT = vec3(1e-3) "(?)")
+ *                                     throughput exceeds 1e-3
+ * 13  crh_spec.raygen_bilinear       0: d = norm(fwd + right * ndc.x * tan(fovy/2)  1: bilinear blend of the four frustum-corner directions by the pixel's
+ *                                     * aspect + up * ndc.y * tan(fovy/2))           position in [0,1]^2, then normalised (SURVEY a2 / Appendix A GenerateRay) --
+ *                                                                                    the corners unnormalised: the same direction up to rounding;
+ *                                                                                    2: the corner directions NORMALISED before the blend (what a shader gets
+ *                                                                                    when the host uploads unit vectors): rays bend towards the image centre
+ * 14  crh_spec.env_orientation       lat-long lookup u = (atan2(d.y, d.x) + pi) /   1: Appendix A's FetchEnvironment: u = atan2(d.y, d.x) / (2 pi) (wraps),
+ *                                     (2 pi), v = acos(d.z) / pi (row 0 = zenith)    v = acos(-d.z) / pi -- the map turned by half a turn and upside down
  *
  * Reference evidence that these are the knobs that matter: the only numbers CADRays itself pins are the BSDF / light / camera /
  * parameter vectors of its input contract (cadrays_hip.h cites them line by line); everything in the table is arithmetic inside
@@ -37,15 +51,46 @@
 #include <stdint.h>
 
 typedef struct crh_spec {
-  uint32_t size;                /* sizeof(crh_spec) of the caller: lets the struct grow without breaking the ABI */
+  uint32_t size;                /* sizeof(crh_spec) AS THE CALLER KNOWS IT: a caller built against an older, shorter struct passes its own size and the
+                                 * fields it does not know take their defaults (crh_spec_normalise); a size larger than this library's is refused */
   int32_t  uniform_32bit;       /* #1 */
   int32_t  texel_gamma2;        /* #2 */
   int32_t  mis_single_lobe;     /* #3 */
   int32_t  eps_rule;            /* #6: 0 = 1e-5 * diagonal, 1 = 1e-4 * radius */
-  float    eta_no_dielectric;   /* #7: >= 1e-2; default 1 */
+  float    eta_no_dielectric;   /* #7: 1e-2 .. 1e3; default 1 */
+  /* ---- round 4 (size 24 -> 48) */
+  int32_t  rr_start_bounce;     /* #9: 0 .. 32; default 3 */
+  float    rr_survival_cap;     /* #10: (0, 1]; default 0.95 */
+  float    min_contribution;    /* #11: >= 0; default 1e-2 */
+  float    min_throughput;      /* #12: >= 0; default 1e-3 */
+  int32_t  raygen_bilinear;     /* #13: 0 tan form, 1 blend of unnormalised corners, 2 blend of normalised corners */
+  int32_t  env_orientation;     /* #14: 0 / 1 */
 } crh_spec;
 
-#define CRH_SPEC_DEFAULTS {(uint32_t)sizeof(crh_spec), 0, 0, 0, 0, 1.0f}
+#define CRH_SPEC_DEFAULTS {(uint32_t)sizeof(crh_spec), 0, 0, 0, 0, 1.0f, 3, 0.95f, 1.0e-2f, 1.0e-3f, 0, 0}
+#define CRH_SPEC_SIZE_R3 24u    /* the struct of round 3: {size .. eta_no_dielectric} */
+
+/* What crh_set_spec (product) and the oracle's twin both do with a caller's struct: copy the first min(in->size, sizeof) bytes over the defaults,
+ * check the ranges, turn the flags into 0 / 1.  Returns 0, or -1 with *why (a static string) set.  Input contract, shared like the structs. */
+static inline int crh_spec_normalise(const crh_spec* in, crh_spec* out, const char** why)
+{
+  static const crh_spec defaults = CRH_SPEC_DEFAULTS;
+  const char* dummy; if (!why) why = &dummy;
+  if (!in || !out) { *why = "null spec"; return -1; }
+  if (in->size < CRH_SPEC_SIZE_R3 || in->size > (uint32_t)sizeof(crh_spec) || (in->size & 3u)) { *why = "crh_spec.size is neither this library's struct nor an older one"; return -1; }
+  crh_spec s = defaults;
+  { const unsigned char* src = (const unsigned char*)in; unsigned char* dst = (unsigned char*)&s; for (uint32_t i = 4; i < in->size; ++i) dst[i] = src[i]; }
+  s.size = (uint32_t)sizeof(crh_spec);
+  if (!(s.eta_no_dielectric >= 1.0e-2f && s.eta_no_dielectric <= 1.0e3f)) { *why = "eta_no_dielectric must be in 1e-2 .. 1e3"; return -1; }
+  if (s.rr_start_bounce < 0 || s.rr_start_bounce > 32) { *why = "rr_start_bounce must be in 0 .. 32"; return -1; }
+  if (!(s.rr_survival_cap > 0.f && s.rr_survival_cap <= 1.0f)) { *why = "rr_survival_cap must be in (0, 1]"; return -1; }
+  if (!(s.min_contribution >= 0.f && s.min_contribution <= 3.0e38f) || !(s.min_throughput >= 0.f && s.min_throughput <= 3.0e38f)) { *why = "min_contribution / min_throughput must be finite and >= 0"; return -1; }
+  if (s.raygen_bilinear < 0 || s.raygen_bilinear > 2) { *why = "raygen_bilinear must be 0, 1 or 2"; return -1; }
+  if (s.env_orientation < 0 || s.env_orientation > 1) { *why = "env_orientation must be 0 or 1"; return -1; }
+  s.uniform_32bit = s.uniform_32bit != 0; s.texel_gamma2 = s.texel_gamma2 != 0; s.mis_single_lobe = s.mis_single_lobe != 0; s.eps_rule = s.eps_rule != 0;
+  *out = s;
+  return 0;
+}
 
 /* #4: build-time (traversal inner loop).  0 = quantised key (default), 1 = exact distance order, ties by slot. */
 #ifndef CRH_SPEC_ORDER_EXACT

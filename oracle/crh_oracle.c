@@ -45,8 +45,6 @@
 #define DIR_EPS        1.0e-15f
 #define SLAB_GUARD     4.76837158203125e-7f   /* 2^-21 */
 #define BSDF_EPS       1.0e-5f     /* roughness / weight threshold ("FLT_EPSILON" in GLSL)  */
-#define MIN_THROUGHPUT 1.0e-3f
-#define MIN_CONTRIB    1.0e-2f
 #define LUMA_R 0.2126f
 #define LUMA_G 0.7152f
 #define LUMA_B 0.0722f
@@ -101,6 +99,7 @@ typedef struct orc_ctx {
   uint32_t frames_done;          /* whole-frame iterations since the last restart: orc_render continues from here (like crh_render) */
   /* camera frame */
   v3 c_eye, c_fwd, c_right, c_up; float c_tanh, c_aspect;
+  v3 c_corner[4];               /* crh_spec.h #13: frustum-corner directions LB, RB, LT, RT */
   /* lights prepared: vec = to-light dir (directional, normalized) or position; param = cosmax or radius */
   v3* l_vec; float* l_par;
   /* accumulator */
@@ -888,6 +887,7 @@ static v3 env_lookup(const orc_ctx* c, v3 d)
   if (!c->env) return crh_mk3(c->par.background[0], c->par.background[1], c->par.background[2]);
   float u = (crh_atan2(d.y, d.x) + CRH_PI) * CRH_INV_TWOPI;
   float v = crh_acos(d.z) * CRH_INV_PI;
+  if (c->spec.env_orientation) { u = crh_atan2(d.y, d.x) * CRH_INV_TWOPI; v = crh_acos(-d.z) * CRH_INV_PI; }      /* crh_spec.h #14 */
   float x = CRH_FMA(u, (float)c->envW, -0.5f), y = CRH_FMA(v, (float)c->envH, -0.5f);
   float xf = (float)(int)x; if (xf > x) xf -= 1.0f;
   float yf = (float)(int)y; if (yf > y) yf -= 1.0f;
@@ -954,6 +954,11 @@ static void gen_camera_ray(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t*
     float sx = (nx * c->cam.ortho_scale) * c->c_aspect, sy = ny * c->cam.ortho_scale;
     *o = crh_madd3(crh_madd3(c->c_eye, c->c_right, sx), c->c_up, sy);
     *d = c->c_fwd;
+  } else if (c->spec.raygen_bilinear) {
+    /* crh_spec.h #13 (SURVEY a2, Appendix A GenerateRay): blend of the four frustum-corner directions by the pixel's position in [0,1]^2 */
+    const float u = ((float)px + jx) / W, v = 1.0f - ((float)py + jy) / H;
+    *o = c->c_eye;
+    *d = crh_norm3(crh_lerp3(crh_lerp3(c->c_corner[0], c->c_corner[1], u), crh_lerp3(c->c_corner[2], c->c_corner[3], u), v));
   } else {
     float sx = (nx * c->c_tanh) * c->c_aspect, sy = ny * c->c_tanh;
     *o = c->c_eye;
@@ -1045,7 +1050,8 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
         float mis = (e_pdf == CRH_MAXFLOAT) ? 1.0f : e_pdf / CRH_FMA(e_pdf, e_pdf, i_pdf * i_pdf);
         v3 contrib = crh_scale3(crh_mul3(crh_mk3(l->emission[0], l->emission[1], l->emission[2]), eval_layered(&b, wi, wo, two)), mis);
         v3 wc = crh_mul3(W, contrib);
-        if (contrib.x > MIN_CONTRIB || contrib.y > MIN_CONTRIB || contrib.z > MIN_CONTRIB) {
+        const float mc = c->spec.min_contribution;      /* crh_spec.h #11 */
+        if (contrib.x > mc || contrib.y > mc || contrib.z > mc) {
           hit_t sh; st->rays_any++;
           v3 so = offset_origin(p, ld, ng, c->eps);
           if (!traverse(c, so, ld, dist, 1, &sh, cn)) rad = crh_add3(rad, wc);
@@ -1056,12 +1062,14 @@ static v3 path_trace(const orc_ctx* c, uint32_t px, uint32_t py, uint32_t fseed,
     v3 wi; int delta, lobe; v3 Wsel = W;      /* lobe-selection weights = throughput before the bounce */
     int alive = sample_layered(&b, wo, &wi, &W, &inside, &delta, &rng, two, &c->spec, &lobe);
     if (alive) imp_pdf = delta ? CRH_MAXFLOAT : pdf_layered(&b, wo, wi, Wsel, two, c->spec.mis_single_lobe ? lobe : -1);
-    float survive = (W.x > MIN_THROUGHPUT || W.y > MIN_THROUGHPUT || W.z > MIN_THROUGHPUT) ? 1.0f : 0.f;
-    if (c->par.russian_roulette && bounce >= 3)
-      survive = crh_min(CRH_FMA(LUMA_B, W.z, CRH_FMA(LUMA_G, W.y, LUMA_R * W.x)), 0.95f) * survive;
+    const float mt = c->spec.min_throughput;            /* crh_spec.h #12, #9, #10 */
+    const int roulette = c->par.russian_roulette && bounce >= (uint32_t)c->spec.rr_start_bounce;
+    float survive = (W.x > mt || W.y > mt || W.z > mt) ? 1.0f : 0.f;
+    if (roulette)
+      survive = crh_min(CRH_FMA(LUMA_B, W.z, CRH_FMA(LUMA_G, W.y, LUMA_R * W.x)), c->spec.rr_survival_cap) * survive;
     float kr = crh_rng_next_mode(&rng, u32);
     if (!alive || !(kr < survive)) break;
-    if (c->par.russian_roulette && bounce >= 3) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
+    if (roulette) W = crh_mk3(W.x / survive, W.y / survive, W.z / survive);
     v3 nd2 = crh_norm3(from_local(&fr, wi));
     o = offset_origin(p, nd2, ng, c->eps);
     d = nd2;
@@ -1079,6 +1087,8 @@ static void prepare(orc_ctx* c)
   float s, cs; crh_sincos((c->cam.fovy_deg * 0.5f) * (CRH_PI / 180.0f), &s, &cs);
   c->c_tanh = s / cs;
   c->c_aspect = c->cam.aspect > 0.f ? c->cam.aspect : (float)c->par.width / (float)c->par.height;
+  for (int k = 0; k < 4; ++k)
+    c->c_corner[k] = crh_frustum_corner(c->c_fwd, c->c_right, c->c_up, c->c_tanh, c->c_aspect, (k & 1) ? 1.0f : -1.0f, (k & 2) ? 1.0f : -1.0f, c->spec.raygen_bilinear == 2);
   free(c->l_vec); free(c->l_par);
   c->l_vec = (v3*)malloc(sizeof(v3) * (c->nL ? c->nL : 1)); c->l_par = (float*)malloc(sizeof(float) * (c->nL ? c->nL : 1));
   for (uint32_t i = 0; i < c->nL; ++i) {
@@ -1293,10 +1303,10 @@ ORC_API int orc_set_params(orc_ctx* c, const crh_params* p)
 }
 ORC_API int orc_set_spec(orc_ctx* c, const crh_spec* sp)
 {
-  if (!c || !sp || sp->size != sizeof(crh_spec) || !(sp->eta_no_dielectric >= 1.0e-2f && sp->eta_no_dielectric <= 1.0e3f)) return CRH_E_INVALID;
-  c->spec = *sp;
-  c->spec.uniform_32bit = sp->uniform_32bit != 0; c->spec.texel_gamma2 = sp->texel_gamma2 != 0; c->spec.mis_single_lobe = sp->mis_single_lobe != 0;
-  c->spec.eps_rule = sp->eps_rule != 0;
+  if (!c) return CRH_E_INVALID;
+  crh_spec n; const char* why = "";
+  if (crh_spec_normalise(sp, &n, &why)) { snprintf(c->err, sizeof c->err, "%s", why); return CRH_E_INVALID; }
+  c->spec = n;
   return orc_reset(c);
 }
 ORC_API int orc_get_spec(orc_ctx* c, crh_spec* out) { if (!c || !out) return CRH_E_INVALID; *out = c->spec; out->size = (uint32_t)sizeof(crh_spec); return 0; }

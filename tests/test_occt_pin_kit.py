@@ -42,6 +42,19 @@ def test_compare_ranks_the_setting_the_other_renderer_agrees_with(tmp_path):
     rows = {(r["scene"], r["setting"]): r for r in rep["rows"]}
     assert rows[(pin_kit.SCENES[0], names[2])]["hdr_rel_l2"] < 1e-3 < rows[(pin_kit.SCENES[0], names[0])]["hdr_rel_l2"]
     assert rows[(pin_kit.SCENES[1], names[2])]["hdr_rel_l2"] is None and rows[(pin_kit.SCENES[1], names[2])]["ldr_mean_abs"] < 1.0
+    # the ready-to-paste defaults (round-3 verdict item 5).  In this fake kit setting k is the base image x (1 + 0.05 k) and the other renderer sits at
+    # k = 2: settings 1 .. 3 are closer to it than the default (k = 0) and are adopted, k = 4 is about as far as the default, the rest are farther
+    rec = rep["recommendation"]
+    assert list(rec["adopted"])[:3] == names[1:4] and not set(names[5:]) & set(rec["adopted"])
+    for n in names[1:4]:
+        for k, v in pin_kit.SETTINGS[n].items():
+            assert rec["spec"][k] == v
+    assert rec["c_initialiser"].startswith("#define CRH_SPEC_DEFAULTS {(uint32_t)sizeof(crh_spec), ") and rec["c_initialiser"].count(",") == 11
+    import io, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        pin_kit.print_report(rep)
+    assert "ready to paste" in buf.getvalue() and rec["c_initialiser"] in buf.getvalue()
     # a folder with images of another size is reported, not crashed on
     cr.write_png(os.path.join(occt, f"Output_{pin_kit.SCENES[0]}_4.png"), np.zeros((3, 3, 3), np.uint8))
     assert any("error" in r for r in pin_kit.compare(kit, occt)["rows"])

@@ -18,6 +18,14 @@ SWITCHES = {
     "mis_single_lobe": dict(mis_single_lobe=1),
     "eps_rule": dict(eps_rule=1),
     "eta_no_dielectric": dict(eta_no_dielectric=1.5),
+    # round 4: the Appendix-A "(?)" choices that were constants (crh_spec.h #9 - #14)
+    "rr_start_bounce": dict(rr_start_bounce=1),
+    "rr_survival_cap": dict(rr_survival_cap=0.25),
+    "min_contribution": dict(min_contribution=0.25),
+    "min_throughput": dict(min_throughput=0.125),
+    "raygen_corners": dict(raygen_bilinear=1),
+    "raygen_unit_corners": dict(raygen_bilinear=2),
+    "env_orientation": dict(env_orientation=1),
 }
 ALL_FLIPPED = {k: v for d in SWITCHES.values() for k, v in d.items()}
 
@@ -43,12 +51,27 @@ def test_spec_struct_round_trips_and_validates(oracle_lib):
     o = oracle_lib.Oracle()
     assert o.get_spec() == abi.SPEC_DEFAULTS
     o.set_spec(**ALL_FLIPPED)
-    assert o.get_spec() == dict(uniform_32bit=1, texel_gamma2=1, mis_single_lobe=1, eps_rule=1, eta_no_dielectric=1.5)
+    assert o.get_spec() == dict(uniform_32bit=1, texel_gamma2=1, mis_single_lobe=1, eps_rule=1, eta_no_dielectric=1.5, rr_start_bounce=1, rr_survival_cap=0.25,
+                                min_contribution=0.25, min_throughput=0.125, raygen_bilinear=2, env_orientation=1)
     o.set_spec()
     assert o.get_spec() == abi.SPEC_DEFAULTS
     from cadrays_amd.binding import BackendError
-    with pytest.raises(BackendError):
-        o.set_spec(eta_no_dielectric=0.0)
+    for bad in (dict(eta_no_dielectric=0.0), dict(rr_start_bounce=-1), dict(rr_start_bounce=33), dict(rr_survival_cap=0.0), dict(rr_survival_cap=1.5),
+                dict(min_contribution=-1.0), dict(min_throughput=float("nan")), dict(raygen_bilinear=3), dict(env_orientation=2)):
+        with pytest.raises(BackendError):
+            o.set_spec(**bad)
+    assert o.get_spec() == abi.SPEC_DEFAULTS                           # a refused struct changes nothing
+    with pytest.raises(ValueError):
+        o.set_spec(mis_single_lobes=1)                                 # a misspelt switch is an error, not a silently ignored one
+    # the struct can grow: a caller built against round 3's 24-byte struct still works, the fields it does not know take their defaults
+    import ctypes as C
+    old = abi.crh_spec(size=24, uniform_32bit=1, eta_no_dielectric=1.25, rr_start_bounce=9, env_orientation=1)      # the tail is NOT read at size 24
+    o._call("set_spec", C.byref(old))
+    assert o.get_spec() == dict(abi.SPEC_DEFAULTS, uniform_32bit=1, eta_no_dielectric=1.25)
+    for size in (0, 20, 26, 52):
+        with pytest.raises(BackendError):
+            o._call("set_spec", C.byref(abi.crh_spec(size=size, eta_no_dielectric=1.0)))
+    o.set_spec()
     assert o.spec_order_exact() == 0                   # the default build uses the quantised child-order key
 
 
@@ -92,9 +115,14 @@ def test_furnace_holds_under_every_switch(oracle_lib):
     b = BSDF.CreateDiffuse(rho); b.Le = np.array([1.0, 1.0, 1.0], np.float32)
     sc = scenes.Scene(pos, nrm, tri, [b], camera=scenes.Camera(eye=(0.5, 0.5, 0.5), dir=(0, 1, 0), up=(0, 0, 1), fovy_deg=60.0),
                       params=scenes.Params(width=16, height=16, max_depth=4, russian_roulette=False))
-    img, _ = render(oracle_lib.Oracle(), sc, spp=2, **ALL_FLIPPED)
+    flipped = {k: v for k, v in ALL_FLIPPED.items() if k != "min_throughput"}
+    img, _ = render(oracle_lib.Oracle(), sc, spp=2, **flipped)
     want = sum(rho ** k for k in range(4))
     assert np.allclose(img, want, rtol=2e-6)
+    # ... and the one switch that IS a truncation rule truncates where it says: with min_throughput = 0.125 the path whose throughput has
+    # fallen to rho^3 = 0.125 (not ABOVE the threshold) ends one bounce early
+    img, _ = render(oracle_lib.Oracle(), sc, spp=2, **ALL_FLIPPED)
+    assert np.allclose(img, sum(rho ** k for k in range(3)), rtol=2e-6)
 
 
 # ------------------------------------------------------------------------------------------------ GPU: product == oracle under every switch
@@ -127,7 +155,10 @@ def test_random_scenes_with_random_switches(hip_lib, oracle_lib, seed):
     from test_gpu_fuzz import random_scene
     r = np.random.default_rng(7000 + seed)
     kw = dict(uniform_32bit=int(r.integers(0, 2)), texel_gamma2=int(r.integers(0, 2)), mis_single_lobe=int(r.integers(0, 2)),
-              eps_rule=int(r.integers(0, 2)), eta_no_dielectric=float(r.choice([1.0, 1.33, 1.5, 0.8])))
+              eps_rule=int(r.integers(0, 2)), eta_no_dielectric=float(r.choice([1.0, 1.33, 1.5, 0.8])),
+              rr_start_bounce=int(r.choice([3, 0, 1, 2, 5])), rr_survival_cap=float(r.choice([0.95, 1.0, 0.5, 0.25])),
+              min_contribution=float(r.choice([1e-2, 0.0, 0.1, 0.5])), min_throughput=float(r.choice([1e-3, 0.0, 0.05, 0.2])),
+              raygen_bilinear=int(r.integers(0, 3)), env_orientation=int(r.integers(0, 2)))
     sc = dataclasses.replace(random_scene(300 + seed), spec=kw)
     v = View(0).load_scene(sc); v.enable_counters(True); v.reset()
     o = oracle_lib.Oracle().load_scene(sc)

@@ -48,6 +48,14 @@ SETTINGS = {
     "mis_single_lobe": dict(mis_single_lobe=1),
     "eps_rule": dict(eps_rule=1),
     "eta_no_dielectric_1.5": dict(eta_no_dielectric=1.5),
+    # round 4: crh_spec.h #9 - #14
+    "rr_start_bounce_1": dict(rr_start_bounce=1),
+    "rr_survival_cap_0.25": dict(rr_survival_cap=0.25),
+    "min_contribution_0.25": dict(min_contribution=0.25),
+    "min_throughput_0.125": dict(min_throughput=0.125),
+    "raygen_corners": dict(raygen_bilinear=1),
+    "raygen_unit_corners": dict(raygen_bilinear=2),
+    "env_orientation": dict(env_orientation=1),
 }
 SCENES = ("CornellBox", "Materials", "Switches")   # the reference's script names data/scripts/<name>.tcl, + this project's scene that exercises
                                                    # the switches those two cannot (no texture / environment / coat-less transmission in them);
@@ -148,7 +156,44 @@ def compare(kit, occt):
     noise = os.path.join(kit, "default@seed2")
     if os.path.isdir(noise):
         report["noise_floor"] = {s: distance(noise, os.path.join(kit, "default"), s, frames) for s in meta["scenes"]}
+    report["recommendation"] = recommend(report, meta["settings"])
     return report
+
+
+SPEC_FIELD_ORDER = ("uniform_32bit", "texel_gamma2", "mis_single_lobe", "eps_rule", "eta_no_dielectric", "rr_start_bounce", "rr_survival_cap",
+                    "min_contribution", "min_throughput", "raygen_bilinear", "env_orientation")      # include/crh_spec.h, after `size`
+
+
+def recommend(rep, meta_settings):
+    """Which switches the other renderer agrees with: a flipped setting is ADOPTED when, in at least one scene, it is closer to the OCCT images than the
+    default by more than the seed-to-seed noise floor (HDR rel L2 where there is a .pfm, LDR mean |d| otherwise) and in no scene farther by more than
+    that.  Returns the spec as a dict and as a ready-to-paste initialiser for include/crh_spec.h."""
+    from cadrays_amd import abi
+    rows = {(r["scene"], r["setting"]): r for r in rep["rows"]}
+    noise = rep.get("noise_floor") or {}
+    spec = dict(abi.SPEC_DEFAULTS); adopted = {}; undecided = []
+    for sname, flips in meta_settings.items():
+        if sname == "default" or not flips:
+            continue
+        better = worse = 0
+        for scene in {r["scene"] for r in rep["rows"]}:
+            a, b = rows.get((scene, sname)), rows.get((scene, "default"))
+            if not a or not b:
+                continue
+            for key in ("hdr_rel_l2", "ldr_mean_abs"):
+                if a.get(key) is None or b.get(key) is None:
+                    continue
+                floor = (noise.get(scene) or {}).get(key) or 0.0
+                if a[key] < b[key] - floor: better += 1
+                elif a[key] > b[key] + floor: worse += 1
+                break
+        if better and not worse:
+            spec.update(flips); adopted[sname] = flips
+        elif not better and not worse:
+            undecided.append(sname)
+    f = lambda v: ("%gf" % v if "." in "%g" % v or "e" in "%g" % v else "%g.0f" % v) if isinstance(v, float) else str(int(v))
+    init = "{(uint32_t)sizeof(crh_spec), " + ", ".join(f(float(spec[k])) if isinstance(abi.SPEC_DEFAULTS[k], float) else f(spec[k]) for k in SPEC_FIELD_ORDER) + "}"
+    return {"adopted": adopted, "undecided_inside_noise": undecided, "spec": spec, "c_initialiser": "#define CRH_SPEC_DEFAULTS " + init}
 
 
 def print_report(rep):
@@ -159,6 +204,12 @@ def print_report(rep):
     for s, n in (rep.get("noise_floor") or {}).items():
         print(f"{s:12s} {'(noise: 2 seeds, default)':24s} {f(n['ldr_mean_abs'], '%.4f'):>12s} {f(n['ldr_diff_fraction'], '%.4f'):>12s} {f(n['hdr_rel_l2'], '%.3e'):>12s}")
     print("closest setting per scene:", json.dumps(rep["best"]))
+    if rep.get("recommendation"):
+        r = rep["recommendation"]
+        print("switches the other renderer agrees with (closer than the default by more than the noise floor):", json.dumps(r["adopted"]))
+        print("inside the noise floor (render more frames to decide):", ", ".join(r["undecided_inside_noise"]) or "-")
+        print("ready to paste into include/crh_spec.h (then regenerate the goldens):")
+        print("  " + r["c_initialiser"])
 
 
 def selfcheck(frames, size, out=None):
