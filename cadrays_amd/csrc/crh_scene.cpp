@@ -249,9 +249,19 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
   for (uint32_t t = 0; t < nT; ++t)
     for (int k = 0; k < 3; ++k)
       if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) { char b[96]; snprintf(b, sizeof b, "triangle %u index out of range", t); return fail(c, CRH_E_INVALID, b); }
-  if (tri_obj && xf && nO)
+  if (tri_obj && xf && nO) {
     for (uint32_t t = 0; t < nT; ++t)
       if (tri_obj[t] < 0 || (uint32_t)tri_obj[t] >= nO) return fail(c, CRH_E_INVALID, "triangle object id out of range");
+    // every vertex belongs to ONE object: crh_build bakes a vertex once, under the build-time transform of its object -- a vertex shared by triangles
+    // of two objects would silently take the placement of whichever comes first.  AisMesh.cxx:372-413 emits one vertex array per object.
+    std::vector<int32_t> owner(nV, -1);
+    for (uint32_t t = 0; t < nT; ++t)
+      for (int k = 0; k < 3; ++k) {
+        int32_t& o = owner[tri[4 * t + k]];
+        if (o < 0) o = tri_obj[t];
+        else if (o != tri_obj[t]) { char b[160]; snprintf(b, sizeof b, "vertex %d is shared by objects %d and %d: each vertex belongs to one object (duplicate it)", tri[4 * t + k], o, tri_obj[t]); return fail(c, CRH_E_INVALID, b); }
+      }
+  }
   // every check passed: only now is the context's state replaced
   c->pos.assign(pos, pos + 3 * (size_t)nV); c->nrm.assign(nrm, nrm + 3 * (size_t)nV);
   if (uv) c->uv.assign(uv, uv + 2 * (size_t)nV); else c->uv.clear();
@@ -273,14 +283,24 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
   if (!c->two_level || nO != c->nO) return fail(c, CRH_E_INVALID, "crh_set_transforms needs a two-level scene with the same object count");
   if (!all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return fail(c, CRH_E_INVALID, "transform holds a NaN / Inf");
   CRH_HIP(hipSetDevice(c->device));
-  c->xf.assign(xf, xf + 12 * (size_t)nO);
-  if (!c->built) return do_reset(c);
+  if (!c->built) { c->xf.assign(xf, xf + 12 * (size_t)nO); return do_reset(c); }
   // The manipulator calls this every frame (ImRaytraceControls.cxx:58-89).  Nothing big is ever rebuilt here: an object of the static tree that
   // leaves the identity has its triangles THERE disabled (a scatter of all-zero records) and, the first time, gets an object tree of its own,
   // appended behind the trees built so far; back at the identity its triangles are restored and the instance dropped.  Then the top-level tree
   // over the instances of this moment is rebuilt on the host and only the new nodes and the instance table travel, stream-ordered.
   const int threads = build_threads_env();
   const uint32_t old_nodes = c->n_blas_nodes, old_pos = c->n_pos;
+  {
+    // leaf positions the object trees built by THIS call will take: checked before anything is touched, so that a refusal leaves the context as it was
+    // (after the loop below the host state has moved on while nothing has been uploaded: ADVICE r3)
+    uint64_t extra = 0;
+    for (uint32_t ob = 0; ob < nO; ++ob) {
+      const crh_ctx::Obj& o = c->objs[ob];
+      if (o.ntri && !o.built && !o.is_inst && std::memcmp(&xf[12 * (size_t)ob], &c->xf0[12 * (size_t)ob], 12 * sizeof(float)) != 0) extra += o.ntri;
+    }
+    if ((uint64_t)c->n_pos + extra > c->cap_pos || (uint64_t)c->n_pos + extra >= (1ull << 28)) return fail(c, CRH_E_NOMEM, "leaf positions exhausted (object trees of moved objects)");
+  }
+  c->xf.assign(xf, xf + 12 * (size_t)nO);
   c->bvh.nodes.resize(c->n_blas_nodes);
   std::vector<uint32_t> ppos; std::vector<float> prec;
   for (uint32_t ob = 0; ob < nO; ++ob) {
@@ -307,7 +327,6 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
   c->n_blas_nodes = (uint32_t)c->bvh.nodes.size();
   int rc;
   if (c->n_pos > old_pos) {                               // records of the object trees just built
-    if (c->n_pos > c->cap_pos || c->n_pos >= (1u << 28)) return fail(c, CRH_E_NOMEM, "leaf positions exhausted (object trees of moved objects)");
     std::vector<float> tr, sh, uvr, vt;
     fill_records(c, old_pos, c->n_pos, tr, sh, uvr, &vt);
     const size_t n = c->n_pos - old_pos;

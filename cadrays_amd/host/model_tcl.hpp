@@ -173,7 +173,7 @@ inline bool load_texture(const std::string& path, Texture& t, std::string& err)
 struct Mesh { std::vector<float> pos, nrm, uv; std::vector<int32_t> faces; bool has_uv = false; };
 
 // PLY: vertex element with x y z [nx ny nz] [s t | u v | texture_u texture_v], face element with one index list; binary LE or ascii
-inline bool read_ply(const std::string& path, Mesh& m, std::string& err)
+inline bool read_ply(const std::string& path, Mesh& m, std::string& err, bool smooth = false)
 {
   std::vector<uint8_t> d8;
   if (!read_file_bytes(path, d8, err)) return false;
@@ -243,16 +243,38 @@ inline bool read_ply(const std::string& path, Mesh& m, std::string& err)
   }
   const size_t nV = m.pos.size() / 3;
   for (int32_t i : m.faces) if (i < 0 || (size_t)i >= nV) { err = path + ": face index out of range"; return false; }
-  if (!has_n) {      // area-weighted vertex normals where the file has none
-    std::vector<double> acc(3 * nV, 0.0);
-    for (size_t t = 0; t + 2 < m.faces.size(); t += 3) {
+  if (!has_n) {
+    // The file has no normals: the reference asks assimp for them (MeshImporter.cxx:80-87) -- aiProcess_GenSmoothNormals with -gensmooth (area-weighted
+    // vertex normals), aiProcess_GenNormals without (ONE normal per face, vertices no longer shared between faces).  Same arithmetic as
+    // cadrays_amd/scene_tcl.py read_ply: float edge vectors, double cross products, normalised in double.
+    auto face_normal = [&](size_t t, double n[3]) {
       const float* a = &m.pos[3 * m.faces[t]]; const float* b = &m.pos[3 * m.faces[t + 1]]; const float* c = &m.pos[3 * m.faces[t + 2]];
       const double e1[3] = {(double)(b[0] - a[0]), (double)(b[1] - a[1]), (double)(b[2] - a[2])}, e2[3] = {(double)(c[0] - a[0]), (double)(c[1] - a[1]), (double)(c[2] - a[2])};
-      const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-      for (int k = 0; k < 3; ++k) for (int x = 0; x < 3; ++x) acc[3 * m.faces[t + k] + x] += n[x];
+      n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+    };
+    if (smooth) {
+      std::vector<double> acc(3 * nV, 0.0);
+      for (size_t t = 0; t + 2 < m.faces.size(); t += 3) {
+        double n[3]; face_normal(t, n);
+        for (int k = 0; k < 3; ++k) for (int x = 0; x < 3; ++x) acc[3 * m.faces[t + k] + x] += n[x];
+      }
+      m.nrm.resize(3 * nV);
+      for (size_t v = 0; v < nV; ++v) { const double l = std::max(std::sqrt(acc[3 * v] * acc[3 * v] + acc[3 * v + 1] * acc[3 * v + 1] + acc[3 * v + 2] * acc[3 * v + 2]), 1e-30); for (int x = 0; x < 3; ++x) m.nrm[3 * v + x] = (float)(acc[3 * v + x] / l); }
+    } else {
+      const size_t nF = m.faces.size() / 3;
+      std::vector<float> pos(9 * nF), nrm(9 * nF), uv(m.has_uv ? 6 * nF : 0);
+      for (size_t f = 0; f < nF; ++f) {
+        double n[3]; face_normal(3 * f, n);
+        const double l = std::max(std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-30);
+        for (int k = 0; k < 3; ++k) {
+          const int32_t v = m.faces[3 * f + k];
+          for (int x = 0; x < 3; ++x) { pos[9 * f + 3 * k + x] = m.pos[3 * v + x]; nrm[9 * f + 3 * k + x] = (float)(n[x] / l); }
+          if (m.has_uv) { uv[6 * f + 2 * k] = m.uv[2 * v]; uv[6 * f + 2 * k + 1] = m.uv[2 * v + 1]; }
+        }
+      }
+      m.pos.swap(pos); m.nrm.swap(nrm); if (m.has_uv) m.uv.swap(uv);
+      for (size_t i = 0; i < 3 * nF; ++i) m.faces[i] = (int32_t)i;
     }
-    m.nrm.resize(3 * nV);
-    for (size_t v = 0; v < nV; ++v) { const double l = std::max(std::sqrt(acc[3 * v] * acc[3 * v] + acc[3 * v + 1] * acc[3 * v + 1] + acc[3 * v + 2] * acc[3 * v + 2]), 1e-30); for (int x = 0; x < 3; ++x) m.nrm[3 * v + x] = (float)(acc[3 * v + x] / l); }
   }
   return true;
 }
@@ -348,9 +370,10 @@ inline bool read_model_tcl(const std::string& path, uint32_t width, uint32_t hei
       if (objs.count(a[1])) return fail(ln, "Error: Mesh with the name '" + a[1] + "' already exists");
       const std::string ext = lower(a[0].size() > 4 ? a[0].substr(a[0].size() - 4) : "");
       if (ext != ".ply") return fail(ln, "rtmeshread: this reader loads PLY meshes (what the exporter writes); " + a[0]);
-      for (size_t i = 2; i < a.size(); ++i) { const std::string k = lower(a[i]); if (k == "-up") { if (i + 1 < a.size() && lower(a[i + 1]) != "z") out.unsupported.push_back("rtmeshread -up " + a[i + 1]); ++i; } else if (k == "-gensmooth" || k == "-gs" || k == "-fixnorms" || k == "-fn") out.unsupported.push_back("rtmeshread " + a[i]); }
+      bool smooth = false;
+      for (size_t i = 2; i < a.size(); ++i) { const std::string k = lower(a[i]); if (k == "-up") { if (i + 1 < a.size() && lower(a[i + 1]) != "z") out.unsupported.push_back("rtmeshread -up " + a[i + 1]); ++i; } else if (k == "-gensmooth" || k == "-gs") smooth = true; else if (k == "-fixnorms" || k == "-fn") out.unsupported.push_back("rtmeshread " + a[i]); }
       Object o; std::string e2;
-      if (!read_ply(a[0], o.mesh, e2)) return fail(ln, e2);
+      if (!read_ply(a[0], o.mesh, e2, smooth)) return fail(ln, e2);
       o.displayed = true;
       objs[a[1]] = std::move(o); order.push_back(a[1]);
     } else if (cmd == "vdisplay" || cmd == "verase") { for (const std::string& n : a) { auto it = objs.find(n); if (it != objs.end()) it->second.displayed = cmd == "vdisplay"; } }

@@ -211,7 +211,7 @@ _PLY_T = {"char": "b", "uchar": "B", "short": "h", "ushort": "H", "int": "i", "u
           "int8": "b", "uint8": "B", "int16": "h", "uint16": "H", "int32": "i", "uint32": "I", "float32": "f", "float64": "d"}
 
 
-def read_ply(path):
+def read_ply(path, smooth=False):
     """vertices (x y z [nx ny nz] [s t | u v]) + triangle/polygon faces; binary little endian or ascii."""
     with open(path, "rb") as f:
         data = f.read()
@@ -272,13 +272,23 @@ def read_ply(path):
                             off += struct.calcsize(_PLY_T[p[0]])
     faces = np.array(faces, np.int32).reshape(-1, 3)
     if nrm is None:
-        # area-weighted vertex normals, in the arithmetic host/model_tcl.hpp uses (both readers must hand over the same bytes): float
-        # edge vectors, double cross products, accumulated face by face and corner by corner, normalised in double
-        nrm = np.zeros((len(pos), 3), np.float64)
+        # The file has no normals: the reference asks assimp for them (MeshImporter.cxx:80-87) -- aiProcess_GenSmoothNormals with -gensmooth,
+        # aiProcess_GenNormals (one normal per FACE, vertices no longer shared between faces) without.  Arithmetic as in host/model_tcl.hpp (both
+        # readers must hand over the same bytes): float edge vectors, double cross products, normalised in double.
+        fn = np.zeros((len(faces), 3), np.float64)
         if len(faces):
             fn = np.cross((pos[faces[:, 1]] - pos[faces[:, 0]]).astype(np.float64), (pos[faces[:, 2]] - pos[faces[:, 0]]).astype(np.float64))
-            np.add.at(nrm, faces.reshape(-1), np.repeat(fn, 3, axis=0))
-        nrm /= np.maximum(np.sqrt((nrm[:, 0] * nrm[:, 0] + nrm[:, 1] * nrm[:, 1]) + nrm[:, 2] * nrm[:, 2]), 1e-30)[:, None]
+        if smooth:                 # area-weighted vertex normals, accumulated face by face and corner by corner
+            nrm = np.zeros((len(pos), 3), np.float64)
+            if len(faces):
+                np.add.at(nrm, faces.reshape(-1), np.repeat(fn, 3, axis=0))
+            nrm /= np.maximum(np.sqrt((nrm[:, 0] * nrm[:, 0] + nrm[:, 1] * nrm[:, 1]) + nrm[:, 2] * nrm[:, 2]), 1e-30)[:, None]
+        else:                      # per-face normals: every triangle gets its own three vertices
+            fn = fn / np.maximum(np.sqrt((fn[:, 0] * fn[:, 0] + fn[:, 1] * fn[:, 1]) + fn[:, 2] * fn[:, 2]), 1e-30)[:, None]
+            flat = faces.reshape(-1)
+            pos = np.ascontiguousarray(pos[flat]); uv = None if uv is None else np.ascontiguousarray(uv[flat])
+            nrm = np.repeat(fn, 3, axis=0)
+            faces = np.arange(len(flat), dtype=np.int32).reshape(-1, 3)
     return pos, nrm.astype(np.float32), faces, uv
 
 
@@ -597,7 +607,7 @@ class SceneBuilder:
             pos, nrm, faces, uv = read_stl(path, opt["smooth"])
             meshes = [{"name": "", "material": None, "pos": pos, "nrm": nrm, "faces": faces, "uv": uv}]
         elif ext == ".ply":
-            pos, nrm, faces, uv = read_ply(path)
+            pos, nrm, faces, uv = read_ply(path, opt["smooth"])
             meshes = [{"name": "", "material": None, "pos": pos, "nrm": nrm, "faces": faces, "uv": uv}]
         else:
             raise TclError(f"rtmeshread: {ext or path} files are not supported (ply, obj, stl are)")

@@ -117,7 +117,7 @@ typedef struct crh_stats {
   uint64_t shaded_hits;           /* H                                  */
   uint64_t samples;               /* pixel-samples accumulated (S)      */
   double   seconds;               /* sum of the device time spans of the crh_render* calls (HIP events around each call's launches).  Frames that are
-                                   * pipelined (back-to-back Redraw()s overlap on up to three streams) each contribute their own span, so the sum can
+                                   * pipelined (back-to-back Redraw()s overlap on up to crh_set_pipeline_depth = 2 .. 8 streams) each contribute their own span, so the sum can
                                    * exceed wall time by up to the pipeline depth: use wall time around crh_sync for rates of a free-running loop */
 } crh_stats;
 

@@ -1221,6 +1221,15 @@ ORC_API int orc_set_geometry(orc_ctx* c, const float* pos, const float* nrm, con
   if (tri_obj && xf && nO) {
     /* two-level mode: vertices stay in object space; each object gets its own tree, instances carry the transforms */
     for (uint32_t t = 0; t < nT; ++t) if (tri_obj[t] < 0 || (uint32_t)tri_obj[t] >= nO) { snprintf(c->err, sizeof c->err, "triangle %u object id out of range", t); return CRH_E_INVALID; }
+    /* every vertex belongs to one object (the bake of do_build applies one transform per vertex): same rule, same refusal as the product */
+    int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * (nV ? nV : 1));
+    for (uint32_t v = 0; v < nV; ++v) owner[v] = -1;
+    for (uint32_t t = 0; t < nT; ++t) for (int k = 0; k < 3; ++k) {
+      int32_t* o = &owner[tri[4 * t + k]];
+      if (*o < 0) *o = tri_obj[t];
+      else if (*o != tri_obj[t]) { snprintf(c->err, sizeof c->err, "vertex %d is shared by objects %d and %d: each vertex belongs to one object (duplicate it)", tri[4 * t + k], *o, tri_obj[t]); free(owner); return CRH_E_INVALID; }
+    }
+    free(owner);
     c->xf = (float*)dup_mem(xf, sizeof(float) * 12 * nO); c->tri_obj = (int32_t*)dup_mem(tri_obj, sizeof(int32_t) * nT);
     c->two_level = 1; c->nO = nO;
   }

@@ -51,8 +51,83 @@ def test_ply_round_trip(tmp_path):
     # ascii variant with a quad face and no normals
     (tmp_path / "a.ply").write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
                                     "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    # without normals in the file the reference has assimp generate them (MeshImporter.cxx:80-87): one per FACE unless -gensmooth is given
     ap, an, af, _ = read_ply(str(tmp_path / "a.ply"))
-    assert af.tolist() == [[0, 1, 2], [0, 2, 3]] and np.allclose(an, [0, 0, 1])
+    assert af.tolist() == [[0, 1, 2], [3, 4, 5]] and len(ap) == 6 and np.allclose(an, [0, 0, 1])
+    sp, sn, sf, _ = read_ply(str(tmp_path / "a.ply"), smooth=True)
+    assert sf.tolist() == [[0, 1, 2], [0, 2, 3]] and len(sp) == 4 and np.allclose(sn, [0, 0, 1])
+
+
+def _ply_without_normals(path, with_uv):
+    """a bent strip: smooth and per-face normals differ along the fold"""
+    r = np.random.default_rng(4)
+    xs = np.linspace(0, 1, 9)
+    pos = np.array([[x, y, 0.35 * abs(x - 0.5) + 0.02 * r.standard_normal()] for y in (0.0, 0.5, 1.0) for x in xs], np.float32)
+    faces = []
+    for j in range(2):
+        for i in range(8):
+            a = j * 9 + i
+            faces += [(a, a + 1, a + 10), (a, a + 10, a + 9)]
+    uv = (pos[:, :2] * 2.0).astype(np.float32)
+    with open(path, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n%selement face %d\n"
+                 "property list uchar int vertex_index\nend_header\n" % (len(pos), "property float s\nproperty float t\n" if with_uv else "", len(faces))).encode())
+        f.write(np.concatenate([pos] + ([uv] if with_uv else []), 1).astype("<f4").tobytes())
+        rec = np.zeros(len(faces), np.dtype([("n", "u1"), ("i", "<i4", 3)])); rec["n"] = 3; rec["i"] = faces
+        f.write(rec.tobytes())
+    return pos, np.array(faces, np.int32), uv
+
+
+def _normalless_model(tmp_path, flag, with_uv=True):
+    d = tmp_path / ("m_" + (flag.strip("-") or "flat")); (d / "meshes").mkdir(parents=True)
+    _ply_without_normals(str(d / "meshes" / "Strip.ply"), with_uv)
+    model = d / "model.tcl"
+    model.write_text("variable Root [file dirname [file normalize [info script]]]\nvclear\nvlight clear\n"
+                     f"rtmeshread $Root/meshes/Strip.ply Strip {flag}\nvbsdf Strip -Kd 0.7 0.6 0.5 -Ks 0.2 0.2 0.2 -baseRoughness 0.3\n"
+                     "vlight add directional direction -0.3 0.4 -1 smoothness 0.2 intensity 6\n"
+                     "vcamera -persp -fovy 40\nvviewparams -eye 0.5 -1.6 1.4 -at 0.5 0.5 0.1 -up 0 0 1\nvrenderparams -ray -gi -rayDepth 4\n")
+    return str(model)
+
+
+def test_normal_less_ply_gets_flat_normals_unless_gensmooth(tmp_path):
+    """MeshImporter.cxx:80-87: aiProcess_GenNormals (per-face normals, vertices split per triangle) without -gensmooth, aiProcess_GenSmoothNormals with it;
+    the Python reader and the C++ reader of the saved-scene format hand over the same bytes either way (round-3 verdict item 7)."""
+    from cadrays_amd import scene_io
+    for flag in ("", "-gensmooth", "-gs"):
+        model = _normalless_model(tmp_path, flag)
+        sc, b = read_scene(model, 64, 48)
+        assert not b.unsupported
+        n_tri = 32
+        if flag:
+            assert len(sc.pos) == 27 and len(sc.tri) == n_tri                       # shared vertices kept, area-weighted normals
+            assert len(np.unique(np.round(sc.nrm, 5), axis=0)) > 9
+        else:
+            assert len(sc.pos) == 3 * n_tri and len(sc.tri) == n_tri                # one vertex triple per face
+            nr = sc.nrm.reshape(n_tri, 3, 3)
+            assert np.array_equal(nr[:, 0], nr[:, 1]) and np.array_equal(nr[:, 0], nr[:, 2])
+            e1 = sc.pos[1::3] - sc.pos[0::3]; e2 = sc.pos[2::3] - sc.pos[0::3]
+            fn = np.cross(e1.astype(np.float64), e2.astype(np.float64)); fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+            assert np.allclose(nr[:, 0], fn, atol=1e-6)
+            _, _, _, ruv = read_ply(os.path.join(os.path.dirname(model), "meshes", "Strip.ply"))
+            assert ruv is not None and len(ruv) == 3 * n_tri                        # texture coordinates follow the split vertices
+        a_path, b_path = tmp_path / f"py{flag}.crhscene", tmp_path / f"cpp{flag}.crhscene"
+        scene_io.save_scene(sc, str(a_path))
+        warn = _cpp_dump(model, b_path, "64x48")
+        assert "not honoured" not in warn, warn
+        assert a_path.read_bytes() == b_path.read_bytes(), f"readers disagree about a PLY without normals ({flag or 'no flag'})"
+
+
+@pytest.mark.gpu
+def test_normal_less_ply_renders_bit_exact_on_gpu(tmp_path, hip_lib, oracle_lib):
+    from cadrays_amd.view import View
+    imgs = {}
+    for flag in ("", "-gensmooth"):
+        sc, _ = read_scene(_normalless_model(tmp_path, flag, with_uv=False), 96, 72)
+        v = View(0).load_scene(sc); v.render(4)
+        o = oracle_lib.Oracle().load_scene(sc); o.render(4)
+        assert np.array_equal(v.read_hdr().view(np.uint32), o.read_hdr().view(np.uint32)), flag
+        imgs[flag] = v.read_hdr()
+    assert not np.array_equal(imgs[""], imgs["-gensmooth"])                          # facets against a smooth fold
 
 
 def test_export_format_round_trip(tmp_path):

@@ -417,3 +417,41 @@ def test_split_scene_with_more_moved_objects_than_the_pretest_looks_at(hip_lib, 
         assert np.array_equal(v.read_hdr().view(np.uint32), ref2.view(np.uint32)), mode
         assert all(v.stats()[k] == st2[k] for k in keys), mode
         v.close()
+
+
+def _shared_vertex_scene():
+    """two triangles of two objects that share vertex 1"""
+    pos = np.array([[0, 1, 0], [1, 1, 0], [0, 1, 1], [1, 1, 1]], np.float32)
+    nrm = np.tile(np.array([[0, -1, 0]], np.float32), (4, 1))
+    tri = np.array([[0, 1, 2, 0], [1, 3, 2, 0]], np.int32)
+    return pos, nrm, tri
+
+
+def test_a_vertex_shared_by_two_objects_is_refused_by_the_oracle(oracle_lib):
+    """crh_build bakes a vertex once, under ITS object's build-time transform -- a vertex used by triangles of two objects would silently take
+    the placement of the first.  Both sides refuse the geometry; with the vertex duplicated (what AisMesh.cxx:372-413 emits: one array per object) it loads."""
+    from cadrays_amd.binding import BackendError
+    pos, nrm, tri = _shared_vertex_scene()
+    xf = np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], [1, 0, 0, 0.5, 0, 1, 0, 0, 0, 0, 1, 0]], np.float32)
+    o = oracle_lib.Oracle()
+    with pytest.raises(BackendError, match="shared by objects 0 and 1"):
+        o.set_geometry(pos, nrm, tri, None, np.array([0, 1], np.int32), xf)
+    o.set_geometry(pos, nrm, tri, None, np.array([0, 0], np.int32), xf)                 # one object: fine
+    o.set_geometry(pos, nrm, tri)                                                       # no objects: fine
+    pos2 = np.concatenate([pos, pos[[1, 2]]]); nrm2 = np.concatenate([nrm, nrm[[1, 2]]])
+    tri2 = np.array([[0, 1, 2, 0], [4, 3, 5, 0]], np.int32)
+    o.set_geometry(pos2, nrm2, tri2, None, np.array([0, 1], np.int32), xf)
+    o.close()
+
+
+@pytest.mark.gpu
+def test_a_vertex_shared_by_two_objects_is_refused_by_the_product(hip_lib):
+    from cadrays_amd.binding import BackendError
+    from cadrays_amd.view import View
+    pos, nrm, tri = _shared_vertex_scene()
+    xf = np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], [1, 0, 0, 0.5, 0, 1, 0, 0, 0, 0, 1, 0]], np.float32)
+    v = View(0)
+    with pytest.raises(BackendError, match="shared by objects 0 and 1"):
+        v.set_geometry(pos, nrm, tri, None, np.array([0, 1], np.int32), xf)
+    v.set_geometry(pos, nrm, tri, None, np.array([0, 0], np.int32), xf)
+    v.close()
