@@ -7,19 +7,27 @@ A "step" = one crh_render_tiles pass over the rank's tiles of the workload (defa
 triangles, glass + glossy double-layer BSDFs, HDR sky, 1080p; `--spp` samples per pixel per step, default one full
 256 M-path batch = 128 spp at 1080p).  Inputs are resident in HBM before the timed region.
 
+N = 1, default workload: after the headline leg the OTHER single-GPU configs of BASELINE.json -- C5 (10 M triangles at 4K: the one whose scene does
+not fit the caches, i.e. where HBM is the roof), C2, C1 -- run as short legs (1 warm-up + 4 timed steps) in the same process, each with its own parity
+gates and roofline: config.other_configs_timed.  `value` stays the headline config.  (--other-configs none switches them off.)
+
 N > 1: one process per GPU.  Under `python -m torch.distributed.run` (WORLD_SIZE set) this process is one of the ranks;
 started by hand as `python bench.py --gpus N` it SPAWNS the N rank processes itself -- before torch or the HIP runtime is
-touched in the parent, which only waits for them -- so the advertised command measures N GPUs.  Tiles are interleaved
-across ranks (k-th tile of the Z-order curve -> rank k mod N, cadrays_amd/sharding.py), no collective while rendering, and every step ends with
-the RCCL reduce of the float4 framebuffer to rank 0.
+touched in the parent, which only waits for them -- so the advertised command measures N GPUs.  The BVH is built ONCE (rank 0) and handed to the other
+ranks (crh_build_prebuilt).  Tiles are interleaved across ranks (k-th tile of the Z-order curve -> rank k mod N, cadrays_amd/sharding.py), no
+collective while rendering, and every step ends with the exchange step that assembles the float4 framebuffer on rank 0: the RCCL reduce of whole
+frames or the gather of owned tiles (1 / N of the bytes), whichever is faster on the fabric (timed before the run; --assemble forces one).  The line
+then carries per-rank render / exchange times, the shard balance and both exchange timings (config.per_rank, .assemble, .scene_hand_over).
   --scaling weak   (default) per-GPU work fixed: every rank renders spp*N samples of its 1/N of the tiles per step
   --scaling strong the job is fixed: every rank renders spp samples of its 1/N of the tiles; `--config C4` = C3's scene,
                    4096 spp per step, strong (BASELINE.json configs[3])
 
 Prints ONE JSON line (rank 0): metric Mrays/s (nearest-hit + any-hit rays actually traced, whole job), `roofline` for the
 dominant kernel (k_trace_nearest: HIP-event kernel time measured inside the timed region, algorithmic bytes from the
-deterministic counters, memory-side traffic from the committed rocprofv3 --pmc passes when they belong to THIS build) and
-`cpu_baseline` (the CPU oracle timed on this box's cores on a bounded tile sample of the same workload).
+deterministic counters, memory-side traffic from the committed rocprofv3 --pmc passes when they belong to THIS build), `cpu_baseline` (the CPU
+oracle timed on this box's cores on a bounded tile sample of the same workload) and two parity gates: `parity` (the oracle re-renders sampled tiles of
+the WHOLE timed region) and `parity_step0` (>= 32 tiles of the first timed step's samples, replayed untimed with the same schedule).  A differing
+pixel ends the run with a non-zero exit; a checker that could not run is reported as `checker_errors` and does not.
 """
 import argparse
 import hashlib
@@ -437,19 +445,29 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     if dist is not None:                                      # RCCL builds its rings / channels on first use: keep that out of the timed steps
         timing = {}
         for name, fn in (("reduce", assemble_reduce), ("gather", assemble_gather)):
-            fn(); barrier()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                fn()
-            barrier()
-            tt = torch.tensor([(time.perf_counter() - t1) / 3 * 1e3], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            timing[name] = round(float(tt.item()), 3)
-        mode = args.assemble if args.assemble != "auto" else ("gather" if timing["gather"] < timing["reduce"] else "reduce")
+            try:
+                fn(); barrier()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    fn()
+                barrier()
+                tt = torch.tensor([(time.perf_counter() - t1) / 3 * 1e3], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                timing[name] = round(float(tt.item()), 3)
+            except (RuntimeError, NotImplementedError) as e:          # a backend without this collective refuses it on every rank alike, before anything is sent
+                if name == "reduce":
+                    raise
+                timing[name] = None
+                timing[name + "_error"] = f"{type(e).__name__}: {e}"[:200]
+        if args.assemble == "gather" and timing["gather"] is None:
+            sys.exit("bench.py: --assemble gather, but this backend refused the gather: " + timing["gather_error"])
+        mode = args.assemble if args.assemble != "auto" else ("gather" if timing["gather"] is not None and timing["gather"] < timing["reduce"] else "reduce")
         assemble = assemble_gather if mode == "gather" else assemble_reduce
         assemble_info = {"mode": mode, "chosen_by": "--assemble" if args.assemble != "auto" else "measurement before the timed steps (3 calls each, max over ranks)",
                          "reduce_ms": timing["reduce"], "gather_ms": timing["gather"],
                          "reduce_bytes_per_rank": int(v.width * v.height * 16), "gather_bytes_per_rank": int(gather.bytes_per_rank)}
+        if timing.get("gather_error"):
+            assemble_info["gather_error"] = timing["gather_error"]
         rccl_ranks = dist.get_world_size()                    # as seen after the first collectives
 
     t_render = [0.0]; t_assemble = [0.0]
