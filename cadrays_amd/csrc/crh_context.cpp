@@ -85,10 +85,13 @@ int ensure_paths(crh_ctx* c, uint32_t need)
     if (*ptrs[i]) { CRH_HIP(hipFree(*ptrs[i])); *ptrs[i] = nullptr; }
     CRH_HIP(hipMalloc(ptrs[i], sz[i] * (size_t)need));
   }
+  CRH_HIP(hipMemsetAsync(c->paths.rad, 0, 16 * (size_t)need, cstream(c)));      // no record carries a batch stamp yet (DPaths::stamp is never 0)
   if (!c->queues.counts) { CRH_HIP(hipMalloc((void**)&c->queues.counts, kCounts * sizeof(uint32_t))); CRH_HIP(hipMemsetAsync(c->queues.counts, 0, kCounts * sizeof(uint32_t), cstream(c))); }
   c->path_cap = need;
   return CRH_OK;
 }
+
+uint32_t next_stamp(crh_ctx* c) { if (++c->stamp_counter == 0u) ++c->stamp_counter; return c->stamp_counter; }
 
 int ensure_scratch(crh_ctx* c, size_t bytes)
 {

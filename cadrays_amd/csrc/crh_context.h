@@ -103,6 +103,7 @@ struct ScheduleState {
   uint32_t lookahead = 1, pending_first = 0, pending_n = 0, pending_off = 0, pending_tiles = 0;
   uint32_t lookahead_auto = 0, ramp_k = 1;               // crh_set_lookahead_auto: the batch grows 1, 4, 16, ... after every restart of the accumulation
   DPaths paths{}; DQueues queues{}; uint32_t path_cap = 0;
+  uint32_t stamp_counter = 0;        // DPaths::stamp of the last batch traced (never 0: the radiance buffer is zeroed when it is allocated)
   uint32_t* d_tile_ids = nullptr; uint32_t tile_cap = 0;
   uint32_t* d_seeds = nullptr; uint32_t seed_cap = 0;
   DCounters* d_counters = nullptr;
@@ -197,6 +198,7 @@ int trim_events(crh_ctx* c);
 void discard_events(crh_ctx* c);
 int ensure_paths(crh_ctx* c, uint32_t need);
 int ensure_scratch(crh_ctx* c, size_t bytes);
+uint32_t next_stamp(crh_ctx* c);     // DPaths::stamp for the batch about to be traced
 int alloc_accum(crh_ctx* c);
 int do_reset(crh_ctx* c);
 int build_threads_env();      // CRH_BUILD_THREADS (0: every usable CPU)

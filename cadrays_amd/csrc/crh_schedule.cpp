@@ -71,6 +71,7 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
               bool accumulate = true)
 {
   c->pending_n = 0;                                  // the path buffer is about to be overwritten
+  c->paths.stamp = next_stamp(c);                    // lanes copy it; a look-ahead batch is folded in later by launch_accumulate(c->paths, ...)
   const uint32_t tpp = S.tile_size * S.tile_size;
   const uint64_t total = (uint64_t)nt * tpp * ns;
   // two ranges pay from about a frame's worth of paths (2 M: 173 -> 182 Redraw/s); below that one schedule with a small grid is
@@ -100,7 +101,7 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
     ln.P.thr[0] = P.thr[0] + base; ln.P.thr[1] = P.thr[1] + base; ln.P.hit = P.hit + base; ln.P.rad = P.rad + base;
-    ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base;
+    ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base; ln.P.stamp = P.stamp;
     ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.q2 = Q.q2 + base; ln.Q.q2_sh = Q.q2_sh + base; ln.Q.counts = c->d_lane_counts + kCounts * k;
     CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
     rc = run_lane(c, ln, S, d_tiles + t0, t1 - t0, seed_per_tile ? d_seeds + t0 : d_seeds, ns, seed_per_tile, true); if (rc) return rc;
@@ -182,7 +183,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
     ln.P.thr[0] = P.thr[0] + base; ln.P.thr[1] = P.thr[1] + base; ln.P.hit = P.hit + base; ln.P.rad = P.rad + base;
-    ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base;
+    ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base; ln.P.stamp = next_stamp(c);      // this frame's own stamp
     ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.q2 = Q.q2 + base; ln.Q.q2_sh = Q.q2_sh + base; ln.Q.counts = c->d_lane_counts + kCounts * k;
     CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
     // the frames in flight own path-state slices [k * total, (k + 1) * total): a batch of ANOTHER size (crh_render_tiles with another
@@ -287,6 +288,7 @@ int adaptive_iteration(crh_ctx* c)
                        c->d_tile_ids, c->d_seeds, c->d_adapt_n);
   c->adaptive_picks += c->adaptive_tiles; c->picked_valid = true;
   c->pending_n = 0;
+  c->paths.stamp = next_stamp(c);
   Lane ln{cstream(c), c->paths, c->queues, (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>(512u, (uint64_t)most * tpp / 1024u)),
           (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(512u, (uint64_t)most * tpp / 2048u)), true};      // grids follow the batch (run_batch)
   ln.n_tiles_dev = c->d_adapt_n; ln.donate = c->donate;

@@ -597,7 +597,8 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
         const float4 c = P.sh_c[tag];
         const uint32_t slot = __float_as_uint(c.w);
         float4 r = P.rad[slot];
-        r.x += c.x; r.y += c.y; r.z += c.z;
+        if (__float_as_uint(r.w) != P.stamp) r = make_float4(0.f, 0.f, 0.f, 0.f);      // not written by this batch yet: zero (DPaths::stamp)
+        r.x += c.x; r.y += c.y; r.z += c.z; r.w = __uint_as_float(P.stamp);
         P.rad[slot] = r;
       }
     }, nn, nt, DON ? &s_bound[threadIdx.x & ~63u] : nullptr);
@@ -1154,8 +1155,9 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
       const v3 le = intersect_light(S, o, d, bounce, found ? h.x : CRH_MAXFLOAT, exp_pdf);
       if (le.x > 0.f || le.y > 0.f || le.z > 0.f || !found) {
         const float mis = (bounce == 0u || imp_pdf == CRH_MAXFLOAT) ? 1.0f : (imp_pdf * imp_pdf) / CRH_FMA(exp_pdf, exp_pdf, imp_pdf * imp_pdf);
-        const float4 r4 = first ? zero4 : P.rad[pid];        // the radiance record is touched only when something is added
-        P.rad[pid] = mk4(crh_add3(xyz(r4), crh_scale3(crh_mul3(W, le), mis)), 0.f);
+        float4 r4 = first ? zero4 : P.rad[pid];              // the radiance record is touched only when something is added
+        if (__float_as_uint(r4.w) != P.stamp) r4 = zero4;    // ... and holds this batch's stamp once it has been (DPaths::stamp): anything else reads as zero
+        P.rad[pid] = mk4(crh_add3(xyz(r4), crh_scale3(crh_mul3(W, le), mis)), __uint_as_float(P.stamp));
       } else {
         ++n_shaded;
         // shading record: one 64-B sector {n0 | material, n1 | instance, n2, geometric normal}.  The geometric normal of a
@@ -1212,9 +1214,10 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
           W = crh_mul3(W, crh_mk3(crh_exp(k * (1.0f - bs.ab.x)), crh_exp(k * (1.0f - bs.ab.y)), crh_exp(k * (1.0f - bs.ab.z))));
         }
         if (bs.Le.x != 0.f || bs.Le.y != 0.f || bs.Le.z != 0.f) {      // emissive surfaces are rare: skip the read-modify-write otherwise
-          const float4 r4 = first ? zero4 : P.rad[pid];
-          P.rad[pid] = mk4(crh_add3(xyz(r4), crh_mul3(W, bs.Le)), 0.f);
-        } else if (first) P.rad[pid] = zero4;                          // bounce 0 initialises the record
+          float4 r4 = first ? zero4 : P.rad[pid];
+          if (__float_as_uint(r4.w) != P.stamp) r4 = zero4;
+          P.rad[pid] = mk4(crh_add3(xyz(r4), crh_mul3(W, bs.Le)), __uint_as_float(P.stamp));
+        }                                                              // nobody initialises the record: an unstamped one reads as zero
         uint32_t rng = st.x;
         // ---- next event estimation
         {
@@ -1315,7 +1318,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f); float q = 0.f;
   auto fold = [&](const float4 r) {
     const float w = 1.0f / (a.w + 1.0f);
-    float v[3] = {r.x, r.y, r.z};
+    const bool written = __float_as_uint(r.w) == P.stamp;      // a path that never added anything left its record alone: zero radiance (DPaths::stamp)
+    float v[3] = {written ? r.x : 0.f, written ? r.y : 0.f, written ? r.z : 0.f};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       if (!(v[k] == v[k])) v[k] = 0.f;

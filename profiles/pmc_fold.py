@@ -72,7 +72,7 @@ def main():
                # everything else that was collected, per launch of the timed instantiation (SQ_* activity counters are in quad-cycles summed over
                # the SIMDs; see bench.roofline_ceilings for what is derived from them)
                "counters_per_launch": {k: vals[k] for k in sorted(vals) if k not in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum")},
-               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum / TCC_REQ_sum TCC_READ_sum / SQ groups in separate passes of `bench.py --config %s --steps 2 --warmup 1 --no-cpu --no-interactive --no-parity` (profiles/pmc_collect.sh); bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 x2 read-side correction); memory-side counter, Infinity-Cache hits included" % cfg}
+               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum / TCC_REQ_sum TCC_READ_sum / SQ groups in separate passes of `bench.py --config %s --steps 2 --warmup 1 --no-cpu --no-interactive --no-parity --other-configs none` (profiles/pmc_collect.sh); bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 x2 read-side correction); memory-side counter, Infinity-Cache hits included" % cfg}
         data["configs"][cfg] = ent
         print(cfg, json.dumps(ent))
     json.dump(data, open(path, "w"), indent=1)

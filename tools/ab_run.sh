@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 : > gpurun_out/ab.txt
 run() {
   local name=$1 lib=$2; shift 2
-  CRH_LIB_PATH=$lib python bench.py --no-cpu --steps 3 --warmup 1 "$@" 2>/dev/null | grep "^{" | python -c "
+  CRH_LIB_PATH=$lib python bench.py --no-cpu --other-configs none --steps 3 --warmup 1 "$@" 2>/dev/null | grep "^{" | python -c "
 import sys, json
 for l in sys.stdin:
     j = json.loads(l); r = j['roofline']

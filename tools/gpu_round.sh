@@ -8,10 +8,8 @@ if [ "$2" != "skip-tests" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
   tail -5 $OUT/pytest_gpu.log
 fi
-for cfg in C3 C2 C5 C1; do
-  extra=""; [ $cfg != C3 ] && extra="--no-cpu"
-  timeout 900 python bench.py --config $cfg $extra 2> $OUT/bench_$cfg.err | tail -1 > $OUT/bench_$cfg.json
-  cat $OUT/bench_$cfg.json | cut -c1-400
-done
-bash profiles/pmc_collect.sh $TAG C3 C2 C5 > $OUT/pmc.log 2>&1
+# the default run: the headline (C3) and, after it, the other single-GPU configs as short legs of the same process (config.other_configs_timed)
+timeout 900 python bench.py --steps 20 --warmup 5 2> $OUT/bench_default.err | tail -1 > $OUT/bench_default.json
+cut -c1-400 $OUT/bench_default.json
+bash profiles/pmc_collect.sh $TAG C3 C2 C5 C1 > $OUT/pmc.log 2>&1
 tail -4 $OUT/pmc.log | cut -c1-600

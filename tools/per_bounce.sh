@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu $BENCH_ARGS > /tmp/kt.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu --other-configs none $BENCH_ARGS > /tmp/kt.log 2>&1
 tail -5 /tmp/kt.log; find /tmp/kt -name "*.csv" | head; f=$(ls /tmp/kt/*/*kernel_trace.csv /tmp/kt/*kernel_trace.csv 2>/dev/null | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
