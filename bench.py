@@ -523,6 +523,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
 
     # ---- counting pass (untimed): the same frames again with node / triangle counters on (rank 0's shard)
     roof = None
+    wide_batch = (spp_step * len(tiles) * sc.params.tile_size ** 2) > (12 << 20) and (spp_step & -spp_step) >= 16
     if rank == 0:
         v.reset(); v.enable_counters(True)
         for i in range(steps):
@@ -540,6 +541,9 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
             "kernel_time_share": round(kt["trace_nearest_ms_total"] / max(kt["render_ms_total"], 1e-9), 3),
             "nodes_per_ray": round(cs["nodes_nearest"] / max(cs["rays_nearest"], 1), 2),
             "tris_per_ray": round(cs["tris_nearest"] / max(cs["rays_nearest"], 1), 2),
+            "camera_rays": ("bounce 0 of a wide batch is walked by k_trace_packets (one packet per wavefront: 64 samples of a pixel share the node fetches) + the per-ray "
+                            "fall-back pass for rays that met two triangles at exactly the same distance; it is one of the `launches`, timed like the others; "
+                            "nodes_per_ray / tris_per_ray / alg_bytes are those of the spec's per-ray walk (counting pass), which the packet walk does not exceed per ray") if wide_batch else None,
             "scene_bytes_detail": mem})
 
     # ---- first-timed-step replay (verdict r3 item 4a): the samples of the FIRST timed step again, untimed, same schedule (one wide batch), counters off;

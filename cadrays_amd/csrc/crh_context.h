@@ -110,6 +110,7 @@ struct ScheduleState {
   uint32_t* d_api_cursor = nullptr;   // work cursor of the API-level trace kernels
   void* d_scratch = nullptr; size_t scratch_bytes = 0;
   bool clamp_grid = true;   // persistent traversal grids are clamped to what the register budget keeps resident (kernels.hip, resident_grid)
+  bool packets = true;      // wide batches walk their camera rays as wavefront packets (kernels.hip, k_trace_packets); CRH_PACKETS=0 switches them off
   bool donate = true;       // small batches use the work-donating traversal kernels (kernels.hip, DON); CRH_DONATE=0 switches them off
                             // (measured with plain kernels + wider grids for the first 1-4 bounces: 232 -> 232 / 226 / 222 / 218 Redraw/s: donate from bounce 0)
   // Small batches (one Redraw() = +1 spp of one frame, AppViewer.cxx:1045-1047) are launch- and drain-bound: every traversal

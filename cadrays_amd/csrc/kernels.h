@@ -10,6 +10,7 @@ struct Launch {
   bool counters;     // collect node / triangle counters (slower)
   int cus = 0;       // compute units of the device: persistent traversal grids are clamped to what is resident at once (0: as given)
   bool donate = false;   // small batches: traversal kernels whose idle lanes take over parts of the long rays' stacks (kernels.hip, DON)
+  bool packets = false;  // wide batches: the camera rays (bounce 0) are walked as wavefront packets (kernels.hip, k_trace_packets)
 };
 
 // camera rays for n_samples x n_tiles x tile^2 path slots; fills queue `qsel` and its count

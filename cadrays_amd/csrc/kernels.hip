@@ -536,7 +536,9 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
 // whole queue, walking the static tree only; the kernels that produced the rays listed the ones that touch a moved object in `q` of this launch
 // (DQueues::q2); this pass walks the top-level tree for them, from the distance the first pass found, and overwrites the hit when it finds a nearer
 // one.  Same visits, same hits as one walk "static tree, then top level" -- the rays that never come near a moved object run the plain kernel.
-template <bool COUNT, bool TWO, bool DON, bool P2 = false>
+// FB: the fall-back pass behind k_trace_packets (below) -- the few camera rays whose packet walk met two triangles at EXACTLY the same distance are walked
+// again, one by one, in the order the spec prescribes; its own cursor word, no launch prologue (the packet kernel has done that).
+template <bool COUNT, bool TWO, bool DON, bool P2 = false, bool FB = false>
 __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, int cur, const uint32_t* __restrict__ q,
                                                   const uint32_t* __restrict__ count, uint32_t* __restrict__ cursors,
                                                   uint32_t* zero_a, uint32_t* zero_b, uint32_t* zero_c, uint32_t* zero_d, DCounters* C)
@@ -544,7 +546,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, int cur, co
   __shared__ uint32_t stk[kLdsStack * kBlock];
   __shared__ uint32_t s_bound[DON ? kBlock : 1];
   const uint32_t n = *count;
-  if (!P2 && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (!P2 && !FB && blockIdx.x == 0 && threadIdx.x == 0) {
     *zero_a = 0u; *zero_b = 0u; *zero_c = 0u; *zero_d = 0u;      // the other queue's count, the shadow count, the second-pass counts shading will fill
     cursors[1] = 0u; cursors[2] = 0u; cursors[5] = 0u;            // shade / any-hit / second-pass any-hit cursors for the launches that follow
     atomicAdd(&C->rays_nearest, (unsigned long long)n);
@@ -552,7 +554,7 @@ __global__ CRH_TRACE_BOUNDS void k_trace_nearest(DScene S, DPaths P, int cur, co
   uint32_t nn = 0, nt = 0;
   const float4* __restrict__ ray_o = P.ray_o[cur]; const float4* __restrict__ ray_d = P.ray_d[cur];
   Top2 t2 = top2_of(S); if (P2) t2.root2 = kQEmpty;             // the second pass starts AT the top level
-  trace_engine<false, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, P2 ? S.root2 : S.root, S.guard_box, t2, cursors + (P2 ? 4 : 0), n, &stk[threadIdx.x],
+  trace_engine<false, COUNT, TWO, DON>(S.nodes, S.tris, S.inst_leaf, P2 ? S.root2 : S.root, S.guard_box, t2, cursors + (FB ? 8 : (P2 ? 4 : 0)), n, &stk[threadIdx.x],
     [&](uint32_t idx, v3& o, v3& d, float& tmax, uint32_t& tag) {
       tag = q[idx];
       const float4 o4 = ld_stream(&ray_o[tag]), d4 = ld_stream(&ray_d[tag]);      // .w lanes carry the path's rng state / slot + flags, not ray data
@@ -605,6 +607,152 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
   if (COUNT) {
     nn = wave_sum(nn); nt = wave_sum(nt);
     if (lane_id() == 0) { atomicAdd(&C->nodes_any, (unsigned long long)nn); atomicAdd(&C->tris_any, (unsigned long long)nt); }
+  }
+}
+
+// ================================================================== camera-ray packets
+// Bounce 0 of a wide batch: the 64 consecutive queue entries a wavefront takes are 64 samples of ONE pixel (or of 2 - 4 neighbouring ones: slot_to_pixel_sample)
+// -- rays that differ by a sub-pixel jitter.  Walked one by one (trace_engine) they fetch the same nodes 64 times through the address path and still run at
+// 0.71 of the lanes, because they reach their leaves in different rounds; it is the launch that costs most (20 % of the traversal time, VALU-issue bound:
+// profiles/r4/per_bounce_counters.txt).  Here the WAVEFRONT walks the tree once for all of them:
+//   * one stack per wavefront, held in three VGPRs (lane i = entry i: a select on push, v_readlane on pop), each entry a node reference + the 64-bit mask of the lanes
+//     whose ray entered that child's box; node and triangle records are fetched with SCALAR loads (one request per wavefront instead of 64 lane requests);
+//   * a lane takes part in a node / triangle test iff its bit is set -- exactly the rays that would get there in a walk of their own (the box test, its guard
+//     band and the pruning against the lane's own `best` are the per-ray ones, bit for bit) -- so every lane computes something useful in every instruction;
+//   * children are taken near to far as the FIRST participating lane sees them (its keys, sorted on the scalar unit); children only other lanes hit follow in
+//     slot order.
+// The hit a ray ends with does not depend on the order triangles are tested in -- the nearest one wins -- EXCEPT among triangles at exactly the same distance,
+// where the spec says "the first in the ray's own near-to-far walk" (strict t < best).  A lane that meets such a tie (a valid hit at t == best) is flagged and
+// written to the fall-back queue instead of the hit buffer; k_trace_nearest<.., FB> walks those rays (a handful per million in scenes with shared edges, none
+// in a triangle soup) in the prescribed order afterwards.  Hits are therefore the spec's, bit for bit; node visits are not counted here -- the counting
+// instantiations never use packets.
+constexpr uint32_t kPacketChunk = 1024;      // queue entries (16 packets) per cursor fetch: one counter word sustains ~88 atomics / us
+__device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__global__ __launch_bounds__(kBlock) void k_trace_packets(DScene S, DPaths P, const float4* __restrict__ nodes, const float4* __restrict__ tris,      // = S.nodes, S.tris: as restrict-qualified PARAMETERS the compiler may read them with scalar loads
+                                                          const uint32_t* __restrict__ q, const uint32_t* __restrict__ count,
+                                                          uint32_t* __restrict__ cursors, uint32_t* zero_a, uint32_t* zero_b, uint32_t* zero_c, uint32_t* zero_d,
+                                                          uint32_t* __restrict__ fb_q, uint32_t* __restrict__ fb_count, DCounters* C)
+{
+  const uint32_t n = *count;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *zero_a = 0u; *zero_b = 0u; *zero_c = 0u; *zero_d = 0u;      // as k_trace_nearest: the other queue's count, the shadow count, the second-pass counts
+    cursors[1] = 0u; cursors[2] = 0u; cursors[5] = 0u;
+    atomicAdd(&C->rays_nearest, (unsigned long long)n);
+  }
+  const uint32_t lane = lane_id();
+  const float4* __restrict__ ray_o = P.ray_o[0]; const float4* __restrict__ ray_d = P.ray_d[0];
+  const float4 gb = S.guard_box;
+  for (;;) {
+    uint32_t cbase = 0;
+    if (lane == 0) cbase = atomicAdd(cursors, kPacketChunk);
+    cbase = sgpr(__shfl(cbase, 0));
+    if (cbase >= n) break;
+    const uint32_t cend = min(cbase + kPacketChunk, n);
+    for (uint32_t pb = cbase; pb < cend; pb += 64u) {
+      const uint32_t idx = pb + lane;
+      const bool act = idx < cend;
+      uint32_t tag = 0; v3 o = crh_mk3(0.f, 0.f, 0.f), d = crh_mk3(1.f, 0.f, 0.f);
+      if (act) { tag = q[idx]; const float4 o4 = ld_stream(&ray_o[tag]), d4 = ld_stream(&ray_d[tag]); o = xyz(o4); d = xyz(d4); }
+      const float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
+      const float R = CRH_FMA(gb.w, 3.0f, (crh_abs(o.x - gb.x) + crh_abs(o.y - gb.y)) + crh_abs(o.z - gb.z)) * kSlabGuard;      // trace_engine::set_guard
+      const float gx = crh_abs(ix) * R, gy = crh_abs(iy) * R, gz = crh_abs(iz) * R;
+      const bool sx = ix < 0.f, sy = iy < 0.f, sz = iz < 0.f;
+      float best = CRH_MAXFLOAT; bool found = false, amb = false;
+      float4 hit = make_float4(CRH_MAXFLOAT, 0.f, 0.f, __int_as_float(-1));
+      // the wavefront's stack: lane i of these three registers is entry i
+      uint32_t st_ref = 0, st_mlo = 0, st_mhi = 0; uint32_t sp = 0; bool ovf = false;
+      unsigned long long cm = __ballot(act);
+      uint32_t cur = S.root;
+      while (cm != 0ull) {
+        const bool in = (cm >> lane) & 1ull;
+        if (!(cur & kQLeafBit)) {
+          const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;      // uniform address: scalar loads
+          const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+          const uint32_t ew = __float_as_uint(n0.w);
+          const uint32_t ni = (ew >> 24) & 7u, nch = ew >> 28;
+          const uint32_t base_inner = __float_as_uint(n2.z), base_leaf = __float_as_uint(n2.w) - ni;
+          const float ax = __builtin_amdgcn_ldexpf(ix, (int)(ew << 24) >> 24), ay = __builtin_amdgcn_ldexpf(iy, (int)(ew << 16) >> 24), az = __builtin_amdgcn_ldexpf(iz, (int)(ew << 8) >> 24);
+          const float ddx = n0.x - o.x, ddy = n0.y - o.y, ddz = n0.z - o.z;
+          const uint32_t lx = __float_as_uint(sx ? n1.w : n1.x), ly = __float_as_uint(sy ? n2.x : n1.y), lz = __float_as_uint(sz ? n2.y : n1.z);
+          const uint32_t hx = __float_as_uint(sx ? n1.x : n1.w), hy = __float_as_uint(sy ? n1.y : n2.x), hz = __float_as_uint(sz ? n1.z : n2.y);
+          const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+          const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ddx, ddx}, (f32x2){ix, ix}, (f32x2){-gx, gx});
+          const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (f32x2){-gy, gy});
+          const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ddz, ddz}, (f32x2){iz, iz}, (f32x2){-gz, gz});
+          const uint32_t L = (uint32_t)__builtin_ctzll(cm);                      // the lane whose keys order the children
+          unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+          uint32_t key[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
+#define CRH_PCHILD(K)                                                                                          \
+          if ((uint32_t)K < nch) {                                                                             \
+            const f32x2 tx = __builtin_elementwise_fma((f32x2){CRH_QB(lx, K), CRH_QB(hx, K)}, ax2, bx2);      \
+            const f32x2 ty = __builtin_elementwise_fma((f32x2){CRH_QB(ly, K), CRH_QB(hy, K)}, ay2, by2);      \
+            const f32x2 tz = __builtin_elementwise_fma((f32x2){CRH_QB(lz, K), CRH_QB(hz, K)}, az2, bz2);      \
+            const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
+            const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), best);                                    \
+            mk[K] = __ballot(in && tmin <= tmx);                                                               \
+            if (mk[K] != 0ull) {                                                                               \
+              const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tmin), (int)L);     \
+              key[K] = ((mk[K] >> L) & 1ull) ? ((tb & 0x7FFFFFFCu) | (uint32_t)K) : (0x7F800000u | (uint32_t)K); \
+            }                                                                                                  \
+          }
+          CRH_PCHILD(0) CRH_PCHILD(1) CRH_PCHILD(2) CRH_PCHILD(3)
+#undef CRH_PCHILD
+#undef CRH_QB
+          { // four unique scalar keys, ascending: the children somebody hit come first (0xFFFFFFFF = nobody)
+            uint32_t a0 = min(key[0], key[1]), a1 = max(key[0], key[1]), b0 = min(key[2], key[3]), b1 = max(key[2], key[3]);
+            const uint32_t lo = min(a0, b0), hi = max(a1, b1), m0 = max(a0, b0), m1 = min(a1, b1);
+            key[0] = lo; key[1] = min(m0, m1); key[2] = max(m0, m1); key[3] = hi;
+          }
+#define CRH_PREF(KEY) ((((KEY) & 3u) < ni ? base_inner : base_leaf) + ((KEY) & 3u))
+#define CRH_PMASK(KEY) (((KEY) & 3u) == 0u ? mk[0] : (((KEY) & 3u) == 1u ? mk[1] : (((KEY) & 3u) == 2u ? mk[2] : mk[3])))
+#define CRH_PPUSH(KEY)                                                                                         \
+          if ((KEY) != 0xFFFFFFFFu) {                                                                          \
+            if (sp < 64u) {                                                                                    \
+              const unsigned long long pm = CRH_PMASK(KEY);                                                    \
+              const bool here = lane == sp;                      /* lane `sp` of the three registers takes the entry */ \
+              st_ref = here ? CRH_PREF(KEY) : st_ref;                                                          \
+              st_mlo = here ? (uint32_t)pm : st_mlo;                                                           \
+              st_mhi = here ? (uint32_t)(pm >> 32) : st_mhi;                                                   \
+              ++sp;                                                                                            \
+            } else ovf = true;      /* deeper than any tree of the builder (<= 60 pending entries): the whole packet takes the fall-back pass */ \
+          }
+          CRH_PPUSH(key[3]) CRH_PPUSH(key[2]) CRH_PPUSH(key[1])                   // far .. near
+          if (ovf) break;
+#undef CRH_PPUSH
+          if (key[0] != 0xFFFFFFFFu) { cur = CRH_PREF(key[0]); cm = CRH_PMASK(key[0]); continue; }
+#undef CRH_PMASK
+#undef CRH_PREF
+        } else {
+          const uint32_t ti = cur & 0x0FFFFFFFu;                                  // one triangle per leaf; uniform address: scalar loads
+          const float4* tp = tris + kTriStride * ti;
+          const float4 a = tp[0], b = tp[1], c = tp[2];
+          const v3 v0 = xyz(a), e0 = xyz(b), e1 = xyz(c), nrm = crh_mk3(a.w, b.w, c.w);
+          const v3 to = crh_sub3(v0, o);                                          // trace_engine::tri_step, operation by operation
+          const float inv = 1.0f / crh_dot3(nrm, d);
+          const v3 vc = crh_cross3(d, to);
+          const float tt = crh_dot3(nrm, to) * inv, uu = crh_dot3(vc, e1) * inv, vv = crh_dot3(vc, e0) * inv;
+          if (in && tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f) {
+            if (found && tt == best) amb = true;                                  // two triangles at exactly this distance: the ray's own walk decides (fall-back pass)
+            if (tt < best) { best = tt; found = true; hit = make_float4(tt, uu, vv, __int_as_float((int)ti)); }
+          }
+        }
+        if (sp == 0u) break;
+        --sp;
+        cur = (uint32_t)__builtin_amdgcn_readlane((int)st_ref, (int)sp);
+        cm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)st_mhi, (int)sp) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)st_mlo, (int)sp);
+      }
+      if (ovf) amb = true;
+      if (act && !amb) st_stream(&P.hit[tag], hit);
+      const unsigned long long am = __ballot(act && amb);
+      if (am != 0ull) {
+        uint32_t fb = 0;
+        if (lane == 0) fb = atomicAdd(fb_count, (uint32_t)__popcll(am));
+        fb = __shfl(fb, 0);
+        if (act && amb) fb_q[fb + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = tag;
+      }
+    }
   }
 }
 
@@ -1007,7 +1155,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
   // split scenes: the camera rays that touch a moved object are listed for the second traversal pass (collected per chunk, one atomic per chunk)
   __shared__ uint32_t s_q2[SPLIT ? kGenIters * kBlock : 1];
   __shared__ uint32_t s_n2, s_b2;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { cursors[0] = 0u; cursors[1] = 0u; cursors[2] = 0u; cursors[4] = 0u; cursors[5] = 0u; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { cursors[0] = 0u; cursors[1] = 0u; cursors[2] = 0u; cursors[4] = 0u; cursors[5] = 0u; cursors[7] = 0u; cursors[8] = 0u; }      // [7], [8]: count and cursor of the packet kernel's fall-back queue
   if (threadIdx.x == 0) s_n2 = 0u;
   const uint32_t per_sample = n_tiles * S.tile_size * S.tile_size;
   const uint32_t total = per_sample * n_samples;
@@ -1637,6 +1785,18 @@ void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, con
 {
   // first pass (or the only one): a split scene walks its static tree with the SINGLE-LEVEL instantiation
   const bool two = S.two_level && !S.split;
+  if (L.packets && bounce == 0u && !two && !S.split && !L.counters && !L.donate) {
+    // camera rays of a wide batch: one walk per wavefront of 64 samples (k_trace_packets), then the rays that met a tie one by one (usually none)
+    static int per_cu = 0;
+    if (per_cu == 0) { int nb = 0; per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_packets, kBlock, 0) == hipSuccess && nb > 0) ? nb : -1; }
+    const int grid = (per_cu > 0 && L.cus > 0) ? min(max(L.grid, 8 * L.cus), per_cu * L.cus) : L.grid;
+    hipLaunchKernelGGL(k_trace_packets, dim3(grid), dim3(kBlock), 0, L.stream, S, P, S.nodes, S.tris, Q.q[qin], Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2,
+                       Q.counts + count2_slot(bounce + 1u), Q.counts + 7, Q.q2, Q.counts + 11, C);
+    // (the donating instantiation: a handful of rays, each walked by a whole wavefront)
+    hipLaunchKernelGGL((k_trace_nearest<false, false, true, false, true>), dim3(64), dim3(kBlock), 0, L.stream, S, P, qin, Q.q2, Q.counts + 11, Q.counts + 4,
+                       Q.counts + (1 - qin), Q.counts + 2, Q.counts + count2_slot(bounce + 1u), Q.counts + 7, C);
+    return;
+  }
 #define CRH_LAUNCH_TN(CNT, TWO, DON, P2, QQ, CC) hipLaunchKernelGGL((k_trace_nearest<CNT, TWO, DON, P2>), dim3(resident_grid<k_trace_nearest<CNT, TWO, DON, P2>>(L)), dim3(kBlock), 0, L.stream, S, P, qin, QQ, \
                                                    CC, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2, Q.counts + count2_slot(bounce + 1u), Q.counts + 7, C)
   if (two) { if (L.counters) CRH_LAUNCH_TN(true, true, false, false, Q.q[qin], Q.counts + qin); else if (L.donate) CRH_LAUNCH_TN(false, true, true, false, Q.q[qin], Q.counts + qin); else CRH_LAUNCH_TN(false, true, false, false, Q.q[qin], Q.counts + qin); }

@@ -3,8 +3,8 @@
 
   python3 profiles/pmc_fold.py gpurun_out/pmc_<tag> C3 C2 C5
 
-Per config: per-launch averages of FETCH_SIZE, WRITE_SIZE, TCC_HIT_sum, TCC_MISS_sum of k_trace_nearest<false, *> (the
-timed instantiation; the counting pass of bench.py runs <true, *>) and the kernel's average duration from the kernel trace.
+Per config: per-launch averages of FETCH_SIZE, WRITE_SIZE, TCC_HIT_sum, TCC_MISS_sum of the traversal launches of the timed path -- k_trace_nearest<false, *>
+and, for the camera rays of wide batches, k_trace_packets with its fall-back pass (the counting pass of bench.py runs <true, *>) -- and their average duration from the kernel trace.
   hbm_bytes_per_launch = FETCH_SIZE * 1024 * 2 + WRITE_SIZE * 1024
 (the x2 on the read side is the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests
 at 64 B; cross-check: TCC_MISS_sum * 128 B).  Memory-side counter: Infinity-Cache hits are included, so this is an UPPER bound
@@ -22,7 +22,16 @@ import bench  # noqa: E402  (hash + file location only; imports nothing GPU-rela
 
 
 def timed_kernel(name):
-    return "k_trace_nearest<false" in name.replace(" ", "").replace("(bool)0", "false").replace("<0", "<false")
+    """a traversal launch of the TIMED path: k_trace_nearest<COUNT = false, ...> of bounces 1 .., and k_trace_packets, which walks the camera rays (bounce 0) of
+    wide batches since round 4.  Its fall-back pass (k_trace_nearest<.., FB = true>: the few rays that met a tie) belongs to the bounce-0 launch: its counters
+    are added, it is not counted as a launch of its own (fallback_kernel)."""
+    n = name.replace(" ", "").replace("(bool)0", "false").replace("(bool)1", "true").replace("<0", "<false")
+    return "k_trace_nearest<false" in n or "k_trace_packets" in n
+
+
+def fallback_kernel(name):
+    n = name.replace(" ", "").replace("(bool)0", "false").replace("(bool)1", "true")
+    return "k_trace_nearest<false" in n and n.split("k_trace_nearest<")[1].split(">")[0].split(",")[-1] == "true" and n.split("k_trace_nearest<")[1].split(">")[0].count(",") == 4
 
 
 def counters(d):
@@ -30,7 +39,7 @@ def counters(d):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if timed_kernel(r["Kernel_Name"]):
-                agg[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
+                agg[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 0 if fallback_kernel(r["Kernel_Name"]) else 1
     return {k: agg[k] / cnt[k] for k in agg}, dict(cnt)
 
 
@@ -53,9 +62,12 @@ def main():
             print(f"{cfg}: counters missing ({sorted(vals)})"); continue
         avg_ms = None
         for f in glob.glob(os.path.join(out, cfg, "trace", "**", "*kernel_stats.csv"), recursive=True):
+            tot_ns, calls = 0.0, 0
             for r in csv.DictReader(open(f)):
                 if timed_kernel(r["Name"]):
-                    avg_ms = float(r["AverageNs"]) * 1e-6
+                    tot_ns += float(r["TotalDurationNs"]); calls += 0 if fallback_kernel(r["Name"]) else int(r["Calls"])
+            if calls:
+                avg_ms = tot_ns / calls * 1e-6
         bj = {}
         try:
             bj = json.loads(open(os.path.join(out, cfg + ".bench.json")).read())

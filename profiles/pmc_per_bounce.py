@@ -33,7 +33,7 @@ def one_step(rows, first_kernel):
     """the launches of the SECOND step that contains a timed traversal launch (the first is the warm-up step; the counting pass comes last)"""
     idx = [i for i, r in enumerate(rows) if r["kernel"] == first_kernel] + [len(rows)]
     steps = [rows[idx[k]:idx[k + 1]] for k in range(len(idx) - 1)]
-    good = [st for st in steps if any(r["kernel"] == "k_trace_nearest" for r in st)]
+    good = [st for st in steps if any(r["kernel"] in ("k_trace_nearest", "k_trace_packets") for r in st)]
     return good[1] if len(good) > 1 else (good[0] if good else rows)
 
 
@@ -44,7 +44,7 @@ def timed(name):
 
 def main():
     root, cfgs = sys.argv[1], sys.argv[2:]
-    want = ("k_raygen", "k_trace_nearest", "k_shade", "k_trace_any", "k_accumulate")
+    want = ("k_raygen", "k_trace_packets", "k_trace_nearest", "k_shade", "k_trace_any", "k_accumulate")
     for cfg in cfgs:
         passes = {os.path.basename(d)[4:]: rows_of(d, want) for d in sorted(glob.glob(os.path.join(root, cfg, "pmc_*")))}
         sq = next((v for k, v in passes.items() if k.startswith("SQ_WAVES")), None)
@@ -57,7 +57,11 @@ def main():
             print(f"{'kernel':18s} {'bounce':>6s} {'ms':>8s} {'VALU insts':>12s} {'lane util':>10s} {'VALU issue':>11s} {'read GB':>9s} {'write GB':>9s} {'TB/s':>7s} {'of 8 TB/s':>9s}")
             bounce = collections.Counter()
             for i, r in enumerate(step):
-                b = bounce[r["kernel"]]; bounce[r["kernel"]] += 1
+                grp = "trace" if r["kernel"] in ("k_trace_packets", "k_trace_nearest") else r["kernel"]
+                if r["kernel"] == "k_trace_nearest" and i and step[i - 1]["kernel"] == "k_trace_packets":
+                    b = bounce[grp] - 1                 # the fall-back pass of the packet launch: same bounce
+                else:
+                    b = bounce[grp]; bounce[grp] += 1
                 lane = r["SQ_THREAD_CYCLES_VALU"] / (64.0 * r["SQ_ACTIVE_INST_VALU"]) if r.get("SQ_ACTIVE_INST_VALU") else float("nan")
                 issue = r["SQ_ACTIVE_INST_VALU"] * (r["SQ_WAVES"] / 1024.0) / r["SQ_WAVE_CYCLES"] if r.get("SQ_WAVE_CYCLES") else float("nan")
                 rd = f_step[i]["FETCH_SIZE"] * 1024 * 2 / 1e9 if i < len(f_step) and f_step[i]["kernel"] == r["kernel"] and "FETCH_SIZE" in f_step[i] else float("nan")

@@ -1,0 +1,73 @@
+"""k_trace_packets: the camera rays of a wide batch walk the tree as one packet per wavefront (64 samples of one pixel: one shared stack with lane masks, scalar
+node / triangle fetches).  The hit of a ray must not depend on that -- except among triangles at EXACTLY the same distance, where the spec says "first in the
+ray's own near-to-far walk"; a lane that meets such a tie leaves the packet's result alone and goes through the per-ray kernel afterwards (the fall-back pass).
+  * packets on / off (CRH_PACKETS): identical whole frames, on scenes with shared edges (Cornell: ties happen) and on a triangle soup;
+  * a scene built to tie EVERYWHERE (every triangle twice, bit for bit) -- every camera ray takes the fall-back pass -- still equals the oracle;
+  * partial packets (image edges, tile subsets, 16 / 48 / 80 samples per batch) and the C1 configuration at its real size against the oracle.
+Reference: the reference's gate compares whole images pixel by pixel (testing/CADRays_Testing.py:226-230)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from cadrays_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def render_wide(sc, spp, batches, packets, monkeypatch, tiles=None):
+    from cadrays_amd.view import View
+    monkeypatch.setenv("CRH_PACKETS", "1" if packets else "0")
+    v = View(0).load_scene(sc)
+    v.set_schedule(abi.SCHEDULE_WIDE)
+    t = np.arange(v.n_tiles(), dtype=np.uint32) if tiles is None else tiles
+    for b in range(batches):
+        v.render_tiles(t, b * spp, spp)
+    img, st = v.read_hdr(), v.stats()
+    v.close()
+    return img, st
+
+
+@pytest.mark.parametrize("name,spp", [("cornell", 64), ("cornell_odd_size", 48), ("materials", 32), ("soup", 16), ("soup", 80)])
+def test_packets_do_not_change_a_bit(hip_lib, monkeypatch, name, spp):
+    sc = {"cornell": lambda: scenes.cornell_box(True, 256, 256), "cornell_odd_size": lambda: scenes.cornell_box(True, 203, 131),
+          "materials": lambda: scenes.materials_scene(320, 240, 24, 12), "soup": lambda: scenes.baseline_config("C2", 416, 300, n_tris=60_000)}[name]()
+    a, sa = render_wide(sc, spp, 2, True, monkeypatch)
+    b, sb = render_wide(sc, spp, 2, False, monkeypatch)
+    assert np.array_equal(bits(a), bits(b)), f"{(bits(a) != bits(b)).sum()} words differ"
+    for k in ("rays_nearest", "rays_any", "shaded_hits", "samples"):
+        assert sa[k] == sb[k]
+
+
+def test_every_camera_ray_in_the_fall_back_pass(hip_lib, oracle_lib, monkeypatch):
+    """every triangle of the Cornell box TWICE (the copy appended: same vertices, same bits): each camera ray that hits anything meets two triangles at
+    exactly the same distance, the walk order decides which one it reports -- packets must hand every such ray to the per-ray pass"""
+    sc = scenes.cornell_box(True, 160, 128)
+    tri2 = np.concatenate([sc.tri, sc.tri[::-1]])              # the copies in reverse order: another builder order than the originals
+    sc2 = dataclasses.replace(sc, tri=tri2)
+    o = oracle_lib.Oracle().load_scene(sc2); o.render(32)
+    ref = o.read_hdr(); o.close()
+    img, _ = render_wide(sc2, 32, 1, True, monkeypatch)
+    assert np.array_equal(bits(img), bits(ref))
+    img0, _ = render_wide(sc2, 32, 1, False, monkeypatch)
+    assert np.array_equal(bits(img0), bits(ref))
+
+
+def test_partial_packets_and_tile_subsets_against_the_oracle(hip_lib, oracle_lib, monkeypatch):
+    sc = scenes.baseline_config("C3", 300, 170, n_tris=30_000)      # 300 x 170 in 32 x 32 tiles: partial tiles right and bottom
+    sc.env = scenes.procedural_sky(256, 128, 1)
+    o = oracle_lib.Oracle().load_scene(sc)
+    sub = np.array([0, 3, 9, 10, 17, 29, 41, 50, 59], np.uint32)     # includes edge tiles (column 9, row 5)
+    o.render_tiles(sub, 16, 48)
+    ref = o.read_accum(); o.close()
+    img, _ = render_wide(sc, 48, 1, True, monkeypatch, tiles=sub)
+    from cadrays_amd.view import View
+    monkeypatch.setenv("CRH_PACKETS", "1")
+    v = View(0).load_scene(sc); v.set_schedule(abi.SCHEDULE_WIDE); v.render_tiles(sub, 16, 48)
+    g = v.read_hdr(); v.close()
+    mask = ref[..., 3] == 48
+    assert mask.sum() > 5000 and np.array_equal(bits(g[mask]), bits(ref[..., :3][mask]))
