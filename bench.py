@@ -523,7 +523,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
 
     # ---- counting pass (untimed): the same frames again with node / triangle counters on (rank 0's shard)
     roof = None
-    wide_batch = (spp_step * len(tiles) * sc.params.tile_size ** 2) > (12 << 20) and (spp_step & -spp_step) >= 16
+    wide_batch = (spp_step * len(tiles) * sc.params.tile_size ** 2) > (12 << 20) and (spp_step & -spp_step) >= 64      # crh_context.h: packets from 64 consecutive samples per pixel on
     if rank == 0:
         v.reset(); v.enable_counters(True)
         for i in range(steps):

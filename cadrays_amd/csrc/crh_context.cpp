@@ -138,7 +138,7 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_BUILD_VERBOSE",      "crh_build prints its phases and their times on stderr"},
   {"CRH_MAX_PATHS",          "path slots per batch, 1024 .. 2^30 (default 2^28); the same knob as crh_set_path_budget"},
   {"CRH_DONATE",             "0: small batches use the plain traversal kernels instead of the work-donating ones (reference schedule of the sequence tests)"},
-  {"CRH_PACKETS",            "0: the camera rays of wide batches are walked one by one like every other bounce instead of as wavefront packets (k_trace_packets)"},
+  {"CRH_PACKETS",            "smallest run of consecutive samples per pixel from which the camera rays of a wide batch are walked as wavefront packets (k_trace_packets); default 64 = one pixel per wavefront, 0 = never"},
   {"CRH_PIPELINE",           "0: free-running Redraw()s are not pipelined across streams (reference schedule of the sequence tests)"},
   {"CRH_PIPE_DEPTH",         "frames in flight of free-running Redraw()s, 2 .. 8; the same knob as crh_set_pipeline_depth (crh_query_pipeline_capacity says what the process supports)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
@@ -163,7 +163,7 @@ static void read_env(crh_ctx* c)
 {
   if (const char* e = getenv("CRH_MAX_PATHS")) { long v = atol(e); if (v >= 1024) c->max_paths = (uint32_t)std::min<long>(v, 1l << 30); }   // a path slot travels in 31 bits
   if (const char* e = getenv("CRH_DONATE")) c->donate = atoi(e) != 0;
-  if (const char* e = getenv("CRH_PACKETS")) c->packets = atoi(e) != 0;
+  if (const char* e = getenv("CRH_PACKETS")) c->packets = atoi(e);
   if (const char* e = getenv("CRH_SPLIT_PASSES")) c->split_passes = atoi(e);
   if (const char* e = getenv("CRH_PIPELINE")) c->pipeline = atoi(e) != 0;
   if (const char* e = getenv("CRH_PIPE_DEPTH")) { int v = atoi(e); if (v >= 2 && v <= (int)pipeline_capacity()) c->pipe_depth = (uint32_t)v; }

@@ -110,7 +110,7 @@ struct ScheduleState {
   uint32_t* d_api_cursor = nullptr;   // work cursor of the API-level trace kernels
   void* d_scratch = nullptr; size_t scratch_bytes = 0;
   bool clamp_grid = true;   // persistent traversal grids are clamped to what the register budget keeps resident (kernels.hip, resident_grid)
-  bool packets = true;      // wide batches walk their camera rays as wavefront packets (kernels.hip, k_trace_packets); CRH_PACKETS=0 switches them off
+  int packets = 64;         // smallest run of consecutive samples per pixel (sample_group) from which wide batches walk their camera rays as wavefront packets (kernels.hip, k_trace_packets): 64 = a wavefront is ONE pixel (C3 +3.3 % at 128 spp per batch, +1.6 % at 64); with two / four pixels per wavefront (32 / 16 samples each) the shared walk loses (C3 -2 % / -5.6 %); CRH_PACKETS=<n> sets the threshold, 0 switches packets off
   bool donate = true;       // small batches use the work-donating traversal kernels (kernels.hip, DON); CRH_DONATE=0 switches them off
                             // (measured with plain kernels + wider grids for the first 1-4 bounces: 232 -> 232 / 226 / 222 / 218 Redraw/s: donate from bounce 0)
   // Small batches (one Redraw() = +1 spp of one frame, AppViewer.cxx:1045-1047) are launch- and drain-bound: every traversal

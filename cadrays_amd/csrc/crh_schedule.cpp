@@ -30,7 +30,8 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
   Launch L{ln.stream, ln.grid, c->counters_on};
   Launch LT{ln.stream, ln.grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0, ln.donate && !c->counters_on};
   // wide batches (a wavefront = >= 16 consecutive samples of one pixel): the camera rays are walked as packets (kernels.hip, k_trace_packets)
-  LT.packets = c->packets && !c->counters_on && !ln.donate && std::min<uint32_t>(ns & (0u - ns), 64u) >= 16u;
+  // (small batches -- a wavefront = an 8 x 8 pixel block -- lose with packets: 468 -> 391 Redraw/s, profiles/r4/ab_camera_ray_packets.txt)
+  LT.packets = c->packets > 0 && !c->counters_on && !ln.donate && std::min<uint32_t>(ns & (0u - ns), 64u) >= (uint32_t)c->packets;
 
   launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev);
   int qin = 0;

@@ -21,7 +21,7 @@ def bits(a):
 
 def render_wide(sc, spp, batches, packets, monkeypatch, tiles=None):
     from cadrays_amd.view import View
-    monkeypatch.setenv("CRH_PACKETS", "1" if packets else "0")
+    monkeypatch.setenv("CRH_PACKETS", "16" if packets else "0")      # 16: packets also where a wavefront holds 2 - 4 pixels (the default threshold is 64)
     v = View(0).load_scene(sc)
     v.set_schedule(abi.SCHEDULE_WIDE)
     t = np.arange(v.n_tiles(), dtype=np.uint32) if tiles is None else tiles
@@ -66,7 +66,7 @@ def test_partial_packets_and_tile_subsets_against_the_oracle(hip_lib, oracle_lib
     ref = o.read_accum(); o.close()
     img, _ = render_wide(sc, 48, 1, True, monkeypatch, tiles=sub)
     from cadrays_amd.view import View
-    monkeypatch.setenv("CRH_PACKETS", "1")
+    monkeypatch.setenv("CRH_PACKETS", "16")
     v = View(0).load_scene(sc); v.set_schedule(abi.SCHEDULE_WIDE); v.render_tiles(sub, 16, 48)
     g = v.read_hdr(); v.close()
     mask = ref[..., 3] == 48
