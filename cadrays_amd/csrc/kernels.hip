@@ -629,7 +629,101 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
 constexpr uint32_t kPacketChunk = 1024;      // queue entries (16 packets) per cursor fetch: one counter word sustains ~88 atomics / us
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-__global__ __launch_bounds__(kBlock) void k_trace_packets(DScene S, DPaths P, const float4* __restrict__ nodes, const float4* __restrict__ tris,      // = S.nodes, S.tris: as restrict-qualified PARAMETERS the compiler may read them with scalar loads
+template <int OCT>
+__device__ __forceinline__ void packet_walk(const float4* __restrict__ nodes, const float4* __restrict__ tris, uint32_t root, uint32_t lane, bool act,
+                                            v3 o, v3 d, float ix, float iy, float iz, float gx, float gy, float gz, float4& hit, bool& amb)
+{
+  float best = CRH_MAXFLOAT; bool found = false;
+  // OCT < 8: the direction signs of the whole packet (bit 0 / 1 / 2 = x / y / z negative), known at compile time -- the lower / upper byte words of a node are
+  // then picked by REGISTER CHOICE (scalar operands of v_cvt_f32_ubyte) instead of six selects per visit; OCT = 8: mixed signs, per-lane selects
+  const bool sx = OCT < 8 ? (OCT & 1) != 0 : ix < 0.f, sy = OCT < 8 ? (OCT & 2) != 0 : iy < 0.f, sz = OCT < 8 ? (OCT & 4) != 0 : iz < 0.f;
+  // the wavefront's stack: lane i of these three registers is entry i
+  uint32_t st_ref = 0, st_mlo = 0, st_mhi = 0; uint32_t sp = 0; bool ovf = false;
+  unsigned long long cm = __ballot(act);
+  uint32_t cur = root;
+  while (cm != 0ull) {
+    const bool in = (cm >> lane) & 1ull;
+    if (!(cur & kQLeafBit)) {
+      const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;      // uniform address: scalar loads
+      const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+      const uint32_t ew = __float_as_uint(n0.w);
+      const uint32_t ni = (ew >> 24) & 7u, nch = ew >> 28;
+      const uint32_t base_inner = __float_as_uint(n2.z), base_leaf = __float_as_uint(n2.w) - ni;
+      const float ax = __builtin_amdgcn_ldexpf(ix, (int)(ew << 24) >> 24), ay = __builtin_amdgcn_ldexpf(iy, (int)(ew << 16) >> 24), az = __builtin_amdgcn_ldexpf(iz, (int)(ew << 8) >> 24);
+      const float ddx = n0.x - o.x, ddy = n0.y - o.y, ddz = n0.z - o.z;
+      const uint32_t lx = __float_as_uint(sx ? n1.w : n1.x), ly = __float_as_uint(sy ? n2.x : n1.y), lz = __float_as_uint(sz ? n2.y : n1.z);
+      const uint32_t hx = __float_as_uint(sx ? n1.x : n1.w), hy = __float_as_uint(sy ? n1.y : n2.x), hz = __float_as_uint(sz ? n1.z : n2.y);
+      const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+      const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ddx, ddx}, (f32x2){ix, ix}, (f32x2){-gx, gx});
+      const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (f32x2){-gy, gy});
+      const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ddz, ddz}, (f32x2){iz, iz}, (f32x2){-gz, gz});
+      const uint32_t L = (uint32_t)__builtin_ctzll(cm);                      // the lane whose keys order the children
+      unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
+      uint32_t key[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
+#define CRH_PCHILD(K)                                                                                          \
+      if ((uint32_t)K < nch) {                                                                             \
+        const f32x2 tx = __builtin_elementwise_fma((f32x2){CRH_QB(lx, K), CRH_QB(hx, K)}, ax2, bx2);      \
+        const f32x2 ty = __builtin_elementwise_fma((f32x2){CRH_QB(ly, K), CRH_QB(hy, K)}, ay2, by2);      \
+        const f32x2 tz = __builtin_elementwise_fma((f32x2){CRH_QB(lz, K), CRH_QB(hz, K)}, az2, bz2);      \
+        const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
+        const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), best);                                    \
+        const bool hitk = tmin <= tmx;                                                                     \
+        mk[K] = __builtin_amdgcn_ballot_w64(hitk) & cm;      /* every lane of the wavefront runs this loop: the vote is a plain compare into a scalar pair */ \
+        const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(hitk ? tmin : __builtin_inff()), (int)L); /* lane L is in cm: +inf when it misses this child */ \
+        key[K] = mk[K] != 0ull ? ((tb & 0x7FFFFFFCu) | (uint32_t)K) : 0xFFFFFFFFu;                         \
+      }
+      CRH_PCHILD(0) CRH_PCHILD(1) CRH_PCHILD(2) CRH_PCHILD(3)
+#undef CRH_PCHILD
+#undef CRH_QB
+      { // four unique scalar keys, ascending: the children somebody hit come first (0xFFFFFFFF = nobody)
+        uint32_t a0 = min(key[0], key[1]), a1 = max(key[0], key[1]), b0 = min(key[2], key[3]), b1 = max(key[2], key[3]);
+        const uint32_t lo = min(a0, b0), hi = max(a1, b1), m0 = max(a0, b0), m1 = min(a1, b1);
+        key[0] = lo; key[1] = min(m0, m1); key[2] = max(m0, m1); key[3] = hi;
+      }
+#define CRH_PREF(KEY) ((((KEY) & 3u) < ni ? base_inner : base_leaf) + ((KEY) & 3u))
+#define CRH_PMASK(KEY) (((KEY) & 3u) == 0u ? mk[0] : (((KEY) & 3u) == 1u ? mk[1] : (((KEY) & 3u) == 2u ? mk[2] : mk[3])))
+#define CRH_PPUSH(KEY)                                                                                         \
+      if ((KEY) != 0xFFFFFFFFu) {                                                                          \
+        if (sp < 64u) {                                                                                    \
+          const unsigned long long pm = CRH_PMASK(KEY);                                                    \
+          const bool here = lane == sp;                      /* lane `sp` of the three registers takes the entry */ \
+          st_ref = here ? CRH_PREF(KEY) : st_ref;                                                          \
+          st_mlo = here ? (uint32_t)pm : st_mlo;                                                           \
+          st_mhi = here ? (uint32_t)(pm >> 32) : st_mhi;                                                   \
+          ++sp;                                                                                            \
+        } else ovf = true;      /* deeper than any tree of the builder (<= 60 pending entries): the whole packet takes the fall-back pass */ \
+      }
+      CRH_PPUSH(key[3]) CRH_PPUSH(key[2]) CRH_PPUSH(key[1])                   // far .. near
+      if (ovf) break;
+#undef CRH_PPUSH
+      if (key[0] != 0xFFFFFFFFu) { cur = CRH_PREF(key[0]); cm = CRH_PMASK(key[0]); continue; }
+#undef CRH_PMASK
+#undef CRH_PREF
+    } else {
+      const uint32_t ti = cur & 0x0FFFFFFFu;                                  // one triangle per leaf; uniform address: scalar loads
+      const float4* tp = tris + kTriStride * ti;
+      const float4 a = tp[0], b = tp[1], c = tp[2];
+      const v3 v0 = xyz(a), e0 = xyz(b), e1 = xyz(c), nrm = crh_mk3(a.w, b.w, c.w);
+      const v3 to = crh_sub3(v0, o);                                          // trace_engine::tri_step, operation by operation
+      const float inv = 1.0f / crh_dot3(nrm, d);
+      const v3 vc = crh_cross3(d, to);
+      const float tt = crh_dot3(nrm, to) * inv, uu = crh_dot3(vc, e1) * inv, vv = crh_dot3(vc, e0) * inv;
+      const bool ok = in && tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f;
+      amb = amb || (ok && found && tt == best);                               // two triangles at exactly this distance: the ray's own walk decides (fall-back pass)
+      const bool acc = ok && tt < best;                                       // selects, not branches: every lane of the wavefront is here anyway
+      best = acc ? tt : best; found = found || acc;
+      hit.x = acc ? tt : hit.x; hit.y = acc ? uu : hit.y; hit.z = acc ? vv : hit.z; hit.w = acc ? __int_as_float((int)ti) : hit.w;
+    }
+    if (sp == 0u) break;
+    --sp;
+    cur = (uint32_t)__builtin_amdgcn_readlane((int)st_ref, (int)sp);
+    cm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)st_mhi, (int)sp) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)st_mlo, (int)sp);
+  }
+  if (ovf) amb = true;
+}
+
+__global__ __launch_bounds__(kBlock, 8) void k_trace_packets(DScene S, DPaths P, const float4* __restrict__ nodes, const float4* __restrict__ tris,      // = S.nodes, S.tris: as restrict-qualified PARAMETERS the compiler may read them with scalar loads
                                                           const uint32_t* __restrict__ q, const uint32_t* __restrict__ count,
                                                           uint32_t* __restrict__ cursors, uint32_t* zero_a, uint32_t* zero_b, uint32_t* zero_c, uint32_t* zero_d,
                                                           uint32_t* __restrict__ fb_q, uint32_t* __restrict__ fb_count, DCounters* C)
@@ -657,93 +751,16 @@ __global__ __launch_bounds__(kBlock) void k_trace_packets(DScene S, DPaths P, co
       const float ix = inv_dir(d.x), iy = inv_dir(d.y), iz = inv_dir(d.z);
       const float R = CRH_FMA(gb.w, 3.0f, (crh_abs(o.x - gb.x) + crh_abs(o.y - gb.y)) + crh_abs(o.z - gb.z)) * kSlabGuard;      // trace_engine::set_guard
       const float gx = crh_abs(ix) * R, gy = crh_abs(iy) * R, gz = crh_abs(iz) * R;
-      const bool sx = ix < 0.f, sy = iy < 0.f, sz = iz < 0.f;
-      float best = CRH_MAXFLOAT; bool found = false, amb = false;
-      float4 hit = make_float4(CRH_MAXFLOAT, 0.f, 0.f, __int_as_float(-1));
-      // the wavefront's stack: lane i of these three registers is entry i
-      uint32_t st_ref = 0, st_mlo = 0, st_mhi = 0; uint32_t sp = 0; bool ovf = false;
-      unsigned long long cm = __ballot(act);
-      uint32_t cur = S.root;
-      while (cm != 0ull) {
-        const bool in = (cm >> lane) & 1ull;
-        if (!(cur & kQLeafBit)) {
-          const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;      // uniform address: scalar loads
-          const float4 n0 = np[0], n1 = np[1], n2 = np[2];
-          const uint32_t ew = __float_as_uint(n0.w);
-          const uint32_t ni = (ew >> 24) & 7u, nch = ew >> 28;
-          const uint32_t base_inner = __float_as_uint(n2.z), base_leaf = __float_as_uint(n2.w) - ni;
-          const float ax = __builtin_amdgcn_ldexpf(ix, (int)(ew << 24) >> 24), ay = __builtin_amdgcn_ldexpf(iy, (int)(ew << 16) >> 24), az = __builtin_amdgcn_ldexpf(iz, (int)(ew << 8) >> 24);
-          const float ddx = n0.x - o.x, ddy = n0.y - o.y, ddz = n0.z - o.z;
-          const uint32_t lx = __float_as_uint(sx ? n1.w : n1.x), ly = __float_as_uint(sy ? n2.x : n1.y), lz = __float_as_uint(sz ? n2.y : n1.z);
-          const uint32_t hx = __float_as_uint(sx ? n1.x : n1.w), hy = __float_as_uint(sy ? n1.y : n2.x), hz = __float_as_uint(sz ? n1.z : n2.y);
-          const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
-          const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ddx, ddx}, (f32x2){ix, ix}, (f32x2){-gx, gx});
-          const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (f32x2){-gy, gy});
-          const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ddz, ddz}, (f32x2){iz, iz}, (f32x2){-gz, gz});
-          const uint32_t L = (uint32_t)__builtin_ctzll(cm);                      // the lane whose keys order the children
-          unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
-          uint32_t key[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
-#define CRH_PCHILD(K)                                                                                          \
-          if ((uint32_t)K < nch) {                                                                             \
-            const f32x2 tx = __builtin_elementwise_fma((f32x2){CRH_QB(lx, K), CRH_QB(hx, K)}, ax2, bx2);      \
-            const f32x2 ty = __builtin_elementwise_fma((f32x2){CRH_QB(ly, K), CRH_QB(hy, K)}, ay2, by2);      \
-            const f32x2 tz = __builtin_elementwise_fma((f32x2){CRH_QB(lz, K), CRH_QB(hz, K)}, az2, bz2);      \
-            const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
-            const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), best);                                    \
-            mk[K] = __ballot(in && tmin <= tmx);                                                               \
-            if (mk[K] != 0ull) {                                                                               \
-              const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tmin), (int)L);     \
-              key[K] = ((mk[K] >> L) & 1ull) ? ((tb & 0x7FFFFFFCu) | (uint32_t)K) : (0x7F800000u | (uint32_t)K); \
-            }                                                                                                  \
-          }
-          CRH_PCHILD(0) CRH_PCHILD(1) CRH_PCHILD(2) CRH_PCHILD(3)
-#undef CRH_PCHILD
-#undef CRH_QB
-          { // four unique scalar keys, ascending: the children somebody hit come first (0xFFFFFFFF = nobody)
-            uint32_t a0 = min(key[0], key[1]), a1 = max(key[0], key[1]), b0 = min(key[2], key[3]), b1 = max(key[2], key[3]);
-            const uint32_t lo = min(a0, b0), hi = max(a1, b1), m0 = max(a0, b0), m1 = min(a1, b1);
-            key[0] = lo; key[1] = min(m0, m1); key[2] = max(m0, m1); key[3] = hi;
-          }
-#define CRH_PREF(KEY) ((((KEY) & 3u) < ni ? base_inner : base_leaf) + ((KEY) & 3u))
-#define CRH_PMASK(KEY) (((KEY) & 3u) == 0u ? mk[0] : (((KEY) & 3u) == 1u ? mk[1] : (((KEY) & 3u) == 2u ? mk[2] : mk[3])))
-#define CRH_PPUSH(KEY)                                                                                         \
-          if ((KEY) != 0xFFFFFFFFu) {                                                                          \
-            if (sp < 64u) {                                                                                    \
-              const unsigned long long pm = CRH_PMASK(KEY);                                                    \
-              const bool here = lane == sp;                      /* lane `sp` of the three registers takes the entry */ \
-              st_ref = here ? CRH_PREF(KEY) : st_ref;                                                          \
-              st_mlo = here ? (uint32_t)pm : st_mlo;                                                           \
-              st_mhi = here ? (uint32_t)(pm >> 32) : st_mhi;                                                   \
-              ++sp;                                                                                            \
-            } else ovf = true;      /* deeper than any tree of the builder (<= 60 pending entries): the whole packet takes the fall-back pass */ \
-          }
-          CRH_PPUSH(key[3]) CRH_PPUSH(key[2]) CRH_PPUSH(key[1])                   // far .. near
-          if (ovf) break;
-#undef CRH_PPUSH
-          if (key[0] != 0xFFFFFFFFu) { cur = CRH_PREF(key[0]); cm = CRH_PMASK(key[0]); continue; }
-#undef CRH_PMASK
-#undef CRH_PREF
-        } else {
-          const uint32_t ti = cur & 0x0FFFFFFFu;                                  // one triangle per leaf; uniform address: scalar loads
-          const float4* tp = tris + kTriStride * ti;
-          const float4 a = tp[0], b = tp[1], c = tp[2];
-          const v3 v0 = xyz(a), e0 = xyz(b), e1 = xyz(c), nrm = crh_mk3(a.w, b.w, c.w);
-          const v3 to = crh_sub3(v0, o);                                          // trace_engine::tri_step, operation by operation
-          const float inv = 1.0f / crh_dot3(nrm, d);
-          const v3 vc = crh_cross3(d, to);
-          const float tt = crh_dot3(nrm, to) * inv, uu = crh_dot3(vc, e1) * inv, vv = crh_dot3(vc, e0) * inv;
-          if (in && tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f) {
-            if (found && tt == best) amb = true;                                  // two triangles at exactly this distance: the ray's own walk decides (fall-back pass)
-            if (tt < best) { best = tt; found = true; hit = make_float4(tt, uu, vv, __int_as_float((int)ti)); }
-          }
-        }
-        if (sp == 0u) break;
-        --sp;
-        cur = (uint32_t)__builtin_amdgcn_readlane((int)st_ref, (int)sp);
-        cm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)st_mhi, (int)sp) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)st_mlo, (int)sp);
+      float4 hit = make_float4(CRH_MAXFLOAT, 0.f, 0.f, __int_as_float(-1)); bool amb = false;
+      {
+        // the packet's direction signs: uniform over the wavefront for all but the packets that straddle an axis of the view -- one specialised walk per octant
+        const unsigned long long am_ = __ballot(act), bx_ = __ballot(act && ix < 0.f), by_ = __ballot(act && iy < 0.f), bz_ = __ballot(act && iz < 0.f);
+        const bool uni = (bx_ == 0ull || bx_ == am_) && (by_ == 0ull || by_ == am_) && (bz_ == 0ull || bz_ == am_);
+        const uint32_t oct = uni ? ((bx_ ? 1u : 0u) | (by_ ? 2u : 0u) | (bz_ ? 4u : 0u)) : 8u;
+#define CRH_WALK(O) case O: packet_walk<O>(nodes, tris, S.root, lane, act, o, d, ix, iy, iz, gx, gy, gz, hit, amb); break;
+        switch (oct) { CRH_WALK(0) CRH_WALK(1) CRH_WALK(2) CRH_WALK(3) CRH_WALK(4) CRH_WALK(5) CRH_WALK(6) CRH_WALK(7) default: packet_walk<8>(nodes, tris, S.root, lane, act, o, d, ix, iy, iz, gx, gy, gz, hit, amb); }
+#undef CRH_WALK
       }
-      if (ovf) amb = true;
       if (act && !amb) st_stream(&P.hit[tag], hit);
       const unsigned long long am = __ballot(act && amb);
       if (am != 0ull) {
