@@ -71,3 +71,25 @@ def test_partial_packets_and_tile_subsets_against_the_oracle(hip_lib, oracle_lib
     g = v.read_hdr(); v.close()
     mask = ref[..., 3] == 48
     assert mask.sum() > 5000 and np.array_equal(bits(g[mask]), bits(ref[..., :3][mask]))
+
+
+# the packet walk is instantiated once per direction octant (the byte words of a node are picked by register choice) plus once with per-lane signs for the
+# packets that straddle an axis of the view: every one of the nine must give the per-ray walk's hits
+_OCTANT_VIEWS = [(sx, sy, sz, 20.0) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)] + [(1, 0, 0, 70.0), (0, -1, 0, 70.0), (0, 0, 1, 70.0)]
+
+
+@pytest.mark.parametrize("dx,dy,dz,fov", _OCTANT_VIEWS)
+def test_every_direction_octant_and_the_axis_straddling_packets(hip_lib, oracle_lib, monkeypatch, dx, dy, dz, fov):
+    sc = scenes.baseline_config("C2", 192, 160, n_tris=40_000)
+    d = np.array([dx, dy, dz], np.float64); d /= np.linalg.norm(d)
+    up = (0.0, 0.0, 1.0) if abs(d[2]) < 0.9 else (0.0, 1.0, 0.0)
+    # narrow views from outside along a diagonal: every pixel's directions share the signs (dx, dy, dz); wide views along an axis: the centre packets mix them
+    sc = dataclasses.replace(sc, camera=dataclasses.replace(sc.camera, eye=tuple(-3.2 * d), dir=tuple(d), up=up, fovy_deg=fov))
+    a, sa = render_wide(sc, 64, 1, True, monkeypatch)
+    b, sb = render_wide(sc, 64, 1, False, monkeypatch)
+    assert sa["rays_nearest"] == sb["rays_nearest"] and sa["shaded_hits"] == sb["shaded_hits"] and sa["shaded_hits"] > 50_000
+    assert np.array_equal(bits(a), bits(b)), f"{(bits(a) != bits(b)).sum()} words differ"
+    if (dx, dy, dz) in ((1, 1, 1), (-1, 1, -1), (0, -1, 0)):
+        o = oracle_lib.Oracle().load_scene(sc); o.render(64)
+        ref = o.read_hdr(); o.close()
+        assert np.array_equal(bits(a), bits(ref))
