@@ -105,6 +105,33 @@ def test_stale_counter_traffic_is_refused(tmp_path, monkeypatch):
     assert bench.pmc_entry("C3", 64, False)[0] is None and bench.pmc_entry("C3", 128, True)[0] is None
 
 
+def test_counter_passes_of_this_run_replace_the_committed_bytes(tmp_path, monkeypatch):
+    """roofline.traffic from counter passes started by the run itself (bench.live_traffic): used when they worked, reported beside the committed bytes of the same
+    build, usable even when the committed file is stale; a failed pass falls back to the committed figures and says why"""
+    sys.path.insert(0, ROOT)
+    import bench
+    f = tmp_path / "pmc.json"
+    ent = {"source_hash": bench.kernel_source_hash(), "spp_per_step": 128, "hbm_bytes_per_launch": 1.0e11, "tcc_hit_per_launch": 6.0, "tcc_miss_per_launch": 4.0}
+    f.write_text(json.dumps({"configs": {"C3": ent}}))
+    monkeypatch.setattr(bench, "PMC_FILE", str(f))
+    live = {"fetch_size_kb_per_launch": 4.0e7, "write_size_kb_per_launch": 1.0e7, "hbm_bytes_per_launch": 4.0e7 * 2048 + 1.0e7 * 1024, "launches_per_pass": 30, "seconds": 41.0, "how": "two passes"}
+    r = bench.roofline_report("C3", 128, False, 1.4e11, 16.0, 81 << 20, {}, live=live)
+    assert r["traffic"] == live["hbm_bytes_per_launch"] and r["traffic_measured"].startswith("IN THIS RUN") and r["traffic_source"] == "two passes"
+    assert r["traffic_committed"] == 1.0e11 and abs(r["traffic_this_run_over_committed"] - live["hbm_bytes_per_launch"] / 1.0e11) < 1e-3
+    assert abs(r["achieved"] - live["hbm_bytes_per_launch"] / 16e-3 / 1e9) < 1 and r["l2_hit_rate"] == 0.6
+    r = bench.roofline_report("C3", 128, False, 1.4e11, 16.0, 81 << 20, {}, live={"error": "rocprofv3 not found"})
+    assert r["traffic"] == 1.0e11 and r["traffic_measured"].startswith("NOT in this run") and r["traffic_live_error"] == "rocprofv3 not found"
+    ent["source_hash"] = "0" * 16                                   # stale committed passes: the live bytes alone
+    f.write_text(json.dumps({"configs": {"C3": ent}}))
+    r = bench.roofline_report("C3", 128, False, 1.4e11, 16.0, 81 << 20, {}, live=live)
+    assert r["traffic"] == live["hbm_bytes_per_launch"] and r["frac"] is not None and r["committed_passes"].startswith("stale") and "ceilings" not in r
+    # the default: on for the plain headline run only; never inside a profiled process
+    assert bench.parse_args([]).live_traffic == "on" and bench.parse_args(["--other-configs", "none"]).live_traffic == "off"
+    assert bench.parse_args(["--config", "C5"]).live_traffic == "off" and bench.parse_args(["--gpus", "2"]).live_traffic == "off"
+    monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")
+    assert bench.being_profiled() and "profiler" in bench.live_traffic("C3")["error"]
+
+
 def test_committed_counter_traffic_belongs_to_this_build():
     """profiles/pmc_traffic.json must be re-collected (profiles/pmc_collect.sh) whenever the traversal kernel or the node format
     changes: a stale file would silently report another kernel's traffic."""
