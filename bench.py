@@ -102,6 +102,19 @@ def live_traffic(config, timeout_s=240.0):
     import shutil
     import subprocess
     import tempfile
+    global _LIVE_FAILED
+    if _LIVE_FAILED:                 # one failed attempt per run: the later legs do not wait for the same time-out again
+        return {"error": "not attempted: " + _LIVE_FAILED}
+    r = _live_traffic(config, timeout_s, shutil, subprocess, tempfile)
+    if "error" in r:
+        _LIVE_FAILED = r["error"]
+    return r
+
+
+_LIVE_FAILED = None
+
+
+def _live_traffic(config, timeout_s, shutil, subprocess, tempfile):
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if prof is None:
         return {"error": "rocprofv3 not found"}
