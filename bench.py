@@ -4,8 +4,8 @@
   python bench.py --gpus N --steps K --warmup W [--config C3|C2|C4|C5|C1] [--scaling weak|strong]
 
 A "step" = one crh_render_tiles pass over the rank's tiles of the workload (default BASELINE.json config C3: 1 M random
-triangles, glass + glossy double-layer BSDFs, HDR sky, 1080p; `--spp` samples per pixel per step, default one full
-256 M-path batch = 128 spp at 1080p).  Inputs are resident in HBM before the timed region.
+triangles, glass + glossy double-layer BSDFs, HDR sky, 1080p; `--spp` samples per pixel per step, default 512 = two batches
+of 1024 tiles x 512 samples: the library cuts a call into batches of <= 2^29 paths).  Inputs are resident in HBM before the timed region.
 
 N = 1, default workload: after the headline leg the OTHER single-GPU configs of BASELINE.json -- C5 (10 M triangles at 4K: the one whose scene does
 not fit the caches, i.e. where HBM is the roof), C2, C1 -- run as short legs (1 warm-up + 4 timed steps) in the same process, each with its own parity
@@ -204,11 +204,12 @@ def roofline_report(config, spp, modified, alg_bytes_per_launch, avg_ms, scene_b
                 r["limited_by"] = f"{names[ceil['binding']]}: {ceil[ceil['binding']]:.2f} of its ceiling (measured: roofline.ceilings)"
         elif resident and t_gbps < 0.75 * HBM_ACHIEVABLE_GBPS:
             r["limited_by"] = "memory side not saturated (Infinity-Cache resident); no SQ counters for this build"
-        if resident:
+        if resident or t_gbps < alg_gbps:
             r["achieved"] = round(min(alg_gbps, t_gbps), 1)
             r["achieved_basis"] = "min(algorithmic, memory-side counter traffic): bytes that were both needed and crossed the L2's memory side"
-            r["frac_note"] = ("cache-resident scene: frac counts only what crossed the L2s' memory side, so it FALLS when the L2s serve more of the gather "
-                              "(the kernel gets faster): the rate against the algorithmic bytes is alg_frac_of_hbm_peak; the HBM-resident config is C5")
+            r["frac_note"] = (("cache-resident scene" if resident else "the caches serve part of the gather (traffic_over_alg < 1: samples of a pixel travel together and share most of their walk)") +
+                              ": frac counts only what crossed the L2s' memory side, so it FALLS when the L2s serve more of the gather "
+                              "(the kernel gets faster): the rate against the algorithmic bytes is alg_frac_of_hbm_peak" + ("; the HBM-resident config is C5" if resident else ""))
         else:
             r["achieved"] = round(alg_gbps, 1)
             r["achieved_basis"] = "algorithmic bytes / kernel time (traffic_over_alg > 1 = over-fetch)"
@@ -331,7 +332,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step; 0 = what fills one 256 M-path batch (128 at 1080p, 32 at 4K); C4: 4096")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (one crh_render_tiles call); 0 = 512 for C3, 256 for C5, 128 for C2, 1024 for C1, 4096 for C4")
     ap.add_argument("--tris", type=int, default=0, help="override triangle count (debug)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -502,8 +503,18 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     fb = sharding.DeviceFramebuffer(v) if world > 1 else None
     tiles = sharding.tiles_for_rank(v.n_tiles(), rank, world, sharding.tiles_x_of(v))       # Morton-interleaved across the ranks
     spp = spp_arg
-    if spp <= 0:                          # one full path batch per step: 2^28 slots / (tiles x 32 x 32 pixels); C4: the named 4096 spp
-        spp = 4096 if config == "C4" else max(1, (256 << 20) // (v.n_tiles() * sc.params.tile_size ** 2))
+    if spp <= 0:
+        # samples per pixel of one step = one crh_render_tiles call.  The library cuts a call into batches of <= 2^29 paths, tile groups first (up to 1024
+        # samples of a pixel travel together: crh_schedule.cpp), so a step is given enough samples for that to matter: 512 at 1080p (C3: two batches of
+        # 1024 tiles), 256 at 4K (C5: four batches of 2048 tiles), C4 its named 4096; C2 / C1 do not care (128 / 1024 as in round 3).  A workload
+        # overridden on the command line gets what fills 2^28 slots, in multiples of 64.
+        named = {"C3": 512, "C4": 4096, "C5": 256, "C2": 128, "C1": 1024}
+        if config in named and not (ov and (args.tris or args.width or args.height)):
+            spp = named[config]
+        else:
+            spp = max(1, (256 << 20) // (v.n_tiles() * sc.params.tile_size ** 2))
+            if spp >= 64:
+                spp &= ~63
     spp_step = spp * world if scaling == "weak" else spp      # samples per pixel each rank renders per step
 
     def barrier():
@@ -660,7 +671,9 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
         try:
             gate = ParityOracle(sc)
             if timed_hdr is not None:
-                parity = gate.check(timed_hdr, timed_first, timed_n, args.parity_seconds, 4)
+                # at least 4 tiles, 2 once the region holds more than 4096 samples per pixel (20 steps x 512: one tile costs the oracle 20 s); the first-step gate
+                # below keeps its >= 32 tiles whatever the region's length
+                parity = gate.check(timed_hdr, timed_first, timed_n, args.parity_seconds, 4 if timed_n <= 4096 else 2)
                 parity["schedule"] = sched + " -- the timed steps' own output"
             if step0_hdr is not None:
                 parity0 = gate.check(step0_hdr, timed_first, spp_step, args.step0_seconds, 32)
@@ -832,7 +845,8 @@ class ParityOracle:
             self.per_tile_sample = (s0["rays_nearest"] + s0["rays_any"]) / len(probe)
             self.rate = (s0["rays_nearest"] + s0["rays_any"]) / max(s0["seconds"], 1e-9)
         want = int(max(min_tiles, min(256, nt, self.rate * seconds / max(self.per_tile_sample * n_samples, 1))))
-        sample = np.unique(np.linspace(0, nt - 1, min(want, nt)).astype(np.uint32))
+        k = min(want, nt)
+        sample = np.unique(((np.arange(k) + 0.5) * nt / k).astype(np.uint32))          # the middle of k equal runs of the tile list (not its ends: the corners of a frame are mostly sky)
         o.reset()
         t0 = time.perf_counter()
         o.render_tiles(sample, first_sample, n_samples)

@@ -136,7 +136,7 @@ struct EnvKnob { const char* name; const char* what; };
 static const EnvKnob kEnvKnobs[] = {
   {"CRH_BUILD_THREADS",      "threads of the host BVH builder and the record fill (default: the CPUs this process may use; bench.py gives each of N ranks its share)"},
   {"CRH_BUILD_VERBOSE",      "crh_build prints its phases and their times on stderr"},
-  {"CRH_MAX_PATHS",          "path slots per batch, 1024 .. 2^30 (default 2^28); the same knob as crh_set_path_budget"},
+  {"CRH_MAX_PATHS",          "path slots per batch, 1024 .. 2^30 (default 2^29); the same knob as crh_set_path_budget"},
   {"CRH_DONATE",             "0: small batches use the plain traversal kernels instead of the work-donating ones (reference schedule of the sequence tests)"},
   {"CRH_PACKETS",            "smallest run of consecutive samples per pixel from which the camera rays of a wide batch are walked as wavefront packets (k_trace_packets); default 64 = one pixel per wavefront, 0 = never"},
   {"CRH_PIPELINE",           "0: free-running Redraw()s are not pipelined across streams (reference schedule of the sequence tests)"},

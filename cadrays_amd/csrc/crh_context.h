@@ -131,11 +131,11 @@ struct ScheduleState {
   int pipe_grid_min = 192, pipe_grid_min_shade = 512;      // floors of a pipelined frame's traversal / streaming grids
   uint32_t pipe_depth = 3;         // frames in flight: 2 / 3 / 4 -> 323 / 391 / 312 Redraw/s on C3, 448 / 558 / 453 on C2
   bool read_since_render = true;   // a host that looks at every frame (read-back / sync between Redraws) gets the two-range schedule instead
-  // path slots per batch (196 B each = 53 GB of the 288 GB; allocated on demand, so small renders stay small).  Every launch of
+  // path slots per batch (196 B each = 105 GB of the 288 GB; allocated on demand, so small renders stay small).  Every launch of
   // the wavefront schedule ends in a drain phase whose length does not depend on the launch's size (~0.24 ms per launch on C3), so
   // the batch is made as wide as the memory comfortably allows: 32 M / 64 M / 128 M / 256 M / 512 M slots -> 2745 / 2960 / 3114 /
-  // 3205 / 3243 Mrays/s on C3
-  uint32_t max_paths = 256u << 20;
+  // 3205 / 3243 Mrays/s on C3 in round 2; round 4, 512 samples per call: 128 M / 256 M / 512 M / 1 G -> 3981 / 4132 / 4204 / 4180
+  uint32_t max_paths = 512u << 20;
   int schedule = CRH_SCHEDULE_AUTO; uint32_t auto_lane_max_paths = 12u << 20; bool auto_donate = true, auto_pipeline = true;   // crh_set_schedule
 };
 

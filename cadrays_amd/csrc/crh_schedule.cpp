@@ -139,8 +139,25 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     c->h_tile_ids.assign(tiles, tiles + nt);
   }
   const uint32_t cap_tiles = std::max<uint32_t>(1u, c->max_paths / tpp);
-  const uint32_t group = std::min(nt, cap_tiles);
-  const uint32_t spb = std::max<uint32_t>(1u, std::min(ns, c->max_paths / (group * tpp)));
+  uint32_t group = std::min(nt, cap_tiles);
+  uint32_t spb = std::max<uint32_t>(1u, std::min(ns, c->max_paths / (group * tpp)));
+  // A wide request that does not fit one batch is cut into TILE groups first and sample batches second: as many of the call's samples per batch as fit
+  // (multiples of 64, so that a wavefront is 64 samples of one pixel and the camera rays walk as packets; at most kBatchSamples), the tiles per batch follow
+  // (at least kBatchMinTiles).  The more samples of a pixel travel together, the more of their later bounces start from the same few triangles and the
+  // smaller the part of the tree a batch touches: on the 10 M-triangle tree at 4K 32 / 64 / 128 / 256 samples per batch give 2956 / 3301 / 3382 / 3410
+  // Mrays/s, on the 1 M-triangle one at 1080p 128 / 256 / 512 / 1024 give 4089 / 4145 / 4204 / 4224 (profiles/r4/ab_batch_shape.txt).  Samples of a pixel
+  // are folded in in the same order whatever the cut, so the frame does not change by a bit.
+  constexpr uint32_t kBatchSamples = 1024u, kBatchMinTiles = 256u;
+  if (c->packets > 0 && c->packets <= 64 && !c->counters_on && ns >= 64u && (uint64_t)nt * tpp * ns > c->lane_max_paths) {
+    uint32_t want = std::min<uint32_t>(ns & ~63u, kBatchSamples);
+    const uint32_t min_group = std::min<uint32_t>(nt, kBatchMinTiles);
+    while (want > 64u && c->max_paths / (want * tpp) < min_group) want = (want / 2u) & ~63u;
+    if (want >= 64u && c->max_paths / (want * tpp) >= 1u) {
+      group = std::min(nt, c->max_paths / (want * tpp));
+      spb = want;
+      if (group == nt) spb = std::max<uint32_t>(want, std::min(ns, c->max_paths / (group * tpp)) & ~63u);
+    }
+  }
   const uint64_t total = (uint64_t)nt * tpp * ns;
   // Measured on C3 at 1080p, 1 spp per call: free-running 232 -> 326 Redraw/s (C2: 323 -> 442); a host that reads every frame back
   // would get 187 instead of 225 (one schedule per frame is slower than two tile ranges when nothing overlaps it), so a

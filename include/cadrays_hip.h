@@ -225,10 +225,11 @@ CRH_API int crh_set_lookahead_auto(crh_ctx* ctx, uint32_t max_frames);
 #define CRH_SCHEDULE_SMALL 2
 CRH_API int crh_set_schedule(crh_ctx* ctx, int mode);
 /* Device-memory budget of the wavefront path state: at most `max_paths` path slots (196 B each) are in flight per batch; a render
- * that needs more is cut into tile groups / sample batches (same image, bit for bit).  Default 2^28 slots = 53 GB of the
- * 288 GB, allocated on demand (a 1080p Redraw() takes 0.4 GB): every launch of the schedule ends in a drain phase of fixed
- * length, so wide batches are faster -- 32 M / 64 M / 128 M / 256 M slots reach 80 / 86 / 91 / 93 % of the 512 M-slot rate on
- * the 1 M-triangle benchmark.  A host that shares the GPU with other consumers lowers it here (the environment variable
+ * that needs more is cut into tile groups / sample batches (same image, bit for bit).  Default 2^29 slots = 105 GB of the
+ * 288 GB, allocated on demand (a 1080p Redraw() takes 0.4 GB, a 128-sample call at 1080p 52 GB): every launch of the schedule ends in a
+ * drain phase of fixed length, so wide batches are faster -- 32 M / 64 M / 128 M / 256 M slots reach 80 / 86 / 91 / 93 % of the 512 M-slot rate on
+ * the 1 M-triangle benchmark.  A call with many samples is cut into tile groups of up to 1024 samples (multiples of 64), not into sample
+ * groups of all tiles: samples of one pixel that travel together share most of their walk.  A host that shares the GPU with other consumers lowers it here (the environment variable
  * CRH_MAX_PATHS sets the initial value).  1024 <= max_paths <= 2^30; buffers already larger are released. */
 /* Frames in flight of free-running crh_render(ctx, 1) calls (the application's loop, AppViewer.cxx:1045-1047, when it does not read every frame
  * back): each call only enqueues, frame i runs on stream i mod `frames` with its own slice of the path state and is folded into the accumulator

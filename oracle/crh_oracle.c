@@ -1134,13 +1134,9 @@ static int render_tiles(orc_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t
   struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
   uint64_t rn = 0, ra = 0, nn = 0, tt = 0, na = 0, ta = 0, hh = 0, sm = 0;
   uint32_t total = tiles ? nt : tx * ty;
-  /* work item = one sub-block of a tile (the whole tile in the parity build; 8x8 pixels in the fast build, so that 256 host
-   * threads are not left waiting for the last of ~8 tiles each) -- pixels are independent, so the image does not depend on it */
-#ifdef ORC_FAST
+  /* work item = one 8x8 sub-block of a tile, so that the host threads are not left waiting for the last of a few tiles each (a parity
+   * gate of 2 - 4 tiles x 10 240 samples would otherwise run on 2 - 4 threads) -- pixels are independent, so the image does not depend on it */
   const uint32_t sub = 8u;
-#else
-  const uint32_t sub = ts;
-#endif
   const uint32_t spr = (ts + sub - 1) / sub, nsub = spr * spr;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rn, ra, nn, tt, na, ta, hh, sm)
   for (uint32_t wi = 0; wi < total * nsub; ++wi) {

@@ -30,7 +30,7 @@ def rows_of(d, want):
 
 
 def one_step(rows, first_kernel):
-    """the launches of the SECOND step that contains a timed traversal launch (the first is the warm-up step; the counting pass comes last)"""
+    """the launches of the SECOND batch (k_raygen .. the next k_raygen) that contains a timed traversal launch (the first belongs to the warm-up step; the counting pass comes last)"""
     idx = [i for i, r in enumerate(rows) if r["kernel"] == first_kernel] + [len(rows)]
     steps = [rows[idx[k]:idx[k + 1]] for k in range(len(idx) - 1)]
     good = [st for st in steps if any(r["kernel"] in ("k_trace_nearest", "k_trace_packets") for r in st)]
@@ -49,7 +49,7 @@ def main():
         passes = {os.path.basename(d)[4:]: rows_of(d, want) for d in sorted(glob.glob(os.path.join(root, cfg, "pmc_*")))}
         sq = next((v for k, v in passes.items() if k.startswith("SQ_WAVES")), None)
         fetch, write = passes.get("FETCH_SIZE"), passes.get("WRITE_SIZE")
-        print(f"== {cfg}: one timed step of `bench.py --config {cfg} --steps 2 --warmup 1` (counting-pass launches excluded), launch order")
+        print(f"== {cfg}: one batch (k_raygen .. k_accumulate; a step of C3 is two of them, of C5 four, of C2 / C1 one) of `bench.py --config {cfg} --steps 2 --warmup 1` (counting-pass launches excluded), launch order")
         if sq:
             step = [r for r in one_step([r for r in sq if r["kernel"] != "k_trace_nearest" or timed(r["name"])], "k_raygen")]
             f_step = one_step([r for r in (fetch or []) if r["kernel"] != "k_trace_nearest" or timed(r["name"])], "k_raygen")
@@ -72,7 +72,7 @@ def main():
             tot = collections.defaultdict(float)
             for r in step:
                 tot[r["kernel"]] += r["ms"]
-            print("step total (profiled ms): " + ", ".join(f"{k} {v:.1f}" for k, v in tot.items()))
+            print("batch total (profiled ms): " + ", ".join(f"{k} {v:.1f}" for k, v in tot.items()))
         print()
 
 

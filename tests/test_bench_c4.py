@@ -29,13 +29,13 @@ def test_c4_as_written_on_one_gpu(hip_lib):
     assert out["config"]["workload"].startswith("C4: 1000000") and out["config"]["spp_per_step_per_rank"] == 4096
     assert out["parity"]["bit_exact"] is True and out["parity"]["spp"] == 4096 and out["parity"]["pixels"] > 0
     assert out["parity_step0"]["bit_exact"] is True and out["parity_step0"]["tiles"] >= 32
-    assert out["roofline"]["launches"] == 32 * 10                    # 32 batches x 10 bounces: every batch is the 256 M-path shape bench.py's headline times
+    assert out["roofline"]["launches"] == 16 * 10                    # four tile groups of 512 tiles x four batches of 1024 samples (crh_schedule.cpp), ten bounces each
 
 
 @pytest.mark.gpu
 def test_c5_wide_batch_on_the_10m_triangle_tree(hip_lib):
     out = _bench(["--config", "C5", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-interactive"], 1500)
-    assert out["config"]["workload"].startswith("C5: 10000000") and out["config"]["spp_per_step_per_rank"] == 32
+    assert out["config"]["workload"].startswith("C5: 10000000") and out["config"]["spp_per_step_per_rank"] == 256
     assert "3840x2160" in out["config"]["workload"] and out["value"] > 500
     assert out["parity"]["bit_exact"] is True and "wide" in out["parity"]["schedule"] and out["parity"]["pixels"] > 0
     assert out["parity_step0"]["bit_exact"] is True and out["parity_step0"]["tiles"] >= 32

@@ -112,21 +112,40 @@ def test_c1_at_its_real_size_bit_exact(hip_lib, oracle_lib):
     v.close(); o.close()
 
 
-def test_wide_batch_of_the_bench_shape_matches_oracle_on_tiles(hip_lib, oracle_lib):
-    """The shape bench.py times -- one crh_render_tiles call of 128 spp over every tile of a 1080p frame (one 256 M-path batch, one pixel
-    x 64 samples per wavefront) -- on a 1080p C3 with a smaller soup (the oracle builds its tree in a second): sampled tiles bit-exact."""
+@pytest.mark.parametrize("spp", [128, 512])
+def test_wide_batch_of_the_bench_shape_matches_oracle_on_tiles(hip_lib, oracle_lib, spp):
+    """The shape bench.py times -- one crh_render_tiles call over every tile of a 1080p frame, one pixel x 64 samples per wavefront: 128 spp (one batch:
+    rounds 2 - 3) and 512 spp (round 4: two tile groups of 1024 tiles x 512 samples, crh_schedule.cpp) -- on a 1080p C3 with a smaller soup (the oracle
+    builds its tree in a second): sampled tiles, the last of the first group and the first of the second among them, bit-exact."""
     from cadrays_amd.view import View
     sc = scenes.baseline_config("C3", n_tris=50_000)
     sc.env = scenes.procedural_sky(512, 256, 1)
     v = View(0).load_scene(sc)
     tiles = np.arange(v.n_tiles(), dtype=np.uint32)
-    v.render_tiles(tiles, 128, 128)                    # samples 128 .. 255, as bench.py's first timed step after one warm-up step
+    v.render_tiles(tiles, spp, spp)                    # samples spp .. 2 spp - 1, as bench.py's first timed step after one warm-up step
     g = v.read_hdr()
     o = oracle_lib.Oracle().load_scene(sc)
-    sample = np.linspace(0, o.n_tiles() - 1, 6).astype(np.uint32)
-    o.render_tiles(sample, 128, 128)
+    sample = np.unique(np.concatenate([np.linspace(0, o.n_tiles() - 1, 6 if spp == 128 else 3), [1023, 1024] if spp == 512 else []]).astype(np.uint32))
+    o.render_tiles(sample, spp, spp)
     ref = o.read_accum()
-    mask = ref[..., 3] == 128
-    assert mask.sum() >= 5 * 32 * 32
+    mask = ref[..., 3] == spp
+    assert mask.sum() >= (len(sample) - 1) * 32 * 32
     assert np.array_equal(bits(g[mask]), bits(ref[..., :3][mask]))
     v.close(); o.close()
+
+
+@pytest.mark.parametrize("budget_tiles,spp", [(5, 320), (3, 200), (70, 320), (16, 700), (300, 96)])
+def test_tile_groups_and_sample_batches_do_not_change_a_bit(hip_lib, oracle_lib, budget_tiles, spp):
+    """a call that does not fit one batch is cut into tile groups of up to 1024 samples (multiples of 64) and the rest of the samples (crh_schedule.cpp):
+    whatever the cut -- path budgets that hold 3 .. 300 tiles x 64 samples, sample counts that are not multiples of 64 -- the frame is the oracle's"""
+    from cadrays_amd.view import View
+    sc = scenes.baseline_config("C3", 208, 150, n_tris=20_000)          # 7 x 5 tiles, partial ones right and bottom
+    sc.env = scenes.procedural_sky(256, 128, 1)
+    o = oracle_lib.Oracle().load_scene(sc); o.render(spp)
+    ref = o.read_hdr(); o.close()
+    v = View(0).load_scene(sc)
+    v.set_schedule(abi.SCHEDULE_WIDE)
+    v.set_path_budget(budget_tiles * 1024 * 64)
+    v.render_tiles(np.arange(v.n_tiles(), dtype=np.uint32), 0, spp)
+    g = v.read_hdr(); v.close()
+    assert np.array_equal(bits(g), bits(ref))
