@@ -727,7 +727,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
 
 def interactive_figures(v):
     interactive = {}
-    for k in (1, 16):
+    for k in (1, 16, 64):
         v.set_lookahead(k); v.reset()
         for _ in range(max(8, 2 * k)):              # the frame pipeline (up to eight in flight) is full before the clock starts
             v.Redraw()
