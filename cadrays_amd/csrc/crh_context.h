@@ -71,6 +71,7 @@ struct BuiltScene {
   QBvh bvh;
   std::vector<float> h_tris;      // 12 floats per triangle, leaf order
   bool built = false;
+  float4* d_pnodes = nullptr; size_t cap_pnodes = 0;      // packet nodes of a single-level scene (128 B per node; kernels.hip k_expand_packet_nodes)
   float4 *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_mats = nullptr, *d_lights = nullptr, *d_env = nullptr;
   float4 *d_uvs = nullptr, *d_texels = nullptr; uint4* d_tex_desc = nullptr;
   float4* d_verts = nullptr;      // two-level scenes: object-space vertices per leaf position (shading of instance hits)

@@ -11,7 +11,7 @@ namespace api {
 void fill_scene(const crh_ctx* c, DScene& S)
 {
   std::memset(&S, 0, sizeof S);
-  S.nodes = c->d_nodes; S.tris = c->d_tris; S.verts = c->d_verts; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = (c->envW && c->envH) ? c->d_env : nullptr;
+  S.nodes = c->d_nodes; S.pnodes = c->d_pnodes; S.tris = c->d_tris; S.verts = c->d_verts; S.shade = c->d_shade; S.mats = c->d_mats; S.lights = c->d_lights; S.env = (c->envW && c->envH) ? c->d_env : nullptr;
   S.inst = c->d_inst; S.inst_leaf = c->d_inst ? c->d_inst + 8 * (size_t)c->nO : nullptr; S.root = c->root; S.two_level = c->inst.empty() ? 0 : 1;
   S.root2 = c->inst.empty() ? kQEmpty : c->root2;
   // render path of a split scene: with at most kMaxIBox moved objects the producers can tell precisely which rays come near one -- two traversal passes
@@ -599,6 +599,15 @@ static int build_scene(crh_ctx* c, const QNode* pre_nodes, uint32_t pre_n_nodes,
   else if (c->d_uvs) { CRH_HIP(hipFree(c->d_uvs)); c->d_uvs = nullptr; }
   if (c->two_level) { if ((rc = alloc_put(c->d_verts, vt, 12))) return rc; }
   else if (c->d_verts) { CRH_HIP(hipFree(c->d_verts)); c->d_verts = nullptr; }
+  // packet nodes for the camera rays of wide batches (k_trace_packets<true>): the node array again with its quantised planes as floats, 128 B per node.
+  // Single-level scenes only (a scene with objects grows its node array while the user drags; its packets read the 64-B nodes)
+  if (!c->two_level && c->packets > 0) {
+    const size_t nn = c->bvh.nodes.size();
+    if (nn > c->cap_pnodes) { if (c->d_pnodes) { CRH_HIP(hipFree(c->d_pnodes)); c->d_pnodes = nullptr; c->cap_pnodes = 0; } CRH_HIP(hipMalloc((void**)&c->d_pnodes, nn * 128)); c->cap_pnodes = nn; }
+    Launch Lx{cstream(c), 64, false};
+    launch_expand_packet_nodes(Lx, c->d_nodes, c->d_pnodes, (uint32_t)nn);
+    CRH_HIP(hipGetLastError());
+  } else if (c->d_pnodes) { CRH_HIP(hipFree(c->d_pnodes)); c->d_pnodes = nullptr; c->cap_pnodes = 0; }
   phase("upload");
   if (c->two_level) {
     // what the FIRST crh_set_transforms would otherwise allocate while the user is dragging: the staging of the triangle patches of the largest object

@@ -31,6 +31,7 @@ constexpr int kOvfStack   = 112;   // spill entries per lane (scratch, rarely to
 // Scene as the kernels see it.  All arrays are float4-granular so every fetch is one dwordx4.
 struct DScene {
   const float4* nodes;    // 3 x float4 used per node (64-B stride): {origin.xyz, exps | child counts}, {qlo xyz, qhi x}, {qhi yz, child base, leaf base}  (crh_bvh_format.h)
+  const float4* pnodes;   // packet nodes (k_trace_packets<true>): 8 x float4 per node, the quantised planes as floats (k_expand_packet_nodes); nullptr: none (two-level scenes)
   const float4* tris;     // 4 x float4 per triangle in leaf order (kTriStride apart; traversal fetches the first three): v0 | n.x, e0 = v1 - v0 | n.y, e1 = v0 - v2 | n.z
                           // (n = e1 x e0), {caller's triangle id, -, -, -}
   const float4* verts;    // two-level scenes: 3 x float4 per leaf position, the object-space vertices (shading transforms them); nullptr otherwise

@@ -20,6 +20,7 @@ void launch_raygen(const Launch&, const DScene&, const DPaths&, const DQueues&, 
 // nearest-hit traversal of queue `qin`; also zeroes the other queue's count and the shadow count
 void launch_trace_nearest(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, uint32_t bounce, DCounters*);
 // emission, NEE, BSDF sampling, Russian roulette; survivors -> queue 1-qin, shadow rays -> q_sh
+void launch_expand_packet_nodes(const Launch&, const float4* nodes, float4* pnodes, uint32_t n_nodes);      // k_trace_packets<true>'s node array
 void launch_shade(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, uint32_t bounce, DCounters*);
 // any-hit traversal of the shadow queue; unoccluded contributions are added to the path radiance
 void launch_trace_any(const Launch&, const DScene&, const DPaths&, const DQueues&, DCounters*);

@@ -629,7 +629,60 @@ __global__ CRH_TRACE_BOUNDS void k_trace_any(DScene S, DPaths P, const uint32_t*
 constexpr uint32_t kPacketChunk = 1024;      // queue entries (16 packets) per cursor fetch: one counter word sustains ~88 atomics / us
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <int OCT>
+// lane `lane` (uniform) of three registers <- three uniform values: v_writelane with the lane in M0 (two different scalar registers in one VALU instruction
+// exceed the constant bus; the compiler's builtin for it is not declared by this toolchain)
+__device__ __forceinline__ void stack_put(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t va, uint32_t vb, uint32_t vc, uint32_t lane)
+{
+  asm("s_mov_b32 m0, %6\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+      : "+v"(a), "+v"(b), "+v"(c) : "s"(va), "s"(vb), "s"(vc), "s"(lane) : "m0");
+}
+// one of four uniform masks by a uniform index: three scalar selects
+__device__ __forceinline__ unsigned long long pick_mask(unsigned long long m0, unsigned long long m1, unsigned long long m2, unsigned long long m3, uint32_t i)
+{
+  unsigned long long m = m0;
+  m = i == 1u ? m1 : m; m = i == 2u ? m2 : m; m = i == 3u ? m3 : m;
+  return m;
+}
+
+// (t & ~3) | K as ONE vector instruction that the compiler may not move behind the v_readlane that follows it (it would: two scalar instructions on values that
+// are uniform by then -- but the packet walk is bound by the scalar unit, k_trace_packets)
+template <int K> __device__ __forceinline__ uint32_t key_bits(uint32_t t)
+{
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "s"(0x7FFFFFFCu), "n"(K));
+  return r;
+}
+
+// Packet nodes (k_trace_packets<true>): node i of the tree as 8 x float4 -- {origin.xyz | exponents, counts}, x planes {lo0, hi0, lo1, hi1} {lo2, hi2, lo3, hi3},
+// y planes, z planes, {first inner child, first leaf reference, -, -} -- the quantised bytes of the 64-B node converted once per scene instead of once per visit
+__global__ __launch_bounds__(kBlock) void k_expand_packet_nodes(const float4* __restrict__ nodes, float4* __restrict__ pn, uint32_t n)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * i;
+  const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+  const uint32_t lo[3] = {__float_as_uint(n1.x), __float_as_uint(n1.y), __float_as_uint(n1.z)}, hi[3] = {__float_as_uint(n1.w), __float_as_uint(n2.x), __float_as_uint(n2.y)};
+  const uint32_t nch = __float_as_uint(n0.w) >> 28;
+  float4* out = pn + 8u * i;
+  out[0] = n0;
+  for (int a = 0; a < 3; ++a) {
+    float f[8];
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = (float)((lo[a] >> (8 * k)) & 0xffu); f[2 * k + 1] = (float)((hi[a] >> (8 * k)) & 0xffu);
+      // a slot without a child: lower plane +inf, upper plane -inf -- the entry distance comes out +inf and the exit distance -inf on every axis whatever the
+      // direction (inf x finite scale; a 0 x inf = NaN on ONE axis is dropped by max / min, and a unit direction cannot scale all three axes to zero), so no
+      // ray enters it and the walk needs no child-count test
+      if ((uint32_t)k >= nch) { f[2 * k] = __builtin_inff(); f[2 * k + 1] = -__builtin_inff(); }
+    }
+    out[1 + 2 * a] = make_float4(f[0], f[1], f[2], f[3]); out[2 + 2 * a] = make_float4(f[4], f[5], f[6], f[7]);
+  }
+  out[7] = make_float4(n2.z, n2.w, 0.f, 0.f);
+}
+
+// PN: the node is read from the PACKET-NODE array (k_expand_packet_nodes: the eight quantised planes of the four children as FLOATS, 128 B per node): a packed
+// multiply-add takes a child's {lower, upper} plane pair straight from the scalar registers the node was loaded into, and the 24 byte-to-float conversions of a
+// visit are gone.  The values are the same floats (0 .. 255), so is every result.  Only with uniform direction signs (OCT < 8).
+template <int OCT, bool PN>
 __device__ __forceinline__ void packet_walk(const float4* __restrict__ nodes, const float4* __restrict__ tris, uint32_t root, uint32_t lane, bool act,
                                             v3 o, v3 d, float ix, float iy, float iz, float gx, float gy, float gz, float4& hit, bool& amb)
 {
@@ -644,61 +697,74 @@ __device__ __forceinline__ void packet_walk(const float4* __restrict__ nodes, co
   while (cm != 0ull) {
     const bool in = (cm >> lane) & 1ull;
     if (!(cur & kQLeafBit)) {
-      const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;      // uniform address: scalar loads
+      // uniform address: scalar loads
+      const float4* np = PN ? nodes + 8u * cur : nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;
       const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+      float4 n3 = n0, n4 = n0, n5 = n0, n6 = n0, n7 = n0;
+      if (PN) { n3 = np[3]; n4 = np[4]; n5 = np[5]; n6 = np[6]; n7 = np[7]; }
       const uint32_t ew = __float_as_uint(n0.w);
       const uint32_t ni = (ew >> 24) & 7u, nch = ew >> 28;
-      const uint32_t base_inner = __float_as_uint(n2.z), base_leaf = __float_as_uint(n2.w) - ni;
+      const uint32_t base_inner = __float_as_uint(PN ? n7.x : n2.z), base_leaf = __float_as_uint(PN ? n7.y : n2.w) - ni;
       const float ax = __builtin_amdgcn_ldexpf(ix, (int)(ew << 24) >> 24), ay = __builtin_amdgcn_ldexpf(iy, (int)(ew << 16) >> 24), az = __builtin_amdgcn_ldexpf(iz, (int)(ew << 8) >> 24);
       const float ddx = n0.x - o.x, ddy = n0.y - o.y, ddz = n0.z - o.z;
       const uint32_t lx = __float_as_uint(sx ? n1.w : n1.x), ly = __float_as_uint(sy ? n2.x : n1.y), lz = __float_as_uint(sz ? n2.y : n1.z);
       const uint32_t hx = __float_as_uint(sx ? n1.x : n1.w), hy = __float_as_uint(sy ? n1.y : n2.x), hz = __float_as_uint(sz ? n1.z : n2.y);
       const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
-      const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ddx, ddx}, (f32x2){ix, ix}, (f32x2){-gx, gx});
-      const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (f32x2){-gy, gy});
-      const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ddz, ddz}, (f32x2){iz, iz}, (f32x2){-gz, gz});
+      // PN: component 0 of a pair belongs to the LOWER plane whatever the direction, so the guard band changes sides with the sign instead of the planes
+      const f32x2 bx2 = __builtin_elementwise_fma((f32x2){ddx, ddx}, (f32x2){ix, ix}, (PN && sx) ? (f32x2){gx, -gx} : (f32x2){-gx, gx});
+      const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (PN && sy) ? (f32x2){gy, -gy} : (f32x2){-gy, gy});
+      const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ddz, ddz}, (f32x2){iz, iz}, (PN && sz) ? (f32x2){gz, -gz} : (f32x2){-gz, gz});
       const uint32_t L = (uint32_t)__builtin_ctzll(cm);                      // the lane whose keys order the children
       unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
       uint32_t key[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 #define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
+#define CRH_PP(A, B, K) ((K) == 0 ? (f32x2){(A).x, (A).y} : (K) == 1 ? (f32x2){(A).z, (A).w} : (K) == 2 ? (f32x2){(B).x, (B).y} : (f32x2){(B).z, (B).w})
 #define CRH_PCHILD(K)                                                                                          \
-      if ((uint32_t)K < nch) {                                                                             \
-        const f32x2 tx = __builtin_elementwise_fma((f32x2){CRH_QB(lx, K), CRH_QB(hx, K)}, ax2, bx2);      \
-        const f32x2 ty = __builtin_elementwise_fma((f32x2){CRH_QB(ly, K), CRH_QB(hy, K)}, ay2, by2);      \
-        const f32x2 tz = __builtin_elementwise_fma((f32x2){CRH_QB(lz, K), CRH_QB(hz, K)}, az2, bz2);      \
+      if (PN || (uint32_t)K < nch) {      /* PN: all four slots, an absent child is masked out below (no branch: the node's loads stay one batch) */ \
+        f32x2 tx, ty, tz;                                                                                  \
+        if (PN) {                                                                                          \
+          const f32x2 px = __builtin_elementwise_fma(CRH_PP(n1, n2, K), ax2, bx2), py = __builtin_elementwise_fma(CRH_PP(n3, n4, K), ay2, by2); \
+          const f32x2 pz = __builtin_elementwise_fma(CRH_PP(n5, n6, K), az2, bz2);                         \
+          tx = sx ? (f32x2){px.y, px.x} : px; ty = sy ? (f32x2){py.y, py.x} : py; tz = sz ? (f32x2){pz.y, pz.x} : pz;      /* {near, far}: a choice of registers */ \
+        } else {                                                                                           \
+          tx = __builtin_elementwise_fma((f32x2){CRH_QB(lx, K), CRH_QB(hx, K)}, ax2, bx2);                \
+          ty = __builtin_elementwise_fma((f32x2){CRH_QB(ly, K), CRH_QB(hy, K)}, ay2, by2);                \
+          tz = __builtin_elementwise_fma((f32x2){CRH_QB(lz, K), CRH_QB(hz, K)}, az2, bz2);                \
+        }                                                                                                  \
         const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
         const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), best);                                    \
         const bool hitk = tmin <= tmx;                                                                     \
-        mk[K] = __builtin_amdgcn_ballot_w64(hitk) & cm;      /* every lane of the wavefront runs this loop: the vote is a plain compare into a scalar pair */ \
-        const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(hitk ? tmin : __builtin_inff()), (int)L); /* lane L is in cm: +inf when it misses this child */ \
-        key[K] = mk[K] != 0ull ? ((tb & 0x7FFFFFFCu) | (uint32_t)K) : 0xFFFFFFFFu;                         \
+        mk[K] = __builtin_amdgcn_ballot_w64(hitk) & cm;      /* every lane of the wavefront runs this loop: the vote is a plain compare into a scalar pair (PN: an empty slot admits nobody, k_expand_packet_nodes) */ \
+        const uint32_t tv = __float_as_uint(hitk ? tmin : __builtin_inff());      /* lane L is in cm: +inf when it misses this child */ \
+        const uint32_t tb = PN ? (uint32_t)__builtin_amdgcn_readlane((int)key_bits<K>(tv), (int)L)      /* PN: the key is finished on the vector unit (one v_and_or), the scalar one is the busier */ \
+                               : (((uint32_t)__builtin_amdgcn_readlane((int)tv, (int)L) & 0x7FFFFFFCu) | (uint32_t)K);         \
+        key[K] = mk[K] != 0ull ? tb : 0xFFFFFFFFu;                                                         \
       }
       CRH_PCHILD(0) CRH_PCHILD(1) CRH_PCHILD(2) CRH_PCHILD(3)
 #undef CRH_PCHILD
+#undef CRH_PP
 #undef CRH_QB
       { // four unique scalar keys, ascending: the children somebody hit come first (0xFFFFFFFF = nobody)
         uint32_t a0 = min(key[0], key[1]), a1 = max(key[0], key[1]), b0 = min(key[2], key[3]), b1 = max(key[2], key[3]);
         const uint32_t lo = min(a0, b0), hi = max(a1, b1), m0 = max(a0, b0), m1 = min(a1, b1);
         key[0] = lo; key[1] = min(m0, m1); key[2] = max(m0, m1); key[3] = hi;
       }
-#define CRH_PREF(KEY) ((((KEY) & 3u) < ni ? base_inner : base_leaf) + ((KEY) & 3u))
-#define CRH_PMASK(KEY) (((KEY) & 3u) == 0u ? mk[0] : (((KEY) & 3u) == 1u ? mk[1] : (((KEY) & 3u) == 2u ? mk[2] : mk[3])))
+#define CRH_PREF(I) (((I) < ni ? base_inner : base_leaf) + (I))
+      if (key[0] != 0xFFFFFFFFu) {
+        if (sp > 61u) { ovf = true; break; }      // deeper than any tree of the builder (<= 60 pending entries): the whole packet takes the fall-back pass
 #define CRH_PPUSH(KEY)                                                                                         \
-      if ((KEY) != 0xFFFFFFFFu) {                                                                          \
-        if (sp < 64u) {                                                                                    \
-          const unsigned long long pm = CRH_PMASK(KEY);                                                    \
-          const bool here = lane == sp;                      /* lane `sp` of the three registers takes the entry */ \
-          st_ref = here ? CRH_PREF(KEY) : st_ref;                                                          \
-          st_mlo = here ? (uint32_t)pm : st_mlo;                                                           \
-          st_mhi = here ? (uint32_t)(pm >> 32) : st_mhi;                                                   \
+        if ((KEY) != 0xFFFFFFFFu) {                                                                        \
+          const uint32_t ci = (KEY) & 3u;                                                                  \
+          const unsigned long long pm = pick_mask(mk[0], mk[1], mk[2], mk[3], ci);                                                 \
+          stack_put(st_ref, st_mlo, st_mhi, CRH_PREF(ci), (uint32_t)pm, (uint32_t)(pm >> 32), sp);      /* lane `sp` of the three registers takes the entry */ \
           ++sp;                                                                                            \
-        } else ovf = true;      /* deeper than any tree of the builder (<= 60 pending entries): the whole packet takes the fall-back pass */ \
-      }
-      CRH_PPUSH(key[3]) CRH_PPUSH(key[2]) CRH_PPUSH(key[1])                   // far .. near
-      if (ovf) break;
+        }
+        CRH_PPUSH(key[3]) CRH_PPUSH(key[2]) CRH_PPUSH(key[1])                 // far .. near
 #undef CRH_PPUSH
-      if (key[0] != 0xFFFFFFFFu) { cur = CRH_PREF(key[0]); cm = CRH_PMASK(key[0]); continue; }
-#undef CRH_PMASK
+        const uint32_t c0 = key[0] & 3u;
+        cur = CRH_PREF(c0); cm = pick_mask(mk[0], mk[1], mk[2], mk[3], c0);
+        continue;
+      }
 #undef CRH_PREF
     } else {
       const uint32_t ti = cur & 0x0FFFFFFFu;                                  // one triangle per leaf; uniform address: scalar loads
@@ -723,7 +789,8 @@ __device__ __forceinline__ void packet_walk(const float4* __restrict__ nodes, co
   if (ovf) amb = true;
 }
 
-__global__ __launch_bounds__(kBlock, 8) void k_trace_packets(DScene S, DPaths P, const float4* __restrict__ nodes, const float4* __restrict__ tris,      // = S.nodes, S.tris: as restrict-qualified PARAMETERS the compiler may read them with scalar loads
+template <bool PN>
+__global__ __launch_bounds__(kBlock, 8) void k_trace_packets(DScene S, DPaths P, const float4* __restrict__ nodes, const float4* __restrict__ pnodes, const float4* __restrict__ tris,      // = S.nodes, S.pnodes, S.tris: as restrict-qualified PARAMETERS the compiler may read them with scalar loads
                                                           const uint32_t* __restrict__ q, const uint32_t* __restrict__ count,
                                                           uint32_t* __restrict__ cursors, uint32_t* zero_a, uint32_t* zero_b, uint32_t* zero_c, uint32_t* zero_d,
                                                           uint32_t* __restrict__ fb_q, uint32_t* __restrict__ fb_count, DCounters* C)
@@ -757,8 +824,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packets(DScene S, DPaths P,
         const unsigned long long am_ = __ballot(act), bx_ = __ballot(act && ix < 0.f), by_ = __ballot(act && iy < 0.f), bz_ = __ballot(act && iz < 0.f);
         const bool uni = (bx_ == 0ull || bx_ == am_) && (by_ == 0ull || by_ == am_) && (bz_ == 0ull || bz_ == am_);
         const uint32_t oct = uni ? ((bx_ ? 1u : 0u) | (by_ ? 2u : 0u) | (bz_ ? 4u : 0u)) : 8u;
-#define CRH_WALK(O) case O: packet_walk<O>(nodes, tris, S.root, lane, act, o, d, ix, iy, iz, gx, gy, gz, hit, amb); break;
-        switch (oct) { CRH_WALK(0) CRH_WALK(1) CRH_WALK(2) CRH_WALK(3) CRH_WALK(4) CRH_WALK(5) CRH_WALK(6) CRH_WALK(7) default: packet_walk<8>(nodes, tris, S.root, lane, act, o, d, ix, iy, iz, gx, gy, gz, hit, amb); }
+#define CRH_WALK(O) case O: packet_walk<O, PN>(PN ? pnodes : nodes, tris, S.root, lane, act, o, d, ix, iy, iz, gx, gy, gz, hit, amb); break;
+        switch (oct) { CRH_WALK(0) CRH_WALK(1) CRH_WALK(2) CRH_WALK(3) CRH_WALK(4) CRH_WALK(5) CRH_WALK(6) CRH_WALK(7) default: packet_walk<8, false>(nodes, tris, S.root, lane, act, o, d, ix, iy, iz, gx, gy, gz, hit, amb); }
 #undef CRH_WALK
       }
       if (act && !amb) st_stream(&P.hit[tag], hit);
@@ -1805,9 +1872,11 @@ void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, con
   if (L.packets && bounce == 0u && !two && !S.split && !L.counters && !L.donate) {
     // camera rays of a wide batch: one walk per wavefront of 64 samples (k_trace_packets), then the rays that met a tie one by one (usually none)
     static int per_cu = 0;
-    if (per_cu == 0) { int nb = 0; per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_packets, kBlock, 0) == hipSuccess && nb > 0) ? nb : -1; }
+    if (per_cu == 0) { int nb = 0; per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_packets<true>, kBlock, 0) == hipSuccess && nb > 0) ? nb : -1; }
     const int grid = (per_cu > 0 && L.cus > 0) ? min(max(L.grid, 8 * L.cus), per_cu * L.cus) : L.grid;
-    hipLaunchKernelGGL(k_trace_packets, dim3(grid), dim3(kBlock), 0, L.stream, S, P, S.nodes, S.tris, Q.q[qin], Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2,
+    if (S.pnodes) hipLaunchKernelGGL(k_trace_packets<true>, dim3(grid), dim3(kBlock), 0, L.stream, S, P, S.nodes, S.pnodes, S.tris, Q.q[qin], Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2,
+                       Q.counts + count2_slot(bounce + 1u), Q.counts + 7, Q.q2, Q.counts + 11, C);
+    else          hipLaunchKernelGGL(k_trace_packets<false>, dim3(grid), dim3(kBlock), 0, L.stream, S, P, S.nodes, S.nodes, S.tris, Q.q[qin], Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2,
                        Q.counts + count2_slot(bounce + 1u), Q.counts + 7, Q.q2, Q.counts + 11, C);
     // (the donating instantiation: a handful of rays, each walked by a whole wavefront)
     hipLaunchKernelGGL((k_trace_nearest<false, false, true, false, true>), dim3(64), dim3(kBlock), 0, L.stream, S, P, qin, Q.q2, Q.counts + 11, Q.counts + 4,
@@ -1822,6 +1891,10 @@ void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, con
     if (L.counters) CRH_LAUNCH_TN(true, true, false, true, Q.q2, Q.counts + count2_slot(bounce)); else if (L.donate) CRH_LAUNCH_TN(false, true, true, true, Q.q2, Q.counts + count2_slot(bounce)); else CRH_LAUNCH_TN(false, true, false, true, Q.q2, Q.counts + count2_slot(bounce));
   }
 #undef CRH_LAUNCH_TN
+}
+void launch_expand_packet_nodes(const Launch& L, const float4* nodes, float4* pnodes, uint32_t n)
+{
+  if (n) hipLaunchKernelGGL(k_expand_packet_nodes, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, L.stream, nodes, pnodes, n);
 }
 void launch_shade(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qin, uint32_t bounce, DCounters* C)
 {

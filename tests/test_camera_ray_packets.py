@@ -93,3 +93,18 @@ def test_every_direction_octant_and_the_axis_straddling_packets(hip_lib, oracle_
         o = oracle_lib.Oracle().load_scene(sc); o.render(64)
         ref = o.read_hdr(); o.close()
         assert np.array_equal(bits(a), bits(ref))
+
+
+def test_a_scene_of_objects_walks_the_64_byte_nodes(hip_lib, oracle_lib, monkeypatch):
+    """single-level scenes get a second node array for the packets (the quantised planes as floats, k_expand_packet_nodes); a scene of placed objects does not
+    (its node array grows while objects are dragged) and its packets read the 64-byte nodes: the other instantiation of k_trace_packets.  Both give the oracle's frame."""
+    from test_two_level import object_scene
+    sc = object_scene(None, 160, 128)                            # every object at its build-time placement: rendered by the single-level kernels
+    o = oracle_lib.Oracle().load_scene(sc); o.render(64)
+    ref = o.read_hdr(); o.close()
+    a, _ = render_wide(sc, 64, 1, True, monkeypatch)
+    b, _ = render_wide(sc, 64, 1, False, monkeypatch)
+    assert np.array_equal(bits(a), bits(ref)) and np.array_equal(bits(b), bits(ref))
+    flat = dataclasses.replace(sc, tri_object=None, obj_xform=None)      # the same triangles without objects: the packet-node array
+    c, _ = render_wide(flat, 64, 1, True, monkeypatch)
+    assert np.array_equal(bits(c), bits(ref))

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../cadrays_amd/csrc"
 mkdir -p ../variants
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wno-unused-function -Wno-unused-result -Wno-unused-value"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wno-unused-function -Wno-unused-result -Wno-unused-value -Wno-inline-asm"
 make -s crh_context.o crh_scene.o crh_schedule.o crh_readback.o crh_reduce.o crh_debug.o bvh_builder.o
 while [ $# -ge 2 ]; do
   NAME=$1; FL=$2; shift 2
