@@ -88,6 +88,7 @@ class Backend:
         tri = np.ascontiguousarray(tri, np.int32).reshape(-1, 4)
         uv = None if uv is None else np.ascontiguousarray(uv, np.float32)
         to = None if tri_object is None else np.ascontiguousarray(tri_object, np.int32)
+        self._has_objects = to is not None
         xf = None if obj_xform is None else np.ascontiguousarray(obj_xform, np.float32).reshape(-1, 12)
         self._call("set_geometry", _fp(pos), _fp(nrm), _fp(uv), C.c_uint32(len(pos)),
                    tri.ctypes.data_as(_i32p), C.c_uint32(len(tri)),

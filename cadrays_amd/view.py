@@ -102,11 +102,13 @@ class View(Backend):
         self._call("load_accum", rgba.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(int(frames_done)))
 
     def scene_bytes(self):
-        """HBM residency of the built scene: 64-B-stride nodes, 64-B-stride triangle records, 64-B shading records"""
+        """HBM residency of the built scene: 64-B-stride nodes, 64-B-stride triangle records, 64-B shading records -- and, for a scene without placed
+        objects, the 128-B packet nodes the camera rays of wide batches read (kernels.hip k_expand_packet_nodes; not part of what the per-ray walk touches)"""
         nn, nt = C.c_uint32(0), C.c_uint32(0)
         self._call("get_bvh", None, C.byref(nn), None, C.byref(nt))
+        two_level = getattr(self, "_has_objects", False)
         return {"nodes": 4 * abi.NODE_DWORDS * nn.value, "triangles": 64 * nt.value, "shading": 64 * nt.value,
-                "n_nodes": nn.value, "n_triangles": nt.value}
+                "packet_nodes": 0 if two_level else 128 * nn.value, "n_nodes": nn.value, "n_triangles": nt.value}
 
     def accum_device_ptr(self):
         p, n = C.c_void_p(0), C.c_uint64(0)
