@@ -715,6 +715,7 @@ __device__ __forceinline__ void packet_walk(const float4* __restrict__ nodes, co
       const f32x2 by2 = __builtin_elementwise_fma((f32x2){ddy, ddy}, (f32x2){iy, iy}, (PN && sy) ? (f32x2){gy, -gy} : (f32x2){-gy, gy});
       const f32x2 bz2 = __builtin_elementwise_fma((f32x2){ddz, ddz}, (f32x2){iz, iz}, (PN && sz) ? (f32x2){gz, -gz} : (f32x2){-gz, gz});
       const uint32_t L = (uint32_t)__builtin_ctzll(cm);                      // the lane whose keys order the children
+      const float best_in = in ? best : -1.0f;                               // PN: entry distances are >= 0, so a lane that is not in this node's mask enters no child
       unsigned long long mk[4] = {0ull, 0ull, 0ull, 0ull};
       uint32_t key[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 #define CRH_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
@@ -732,10 +733,12 @@ __device__ __forceinline__ void packet_walk(const float4* __restrict__ nodes, co
           tz = __builtin_elementwise_fma((f32x2){CRH_QB(lz, K), CRH_QB(hz, K)}, az2, bz2);                \
         }                                                                                                  \
         const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                     \
-        const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), best);                                    \
+        const float tmx  = fminf(fminf(fminf(tx.y, ty.y), tz.y), PN ? best_in : best);                     \
         const bool hitk = tmin <= tmx;                                                                     \
-        mk[K] = __builtin_amdgcn_ballot_w64(hitk) & cm;      /* every lane of the wavefront runs this loop: the vote is a plain compare into a scalar pair (PN: an empty slot admits nobody, k_expand_packet_nodes) */ \
-        const uint32_t tv = __float_as_uint(hitk ? tmin : __builtin_inff());      /* lane L is in cm: +inf when it misses this child */ \
+        /* every lane of the wavefront runs this loop: the vote is a plain compare into a scalar pair.  PN: an empty slot admits nobody (k_expand_packet_nodes), a lane \
+           outside the node's mask prunes against -1 (best_in), and the ordering key is lane L's entry distance whether or not L itself enters the child */ \
+        mk[K] = PN ? __builtin_amdgcn_ballot_w64(hitk) : (__builtin_amdgcn_ballot_w64(hitk) & cm);         \
+        const uint32_t tv = __float_as_uint((PN || hitk) ? tmin : __builtin_inff());      /* !PN: lane L is in cm: +inf when it misses this child */ \
         const uint32_t tb = PN ? (uint32_t)__builtin_amdgcn_readlane((int)key_bits<K>(tv), (int)L)      /* PN: the key is finished on the vector unit (one v_and_or), the scalar one is the busier */ \
                                : (((uint32_t)__builtin_amdgcn_readlane((int)tv, (int)L) & 0x7FFFFFFCu) | (uint32_t)K);         \
         key[K] = mk[K] != 0ull ? tb : 0xFFFFFFFFu;                                                         \
