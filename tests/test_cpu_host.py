@@ -54,7 +54,7 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in txt.lower() or f in ("binding.py", "kernels.hip", "sharding.py", "abi.py", "bvh_builder.cpp"), f
+                assert "oracle" not in txt.lower() or f in ("binding.py", "kernels.hip", "sharding.py", "abi.py", "bvh_builder.cpp") or (f.startswith("k_") and f.endswith(".h")), f      # comments only (the parts of kernels.hip)
                 assert "pyoracle" not in txt and "crh_oracle" not in txt and "libcrh_oracle" not in txt, f
     # tools/ neither: hunts that use the checker live in tests/hunts/
     for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
