@@ -332,7 +332,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (one crh_render_tiles call); 0 = 512 for C3, 256 for C5, 128 for C2, 1024 for C1, 4096 for C4")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (one crh_render_tiles call); 0 = 512 for C3, 256 for C5 and C2, 1024 for C1, 4096 for C4")
     ap.add_argument("--tris", type=int, default=0, help="override triangle count (debug)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -506,9 +506,9 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     if spp <= 0:
         # samples per pixel of one step = one crh_render_tiles call.  The library cuts a call into batches of <= 2^29 paths, tile groups first (up to 1024
         # samples of a pixel travel together: crh_schedule.cpp), so a step is given enough samples for that to matter: 512 at 1080p (C3: two batches of
-        # 1024 tiles), 256 at 4K (C5: four batches of 2048 tiles), C4 its named 4096; C2 / C1 do not care (128 / 1024 as in round 3).  A workload
+        # 1024 tiles), 256 at 4K (C5: four batches of 2048 tiles), C4 its named 4096; C2 its named 256 (one batch of 2040 tiles; it does not care: 128 / 256 / 512 give 5572 / 5576 / 5585), C1 1024 as in round 3.  A workload
         # overridden on the command line gets what fills 2^28 slots, in multiples of 64.
-        named = {"C3": 512, "C4": 4096, "C5": 256, "C2": 128, "C1": 1024}
+        named = {"C3": 512, "C4": 4096, "C5": 256, "C2": 256, "C1": 1024}
         if config in named and not (ov and (args.tris or args.width or args.height)):
             spp = named[config]
         else:
