@@ -173,7 +173,7 @@ def _model_stack_depth(nodes):
 def test_deep_stack_spills_to_scratch(view_cls, Oracle):
     """16 384 parallel corner triangles stacked along z, their boxes all [-1,1]^2 in xy: a ray along z through the free half of
     the square enters every box and hits nothing, so nothing is ever pruned and the per-lane stack grows by three entries per
-    level -- past the 16 LDS entries into the scratch spill (kernels.hip: CRH_PUSH / read_top slow paths), which ordinary
+    level -- past the 16 LDS entries into the scratch spill (k_traversal.h: CRH_PUSH / read_top slow paths), which ordinary
     scenes never reach.  Hits, any-hit flags and visit counters must still equal the oracle's."""
     n = 16384
     z = np.linspace(-1, 1, n, dtype=np.float32)
