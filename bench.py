@@ -658,7 +658,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     if headline and rank == 0 and world == 1 and not args.no_interactive:
         interactive = interactive_figures(v)
 
-    v.close()                                                 # the path state (up to 53 GB) and the scene go before the next leg / the CPU legs
+    v.close()                                                 # the path state (up to 105 GB) and the scene go before the next leg / the CPU legs
 
     # ---- parity gates ("parity gate accompanying every number"; the reference's own gate is pixel-exact,
     # testing/CADRays_Testing.py:226-230): the oracle renders the SAME samples the timed steps rendered on sampled tiles; those pixels of
