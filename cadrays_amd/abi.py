@@ -61,7 +61,7 @@ SPEC_DEFAULTS = dict(uniform_32bit=0, texel_gamma2=0, mis_single_lobe=0, eps_rul
 
 assert C.sizeof(crh_bsdf) == 128 and C.sizeof(crh_light) == 32 and C.sizeof(crh_spec) == 48
 
-SCHEDULE_AUTO, SCHEDULE_WIDE, SCHEDULE_SMALL = 0, 1, 2      # crh_set_schedule
+SCHEDULE_AUTO, SCHEDULE_WIDE, SCHEDULE_SMALL, SCHEDULE_STAGED = 0, 1, 2, 3      # crh_set_schedule
 
 NODE_DWORDS = 16          # CRH_NODE_DWORDS of include/crh_bvh_format.h: 4-wide BVH node, 12 dwords used on a 64-B stride
 

@@ -169,7 +169,7 @@ class Backend:
         self._call("set_spec", C.byref(sp))
 
     def get_spec(self):
-        sp = abi.crh_spec()
+        sp = abi.crh_spec(size=C.sizeof(abi.crh_spec))      # in / out: the caller's struct size, exactly that many bytes are written
         self._call("get_spec", C.byref(sp))
         return sp.as_dict()
 

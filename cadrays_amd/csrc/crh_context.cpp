@@ -141,6 +141,11 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_PACKETS",            "smallest run of consecutive samples per pixel from which the camera rays of a wide batch are walked as wavefront packets (k_trace_packets); default 64 = one pixel per wavefront, 0 = never"},
   {"CRH_PIPELINE",           "0: free-running Redraw()s are not pipelined across streams (reference schedule of the sequence tests)"},
   {"CRH_PIPE_DEPTH",         "frames in flight of free-running Redraw()s, 2 .. 8; the same knob as crh_set_pipeline_depth (crh_query_pipeline_capacity says what the process supports)"},
+  {"CRH_FRAME_KERNEL",       "0: small batches take the staged small-batch schedule (one launch per stage and bounce) instead of the frame kernel (reference schedule of the sequence tests)"},
+  {"CRH_FRAME_LIVE",         "frame kernel: paths a workgroup keeps alive at most, 64 .. 1024 (default 512)"},
+  {"CRH_FRAME_CHUNK",        "frame kernel: path slots a wavefront claims at a time, multiples of 64 up to 1024 (default 256)"},
+  {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident, 4 per CU)"},
+  {"CRH_FRAME_PIPE",         "frame kernel: frames in flight of free-running Redraw()s, 1 .. 8 (default 2)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
   {"CRH_SPLIT_PASSES",       "split scenes (static tree + moved objects): 0 one walk in the two-level kernels, 1 two traversal passes, unset: by the number of moved objects"},
   {"CRH_REDUCE_RCCL_SINGLE", "crh_reduce sends even a one-context group through RCCL (exercises the library binding on a 1-GPU box)"},
@@ -167,6 +172,11 @@ static void read_env(crh_ctx* c)
   if (const char* e = getenv("CRH_SPLIT_PASSES")) c->split_passes = atoi(e);
   if (const char* e = getenv("CRH_PIPELINE")) c->pipeline = atoi(e) != 0;
   if (const char* e = getenv("CRH_PIPE_DEPTH")) { int v = atoi(e); if (v >= 2 && v <= (int)pipeline_capacity()) c->pipe_depth = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_KERNEL")) c->frame_kernel = c->auto_frame_kernel = atoi(e) != 0;
+  if (const char* e = getenv("CRH_FRAME_LIVE")) { int v = atoi(e); if (v >= 64 && v <= 1024) c->frame_live = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 1024) c->frame_chunk = (uint32_t)v & ~63u; }
+  if (const char* e = getenv("CRH_FRAME_GRID")) { int v = atoi(e); if (v >= 1) c->frame_grid = v; }
+  if (const char* e = getenv("CRH_FRAME_PIPE")) { int v = atoi(e); if (v >= 1 && v <= 8) c->frame_pipe_depth = (uint32_t)v; }
   if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }
 }
 

@@ -128,6 +128,7 @@ struct ScheduleState {
   // frame order (an event between the two accumulate launches)
   bool pipeline = true; bool pipe_pending[8] = {false, false, false, false, false, false, false, false}; uint32_t pipe_seq = 0; uint32_t* d_pipe_seeds = nullptr; int pipe_div = 4096;
   uint64_t pipe_total = 0;         // batch size of the frames in flight (their path-state slices are laid out by it)
+  uint32_t pipe_last_depth = 0;    // frames in flight the last pipelined frame was submitted with
   std::chrono::steady_clock::time_point pipe_last_submit{};      // when the previous pipelined frame was submitted
   int pipe_grid_min = 192, pipe_grid_min_shade = 512;      // floors of a pipelined frame's traversal / streaming grids
   uint32_t pipe_depth = 3;         // frames in flight: 2 / 3 / 4 -> 323 / 391 / 312 Redraw/s on C3, 448 / 558 / 453 on C2
@@ -137,6 +138,13 @@ struct ScheduleState {
   // the batch is made as wide as the memory comfortably allows: 32 M / 64 M / 128 M / 256 M / 512 M slots -> 2745 / 2960 / 3114 /
   // 3205 / 3243 Mrays/s on C3 in round 2; round 4, 512 samples per call: 128 M / 256 M / 512 M / 1 G -> 3981 / 4132 / 4204 / 4180
   uint32_t max_paths = 512u << 20;
+  // The frame kernel (k_frame.h): a small batch in ONE launch -- every workgroup streams its own paths through ray generation, traversal and shading, no
+  // launch boundary between bounces.  Takes the place of the staged small-batch schedule (lanes / pipelined launches per bounce) wherever a batch is small,
+  // not counted and not timed per kernel; CRH_FRAME_KERNEL=0 or crh_set_schedule(CRH_SCHEDULE_STAGED) keeps the staged form (the reference of the sequence tests).
+  bool frame_kernel = true, auto_frame_kernel = true;
+  uint32_t frame_live = 512, frame_chunk = 256;     // paths a workgroup keeps alive at most; path slots a wavefront claims at a time
+  int frame_grid = 0;                               // workgroups of a lone frame (0: what is resident, 4 per CU)
+  uint32_t frame_pipe_depth = 2;                    // frames in flight of free-running Redraw()s on the frame kernel (a frame keeps the chip busy but for its tail)
   int schedule = CRH_SCHEDULE_AUTO; uint32_t auto_lane_max_paths = 12u << 20; bool auto_donate = true, auto_pipeline = true;   // crh_set_schedule
 };
 

@@ -22,7 +22,18 @@ namespace {
 
 // One batch: `ns` samples of `nt` tiles whose ids sit at d_tiles; seeds at d_seeds.
 // One wavefront schedule: `ns` samples of `nt` tiles (ids at d_tiles, seeds at d_seeds) on one stream and one slice of the path state.
-struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; bool donate = false; };
+struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; bool donate = false;
+              bool frame = false; int grid_frame = 0; };      // frame: the whole batch in one launch of the frame kernel (k_frame.h) with grid_frame workgroups
+
+// May this batch take the frame kernel?  Small, not counted, not timed per kernel, slots that fit the bits the kernel keeps them in.
+bool frame_ok(const crh_ctx* c, uint64_t total)
+{ return c->frame_kernel && !c->counters_on && !c->timing_on && total <= c->lane_max_paths && total < (uint64_t)kFrameMaxPaths; }
+int frame_grid(const crh_ctx* c, const DScene& S, uint32_t share = 1u)
+{
+  const int res = frame_resident_grid(c->clamp_grid ? c->cus : 0, S.two_level != 0);
+  const int want = c->frame_grid > 0 ? std::min(c->frame_grid, res) : res;
+  return std::max(64, want / (int)std::max(1u, share));
+}
 
 int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile,
              bool accumulate, hipEvent_t before_accumulate = nullptr, hipEvent_t before_accumulate2 = nullptr)
@@ -33,6 +44,12 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
   // (small batches -- a wavefront = an 8 x 8 pixel block -- lose with packets: 468 -> 391 Redraw/s, profiles/r4/ab_camera_ray_packets.txt)
   LT.packets = c->packets > 0 && !c->counters_on && !ln.donate && std::min<uint32_t>(ns & (0u - ns), 64u) >= (uint32_t)c->packets;
 
+  if (ln.frame) {
+    // the frame kernel: camera rays, every bounce's traversal, shading and shadow rays of this batch in ONE launch (k_frame.h); its two control words live behind
+    // the queue counters of this lane (zero when allocated, left zero by every launch)
+    Launch LF{ln.stream, ln.grid_frame, false, c->clamp_grid ? c->cus : 0};
+    launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->d_counters);
+  } else {
   launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev);
   int qin = 0;
   for (uint32_t b = 0; b < S.max_depth; ++b) {
@@ -47,6 +64,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     launch_shade(L, S, ln.P, ln.Q, qin, b, c->d_counters);
     if (S.n_lights > 0) launch_trace_any(T, S, ln.P, ln.Q, c->d_counters);
     qin = 1 - qin;
+  }
   }
   if (accumulate && before_accumulate) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate, 0));      // samples are folded in in frame order
   if (accumulate && before_accumulate2) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate2, 0));    // ... and not while a read-back tone-maps the accumulator
@@ -85,10 +103,12 @@ int run_batch(crh_ctx* c, const DScene& S, const uint32_t* d_tiles, uint32_t nt,
   // C3 at 1080p, 1 spp per call: traversal grids of 1536 / 1024 / 768 / 512 workgroups -> 163 / 174 / 173 / 165 Redraw/s; 128
   // tiles per call: 257 / 275 / 284 / 293 calls/s.
   auto small_grid = [&](uint64_t paths, int full, int per) { return (int)std::min<uint64_t>((uint64_t)full, std::max<uint64_t>(512u, paths / (uint64_t)per)); };
-  if (K < 2 || total > c->lane_max_paths || !accumulate || c->counters_on) {
+  const bool frame = frame_ok(c, total);
+  if (frame || K < 2 || total > c->lane_max_paths || !accumulate || c->counters_on) {
     const bool small = total <= c->lane_max_paths && !c->counters_on;
     Lane one{cstream(c), c->paths, c->queues, small ? small_grid(total, c->grid, 2048) : c->grid, small ? small_grid(total, c->grid_trace, 2048) : c->grid_trace, true};
     one.donate = small && c->donate;
+    one.frame = frame; one.grid_frame = frame ? frame_grid(c, S) : 0;
     return run_lane(c, one, S, d_tiles, nt, d_seeds, ns, seed_per_tile, accumulate);
   }
   // small batch: K tile ranges on K streams, each with its own slice [base, base + n_k * tpp * ns) of every path-state array
@@ -165,12 +185,14 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   const bool host_runs_ahead = !c->read_since_render;
   if (c->pipeline && host_runs_ahead && !c->counters_on && !c->timing_on && !c->adaptive && group == nt && spb == ns && ns <= 16u && total >= (1u << 20) &&
       total <= c->lane_max_paths && (uint64_t)c->pipe_depth * total <= c->max_paths) {
+    const bool frame = frame_ok(c, total);
+    const uint32_t depth = frame ? std::min(c->frame_pipe_depth, c->pipe_depth) : c->pipe_depth;      // frames in flight
     // ---- frame pipelining: this batch (one Redraw() worth) goes to pipeline stream k with its own half of the path state; it
     // starts as soon as the previous frame ON THAT STREAM is done and overlaps the frame on the other stream; its samples are
     // folded in after that frame's.  Nothing is joined into the context's stream here -- cstream() does that on demand.
     int rc = ensure_paths(c, (uint32_t)(c->pipe_depth * total)); if (rc) return rc;
     rc = ensure_lanes(c); if (rc) return rc;
-    const uint32_t k = c->pipe_seq % c->pipe_depth, prev = (c->pipe_seq + c->pipe_depth - 1u) % c->pipe_depth;      // this frame's stream, the previous frame's
+    const uint32_t k = c->pipe_seq % depth, prev = (c->pipe_seq + depth - 1u) % depth;      // this frame's stream, the previous frame's
     ++c->pipe_seq;
     const hipStream_t cs = c->stream_;                 // raw: no join
     if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(cs, c->lane_join[k], 0));      // this stream's seed slot is free once its last frame is done
@@ -194,11 +216,12 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
       // a host that submitted the previous frame a moment ago is not waiting for anything: the pipeline is about to fill (counting what is in flight NOW
       // would give the first frames of a burst grids for a nearly empty chip: eight of them, 2900 workgroups)
       const auto now = std::chrono::steady_clock::now();
-      if (c->pipe_last_submit.time_since_epoch().count() != 0 && now - c->pipe_last_submit < std::chrono::microseconds(300)) in_flight = std::max(in_flight, c->pipe_depth);
+      if (c->pipe_last_submit.time_since_epoch().count() != 0 && now - c->pipe_last_submit < std::chrono::microseconds(300)) in_flight = std::max(in_flight, depth);
       c->pipe_last_submit = now;
     }
     const uint64_t share = std::min<uint64_t>(512u, std::max<uint64_t>((uint64_t)c->pipe_grid_min, (uint64_t)c->grid_trace / in_flight));
     ln.grid_trace = (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(share, total / (uint64_t)c->pipe_div));
+    ln.frame = frame; ln.grid_frame = frame ? frame_grid(c, S, std::min(in_flight, depth)) : 0;
     const size_t base = (size_t)k * total;
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
@@ -208,9 +231,10 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
     // the frames in flight own path-state slices [k * total, (k + 1) * total): a batch of ANOTHER size (crh_render_tiles with another
     // sample count or tile list) would lay its slice across theirs -- it starts only when they are all done
-    if (total != c->pipe_total) {
+    // ... and so does the first frame after the number of frames in flight changed (frame kernel <-> staged form): stream k's predecessor is not frame n - 1 then
+    if (total != c->pipe_total || depth != c->pipe_last_depth) {
       for (int j = 0; j < 8; ++j) if (c->pipe_pending[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));
-      c->pipe_total = total;
+      c->pipe_total = total; c->pipe_last_depth = depth;
     }
     c->pending_n = 0;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);          // crh_stats.seconds: device time of this frame (frames in flight overlap)
@@ -312,6 +336,7 @@ int adaptive_iteration(crh_ctx* c)
   Lane ln{cstream(c), c->paths, c->queues, (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>(512u, (uint64_t)most * tpp / 1024u)),
           (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(512u, (uint64_t)most * tpp / 2048u)), true};      // grids follow the batch (run_batch)
   ln.n_tiles_dev = c->d_adapt_n; ln.donate = c->donate;
+  ln.frame = frame_ok(c, (uint64_t)most * tpp); ln.grid_frame = ln.frame ? std::min(frame_grid(c, S), (int)std::max<uint64_t>(64u, (uint64_t)most * tpp / 512u)) : 0;
   rc = run_lane(c, ln, S, c->d_tile_ids, most, c->d_seeds, 1, 1, true); if (rc) return rc;
   hipEventRecord(e1, cstream(c));
   c->render_ev.emplace_back(e0, e1);
@@ -431,13 +456,15 @@ int crh_set_lookahead_auto(crh_ctx* c, uint32_t max_frames)
 
 int crh_set_schedule(crh_ctx* c, int mode)
 {
-  if (!c || mode < CRH_SCHEDULE_AUTO || mode > CRH_SCHEDULE_SMALL) return fail(c, CRH_E_INVALID, "schedule must be CRH_SCHEDULE_AUTO / _WIDE / _SMALL");
-  if (c->schedule == CRH_SCHEDULE_AUTO) { c->auto_lane_max_paths = c->lane_max_paths; c->auto_donate = c->donate; c->auto_pipeline = c->pipeline; }
+  if (!c || mode < CRH_SCHEDULE_AUTO || mode > CRH_SCHEDULE_STAGED) return fail(c, CRH_E_INVALID, "schedule must be CRH_SCHEDULE_AUTO / _WIDE / _SMALL / _STAGED");
+  if (c->schedule == CRH_SCHEDULE_AUTO) { c->auto_lane_max_paths = c->lane_max_paths; c->auto_donate = c->donate; c->auto_pipeline = c->pipeline; c->auto_frame_kernel = c->frame_kernel; }
   c->schedule = mode; c->pending_n = 0;
   c->read_since_render = true;                           // the next frame is not pipelined behind frames of the other schedule
   // WIDE: no batch counts as small (run_batch: one stream, full grids, plain kernels; render_impl: no frame pipelining; adaptive
-  // iterations: plain kernels).  SMALL: every batch up to the path budget does.
-  c->lane_max_paths = mode == CRH_SCHEDULE_WIDE ? 0u : (mode == CRH_SCHEDULE_SMALL ? (1u << 30) : c->auto_lane_max_paths);
+  // iterations: plain kernels).  SMALL: every batch up to the path budget does (the frame kernel takes those below 2^25 slots, the staged form the rest).
+  // STAGED: like SMALL, in the staged form only (lanes / pipelined launches per stage and bounce, the donating kernels) -- the schedule the frame kernel replaced.
+  c->lane_max_paths = mode == CRH_SCHEDULE_WIDE ? 0u : (mode == CRH_SCHEDULE_SMALL || mode == CRH_SCHEDULE_STAGED ? (1u << 30) : c->auto_lane_max_paths);
+  c->frame_kernel = mode == CRH_SCHEDULE_STAGED ? false : c->auto_frame_kernel;
   c->donate = mode == CRH_SCHEDULE_WIDE ? false : c->auto_donate;
   c->pipeline = mode == CRH_SCHEDULE_WIDE ? false : c->auto_pipeline;
   return CRH_OK;

@@ -1,0 +1,217 @@
+// k_frame.h -- part of kernels.hip (ONE translation unit: included there inside namespace crh::(anonymous), after k_shade).  The frame kernel: a small batch --
+// one Redraw() = +1 sample per pixel of one frame (reference AppViewer.cxx:1045-1047) -- in ONE launch instead of 1 + 2-3 per bounce.
+// ================================================================== the frame kernel
+// Why.  The wavefront schedule (kernels.hip: k_raygen -> [k_trace_nearest -> k_shade -> k_trace_any] x depth) ends every launch with the longest rays of a few
+// wavefronts while the rest of the chip idles; a 512-sample batch hides that (25 ms per launch), a lone 1080p frame of 2 M paths is twenty such drains: 4.3 ms
+// for 1.2 ms of work at the batch rate, and the application restarts with a lone frame on every camera move (AppViewer.cxx:979-984).
+// What.  Every workgroup is a small streaming path tracer over its own paths: it claims path slots in chunks from ONE global cursor, generates their camera rays,
+// and keeps two rings in LDS -- rays to trace (nearest-hit and shadow rays mixed) and hit records to shade.  Its four wavefronts pick work by what is waiting:
+// a full wavefront of hits -> shade them (survivors and shadow rays go back into the ray ring), rays -> trace them with the persistent engine of k_traversal.h
+// (lanes refill from the ring as rays finish; when the ring is dry the idle lanes take over parts of the long rays' stacks, DON), nothing -> claim the next
+// chunk.  No stage ever waits for another workgroup, and a path's bounces follow each other without a launch boundary: the only drain is the end of the frame.
+// Per path nothing changes: the same camera_ray / trace steps / shade_path in the same order, the shadow ray of bounce b is resolved BEFORE the ray of bounce
+// b + 1 is traced (the lane that finishes the shadow ray goes on with the continuation itself), so the radiance record receives its terms in the order of the
+// wavefront schedule and every frame is bit-identical to it.  A path lives at the position of its slot for its whole life (no compaction: a queue entry is the
+// slot; the state is rewritten in place by the one lane that holds the path).
+constexpr uint32_t kFrameRing  = 1024;          // entries of each ring = the most paths a workgroup may have alive (every live path is in at most one ring)
+constexpr uint32_t kFrameEmpty = 0xFFFFFFFFu;   // a ring slot nobody has written yet
+constexpr uint32_t kFrameAny   = 0x80000000u;   // ray-ring entry: the path's shadow ray (else its camera-path ray)
+constexpr uint32_t kFrameBounceShift = 26;      // ray_d.w of a frame-kernel path: bounce << 26 | slot << 1 | inside-a-medium (slots < 2^25: small batches only)
+constexpr int      kFrameMats  = 32;            // materials staged in LDS (4 KB)
+
+struct FrameArgs {
+  const uint32_t* tile_ids; uint32_t n_tiles; const uint32_t* n_tiles_dev;      // as k_raygen's
+  const uint32_t* seeds; uint32_t n_samples; int seed_per_tile;
+  uint32_t* ctl;              // [0] slot cursor, [1] workgroups finished (both zero at launch; the last workgroup to leave zeroes them again)
+  uint32_t max_live;          // paths a workgroup keeps alive at most (<= kFrameRing)
+  uint32_t gen_chunk;         // path slots a wavefront claims at a time (a multiple of 64)
+};
+
+// ---- rings: multi-producer / multi-consumer inside one workgroup.  head / tail are tickets; a slot holds kFrameEmpty until its producer has written it and is
+// emptied again by its consumer, so neither side ever sees the other's half-done work.  A workgroup never has more entries than live paths <= kFrameRing.
+__device__ __forceinline__ uint32_t ring_claim(uint32_t* head, uint32_t* tail, uint32_t want, uint32_t& base)      // whole wavefront; returns the number claimed
+{
+  uint32_t n = 0, b = 0;
+  if (lane_id() == 0) {
+    for (;;) {
+      const uint32_t h = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), t = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t avail = t - h;
+      if (avail == 0u || avail > 0x7FFFFFFFu) break;
+      n = min(avail, want);
+      if (atomicCAS(head, h, h + n) == h) { b = h; break; }
+      n = 0;
+    }
+  }
+  base = __shfl(b, 0);
+  return __shfl(n, 0);
+}
+__device__ __forceinline__ uint32_t ring_take(uint32_t* slots, uint32_t ticket)
+{
+  uint32_t* p = slots + (ticket & (kFrameRing - 1u));
+  uint32_t v;
+  while ((v = atomicExch(p, kFrameEmpty)) == kFrameEmpty) __builtin_amdgcn_s_sleep(1);      // its producer holds the ticket and is about to write
+  return v;
+}
+__device__ __forceinline__ void ring_push(uint32_t* slots, uint32_t* tail, bool pred, uint32_t value)      // whole wavefront
+{
+  const unsigned long long m = __ballot(pred);
+  if (m == 0ull) return;
+  const uint32_t lane = lane_id(), leader = (uint32_t)__ffsll((long long)m) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(tail, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (pred) {
+    uint32_t* p = slots + ((base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (kFrameRing - 1u));
+    while (atomicCAS(p, kFrameEmpty, value) != kFrameEmpty) __builtin_amdgcn_s_sleep(1);                  // the consumer of the entry a lap ago is about to empty it
+  }
+}
+__device__ __forceinline__ uint32_t ring_count(uint32_t* head, uint32_t* tail)
+{
+  const uint32_t d = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return d > 0x7FFFFFFFu ? 0u : d;
+}
+__device__ __forceinline__ void wave_sub(uint32_t* word, bool pred)          // *word -= number of lanes with pred, one LDS atomic per wavefront
+{
+  const unsigned long long m = __ballot(pred);
+  if (m != 0ull && lane_id() == (uint32_t)__ffsll((long long)m) - 1u) atomicSub(word, (uint32_t)__popcll(m));
+}
+
+template <bool TWO>
+__global__ __launch_bounds__(kBlock, 4) void k_frame(DScene S, DPaths P, FrameArgs A, DCounters* C)
+{
+  __shared__ uint32_t stk[kLdsStack * kBlock];
+  __shared__ uint32_t s_bound[kBlock];
+  __shared__ float4 s_mats[kFrameMats * 8];
+  __shared__ uint32_t s_rq[kFrameRing], s_sq[kFrameRing];
+  __shared__ uint32_t s_ctl[8];      // [0] ray head, [1] ray tail, [2] shade head, [3] shade tail, [4] live paths, [5] the slot cursor has run out
+  uint32_t* const rq_head = &s_ctl[0]; uint32_t* const rq_tail = &s_ctl[1]; uint32_t* const sq_head = &s_ctl[2]; uint32_t* const sq_tail = &s_ctl[3];
+  uint32_t* const live = &s_ctl[4]; uint32_t* const cursor_out = &s_ctl[5];
+  for (uint32_t i = threadIdx.x; i < kFrameRing; i += kBlock) { s_rq[i] = kFrameEmpty; s_sq[i] = kFrameEmpty; }
+  if (threadIdx.x < 8u) s_ctl[threadIdx.x] = 0u;
+  const bool mats_in_lds = S.n_mats <= (uint32_t)kFrameMats;
+  if (mats_in_lds) for (uint32_t i = threadIdx.x; i < S.n_mats * 8u; i += kBlock) s_mats[i] = S.mats[i];
+  __syncthreads();
+
+  const uint32_t n_tiles = A.n_tiles_dev ? *A.n_tiles_dev : A.n_tiles;
+  const uint32_t total = n_tiles * S.tile_size * S.tile_size * A.n_samples;
+  const uint32_t lane = lane_id();
+  float4* const ray_o = P.ray_o[0]; float4* const ray_d = P.ray_d[0]; float4* const thr = P.thr[0];
+  uint32_t n_near = 0, n_any = 0, n_shaded = 0;      // this wavefront's share of crh_stats
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const Top2 t2 = top2_of(S);
+
+  for (;;) {
+    const uint32_t nr = ring_count(rq_head, rq_tail), ns = ring_count(sq_head, sq_tail);
+    // ------------------------------------------------------------------ shade a wavefront of hit records
+    if (ns >= 64u || (ns != 0u && nr == 0u && (__hip_atomic_load(cursor_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u ||
+                                                  __hip_atomic_load(live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + A.gen_chunk > A.max_live))) {
+      uint32_t base = 0;
+      const uint32_t n = ring_claim(sq_head, sq_tail, 64u, base);
+      if (n == 0u) continue;
+      const bool mine = lane < n;
+      uint32_t pos = 0;
+      if (mine) pos = ring_take(s_sq, base + lane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");          // the hit record and the path state were written by another wavefront of this workgroup
+      bool cont = false, shadow = false;
+      float4 n_o = zero4, n_d = zero4, n_t = zero4, s_o = zero4, s_d = zero4, s_c = zero4;
+      if (mine) {
+        const float4 o4 = ray_o[pos], d4 = ray_d[pos], h = P.hit[pos];
+        const uint32_t dw = __float_as_uint(d4.w), bounce = dw >> kFrameBounceShift;
+        const bool first = bounce == 0u, last = bounce + 1u >= S.max_depth;
+        const float4 t4 = first ? make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT) : thr[pos];
+        shade_path<false>(S, P, s_mats, mats_in_lds, bounce, first, last, o4, d4, t4, h, pos, cont, shadow, n_o, n_d, n_t, s_o, s_d, s_c, n_shaded);
+        if (cont) {
+          n_d.w = __uint_as_float(((bounce + 1u) << kFrameBounceShift) | (__float_as_uint(n_d.w) & ((1u << kFrameBounceShift) - 1u)));
+          ray_o[pos] = n_o; ray_d[pos] = n_d; thr[pos] = n_t;
+        }
+        if (shadow) { s_c.w = cont ? 1.0f : 0.f; P.sh_o[pos] = s_o; P.sh_d[pos] = s_d; P.sh_c[pos] = s_c; }      // .w: a camera-path ray waits behind this shadow ray
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      ring_push(s_rq, rq_tail, shadow, pos | kFrameAny);
+      ring_push(s_rq, rq_tail, cont && !shadow, pos);
+      wave_sub(live, mine && !cont && !shadow);                        // the path ends here
+      n_any += (uint32_t)__popcll(__ballot(shadow)); n_near += (uint32_t)__popcll(__ballot(cont));
+      continue;
+    }
+    // ------------------------------------------------------------------ trace what waits in the ray ring (returns when the ring is dry and every lane is done)
+    if (nr != 0u) {
+      uint32_t nn = 0, nt = 0;
+      trace_engine<false, false, TWO, true, true>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, t2, nullptr, 0u, &stk[threadIdx.x],
+        [&](uint32_t ticket, v3& o, v3& d, float& tmax, uint32_t& tag, bool& any_l) {
+          tag = ring_take(s_rq, ticket);
+          any_l = (tag & kFrameAny) != 0u; tag &= ~kFrameAny;
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          const float4 o4 = any_l ? P.sh_o[tag] : ray_o[tag], d4 = any_l ? P.sh_d[tag] : ray_d[tag];
+          o = xyz(o4); d = xyz(d4); tmax = any_l ? o4.w : CRH_MAXFLOAT;
+        },
+        [&](bool fin, uint32_t tag, float4 h, bool f, bool any_l, v3& o, v3& d, float& tmax) -> bool {
+          bool go_on = false;
+          if (fin && any_l) {
+            const float4 c = P.sh_c[tag];
+            if (!f) {                                                   // unoccluded: the pending contribution joins the path's radiance
+              float4 r = P.rad[tag];
+              if (__float_as_uint(r.w) != P.stamp) r = zero4;
+              r.x += c.x; r.y += c.y; r.z += c.z; r.w = __uint_as_float(P.stamp);
+              P.rad[tag] = r;
+            }
+            go_on = c.w != 0.f;
+            if (go_on) { const float4 o4 = ray_o[tag], d4 = ray_d[tag]; o = xyz(o4); d = xyz(d4); tmax = CRH_MAXFLOAT; }
+          }
+          const bool to_shade = fin && !any_l;
+          if (to_shade) P.hit[tag] = h;
+          if (__ballot(to_shade) != 0ull) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            ring_push(s_sq, sq_tail, to_shade, tag);
+          }
+          wave_sub(live, fin && any_l && !go_on);                      // a shadow ray with nothing behind it: the path is done
+          return go_on;
+        }, nn, nt, &s_bound[threadIdx.x & ~63u],
+        [&](uint32_t want, uint32_t& base) -> uint32_t { return ring_claim(rq_head, rq_tail, want, base); });
+      continue;
+    }
+    // ------------------------------------------------------------------ nothing waits: the next chunk of path slots, if the workgroup may hold more paths
+    uint32_t ok = 0, cbase = 0;
+    if (lane == 0 && __hip_atomic_load(cursor_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+      const uint32_t before = atomicAdd(live, A.gen_chunk);             // counted BEFORE the slots are claimed: nobody sees "no paths, no slots" in between
+      if (before + A.gen_chunk > A.max_live) atomicSub(live, A.gen_chunk);
+      else {
+        cbase = atomicAdd(A.ctl, A.gen_chunk);
+        if (cbase >= total) { atomicSub(live, A.gen_chunk); __hip_atomic_store(cursor_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        else ok = 1u;
+      }
+    }
+    ok = __shfl(ok, 0); cbase = __shfl(cbase, 0);
+    if (ok) {
+      uint32_t made = 0;
+      for (uint32_t it = 0; it < A.gen_chunk; it += 64u) {
+        const uint32_t pid = cbase + it + lane;
+        bool valid = pid < total;
+        uint32_t px = 0, py = 0, s = 0, local = 0;
+        if (valid) { slot_to_pixel_sample(pid, A.n_samples, local, s); valid = slot_pixel(S, A.tile_ids, local, px, py); }
+        if (valid) {
+          v3 o, d; uint32_t rng;
+          camera_ray(S, A.seeds, A.seed_per_tile, px, py, s, local, o, d, rng);
+          ray_o[pid] = mk4(o, __uint_as_float(rng));
+          ray_d[pid] = mk4(d, __uint_as_float(pid << 1));               // bounce 0, outside
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        ring_push(s_rq, rq_tail, valid, pid);
+        made += (uint32_t)__popcll(__ballot(valid));
+      }
+      if (lane == 0 && made != A.gen_chunk) atomicSub(live, A.gen_chunk - made);      // slots past the end or outside the image (edge tiles are partial)
+      n_near += made;
+      continue;
+    }
+    // ------------------------------------------------------------------ idle: other wavefronts of the workgroup still hold paths, or the frame is done
+    if (__hip_atomic_load(cursor_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u && __hip_atomic_load(live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  if (lane == 0) {
+    if (n_near) atomicAdd(&C->rays_nearest, (unsigned long long)n_near);
+    if (n_any) atomicAdd(&C->rays_any, (unsigned long long)n_any);
+  }
+  n_shaded = wave_sum(n_shaded);
+  if (lane == 0 && n_shaded) atomicAdd(&C->shaded_hits, (unsigned long long)n_shaded);
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(A.ctl + 1, 1u) == gridDim.x - 1u) { A.ctl[0] = 0u; A.ctl[1] = 0u; }      // the last workgroup leaves the control words as it found them
+}

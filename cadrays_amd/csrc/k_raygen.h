@@ -45,6 +45,42 @@ __device__ __forceinline__ uint32_t pixel_sample_to_slot(uint32_t local, uint32_
   return B * 64u * ns + (((c << lg) + b) << 6) + (CRH_SLOT_SAMPLE_MAJOR ? si * P + pi_ : (pi_ << lg) + si);
 }
 
+// The camera ray of pixel (px, py), sample s of the batch (a2 / a14): rng seed, sub-pixel jitter, pinhole / orthographic / frustum-corner ray, thin lens.  Shared by
+// k_raygen and the frame kernel's own ray generation (k_frame.h).  `local` = the pixel's slot among the batch's tiles (adaptive passes seed per tile).
+__device__ __forceinline__ void camera_ray(const DScene& S, const uint32_t* __restrict__ seeds, const int seed_per_tile, const uint32_t px, const uint32_t py,
+                                           const uint32_t s, const uint32_t local, v3& o, v3& d, uint32_t& rng)
+{
+  const uint32_t pix = S.coherent ? ((py / 16u) * ((S.width + 15u) / 16u) + (px / 16u)) : (py * S.width + px);
+  // whole-frame passes share one frame seed per sample; adaptive passes give every tile its own sample index
+  const uint32_t fseed = seed_per_tile ? seeds[local / (S.tile_size * S.tile_size)] : seeds[s];
+  rng = crh_rng_seed(pix, fseed);
+  const float jx = crh_rng_next_mode(&rng, S.spec_u32), jy = crh_rng_next_mode(&rng, S.spec_u32);
+  const float nx = CRH_FMA(((float)px + jx) / (float)S.width, 2.0f, -1.0f);
+  const float ny = CRH_FMA(((float)py + jy) / (float)S.height, -2.0f, 1.0f);
+  if (S.is_ortho) {
+    const float sx = (nx * S.ortho_scale) * S.aspect, sy = ny * S.ortho_scale;
+    o = crh_madd3(crh_madd3(S.eye, S.right, sx), S.up, sy);
+    d = S.fwd;
+  } else if (S.spec_raygen) {
+    // crh_spec.h #13 (SURVEY a2, Appendix A GenerateRay): blend of the four frustum-corner directions by the pixel's position in [0,1]^2
+    const float u = ((float)px + jx) / (float)S.width, v = 1.0f - ((float)py + jy) / (float)S.height;
+    o = S.eye;
+    d = crh_norm3(crh_lerp3(crh_lerp3(S.corner[0], S.corner[1], u), crh_lerp3(S.corner[2], S.corner[3], u), v));
+  } else {
+    const float sx = (nx * S.tan_half) * S.aspect, sy = ny * S.tan_half;
+    o = S.eye;
+    d = crh_norm3(crh_madd3(crh_madd3(S.fwd, S.right, sx), S.up, sy));
+  }
+  if (S.aperture > 0.f) {
+    const float k1 = crh_rng_next_mode(&rng, S.spec_u32), k2 = crh_rng_next_mode(&rng, S.spec_u32);
+    const float ft = S.focal / crh_dot3(d, S.fwd);
+    const v3 focus = crh_madd3(o, d, ft);
+    const float r = S.aperture * crh_sqrt(k1); float sn, cs; crh_sincos2pi(k2, &sn, &cs);
+    o = crh_madd3(crh_madd3(o, S.right, r * cs), S.up, r * sn);
+    d = crh_norm3(crh_sub3(focus, o));
+  }
+}
+
 // SPLIT: the instantiation for split scenes (static tree + moved objects) also lists the rays that touch a moved object; the plain one carries none of it
 template <bool SPLIT>
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t* __restrict__ q, uint32_t* __restrict__ count,
@@ -94,36 +130,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
     uint32_t px = 0, py = 0, s = 0, local = 0;
     if (valid) { slot_to_pixel_sample(pid, n_samples, local, s); valid = slot_pixel(S, tile_ids, local, px, py); }
     if (valid) {
-      const uint32_t pix = S.coherent ? ((py / 16u) * ((S.width + 15u) / 16u) + (px / 16u)) : (py * S.width + px);
-      // whole-frame passes share one frame seed per sample; adaptive passes give every tile its own sample index
-      const uint32_t fseed = seed_per_tile ? seeds[local / (S.tile_size * S.tile_size)] : seeds[s];
-      uint32_t rng = crh_rng_seed(pix, fseed);
-      const float jx = crh_rng_next_mode(&rng, S.spec_u32), jy = crh_rng_next_mode(&rng, S.spec_u32);
-      const float nx = CRH_FMA(((float)px + jx) / (float)S.width, 2.0f, -1.0f);
-      const float ny = CRH_FMA(((float)py + jy) / (float)S.height, -2.0f, 1.0f);
-      v3 o, d;
-      if (S.is_ortho) {
-        const float sx = (nx * S.ortho_scale) * S.aspect, sy = ny * S.ortho_scale;
-        o = crh_madd3(crh_madd3(S.eye, S.right, sx), S.up, sy);
-        d = S.fwd;
-      } else if (S.spec_raygen) {
-        // crh_spec.h #13 (SURVEY a2, Appendix A GenerateRay): blend of the four frustum-corner directions by the pixel's position in [0,1]^2
-        const float u = ((float)px + jx) / (float)S.width, v = 1.0f - ((float)py + jy) / (float)S.height;
-        o = S.eye;
-        d = crh_norm3(crh_lerp3(crh_lerp3(S.corner[0], S.corner[1], u), crh_lerp3(S.corner[2], S.corner[3], u), v));
-      } else {
-        const float sx = (nx * S.tan_half) * S.aspect, sy = ny * S.tan_half;
-        o = S.eye;
-        d = crh_norm3(crh_madd3(crh_madd3(S.fwd, S.right, sx), S.up, sy));
-      }
-      if (S.aperture > 0.f) {
-        const float k1 = crh_rng_next_mode(&rng, S.spec_u32), k2 = crh_rng_next_mode(&rng, S.spec_u32);
-        const float ft = S.focal / crh_dot3(d, S.fwd);
-        const v3 focus = crh_madd3(o, d, ft);
-        const float r = S.aperture * crh_sqrt(k1); float sn, cs; crh_sincos2pi(k2, &sn, &cs);
-        o = crh_madd3(crh_madd3(o, S.right, r * cs), S.up, r * sn);
-        d = crh_norm3(crh_sub3(focus, o));
-      }
+      v3 o, d; uint32_t rng;
+      camera_ray(S, seeds, seed_per_tile, px, py, s, local, o, d, rng);
       P.ray_o[0][pid] = mk4(o, __uint_as_float(rng));           // .w = rng state; position = path slot at bounce 0
       P.ray_d[0][pid] = mk4(d, __uint_as_float(pid << 1));      // .w = (path slot << 1) | inside-a-medium flag
       if (SPLIT) flagged = ray_touches_instances(S, o, d, CRH_MAXFLOAT);

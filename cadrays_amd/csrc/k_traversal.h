@@ -109,12 +109,18 @@ __device__ __forceinline__ bool touches_instances(const Top2& t2, v3 o, v3 d, fl
 }
 __device__ __forceinline__ bool ray_touches_instances(const DScene& S, v3 o, v3 d, float tmax) { return touches_instances(top2_of(S), o, d, tmax); }
 
-template <bool ANY, bool COUNT, bool TWO, bool DON, class Load, class Store>
+// FRM (the frame kernel, k_frame.h): the rays come from the workgroup's ray ring in LDS instead of a global queue -- `claim(want, base)` hands out up to `want`
+// ring entries (0: the ring is empty RIGHT NOW; shading may refill it, so the walk goes on with donation and the engine returns only when no lane holds a ray and
+// the ring has nothing); nearest-hit and any-hit rays travel mixed (load() says which, per lane: `any_l` takes the place of the template constant ANY); store() is
+// called by the whole wavefront with a predicate (it appends to the shade ring with one LDS atomic per wavefront) and may hand the lane its path's NEXT ray -- the
+// camera-path continuation that waited behind a shadow ray -- which the lane starts at once.
+template <bool ANY, bool COUNT, bool TWO, bool DON, bool FRM = false, class Load, class Store, class Claim = int>
 __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                              const float4* __restrict__ inst, uint32_t root, float4 gbox, const Top2 t2,
                                              uint32_t* __restrict__ cursor, uint32_t n, uint32_t* lds,
-                                             Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris, uint32_t* bound = nullptr)
+                                             Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris, uint32_t* bound = nullptr, Claim claim = Claim())
 {
+  static_assert(!FRM || (DON && !COUNT), "the frame kernel's engine donates (its retire step lives there) and does not count visits");
   // bound (DON): one word per lane of this wavefront in LDS -- the smallest hit distance any part of the ray that STARTED in that
   // lane has found so far (float bits; distances are >= 0, so unsigned order = float order).  Every part prunes BOXES with it
   // (a box entered later than the bound holds nothing that can win the fold; equality is kept, ties are decided by order);
@@ -124,6 +130,8 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   // per-lane ray state
   bool have = false;
+  bool any_l = ANY;                     // FRM: this lane's ray is an occlusion query (per lane); otherwise the template constant
+#define CRH_ISANY (FRM ? any_l : ANY)
   uint32_t cur = kDone, tag = 0;
   int sp = 0;
   v3 o = crh_mk3(0.f, 0.f, 0.f), d = o;
@@ -157,7 +165,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   // DON, thin mode: a queue too short to give every wavefront 32 rays is dealt out in chunks of 8 ... 32 rays (about one per wavefront); a wavefront
   // takes ONE chunk at a time and all of its 64 lanes work on it (donation from the start), so the launch ends after ~the
   // average ray instead of after the longest one
-  const bool thin = DON && per_wave < 17u;                                   // at most half of the lanes get a ray of their own
+  const bool thin = !FRM && DON && per_wave < 17u;                           // at most half of the lanes get a ray of their own
   const uint32_t chunk = thin ? max(8u, (2u * per_wave + 7u) & ~7u) : min(kPoolChunk, max(64u, (per_wave + 63u) & ~63u));
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
@@ -165,6 +173,25 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   for (;;) {
     // ------------------------------------------------------------------ refill idle lanes
     unsigned long long idle = __ballot(!have);
+    if constexpr (FRM) {
+      if ((uint32_t)__popcll(idle) >= (uint32_t)CRH_REFILL_IDLE) {
+        uint32_t base = 0;
+        const uint32_t take = claim((uint32_t)__popcll(idle), base);
+        exhausted = take == 0u;                                  // "dry" for now: asked again on the next turn
+        const bool mine = !have && (uint32_t)__popcll(idle & lt_mask) < take;
+        if (mine) {
+          float tmax;
+          load(base + (uint32_t)__popcll(idle & lt_mask), o, d, tmax, tag, any_l);
+          ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
+          set_guard(gbox);
+          if (TWO) save_world();
+          best = tmax; found = false; sp = 0; cur = root; have = true;
+          if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, d, tmax)) { lds[0] = t2.root2; sp = 1; }
+          hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
+          if (DON) { sbase = 0; is_child = false; cfound = false; next = kNoLane; head = lane; bound[lane] = __float_as_uint(tmax); }
+        }
+      }
+    } else
     if (!exhausted && (thin ? idle == ~0ull : (uint32_t)__popcll(idle) >= (uint32_t)CRH_REFILL_IDLE)) {
       for (int round = 0; round < (thin ? 1 : 2) && idle != 0ull; ++round) {
         if (pool_next == pool_end) {
@@ -203,7 +230,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       if (idle_m != 0ull) {
         // a donor gives the FAR half of its stack (the entries below the middle, all of them in the LDS part); the helper
         // copies them into its own column and starts with the nearest of them
-        bool can = have && cur != kDone && sp > sbase && sp <= kLdsStack && !(ANY && found);
+        bool can = have && cur != kDone && sp > sbase && sp <= kLdsStack && !(CRH_ISANY && found);
         if (TWO && can && lds[sbase * kBlock] == CRH_REF_SENTINEL) can = false;
         const int give_n = (sp - sbase + 1) >> 1;
         if (TWO && can)      // only world-level entries travel (the helper starts with the world ray): stop below an object sentinel
@@ -232,6 +259,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
             rox = __shfl(o.x, src); roy = __shfl(o.y, src); roz = __shfl(o.z, src); rdx = __shfl(d.x, src); rdy = __shfl(d.y, src); rdz = __shfl(d.z, src);
           }
           const float rbest = __shfl(best, src);
+          const int rany = FRM ? __shfl((int)any_l, src) : 0;
           const uint32_t rnext = __shfl(next, src), rhead = __shfl(head, src);
           if (gives) { next = kth_bit(idle_m, rank_d); sbase += give_n; }          // the helper comes right after the donor ...
           if (takes) {
@@ -242,6 +270,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
             best = rbest; found = false; sbase = 0; sp = rcnt - 1; cur = lds[sp * kBlock]; have = true;      // the nearest of the entries received
             hit = make_float4(rbest, 0.f, 0.f, __int_as_float(-1));
             is_child = true; cfound = false; next = rnext; head = rhead;            // ... and before what the donor gave away earlier
+            if (FRM) any_l = rany != 0;
           }
         }
       }
@@ -253,7 +282,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       else { cur = ovf[sp - kLdsStack]; asm volatile("" : "+v"(cur)); }
     };
     auto pop = [&]() {
-      if ((ANY && found) || sp == (DON ? sbase : 0)) { cur = kDone; return; }
+      if ((CRH_ISANY && found) || sp == (DON ? sbase : 0)) { cur = kDone; return; }
       read_top();
       if (TWO && cur == CRH_REF_SENTINEL) {          // leaving an object: back to the world-space ray
         o = crh_mk3(wray[0 * kBlock], wray[1 * kBlock], wray[2 * kBlock]); d = crh_mk3(wray[3 * kBlock], wray[4 * kBlock], wray[5 * kBlock]);
@@ -311,7 +340,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       CRH_CHILD(3)
 #undef CRH_CHILD
 #undef CRH_QB
-      if (ANY && CRH_SPEC_ANYHIT_SLOT_ORDER) {
+      if (CRH_SPEC_ANYHIT_SLOT_ORDER && CRH_ISANY) {
         // crh_spec.h #8: an occlusion query needs no near-to-far order -- the hit children are taken in SLOT order (no sort, no keys): the
         // lowest hit slot continues, the others go onto the stack so that they pop in slot order; three unconditional stores, the ones of
         // children that were not hit (and of the one that continues) land in dead slots at / above the new top
@@ -397,7 +426,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float vv = crh_dot3(vc, e0) * inv;
       if (tt >= 0.f && uu >= 0.f && vv >= 0.f && (uu + vv) <= 1.0f && tt < best) {
         best = tt; found = true;
-        if (DON) atomicMin(&bound[head], ANY ? 0u : __float_as_uint(tt));      // any-hit: one occluder ends every part's walk
+        if (DON) atomicMin(&bound[head], CRH_ISANY ? 0u : __float_as_uint(tt));      // any-hit: one occluder ends every part's walk
         hit = make_float4(tt, uu, vv, __int_as_float((int)ti));
       }
     };
@@ -434,7 +463,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       // own part walked and no successor left: fold what was absorbed behind the own hit (left-biased minimum: a later part
       // wins only with a strictly smaller t); helpers then wait to be absorbed by their predecessor, the head stores
       const bool finished = have && cur == kDone && next == kNoLane;
-      if (finished && cfound) { if (ANY || !found || chit.x < hit.x) { hit = chit; found = true; } cfound = false; }
+      if (finished && cfound) { if (CRH_ISANY || !found || chit.x < hit.x) { hit = chit; found = true; } cfound = false; }
       const unsigned long long fin_children = __ballot(finished && is_child);
       if (fin_children != 0ull) {
         const bool takes = have && next != kNoLane && ((fin_children >> next) & 1ull);
@@ -443,17 +472,33 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         const int hf = __shfl((int)found, from);
         if (takes) {
           // the successor's total goes IN FRONT of what this lane absorbed before (it was donated later = it comes earlier)
-          if (hf && (ANY || !cfound || !(chit.x < hx))) { chit = make_float4(hx, hy, hz, hw); cfound = true; }
+          if (hf && (CRH_ISANY || !cfound || !(chit.x < hx))) { chit = make_float4(hx, hy, hz, hw); cfound = true; }
           next = kNoLane;
         }
         if ((fin_children >> lane) & 1ull) { have = false; is_child = false; }           // absorbed: the lane is free again
       }
-      if (have && !is_child && cur == kDone && next == kNoLane) {
-        if (cfound) { if (ANY || !found || chit.x < hit.x) { hit = chit; found = true; } cfound = false; }
-        store(tag, hit, found); have = false;
-      }
-    } else if (have && cur == kDone) { store(tag, hit, found); have = false; }
+      const bool fin = have && !is_child && cur == kDone && next == kNoLane;
+      if (fin && cfound) { if (CRH_ISANY || !found || chit.x < hit.x) { hit = chit; found = true; } cfound = false; }
+      if constexpr (FRM) {
+        float tmax = CRH_MAXFLOAT;
+        const bool go_on = store(fin, tag, hit, found, any_l, o, d, tmax);      // the whole wavefront calls; true: the lane's path continues with the ray in o, d
+        if (fin) {
+          have = go_on;
+          if (go_on) {
+            any_l = false;
+            ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
+            set_guard(gbox);
+            if (TWO) save_world();
+            best = tmax; found = false; sp = 0; cur = root;
+            if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, d, tmax)) { lds[0] = t2.root2; sp = 1; }
+            hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
+            sbase = 0; is_child = false; cfound = false; next = kNoLane; head = lane; bound[lane] = __float_as_uint(tmax);
+          }
+        }
+      } else if (fin) { store(tag, hit, found); have = false; }
+    } else if constexpr (!FRM) { if (have && cur == kDone) { store(tag, hit, found); have = false; } }
   }
+#undef CRH_ISANY
 }
 
 // P2: the SECOND pass of a split scene (static tree + moved objects).  The first pass is the single-level instantiation over the

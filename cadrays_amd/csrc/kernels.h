@@ -24,6 +24,12 @@ void launch_expand_packet_nodes(const Launch&, const float4* nodes, float4* pnod
 void launch_shade(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, uint32_t bounce, DCounters*);
 // any-hit traversal of the shadow queue; unoccluded contributions are added to the path radiance
 void launch_trace_any(const Launch&, const DScene&, const DPaths&, const DQueues&, DCounters*);
+// the frame kernel (k_frame.h): a whole small batch -- camera rays, every bounce's traversal, shading and shadow rays -- in one launch; `ctl` = two control words, zero
+// at launch and left zero; L.grid = workgroups wanted (clamped to what is resident); slots must stay below kFrameMaxPaths
+constexpr uint32_t kFrameMaxPaths = 1u << 25;
+int frame_resident_grid(int cus, bool two_level);
+void launch_frame(const Launch&, const DScene&, const DPaths&, uint32_t* ctl, const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_frame_seeds,
+                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, DCounters*);
 // clamp + running mean of the finished paths of batch samples [first_sample, first_sample + n_samples) into the float4
 // accumulator, sample by sample; batch_samples = the sample count the batch was generated with (it fixes the slot layout)
 void launch_accumulate(const Launch&, const DScene&, const DPaths&, float4* accum, float* m2 /* or nullptr */,

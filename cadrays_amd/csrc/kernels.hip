@@ -27,6 +27,7 @@ namespace {
 #include "k_lights_env.h"
 #include "k_raygen.h"
 #include "k_shade.h"
+#include "k_frame.h"
 #include "k_accumulate.h"
 
 }  // namespace
@@ -102,6 +103,27 @@ void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const D
     if (L.counters) CRH_LAUNCH_TA(true, true, false, true, Q.q2_sh, Q.counts + 7); else if (L.donate) CRH_LAUNCH_TA(false, true, true, true, Q.q2_sh, Q.counts + 7); else CRH_LAUNCH_TA(false, true, false, true, Q.q2_sh, Q.counts + 7);
   }
 #undef CRH_LAUNCH_TA
+}
+// The frame kernel (k_frame.h): ray generation, every bounce's traversal and shading of a small batch in ONE launch.  `ctl`: two words, zero at launch (the kernel
+// leaves them zero).  The grid is what the register budget keeps resident (every workgroup is a persistent streaming path tracer), or less for a frame that
+// shares the chip with others in flight.
+int frame_resident_grid(int cus, bool two_level)
+{
+  static int per_cu[2] = {0, 0};
+  int& pc = per_cu[two_level ? 1 : 0];
+  if (pc == 0) { int n = 0; pc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, two_level ? k_frame<true> : k_frame<false>, kBlock, 0) == hipSuccess && n > 0) ? n : -1; }
+  return (pc > 0 ? pc : 4) * (cus > 0 ? cus : 256);
+}
+void launch_frame(const Launch& L, const DScene& S, const DPaths& P, uint32_t* ctl, const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds,
+                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, DCounters* C)
+{
+  FrameArgs A;
+  A.tile_ids = d_tile_ids; A.n_tiles = n_tiles; A.n_tiles_dev = d_n_tiles; A.seeds = d_seeds; A.n_samples = n_samples; A.seed_per_tile = seed_per_tile;
+  A.ctl = ctl; A.gen_chunk = min(max(gen_chunk & ~63u, 64u), kFrameRing); A.max_live = min(max(max_live, A.gen_chunk), kFrameRing);
+  DScene S1 = S; S1.split = 0;                  // a split scene is walked in one go: static tree, then the top level (the two-pass form is a wavefront-schedule device)
+  const int grid = min(L.grid, frame_resident_grid(L.cus, S.two_level != 0));
+  if (S.two_level) hipLaunchKernelGGL(k_frame<true>, dim3(grid), dim3(kBlock), 0, L.stream, S1, P, A, C);
+  else             hipLaunchKernelGGL(k_frame<false>, dim3(grid), dim3(kBlock), 0, L.stream, S1, P, A, C);
 }
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,
                        uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, uint32_t batch_samples, DCounters* C, const uint32_t* d_n_tiles)

@@ -169,6 +169,8 @@ CRH_API int crh_set_params(crh_ctx* ctx, const crh_params* p);
  * shaders behind V3d_View::Redraw() (AppViewer.cxx:1047).  Defaults = the spec every golden vector was generated with.  Setting
  * them restarts accumulation.  crh_spec_order_exact() reports the one build-time switch (CRH_SPEC_ORDER_EXACT) of this library. */
 CRH_API int crh_set_spec(crh_ctx* ctx, const crh_spec* spec);
+/* spec_out->size is IN / OUT: set it to sizeof(crh_spec) as the caller's header defines the struct before the call; exactly that many bytes are written
+ * (a caller built against round 3's 24-byte struct gets its five switches and nothing past its buffer); any other size -> CRH_E_INVALID, nothing written. */
 CRH_API int crh_get_spec(crh_ctx* ctx, crh_spec* spec_out);
 CRH_API int crh_spec_order_exact(void);
 CRH_API int crh_spec_anyhit_slot_order(void);      /* the other build-time switch, CRH_SPEC_ANYHIT_SLOT_ORDER */
@@ -223,6 +225,11 @@ CRH_API int crh_set_lookahead_auto(crh_ctx* ctx, uint32_t max_frames);
 #define CRH_SCHEDULE_AUTO  0
 #define CRH_SCHEDULE_WIDE  1
 #define CRH_SCHEDULE_SMALL 2
+/* Round 5: a small batch is ONE launch of the frame kernel (cadrays_amd/csrc/k_frame.h: every workgroup streams its own paths through ray generation, traversal
+ * and shading; no launch boundary between bounces) -- that is what AUTO and SMALL run for batches below 2^25 path slots.  CRH_SCHEDULE_STAGED: every batch that
+ * fits takes the small-batch schedule in its STAGED form instead (one launch per stage and bounce on tile-range / frame-pipeline streams, the work-donating
+ * traversal kernels): the schedule of rounds 2-4, kept as the reference the frame kernel's frames are compared with.  Same image, bit for bit, in every mode. */
+#define CRH_SCHEDULE_STAGED 3
 CRH_API int crh_set_schedule(crh_ctx* ctx, int mode);
 /* Device-memory budget of the wavefront path state: at most `max_paths` path slots (196 B each) are in flight per batch; a render
  * that needs more is cut into tile groups / sample batches (same image, bit for bit).  Default 2^29 slots = 105 GB of the

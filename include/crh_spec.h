@@ -92,6 +92,20 @@ static inline int crh_spec_normalise(const crh_spec* in, crh_spec* out, const ch
   return 0;
 }
 
+/* What crh_get_spec (product) and the oracle's twin do: `out->size` is IN / OUT -- the caller sets it to sizeof(crh_spec) AS IT KNOWS THE STRUCT
+ * (24 for a caller built against round 3's header) and exactly that many bytes are written: the switches the caller's struct has room for, nothing
+ * past it; size stays the caller's.  A size that is neither this library's nor an older struct's (below CRH_SPEC_SIZE_R3, above sizeof(crh_spec),
+ * not a multiple of 4 -- which includes an unset 0) is refused and nothing is written.  Returns 0 / -1 with *why set. */
+static inline int crh_spec_export(const crh_spec* have, crh_spec* out, const char** why)
+{
+  const char* dummy; if (!why) why = &dummy;
+  if (!have || !out) { *why = "null spec"; return -1; }
+  const uint32_t n = out->size;
+  if (n < CRH_SPEC_SIZE_R3 || n > (uint32_t)sizeof(crh_spec) || (n & 3u)) { *why = "crh_spec.size must hold the caller's sizeof(crh_spec) before crh_get_spec (24 .. this library's, a multiple of 4)"; return -1; }
+  { const unsigned char* src = (const unsigned char*)have; unsigned char* dst = (unsigned char*)out; for (uint32_t i = 4; i < n; ++i) dst[i] = src[i]; }
+  return 0;
+}
+
 /* #4: build-time (traversal inner loop).  0 = quantised key (default), 1 = exact distance order, ties by slot. */
 #ifndef CRH_SPEC_ORDER_EXACT
 #define CRH_SPEC_ORDER_EXACT 0

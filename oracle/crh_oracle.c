@@ -1314,7 +1314,7 @@ ORC_API int orc_set_spec(orc_ctx* c, const crh_spec* sp)
   c->spec = n;
   return orc_reset(c);
 }
-ORC_API int orc_get_spec(orc_ctx* c, crh_spec* out) { if (!c || !out) return CRH_E_INVALID; *out = c->spec; out->size = (uint32_t)sizeof(crh_spec); return 0; }
+ORC_API int orc_get_spec(orc_ctx* c, crh_spec* out) { if (!c || !out) return CRH_E_INVALID; return crh_spec_export(&c->spec, out, NULL) ? CRH_E_INVALID : 0; }
 ORC_API int orc_spec_order_exact(void) { return CRH_SPEC_ORDER_EXACT; }
 ORC_API int orc_spec_anyhit_slot_order(void) { return CRH_SPEC_ANYHIT_SLOT_ORDER; }
 ORC_API int orc_build(orc_ctx* c)

@@ -73,6 +73,34 @@ def test_spec_struct_round_trips_and_validates(oracle_lib):
             o._call("set_spec", C.byref(abi.crh_spec(size=size, eta_no_dielectric=1.0)))
     o.set_spec()
     assert o.spec_order_exact() == 0                   # the default build uses the quantised child-order key
+    check_get_spec_honours_the_callers_size(o)
+
+
+def check_get_spec_honours_the_callers_size(b):
+    """get_spec writes exactly `size` bytes (in / out field) -- a caller built against round 3's 24-byte struct gets its five switches and
+    nothing behind its buffer; an unset or impossible size is refused and nothing is written.  Runs on the oracle (CPU) and on the product (GPU)."""
+    import ctypes as C
+    from cadrays_amd.binding import BackendError
+    b.set_spec(uniform_32bit=1, eta_no_dielectric=1.25, rr_start_bounce=9, env_orientation=1)
+
+    class Old(C.Structure):                            # round 3's struct followed by what the caller's stack holds next
+        _fields_ = [("size", C.c_uint32), ("uniform_32bit", C.c_int32), ("texel_gamma2", C.c_int32), ("mis_single_lobe", C.c_int32), ("eps_rule", C.c_int32),
+                    ("eta_no_dielectric", C.c_float), ("canary", C.c_uint32 * 8)]
+    old = Old(size=24)
+    for i in range(8):
+        old.canary[i] = 0xC0FFEE00 + i
+    b._call("get_spec", C.byref(old))
+    assert (old.size, old.uniform_32bit, old.texel_gamma2, old.eps_rule, old.eta_no_dielectric) == (24, 1, 0, 0, 1.25)
+    assert [old.canary[i] for i in range(8)] == [0xC0FFEE00 + i for i in range(8)], "get_spec wrote past a 24-byte struct"
+    for size in (0, 20, 26, C.sizeof(abi.crh_spec) + 4):
+        bad = Old(size=size, eta_no_dielectric=-7.0)
+        with pytest.raises(BackendError):
+            b._call("get_spec", C.byref(bad))
+        assert bad.eta_no_dielectric == -7.0 and bad.size == size          # refused: nothing written
+    full = abi.crh_spec(size=C.sizeof(abi.crh_spec))
+    b._call("get_spec", C.byref(full))
+    assert full.size == C.sizeof(abi.crh_spec) and full.rr_start_bounce == 9 and full.env_orientation == 1
+    b.set_spec()
 
 
 def test_defaults_are_the_frozen_spec_and_every_switch_is_real(oracle_lib):
@@ -135,6 +163,8 @@ def test_hip_equals_oracle_with_switch_flipped(hip_lib, oracle_lib, name):
     ref, o = render(oracle_lib.Oracle(), sc, spp=4, **kw)
     v = View(0)
     assert v.get_spec() == abi.SPEC_DEFAULTS and v.spec_order_exact() == 0
+    if name == "defaults":
+        check_get_spec_honours_the_callers_size(v)
     g, v = render(v, sc, spp=4, **kw)
     assert v.get_spec() == o.get_spec()
     assert np.array_equal(bits(g), bits(ref)), name

@@ -4,8 +4,9 @@ bench.py times the big-batch schedule: one stream, full persistent grids, `k_tra
 (`crh_api.cpp` run_batch).  The other render-parity tests either switch the visit counters on (-> the COUNT=true instantiations) or
 render batches small enough for the small-batch schedule (two tile ranges / pipelined frames, the work-DONATING instantiations).  Here
 every scene goes through `crh_set_schedule(CRH_SCHEDULE_WIDE)` with the counters OFF -- exactly the timed instantiation and launch
-order -- and, separately, through CRH_SCHEDULE_SMALL with the counters off (the donating kernels against the oracle, not only against
-another GPU run), and the HDR image must equal the CPU oracle's bit for bit.  C1 runs at its real size (BASELINE.json configs[0]:
+order -- and, separately, through CRH_SCHEDULE_SMALL (round 5: the frame kernel, one launch per batch) and CRH_SCHEDULE_STAGED (the small-batch
+schedule of rounds 2 - 4: the donating kernels) with the counters off, each against the oracle, not only against another GPU run, and the HDR image
+must equal the CPU oracle's bit for bit.  C1 runs at its real size (BASELINE.json configs[0]:
 512 x 512, 64 spp, depth 5).  The reference's own gate is pixel-exact as well (testing/CADRays_Testing.py:226-230)."""
 import dataclasses
 
@@ -50,14 +51,15 @@ def oracle_image(oracle_lib, name):
     return _oracle_cache[name]
 
 
-@pytest.mark.parametrize("schedule", ["wide", "small"])
+@pytest.mark.parametrize("schedule", ["wide", "small", "staged"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_timed_instantiation_matches_oracle(hip_lib, oracle_lib, name, schedule):
     from cadrays_amd.view import View
     mk, spp = CASES[name]
     ref_hdr, ref_ldr, ref_st = oracle_image(oracle_lib, name)
     v = View(0).load_scene(mk())
-    v.set_schedule(abi.SCHEDULE_WIDE if schedule == "wide" else abi.SCHEDULE_SMALL)
+    # small: the frame kernel (one launch per batch, k_frame.h; round 5); staged: the small-batch schedule of rounds 2 - 4 (launches per stage and bounce)
+    v.set_schedule({"wide": abi.SCHEDULE_WIDE, "small": abi.SCHEDULE_SMALL, "staged": abi.SCHEDULE_STAGED}[schedule])
     v.enable_counters(False); v.reset()
     v.render(spp)
     g = v.read_hdr()
@@ -83,7 +85,7 @@ def test_schedule_switch_validates_and_restores(hip_lib):
     with pytest.raises(BackendError):
         v.set_schedule(7)
     v.render(3); a = v.read_hdr()
-    for mode in (abi.SCHEDULE_WIDE, abi.SCHEDULE_SMALL, abi.SCHEDULE_AUTO):
+    for mode in (abi.SCHEDULE_WIDE, abi.SCHEDULE_SMALL, abi.SCHEDULE_STAGED, abi.SCHEDULE_AUTO):
         v.set_schedule(mode); v.reset(); v.render(3)
         assert np.array_equal(bits(v.read_hdr()), bits(a))
     v.close()
