@@ -144,6 +144,9 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_FRAME_KERNEL",       "0: small batches take the staged small-batch schedule (one launch per stage and bounce) instead of the frame kernel (reference schedule of the sequence tests)"},
   {"CRH_FRAME_LIVE",         "frame kernel: paths a workgroup keeps alive at most, 64 .. 1024 (default 512)"},
   {"CRH_FRAME_CHUNK",        "frame kernel: path slots a wavefront claims at a time, multiples of 64 up to 1024 (default 256)"},
+  {"CRH_FRAME_LOW",          "frame kernel: the feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring (default 128)"},
+  {"CRH_FRAME_FEED",         "frame kernel: wavefronts of a workgroup that only shade and generate, 0 .. 15 (default 3 of 16)"},
+  {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 16)"},
   {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident, 4 per CU)"},
   {"CRH_FRAME_PIPE",         "frame kernel: frames in flight of free-running Redraw()s, 1 .. 8 (default 2)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
@@ -173,8 +176,11 @@ static void read_env(crh_ctx* c)
   if (const char* e = getenv("CRH_PIPELINE")) c->pipeline = atoi(e) != 0;
   if (const char* e = getenv("CRH_PIPE_DEPTH")) { int v = atoi(e); if (v >= 2 && v <= (int)pipeline_capacity()) c->pipe_depth = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_KERNEL")) c->frame_kernel = c->auto_frame_kernel = atoi(e) != 0;
-  if (const char* e = getenv("CRH_FRAME_LIVE")) { int v = atoi(e); if (v >= 64 && v <= 1024) c->frame_live = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_LIVE")) { int v = atoi(e); if (v >= 64 && v <= 4096) c->frame_live = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 1024) c->frame_chunk = (uint32_t)v & ~63u; }
+  if (const char* e = getenv("CRH_FRAME_LOW")) { int v = atoi(e); if (v >= 0 && v <= 4096) c->frame_low_water = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_FEED")) { int v = atoi(e); if (v >= 0 && v <= 15) c->frame_feeders = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_STEP")) { int v = atoi(e); if (v >= 0 && v <= 256) c->frame_claim_step = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_GRID")) { int v = atoi(e); if (v >= 1) c->frame_grid = v; }
   if (const char* e = getenv("CRH_FRAME_PIPE")) { int v = atoi(e); if (v >= 1 && v <= 8) c->frame_pipe_depth = (uint32_t)v; }
   if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }

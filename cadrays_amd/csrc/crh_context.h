@@ -142,7 +142,9 @@ struct ScheduleState {
   // launch boundary between bounces.  Takes the place of the staged small-batch schedule (lanes / pipelined launches per bounce) wherever a batch is small,
   // not counted and not timed per kernel; CRH_FRAME_KERNEL=0 or crh_set_schedule(CRH_SCHEDULE_STAGED) keeps the staged form (the reference of the sequence tests).
   bool frame_kernel = true, auto_frame_kernel = true;
-  uint32_t frame_live = 512, frame_chunk = 256;     // paths a workgroup keeps alive at most; path slots a wavefront claims at a time
+  uint32_t frame_live = 4096, frame_chunk = 256;    // paths a workgroup (16 wavefronts, one per compute unit) keeps alive at most; path slots a wavefront claims at a time
+  uint32_t frame_low_water = 512;                   // a feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring
+  uint32_t frame_feeders = 3, frame_claim_step = 16;   // wavefronts that only shade and generate; tracer w takes rays only while >= w * claim_step wait
   int frame_grid = 0;                               // workgroups of a lone frame (0: what is resident, 4 per CU)
   uint32_t frame_pipe_depth = 2;                    // frames in flight of free-running Redraw()s on the frame kernel (a frame keeps the chip busy but for its tail)
   int schedule = CRH_SCHEDULE_AUTO; uint32_t auto_lane_max_paths = 12u << 20; bool auto_donate = true, auto_pipeline = true;   // crh_set_schedule

@@ -32,7 +32,7 @@ int frame_grid(const crh_ctx* c, const DScene& S, uint32_t share = 1u)
 {
   const int res = frame_resident_grid(c->clamp_grid ? c->cus : 0, S.two_level != 0);
   const int want = c->frame_grid > 0 ? std::min(c->frame_grid, res) : res;
-  return std::max(64, want / (int)std::max(1u, share));
+  return std::max(std::min(res, 32), want / (int)std::max(1u, share));
 }
 
 int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile,
@@ -48,7 +48,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     // the frame kernel: camera rays, every bounce's traversal, shading and shadow rays of this batch in ONE launch (k_frame.h); its two control words live behind
     // the queue counters of this lane (zero when allocated, left zero by every launch)
     Launch LF{ln.stream, ln.grid_frame, false, c->clamp_grid ? c->cus : 0};
-    launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->d_counters);
+    launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->frame_low_water, c->frame_feeders, c->frame_claim_step, c->d_counters);
   } else {
   launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev);
   int qin = 0;

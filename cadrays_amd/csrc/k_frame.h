@@ -13,11 +13,15 @@
 // b + 1 is traced (the lane that finishes the shadow ray goes on with the continuation itself), so the radiance record receives its terms in the order of the
 // wavefront schedule and every frame is bit-identical to it.  A path lives at the position of its slot for its whole life (no compaction: a queue entry is the
 // slot; the state is rewritten in place by the one lane that holds the path).
-constexpr uint32_t kFrameRing  = 1024;          // entries of each ring = the most paths a workgroup may have alive (every live path is in at most one ring)
 constexpr uint32_t kFrameEmpty = 0xFFFFFFFFu;   // a ring slot nobody has written yet
 constexpr uint32_t kFrameAny   = 0x80000000u;   // ray-ring entry: the path's shadow ray (else its camera-path ray)
 constexpr uint32_t kFrameBounceShift = 26;      // ray_d.w of a frame-kernel path: bounce << 26 | slot << 1 | inside-a-medium (slots < 2^25: small batches only)
 constexpr int      kFrameMats  = 32;            // materials staged in LDS (4 KB)
+#ifndef CRH_FRAME_BLOCK
+#define CRH_FRAME_BLOCK 1024                    // threads per workgroup of the frame kernel: ONE workgroup of 16 wavefronts per compute unit shares the rings, so that the
+#endif                                          // few rays of the late bounces gather in a few full wavefronts instead of trickling through all of them
+constexpr int      kFrameBlock = CRH_FRAME_BLOCK;
+constexpr uint32_t kFrameRing  = 4u * kFrameBlock;      // entries of each ring = the most paths a workgroup may have alive (every live path is in at most one ring)
 
 struct FrameArgs {
   const uint32_t* tile_ids; uint32_t n_tiles; const uint32_t* n_tiles_dev;      // as k_raygen's
@@ -25,6 +29,9 @@ struct FrameArgs {
   uint32_t* ctl;              // [0] slot cursor, [1] workgroups finished (both zero at launch; the last workgroup to leave zeroes them again)
   uint32_t max_live;          // paths a workgroup keeps alive at most (<= kFrameRing)
   uint32_t gen_chunk;         // path slots a wavefront claims at a time (a multiple of 64)
+  uint32_t low_water;         // a feeder wavefront claims the next chunk once fewer rays than this wait in the ring
+  uint32_t n_feed;            // wavefronts of a workgroup that only shade and generate (the last ones)
+  uint32_t claim_step;        // tracer wavefront w takes rays from the ring only while >= w * claim_step wait there: scarce rays go to the first wavefronts
 };
 
 // ---- rings: multi-producer / multi-consumer inside one workgroup.  head / tail are tickets; a slot holds kFrameEmpty until its producer has written it and is
@@ -77,8 +84,9 @@ __device__ __forceinline__ void wave_sub(uint32_t* word, bool pred)          // 
 }
 
 template <bool TWO>
-__global__ __launch_bounds__(kBlock, 4) void k_frame(DScene S, DPaths P, FrameArgs A, DCounters* C)
+__global__ __launch_bounds__(kFrameBlock, 4) void k_frame(DScene S, DPaths P, FrameArgs A, DCounters* C)
 {
+  constexpr int kBlock = kFrameBlock;
   __shared__ uint32_t stk[kLdsStack * kBlock];
   __shared__ uint32_t s_bound[kBlock];
   __shared__ float4 s_mats[kFrameMats * 8];
@@ -86,10 +94,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_frame(DScene S, DPaths P, FrameAr
   __shared__ uint32_t s_ctl[8];      // [0] ray head, [1] ray tail, [2] shade head, [3] shade tail, [4] live paths, [5] the slot cursor has run out
   uint32_t* const rq_head = &s_ctl[0]; uint32_t* const rq_tail = &s_ctl[1]; uint32_t* const sq_head = &s_ctl[2]; uint32_t* const sq_tail = &s_ctl[3];
   uint32_t* const live = &s_ctl[4]; uint32_t* const cursor_out = &s_ctl[5];
-  for (uint32_t i = threadIdx.x; i < kFrameRing; i += kBlock) { s_rq[i] = kFrameEmpty; s_sq[i] = kFrameEmpty; }
+  for (uint32_t i = threadIdx.x; i < kFrameRing; i += (uint32_t)kBlock) { s_rq[i] = kFrameEmpty; s_sq[i] = kFrameEmpty; }
   if (threadIdx.x < 8u) s_ctl[threadIdx.x] = 0u;
   const bool mats_in_lds = S.n_mats <= (uint32_t)kFrameMats;
-  if (mats_in_lds) for (uint32_t i = threadIdx.x; i < S.n_mats * 8u; i += kBlock) s_mats[i] = S.mats[i];
+  if (mats_in_lds) for (uint32_t i = threadIdx.x; i < S.n_mats * 8u; i += (uint32_t)kBlock) s_mats[i] = S.mats[i];
   __syncthreads();
 
   const uint32_t n_tiles = A.n_tiles_dev ? *A.n_tiles_dev : A.n_tiles;
@@ -100,78 +108,51 @@ __global__ __launch_bounds__(kBlock, 4) void k_frame(DScene S, DPaths P, FrameAr
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const Top2 t2 = top2_of(S);
 
-  for (;;) {
-    const uint32_t nr = ring_count(rq_head, rq_tail), ns = ring_count(sq_head, sq_tail);
-    // ------------------------------------------------------------------ shade a wavefront of hit records
-    if (ns >= 64u || (ns != 0u && nr == 0u && (__hip_atomic_load(cursor_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u ||
-                                                  __hip_atomic_load(live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + A.gen_chunk > A.max_live))) {
-      uint32_t base = 0;
-      const uint32_t n = ring_claim(sq_head, sq_tail, 64u, base);
-      if (n == 0u) continue;
-      const bool mine = lane < n;
-      uint32_t pos = 0;
-      if (mine) pos = ring_take(s_sq, base + lane);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");          // the hit record and the path state were written by another wavefront of this workgroup
-      bool cont = false, shadow = false;
-      float4 n_o = zero4, n_d = zero4, n_t = zero4, s_o = zero4, s_d = zero4, s_c = zero4;
-      if (mine) {
-        const float4 o4 = ray_o[pos], d4 = ray_d[pos], h = P.hit[pos];
-        const uint32_t dw = __float_as_uint(d4.w), bounce = dw >> kFrameBounceShift;
-        const bool first = bounce == 0u, last = bounce + 1u >= S.max_depth;
-        const float4 t4 = first ? make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT) : thr[pos];
-        shade_path<false>(S, P, s_mats, mats_in_lds, bounce, first, last, o4, d4, t4, h, pos, cont, shadow, n_o, n_d, n_t, s_o, s_d, s_c, n_shaded);
-        if (cont) {
-          n_d.w = __uint_as_float(((bounce + 1u) << kFrameBounceShift) | (__float_as_uint(n_d.w) & ((1u << kFrameBounceShift) - 1u)));
-          ray_o[pos] = n_o; ray_d[pos] = n_d; thr[pos] = n_t;
-        }
-        if (shadow) { s_c.w = cont ? 1.0f : 0.f; P.sh_o[pos] = s_o; P.sh_d[pos] = s_d; P.sh_c[pos] = s_c; }      // .w: a camera-path ray waits behind this shadow ray
+  // Who does what.  Shading and ray generation are what keeps the ray ring from running dry, and a wavefront can only turn to them when none of its lanes holds a
+  // ray -- so the LAST n_feed wavefronts of the workgroup (the "feeders") never trace: they shade as soon as hits wait and claim the next chunk of slots when
+  // the ray ring runs low; asleep they cost no issue slot.  The others trace; tracer w takes rays from the ring only while >= w * claim_step of them wait, so
+  // when rays are scarce (the late bounces: fewer rays than lanes) they gather in the first wavefronts, which run full, instead of a few lanes of each.
+  const uint32_t wave = threadIdx.x >> 6, n_waves = (uint32_t)kBlock >> 6;
+  const bool feeder = wave + A.n_feed >= n_waves;
+  const uint32_t claim_min = feeder ? 0u : wave * A.claim_step;
+  auto load_u = [](uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto may_generate = [&]() { return load_u(cursor_out) == 0u && load_u(live) + A.gen_chunk <= A.max_live; };
+
+  auto shade_some = [&]() {
+    uint32_t base = 0;
+    const uint32_t n = ring_claim(sq_head, sq_tail, 64u, base);
+    if (n == 0u) return;
+    const bool mine = lane < n;
+#if CRH_FRAME_STATS
+    if (lane == 0) { atomicAdd(&g_frame_stats[7], 1ull); atomicAdd(&g_frame_stats[8], (unsigned long long)n); }
+#endif
+    uint32_t pos = 0;
+    if (mine) pos = ring_take(s_sq, base + lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");          // the hit record and the path state were written by another wavefront of this workgroup
+    bool cont = false, shadow = false;
+    float4 n_o = zero4, n_d = zero4, n_t = zero4, s_o = zero4, s_d = zero4, s_c = zero4;
+    if (mine) {
+      const float4 o4 = ray_o[pos], d4 = ray_d[pos], h = P.hit[pos];
+      const uint32_t dw = __float_as_uint(d4.w), bounce = dw >> kFrameBounceShift;
+      const bool first = bounce == 0u, last = bounce + 1u >= S.max_depth;
+      const float4 t4 = first ? make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT) : thr[pos];
+      shade_path<false>(S, P, s_mats, mats_in_lds, bounce, first, last, o4, d4, t4, h, pos, cont, shadow, n_o, n_d, n_t, s_o, s_d, s_c, n_shaded);
+      if (cont) {
+        n_d.w = __uint_as_float(((bounce + 1u) << kFrameBounceShift) | (__float_as_uint(n_d.w) & ((1u << kFrameBounceShift) - 1u)));
+        ray_o[pos] = n_o; ray_d[pos] = n_d; thr[pos] = n_t;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      ring_push(s_rq, rq_tail, shadow, pos | kFrameAny);
-      ring_push(s_rq, rq_tail, cont && !shadow, pos);
-      wave_sub(live, mine && !cont && !shadow);                        // the path ends here
-      n_any += (uint32_t)__popcll(__ballot(shadow)); n_near += (uint32_t)__popcll(__ballot(cont));
-      continue;
+      if (shadow) { s_c.w = cont ? 1.0f : 0.f; P.sh_o[pos] = s_o; P.sh_d[pos] = s_d; P.sh_c[pos] = s_c; }      // .w: a camera-path ray waits behind this shadow ray
     }
-    // ------------------------------------------------------------------ trace what waits in the ray ring (returns when the ring is dry and every lane is done)
-    if (nr != 0u) {
-      uint32_t nn = 0, nt = 0;
-      trace_engine<false, false, TWO, true, true>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, t2, nullptr, 0u, &stk[threadIdx.x],
-        [&](uint32_t ticket, v3& o, v3& d, float& tmax, uint32_t& tag, bool& any_l) {
-          tag = ring_take(s_rq, ticket);
-          any_l = (tag & kFrameAny) != 0u; tag &= ~kFrameAny;
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          const float4 o4 = any_l ? P.sh_o[tag] : ray_o[tag], d4 = any_l ? P.sh_d[tag] : ray_d[tag];
-          o = xyz(o4); d = xyz(d4); tmax = any_l ? o4.w : CRH_MAXFLOAT;
-        },
-        [&](bool fin, uint32_t tag, float4 h, bool f, bool any_l, v3& o, v3& d, float& tmax) -> bool {
-          bool go_on = false;
-          if (fin && any_l) {
-            const float4 c = P.sh_c[tag];
-            if (!f) {                                                   // unoccluded: the pending contribution joins the path's radiance
-              float4 r = P.rad[tag];
-              if (__float_as_uint(r.w) != P.stamp) r = zero4;
-              r.x += c.x; r.y += c.y; r.z += c.z; r.w = __uint_as_float(P.stamp);
-              P.rad[tag] = r;
-            }
-            go_on = c.w != 0.f;
-            if (go_on) { const float4 o4 = ray_o[tag], d4 = ray_d[tag]; o = xyz(o4); d = xyz(d4); tmax = CRH_MAXFLOAT; }
-          }
-          const bool to_shade = fin && !any_l;
-          if (to_shade) P.hit[tag] = h;
-          if (__ballot(to_shade) != 0ull) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            ring_push(s_sq, sq_tail, to_shade, tag);
-          }
-          wave_sub(live, fin && any_l && !go_on);                      // a shadow ray with nothing behind it: the path is done
-          return go_on;
-        }, nn, nt, &s_bound[threadIdx.x & ~63u],
-        [&](uint32_t want, uint32_t& base) -> uint32_t { return ring_claim(rq_head, rq_tail, want, base); });
-      continue;
-    }
-    // ------------------------------------------------------------------ nothing waits: the next chunk of path slots, if the workgroup may hold more paths
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    ring_push(s_rq, rq_tail, shadow, pos | kFrameAny);
+    ring_push(s_rq, rq_tail, cont && !shadow, pos);
+    wave_sub(live, mine && !cont && !shadow);                        // the path ends here
+    n_any += (uint32_t)__popcll(__ballot(shadow)); n_near += (uint32_t)__popcll(__ballot(cont));
+  };
+
+  auto generate = [&]() -> bool {
     uint32_t ok = 0, cbase = 0;
-    if (lane == 0 && __hip_atomic_load(cursor_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+    if (lane == 0 && load_u(cursor_out) == 0u) {
       const uint32_t before = atomicAdd(live, A.gen_chunk);             // counted BEFORE the slots are claimed: nobody sees "no paths, no slots" in between
       if (before + A.gen_chunk > A.max_live) atomicSub(live, A.gen_chunk);
       else {
@@ -181,30 +162,88 @@ __global__ __launch_bounds__(kBlock, 4) void k_frame(DScene S, DPaths P, FrameAr
       }
     }
     ok = __shfl(ok, 0); cbase = __shfl(cbase, 0);
-    if (ok) {
-      uint32_t made = 0;
-      for (uint32_t it = 0; it < A.gen_chunk; it += 64u) {
-        const uint32_t pid = cbase + it + lane;
-        bool valid = pid < total;
-        uint32_t px = 0, py = 0, s = 0, local = 0;
-        if (valid) { slot_to_pixel_sample(pid, A.n_samples, local, s); valid = slot_pixel(S, A.tile_ids, local, px, py); }
-        if (valid) {
-          v3 o, d; uint32_t rng;
-          camera_ray(S, A.seeds, A.seed_per_tile, px, py, s, local, o, d, rng);
-          ray_o[pid] = mk4(o, __uint_as_float(rng));
-          ray_d[pid] = mk4(d, __uint_as_float(pid << 1));               // bounce 0, outside
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        ring_push(s_rq, rq_tail, valid, pid);
-        made += (uint32_t)__popcll(__ballot(valid));
+    if (!ok) return false;
+    uint32_t made = 0;
+    for (uint32_t it = 0; it < A.gen_chunk; it += 64u) {
+      const uint32_t pid = cbase + it + lane;
+      bool valid = pid < total;
+      uint32_t px = 0, py = 0, s = 0, local = 0;
+      if (valid) { slot_to_pixel_sample(pid, A.n_samples, local, s); valid = slot_pixel(S, A.tile_ids, local, px, py); }
+      if (valid) {
+        v3 o, d; uint32_t rng;
+        camera_ray(S, A.seeds, A.seed_per_tile, px, py, s, local, o, d, rng);
+        ray_o[pid] = mk4(o, __uint_as_float(rng));
+        ray_d[pid] = mk4(d, __uint_as_float(pid << 1));               // bounce 0, outside
       }
-      if (lane == 0 && made != A.gen_chunk) atomicSub(live, A.gen_chunk - made);      // slots past the end or outside the image (edge tiles are partial)
-      n_near += made;
-      continue;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      ring_push(s_rq, rq_tail, valid, pid);
+      made += (uint32_t)__popcll(__ballot(valid));
     }
-    // ------------------------------------------------------------------ idle: other wavefronts of the workgroup still hold paths, or the frame is done
-    if (__hip_atomic_load(cursor_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u && __hip_atomic_load(live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
-    __builtin_amdgcn_s_sleep(16);
+    if (lane == 0 && made != A.gen_chunk) atomicSub(live, A.gen_chunk - made);      // slots past the end or outside the image (edge tiles are partial)
+    n_near += made;
+    return true;
+  };
+
+  auto trace_some = [&]() {
+    uint32_t nn = 0, nt = 0;
+    trace_engine<false, false, TWO, true, true, kFrameBlock>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, t2, nullptr, 0u, &stk[threadIdx.x],
+      [&](uint32_t ticket, v3& o, v3& d, float& tmax, uint32_t& tag, bool& any_l) {
+        tag = ring_take(s_rq, ticket);
+        any_l = (tag & kFrameAny) != 0u; tag &= ~kFrameAny;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const float4 o4 = any_l ? P.sh_o[tag] : ray_o[tag], d4 = any_l ? P.sh_d[tag] : ray_d[tag];
+        o = xyz(o4); d = xyz(d4); tmax = any_l ? o4.w : CRH_MAXFLOAT;
+      },
+      [&](bool fin, uint32_t tag, float4 h, bool f, bool any_l, v3& o, v3& d, float& tmax) -> bool {
+        bool go_on = false;
+        if (fin && any_l) {
+          const float4 c = P.sh_c[tag];
+          if (!f) {                                                   // unoccluded: the pending contribution joins the path's radiance
+            float4 r = P.rad[tag];
+            if (__float_as_uint(r.w) != P.stamp) r = zero4;
+            r.x += c.x; r.y += c.y; r.z += c.z; r.w = __uint_as_float(P.stamp);
+            P.rad[tag] = r;
+          }
+          go_on = c.w != 0.f;
+          if (go_on) { const float4 o4 = ray_o[tag], d4 = ray_d[tag]; o = xyz(o4); d = xyz(d4); tmax = CRH_MAXFLOAT; }
+        }
+        const bool to_shade = fin && !any_l;
+        if (to_shade) P.hit[tag] = h;
+        if (__ballot(to_shade) != 0ull) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          ring_push(s_sq, sq_tail, to_shade, tag);
+        }
+        wave_sub(live, fin && any_l && !go_on);                      // a shadow ray with nothing behind it: the path is done
+        return go_on;
+      }, nn, nt, &s_bound[threadIdx.x & ~63u],
+      [&](uint32_t want, uint32_t& base) -> uint32_t {
+        if (ring_count(rq_head, rq_tail) < max(claim_min, 1u)) return 0u;      // scarce rays are left to the wavefronts before this one
+        return ring_claim(rq_head, rq_tail, want, base);
+      });
+  };
+
+  for (;;) {
+    const uint32_t nr = ring_count(rq_head, rq_tail), ns = ring_count(sq_head, sq_tail);
+    // one call site per stage (each is a few thousand instructions, inlined): decide first, then act
+    int act = 0;                                                     // 0 idle, 1 shade, 2 generate, 3 trace
+    if (feeder) {
+      if (ns >= 64u) act = 1;
+      else if (nr < A.low_water && may_generate()) act = 2;
+      else if (ns != 0u) act = 1;                                    // nothing better to do: whatever waits is shaded now (the tracers get their rays sooner)
+    } else {
+      if (nr != 0u && nr >= claim_min) act = 3;
+      else if (ns >= 256u || (A.n_feed == 0u && ns != 0u && !(nr == 0u && may_generate()))) act = 1;      // the feeders have fallen behind (or there are none)
+      else if (nr == 0u && may_generate()) act = 2;
+    }
+    if (act == 1) { shade_some(); continue; }
+    if (act == 2) { if (generate()) continue; }
+    if (act == 3) { trace_some(); continue; }
+    // idle: other wavefronts of the workgroup still hold paths, or the frame is done
+    if (load_u(cursor_out) != 0u && load_u(live) == 0u) break;
+#if CRH_FRAME_STATS
+    if (lane == 0) atomicAdd(&g_frame_stats[feeder ? 9 : 10], 1ull);
+#endif
+    __builtin_amdgcn_s_sleep(4);
   }
   if (lane == 0) {
     if (n_near) atomicAdd(&C->rays_nearest, (unsigned long long)n_near);

@@ -18,6 +18,12 @@
 #ifndef CRH_REFILL_IDLE
 #define CRH_REFILL_IDLE 12     // refill a wavefront once this many of its 64 lanes have no ray
 #endif
+#ifndef CRH_FRAME_STATS
+#define CRH_FRAME_STATS 0      // 1: an instrumented build (tools/ab_build.sh): the frame kernel's engine counts its turns, active rays, dry turns and step executions
+#endif
+#if CRH_FRAME_STATS
+__device__ unsigned long long g_frame_stats[16];
+#endif
 #ifndef CRH_POOL_CHUNK
 #define CRH_POOL_CHUNK 256     // measured: 64 -> 2257, 128 -> 2305, 256 -> 2308, 512 -> 2266, 1024 -> 2136 Mrays/s (big pools starve late bounces)
 #endif
@@ -114,12 +120,13 @@ __device__ __forceinline__ bool ray_touches_instances(const DScene& S, v3 o, v3 
 // the ring has nothing); nearest-hit and any-hit rays travel mixed (load() says which, per lane: `any_l` takes the place of the template constant ANY); store() is
 // called by the whole wavefront with a predicate (it appends to the shade ring with one LDS atomic per wavefront) and may hand the lane its path's NEXT ray -- the
 // camera-path continuation that waited behind a shadow ray -- which the lane starts at once.
-template <bool ANY, bool COUNT, bool TWO, bool DON, bool FRM = false, class Load, class Store, class Claim = int>
+template <bool ANY, bool COUNT, bool TWO, bool DON, bool FRM = false, int BS = crh::kBlock, class Load, class Store, class Claim = int>
 __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                              const float4* __restrict__ inst, uint32_t root, float4 gbox, const Top2 t2,
                                              uint32_t* __restrict__ cursor, uint32_t n, uint32_t* lds,
                                              Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris, uint32_t* bound = nullptr, Claim claim = Claim())
 {
+  constexpr int kBlock = BS;      // threads of the calling workgroup = row stride of its LDS stack and world-ray columns (the frame kernel runs wider workgroups)
   static_assert(!FRM || (DON && !COUNT), "the frame kernel's engine donates (its retire step lives there) and does not count visits");
   // bound (DON): one word per lane of this wavefront in LDS -- the smallest hit distance any part of the ray that STARTED in that
   // lane has found so far (float bits; distances are >= 0, so unsigned order = float order).  Every part prunes BOXES with it
@@ -170,6 +177,9 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
 
+#if CRH_FRAME_STATS
+  uint32_t fs_turns = 0, fs_have = 0, fs_dry = 0, fs_inner_w = 0, fs_tri_w = 0, fs_don = 0;
+#endif
   for (;;) {
     // ------------------------------------------------------------------ refill idle lanes
     unsigned long long idle = __ballot(!have);
@@ -223,11 +233,17 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       }
     }
     if (__ballot(have) == 0ull) { if (exhausted) break; else continue; }
+#if CRH_FRAME_STATS
+    if (FRM) { ++fs_turns; fs_have += (uint32_t)__popcll(__ballot(have)); fs_dry += exhausted ? 1u : 0u; }
+#endif
 
     if (DON && (exhausted || thin)) {
       // ---------------------------------------------------------------- donation: bottom stack entries -> idle lanes
       const unsigned long long idle_m = __ballot(!have);
       if (idle_m != 0ull) {
+#if CRH_FRAME_STATS
+        if (FRM) ++fs_don;
+#endif
         // a donor gives the FAR half of its stack (the entries below the middle, all of them in the LDS part); the helper
         // copies them into its own column and starts with the nearest of them
         bool can = have && cur != kDone && sp > sbase && sp <= kLdsStack && !(CRH_ISANY && found);
@@ -295,7 +311,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     auto inner_step = [&]() {
       const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;
       const float4 n0 = np[0], n1 = np[1], n2 = np[2];
-      if (COUNT) ++n_nodes;
+      if (COUNT || (FRM && CRH_FRAME_STATS)) ++n_nodes;
       // per-node grid: face t = fma(q, step * inv_d, fma(origin - o, inv_d, -+ guard)).  The difference is taken BEFORE the
       // multiplication: fma(origin, inv_d, -o * inv_d) cancels catastrophically when |o * inv_d| >> t (a ray grazing a box
       // corner was culled by 2e-5 of t); the guard is the per-ray constant above.
@@ -412,7 +428,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     auto tri_step = [&](uint32_t ti) {
       const float4* tp = tris + kTriStride * ti;
       const float4 a = tp[0], b = tp[1], c = tp[2];
-      if (COUNT) ++n_tris;
+      if (COUNT || (FRM && CRH_FRAME_STATS)) ++n_tris;
       // record = {v0 | n.x}, {e0 = v1 - v0 | n.y}, {e1 = v0 - v2 | n.z}: the two edges and n = e1 x e0 are evaluated ONCE per triangle on the host
       // with the inline arithmetic this function used to apply per test (crh_sub3 / crh_cross3, same bits) -- 15 VALU instructions per test
       // fewer in a kernel that runs at the VALU issue limit
@@ -499,6 +515,16 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     } else if constexpr (!FRM) { if (have && cur == kDone) { store(tag, hit, found); have = false; } }
   }
 #undef CRH_ISANY
+#if CRH_FRAME_STATS
+  if (FRM) {
+    const uint32_t li = wave_sum(n_nodes), lt = wave_sum(n_tris);
+    if (lane == 0) {
+      atomicAdd(&g_frame_stats[0], (unsigned long long)fs_turns); atomicAdd(&g_frame_stats[1], (unsigned long long)fs_have); atomicAdd(&g_frame_stats[2], (unsigned long long)fs_dry);
+      atomicAdd(&g_frame_stats[3], (unsigned long long)li); atomicAdd(&g_frame_stats[4], (unsigned long long)lt); atomicAdd(&g_frame_stats[5], (unsigned long long)fs_don);
+      atomicAdd(&g_frame_stats[6], 1ull);
+    }
+  }
+#endif
 }
 
 // P2: the SECOND pass of a split scene (static tree + moved objects).  The first pass is the single-level instantiation over the

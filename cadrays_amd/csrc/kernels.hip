@@ -111,20 +111,32 @@ int frame_resident_grid(int cus, bool two_level)
 {
   static int per_cu[2] = {0, 0};
   int& pc = per_cu[two_level ? 1 : 0];
-  if (pc == 0) { int n = 0; pc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, two_level ? k_frame<true> : k_frame<false>, kBlock, 0) == hipSuccess && n > 0) ? n : -1; }
-  return (pc > 0 ? pc : 4) * (cus > 0 ? cus : 256);
+  if (pc == 0) { int n = 0; pc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, two_level ? k_frame<true> : k_frame<false>, kFrameBlock, 0) == hipSuccess && n > 0) ? n : -1; }
+  return (pc > 0 ? pc : 1024 / kFrameBlock) * (cus > 0 ? cus : 256);
 }
 void launch_frame(const Launch& L, const DScene& S, const DPaths& P, uint32_t* ctl, const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds,
-                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, DCounters* C)
+                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, uint32_t low_water, uint32_t n_feed, uint32_t claim_step, DCounters* C)
 {
   FrameArgs A;
   A.tile_ids = d_tile_ids; A.n_tiles = n_tiles; A.n_tiles_dev = d_n_tiles; A.seeds = d_seeds; A.n_samples = n_samples; A.seed_per_tile = seed_per_tile;
-  A.ctl = ctl; A.gen_chunk = min(max(gen_chunk & ~63u, 64u), kFrameRing); A.max_live = min(max(max_live, A.gen_chunk), kFrameRing);
+  A.ctl = ctl; A.gen_chunk = min(max(gen_chunk & ~63u, 64u), kFrameRing); A.max_live = min(max(max_live, A.gen_chunk), kFrameRing); A.low_water = low_water;
+  A.n_feed = min(n_feed, (uint32_t)kFrameBlock / 64u - 1u); A.claim_step = claim_step;
   DScene S1 = S; S1.split = 0;                  // a split scene is walked in one go: static tree, then the top level (the two-pass form is a wavefront-schedule device)
   const int grid = min(L.grid, frame_resident_grid(L.cus, S.two_level != 0));
-  if (S.two_level) hipLaunchKernelGGL(k_frame<true>, dim3(grid), dim3(kBlock), 0, L.stream, S1, P, A, C);
-  else             hipLaunchKernelGGL(k_frame<false>, dim3(grid), dim3(kBlock), 0, L.stream, S1, P, A, C);
+  if (S.two_level) hipLaunchKernelGGL(k_frame<true>, dim3(grid), dim3(kFrameBlock), 0, L.stream, S1, P, A, C);
+  else             hipLaunchKernelGGL(k_frame<false>, dim3(grid), dim3(kFrameBlock), 0, L.stream, S1, P, A, C);
 }
+#if CRH_FRAME_STATS
+}  // namespace crh
+// instrumented builds only (tools/ab_build.sh NAME "-DCRH_FRAME_STATS=1"): what the frame kernel's engines counted since the last call
+extern "C" __attribute__((visibility("default"))) int crh_exp_frame_stats(unsigned long long* out16)
+{
+  unsigned long long zero[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(crh::g_frame_stats), sizeof zero) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(crh::g_frame_stats), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+namespace crh {
+#endif
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,
                        uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, uint32_t batch_samples, DCounters* C, const uint32_t* d_n_tiles)
 {
