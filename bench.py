@@ -29,7 +29,9 @@ WRITE_SIZE in separate passes of a 2-step run of the same workload, --pmc combin
 rocprofv3 or a profiler around this process: the committed passes of profiles/pmc_traffic.json, used only when they belong to THIS build)), `cpu_baseline` (the CPU
 oracle timed on this box's cores on a bounded tile sample of the same workload) and two parity gates: `parity` (the oracle re-renders sampled tiles of
 the WHOLE timed region) and `parity_step0` (>= 32 tiles of the first timed step's samples, replayed untimed with the same schedule).  A differing
-pixel ends the run with a non-zero exit; a checker that could not run is reported as `checker_errors` and does not.
+pixel ends the run with exit code 1; a checker that could not run is reported as `checker_errors` -- and when NO gate of the headline leg produced a verdict the
+run ends with exit code 3 (--allow-unchecked accepts the unchecked number).  Every leg's rate, fractions and gate result, the interactive figures and the measured
+ceilings are also flat scalar keys (top level, `config`, `roofline`) and the last key `legs_summary` (flatten_line).
 """
 import argparse
 import hashlib
@@ -352,6 +354,8 @@ def parse_args(argv=None):
                     help="roofline.traffic from counter passes taken IN this run: after the timed region the same command runs twice more as a child under "
                          "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (2 steps each, about 20 s per pass); default on for the plain headline run at N = 1, "
                          "off otherwise; without rocprofv3, or when this process is itself being profiled, the committed passes (profiles/pmc_traffic.json) are used")
+    ap.add_argument("--allow-unchecked", action="store_true",
+                    help="exit 0 even when NO parity gate of the headline leg produced a verdict (checker could not run); default: exit code 3 (a failed gate: 1)")
     ap.add_argument("--no-shared-build", action="store_true", help="N > 1: every rank builds its own BVH (default: rank 0 builds, the others take its tree)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
@@ -445,9 +449,14 @@ def main():
         out["config"]["other_configs_timed"] = others
         out["config"]["other_configs_note"] = ("timed in this very run after the headline, inputs resident in HBM, 1 warm-up + %d timed steps each, same kernels and schedule; "
                                                "NOT part of `value`" % args.other_steps)
+    unchecked = False
     if rank == 0:
         if errors:
             out["checker_errors"] = errors
+        # a headline number no gate looked at is not a measurement (a parity gate accompanies every number)
+        verdicts = [p for p in (out.get("parity"), out.get("parity_step0")) if p is not None and "error" not in p]
+        unchecked = not args.no_parity and not verdicts
+        flatten_line(out)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()                                       # rank 0 may still be in its counting pass
@@ -455,7 +464,48 @@ def main():
     if failed:
         sys.exit("bench.py: PARITY GATE FAILED -- timed frames differ from the oracle (see \"parity\" / \"parity_step0\" in the JSON line)")
     if errors:
-        print("bench.py: a checker leg could not run (the measurement stands; see \"checker_errors\" in the JSON line): " + "; ".join(errors), file=sys.stderr)
+        print("bench.py: a checker leg could not run (see \"checker_errors\" in the JSON line): " + "; ".join(errors), file=sys.stderr)
+    if unchecked and not args.allow_unchecked:
+        print("bench.py: NO parity gate of the headline leg produced a verdict -- the number is unchecked (exit 3; --allow-unchecked accepts it)", file=sys.stderr)
+        sys.exit(3)
+
+
+def flatten_line(out):
+    """The driver's record keeps top-level scalars and the scalars inside `config` / `roofline` (nested objects are dropped, the stdout tail starts somewhere in the
+    line): every leg's rate, gate and fractions, the interactive figures and the measured ceilings are therefore ALSO written as flat scalar keys -- at the top level,
+    inside `config` and `roofline` -- and once more as one small object, `legs_summary`, the LAST key of the line (verdict r4 item 3)."""
+    cfg, roof = out.get("config") or {}, out.get("roofline") or {}
+    flat = {}
+    def gate(o):
+        ps = [p for p in (o.get("parity"), o.get("parity_step0")) if p is not None]
+        return None if not ps or any("error" in p for p in ps) else all(bool(p.get("bit_exact")) for p in ps)
+    def leg(tag, o, r):
+        flat[f"{tag}_mrays"] = o.get("value"); flat[f"{tag}_ms_per_step"] = o.get("ms_per_step")
+        flat[f"{tag}_frac_counter"] = r.get("traffic_frac", r.get("traffic_frac_of_peak")); flat[f"{tag}_alg_frac"] = r.get("alg_frac", r.get("alg_frac_of_hbm_peak"))
+        flat[f"{tag}_parity_bit_exact"] = gate(o)
+        c = r.get("ceilings") or {}
+        flat[f"{tag}_valu_issue"] = c.get("valu_issue"); flat[f"{tag}_lane_util"] = c.get("lane_util")
+    head = (cfg.get("workload") or "C?").split(":")[0].lower()
+    leg(head, out, roof)
+    for name, o in (cfg.get("other_configs_timed") or {}).items():
+        if "error" in o:
+            flat[f"{name.lower()}_error"] = o["error"][:120]
+        else:
+            leg(name.lower(), o, o.get("roofline") or {})
+    it = cfg.get("interactive") or {}
+    for k_src, k_dst in (("redraw_per_s_lookahead_1", "interactive_redraw_per_s"), ("first_frame_after_a_restart_ms", "interactive_first_frame_ms"),
+                         ("drag_frames_per_s", "interactive_drag_frames_per_s"), ("displayed_frames_per_s", "interactive_displayed_frames_per_s"),
+                         ("redraw_per_s_lookahead_64", "interactive_redraw_per_s_lookahead_64")):
+        if k_src in it:
+            flat[k_dst] = it[k_src]
+    ceil = roof.get("ceilings") or {}
+    for k in ("valu_issue", "lane_util", "hbm", "l2"):
+        if k in ceil and isinstance(ceil[k], (int, float)):
+            roof[k if k in ("valu_issue", "lane_util") else k + "_frac_ceiling"] = ceil[k]
+    cfg.update(flat)
+    out.pop("legs_summary", None)
+    out.update(flat)
+    out["legs_summary"] = flat          # last key: the tail of the line carries every leg
 
 
 def compact_leg(o):
@@ -633,7 +683,11 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
         mem = v.scene_bytes()
         modified = bool(ov and (args.tris or args.width or args.height))
         # the memory-side counters of THIS run (two child passes under rocprofv3, after the timed region; the parent idles meanwhile)
-        live = live_traffic(config) if (world == 1 and args.live_traffic == "on" and not modified) else None        # the headline and every other-config leg
+        live = None
+        if world == 1 and args.live_traffic == "on" and not modified:          # the headline and every other-config leg
+            v.set_path_budget(1 << 20)                                          # the child holds a full path budget of its own (up to 105 GB): this process's goes first
+            live = live_traffic(config)
+            v.set_path_budget(512 << 20)
         roof = roofline_report(config if world == 1 else f"{config}@{world}", spp_step, modified,
                                alg_bytes / launches, avg_ms, mem["nodes"] + mem["triangles"], live=live, extra={
             "launches": int(launches),
@@ -656,7 +710,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     # ---- the reference's interactive regime (one Redraw() = +1 spp per call, AppViewer.cxx:1045-1047), reported beside `value`
     interactive = None
     if headline and rank == 0 and world == 1 and not args.no_interactive:
-        interactive = interactive_figures(v)
+        interactive = interactive_figures(v, sc.camera)
 
     v.close()                                                 # the path state (up to 105 GB) and the scene go before the next leg / the CPU legs
 
@@ -671,9 +725,9 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
         try:
             gate = ParityOracle(sc)
             if timed_hdr is not None:
-                # at least 4 tiles, 2 once the region holds more than 4096 samples per pixel (20 steps x 512: one tile costs the oracle 20 s); the first-step gate
-                # below keeps its >= 32 tiles whatever the region's length
-                parity = gate.check(timed_hdr, timed_first, timed_n, args.parity_seconds, 4 if timed_n <= 4096 else 2)
+                # at least 4 tiles whatever the region's length (20 steps x 512 samples: one tile costs the oracle ~7 s on 16 threads); the first-step gate
+                # below keeps its >= 32 tiles
+                parity = gate.check(timed_hdr, timed_first, timed_n, args.parity_seconds, 4)
                 parity["schedule"] = sched + " -- the timed steps' own output"
             if step0_hdr is not None:
                 parity0 = gate.check(step0_hdr, timed_first, spp_step, args.step0_seconds, 32)
@@ -700,7 +754,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     out = None
     if rank == 0:
         mrays = (rays_n + rays_a) / dt / 1e6
-        cfgd = {"workload": f"{config}: {len(sc.tri)} random triangles, {len(sc.materials)} BSDF(s), "
+        cfgd = {"workload": f"{config}: {len(sc.tri)} {'triangles of the Cornell box (CornellBox.tcl without the spheres)' if scene_cfg == 'C1' else 'random triangles'}, {len(sc.materials)} BSDF(s), "
                             f"{'HDR sky env' if sc.env is not None else 'constant env'}, {len(sc.lights)} light(s), "
                             f"{sc.params.width}x{sc.params.height}, depth {sc.params.max_depth}",
                 "spp_per_step_per_rank": spp_step, "spp_per_step_whole_frame": spp_step if scaling == "strong" or world == 1 else spp,
@@ -725,7 +779,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     return out, failed, errors
 
 
-def interactive_figures(v):
+def interactive_figures(v, cam0):
     interactive = {}
     for k in (1, 16, 64):
         v.set_lookahead(k); v.reset()
@@ -748,11 +802,14 @@ def interactive_figures(v):
             v.Redraw()
     v.sync()
     interactive["redraw_per_s_lookahead_auto_16_first_64_frames_after_a_restart"] = round(3 * 64 / (time.perf_counter() - t1), 1)
-    v.reset(); v.sync()
-    t1 = time.perf_counter()
-    v.Redraw(); v.sync()
-    interactive["first_frame_after_a_restart_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
     v.set_lookahead_auto(0); v.reset()
+    # ---- the application's own call pattern (AppViewer.cxx:979-984, 1045-1047, 1099): a lone frame after a restart (median of 9), the restart-every-frame
+    # drag, every frame displayed (asynchronous LDR read-back two frames behind) -- tools/bench_redraw.py holds the loops
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_redraw
+    interactive.update(bench_redraw.measure(v, cam0, frames=96, trials=9))
+    interactive.pop("free_running_redraw_per_s", None)          # = redraw_per_s_lookahead_1 above
+    v.reset()
     import cadrays_amd
     frames, queues = cadrays_amd.pipeline_capacity()
     interactive["frames_in_flight"] = frames

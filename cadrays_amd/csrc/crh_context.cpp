@@ -119,10 +119,23 @@ int do_reset(crh_ctx* c)
   // stream-ordered: kernels still in flight finish into the old accumulator contents first, nothing is waited for
   CRH_HIP(hipSetDevice(c->device));
   int rc = alloc_accum(c); if (rc) return rc;
-  CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, cstream(c)));
-  CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, cstream(c)));
+  // A restart touches the ACCUMULATOR, not what a frame's tracing reads: the frame pipeline (render_impl) lets the first frame of the new accumulation trace while
+  // the last frames of the old one finish -- its accumulate waits for reset_ev, its counters go to the next block of the ring (zeroed one restart ago).
+  const uint64_t uses = c->stream_uses;
+  const hipStream_t cs = cstream(c);                     // joins the frames in flight: the memsets come after their accumulates and after a read-back's tone map
+  CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, cs));
+  CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, cs));
   c->adaptive_picks = 0; c->pending_n = 0; c->ramp_k = 1; c->picked_valid = false; c->assembled_valid = false;
-  CRH_HIP(hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), cstream(c)));
+  if (!c->reset_ev) CRH_HIP(hipEventCreateWithFlags(&c->reset_ev, hipEventDisableTiming));
+  CRH_HIP(hipEventRecord(c->reset_ev, cs)); c->reset_pending = true;
+  {
+    const uint32_t now = ++c->counter_epoch & 3u, next = (c->counter_epoch + 1u) & 3u;
+    c->d_counters = c->d_counters_ring + now;                                        // zeroed at the previous restart (counters_zeroed[now]) or at creation
+    CRH_HIP(hipMemsetAsync(c->d_counters_ring + next, 0, sizeof(DCounters), cs));   // last used three restarts ago; its frames were joined above
+    if (!c->counters_zeroed[next]) CRH_HIP(hipEventCreateWithFlags(&c->counters_zeroed[next], hipEventDisableTiming));
+    CRH_HIP(hipEventRecord(c->counters_zeroed[next], cs));
+  }
+  c->stream_uses = uses;                                 // none of this is input of a frame's tracing
   discard_events(c);
   c->seconds_acc = c->trace_ms_acc = c->all_ms_acc = 0.0; c->trace_launches = 0; c->frames_done = 0;
   return CRH_OK;
@@ -146,6 +159,7 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_FRAME_CHUNK",        "frame kernel: path slots a wavefront claims at a time, multiples of 64 up to 1024 (default 256)"},
   {"CRH_FRAME_LOW",          "frame kernel: the feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring (default 128)"},
   {"CRH_FRAME_FEED",         "frame kernel: wavefronts of a workgroup that only shade and generate, 0 .. 15 (default 3 of 16)"},
+  {"CRH_FRAME_STARVE",       "frame kernel: a feeder shades fewer than 64 waiting hits only while fewer rays than this wait in the ring"},
   {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 16)"},
   {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident, 4 per CU)"},
   {"CRH_FRAME_PIPE",         "frame kernel: frames in flight of free-running Redraw()s, 1 .. 8 (default 2)"},
@@ -180,6 +194,7 @@ static void read_env(crh_ctx* c)
   if (const char* e = getenv("CRH_FRAME_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 1024) c->frame_chunk = (uint32_t)v & ~63u; }
   if (const char* e = getenv("CRH_FRAME_LOW")) { int v = atoi(e); if (v >= 0 && v <= 4096) c->frame_low_water = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_FEED")) { int v = atoi(e); if (v >= 0 && v <= 15) c->frame_feeders = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_STARVE")) { int v = atoi(e); if (v >= 0) c->frame_starve = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_STEP")) { int v = atoi(e); if (v >= 0 && v <= 256) c->frame_claim_step = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_GRID")) { int v = atoi(e); if (v >= 1) c->frame_grid = v; }
   if (const char* e = getenv("CRH_FRAME_PIPE")) { int v = atoi(e); if (v >= 1 && v <= 8) c->frame_pipe_depth = (uint32_t)v; }
@@ -202,11 +217,12 @@ crh_ctx* crh_create(int device_ordinal)
   crh_ctx* c = new crh_ctx();
   c->device = device_ordinal;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&c->d_counters, sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemsetAsync(c->d_counters, 0, sizeof(DCounters), cstream(c)) != hipSuccess ||
+      hipMalloc((void**)&c->d_counters_ring, 4 * sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemsetAsync(c->d_counters_ring, 0, 4 * sizeof(DCounters), cstream(c)) != hipSuccess ||
       hipStreamSynchronize(cstream(c)) != hipSuccess) {
     fprintf(stderr, "crh_create: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
     delete c; return nullptr;
   }
+  c->d_counters = c->d_counters_ring;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) { c->cus = prop.multiProcessorCount; c->grid = prop.multiProcessorCount * 4; c->grid_trace = prop.multiProcessorCount * 6; }
   api::read_env(c);
@@ -226,7 +242,7 @@ void crh_destroy(crh_ctx* c)
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {c->d_nodes, c->d_pnodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o[0], c->paths.ray_d[0], c->paths.ray_o[1], c->paths.ray_d[1], c->paths.thr[1],
                   c->paths.hit, c->paths.thr[0], c->paths.rad, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
-                  c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters, c->d_api_cursor, c->d_scratch,
+                  c->queues.q[0], c->queues.q[1], c->queues.q_sh, c->queues.counts, c->d_tile_ids, c->d_seeds, c->d_counters_ring, c->d_api_cursor, c->d_scratch,
                   c->d_m2, c->d_tile_err, c->d_tile_cnt, c->d_uvs, c->d_texels, c->d_tex_desc, c->d_inst, c->d_patch, c->d_verts, c->d_ibox, c->queues.q2, c->queues.q2_sh};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->d_assembled) hipFree(c->d_assembled);
@@ -234,6 +250,8 @@ void crh_destroy(crh_ctx* c)
   for (BuiltScene::Stage& st : c->stage) { if (st.p) hipHostFree(st.p); if (st.ev) hipEventDestroy(st.ev); }
   for (int k = 0; k < 8; ++k) { if (c->lane_stream[k]) { hipStreamSynchronize(c->lane_stream[k]); hipStreamDestroy(c->lane_stream[k]); } if (c->lane_join[k]) hipEventDestroy(c->lane_join[k]); }
   if (c->lane_fork) hipEventDestroy(c->lane_fork);
+  if (c->reset_ev) hipEventDestroy(c->reset_ev);
+  for (hipEvent_t e : c->counters_zeroed) if (e) hipEventDestroy(e);
   if (c->d_lane_counts) hipFree(c->d_lane_counts);
   if (c->d_pipe_seeds) hipFree(c->d_pipe_seeds);
   if (c->rb_stream) { hipStreamSynchronize(c->rb_stream); hipStreamDestroy(c->rb_stream); }

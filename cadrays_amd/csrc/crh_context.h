@@ -107,7 +107,15 @@ struct ScheduleState {
   uint32_t stamp_counter = 0;        // DPaths::stamp of the last batch traced (never 0: the radiance buffer is zeroed when it is allocated)
   uint32_t* d_tile_ids = nullptr; uint32_t tile_cap = 0;
   uint32_t* d_seeds = nullptr; uint32_t seed_cap = 0;
-  DCounters* d_counters = nullptr;
+  // Counters of the CURRENT accumulation (crh_stats counts since the last restart).  Four blocks, used in turn: crh_reset moves on to the next one -- zeroed one
+  // restart earlier, stream-ordered -- instead of zeroing the one in use, so the first frame after a restart need not wait for the frames of the old accumulation
+  // that are still in flight to have added their last counts (render_impl, frame pipeline).
+  DCounters* d_counters = nullptr; DCounters* d_counters_ring = nullptr; uint32_t counter_epoch = 0; hipEvent_t counters_zeroed[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t reset_ev = nullptr; bool reset_pending = false;       // crh_reset's memsets of the accumulator: the next frame's ACCUMULATE waits for them, its tracing does not
+  uint64_t stream_uses = 0;                                        // cstream() calls (anything enqueued on the context's stream) ...
+  uint64_t lane_stream_uses[8] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};      // ... and the count at which each pipeline stream last forked from it
+  uint32_t lane_counter_epoch[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};                    // the accumulation whose counter block each pipeline stream has waited for
+  bool pipe_running[8] = {false, false, false, false, false, false, false, false};      // a frame was submitted on that pipeline stream and has not been seen finished (the frames-in-flight estimate)
   uint32_t* d_api_cursor = nullptr;   // work cursor of the API-level trace kernels
   void* d_scratch = nullptr; size_t scratch_bytes = 0;
   bool clamp_grid = true;   // persistent traversal grids are clamped to what the register budget keeps resident (kernels.hip, resident_grid)
@@ -144,6 +152,7 @@ struct ScheduleState {
   bool frame_kernel = true, auto_frame_kernel = true;
   uint32_t frame_live = 4096, frame_chunk = 256;    // paths a workgroup (16 wavefronts, one per compute unit) keeps alive at most; path slots a wavefront claims at a time
   uint32_t frame_low_water = 512;                   // a feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring
+  uint32_t frame_starve = 1u << 20;                 // a feeder shades fewer than 64 hits only while fewer rays than this wait in the ring
   uint32_t frame_feeders = 3, frame_claim_step = 16;   // wavefronts that only shade and generate; tracer w takes rays only while >= w * claim_step wait
   int frame_grid = 0;                               // workgroups of a lone frame (0: what is resident, 4 per CU)
   uint32_t frame_pipe_depth = 2;                    // frames in flight of free-running Redraw()s on the frame kernel (a frame keeps the chip busy but for its tail)
@@ -189,6 +198,7 @@ static inline hipStream_t cstream(crh_ctx* c)
     if (c->pipe_pending[k]) { hipStreamWaitEvent(c->stream_, c->lane_join[k], 0); c->pipe_pending[k] = false; }
   if (c->rb_guard_pending) { hipStreamWaitEvent(c->stream_, c->rb_guard, 0); c->rb_guard_pending = false; }      // an asynchronous read-back still tone-maps the accumulator
   c->read_since_render = true;      // something other than the next frame used the stream (render_impl clears this when it is done)
+  ++c->stream_uses;
   return c->stream_;
 }
 

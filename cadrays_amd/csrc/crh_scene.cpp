@@ -680,35 +680,44 @@ int crh_build_prebuilt(crh_ctx* c, const float* nodes, uint32_t n_nodes, const u
     // Depth: the per-lane traversal stack holds kLdsStack + kOvfStack entries and is not bounds-checked on the device.  A walk that arrives at a
     // node has at most `pend` entries waiting (every ancestor left <= n_children - 1 siblings behind) and pushes <= n_children - 1 more.  Links only point
     // forward (checked above), so one pass in index order sees every parent before its children.
-    // Containment: a child box that does not hold what hangs below it gives silently wrong images -- every leaf's triangle must lie inside its slot's box,
-    // every inner child's own box (origin + the span of its planes) inside its slot's box (the quantiser is conservative, so a correct tree passes exactly).
     {
       std::vector<uint16_t> pend(n_nodes, 0); std::vector<uint8_t> reached(n_nodes, 0);
       reached[0] = 1;
-      auto plane = [&](const QNode& n, int a, uint32_t qv) { return (double)crh_u2f(n.w[a]) + (double)qv * (double)crh_quant_step(CRH_NODE_STEP_E(n.w[3], a)); };
       for (uint32_t i = 0; i < n_nodes; ++i) {
         const uint32_t w3 = q[i].w[3], ni = CRH_NODE_NINNER(w3), nc = CRH_NODE_NCHILDREN(w3);
         if (!reached[i] || nc == 0) continue;
         if ((uint32_t)pend[i] + (nc - 1u) > (uint32_t)(kLdsStack + kOvfStack)) return fail(c, CRH_E_INVALID, "prebuilt tree is deeper than the traversal stack (kLdsStack + kOvfStack pending entries)");
+        for (uint32_t k = 0; k < ni; ++k) {
+          const uint32_t ch = q[i].w[10] + k;
+          if (reached[ch]) return fail(c, CRH_E_INVALID, "prebuilt node has two parents");
+          reached[ch] = 1; pend[ch] = (uint16_t)(pend[i] + (nc - 1u));
+        }
+      }
+      // Containment: a child box that does not hold what hangs below it gives silently wrong images.  The TRUE bounds of every subtree follow bottom-up from the
+      // triangles (children have larger indices than their parent: one pass from the last node to the first); every slot's box -- origin + q * 2^k on the node's
+      // grid -- must contain them.  The quantiser is conservative, so a tree this library built passes exactly.
+      std::vector<float> tb(6 * (size_t)n_nodes);
+      auto plane = [&](const QNode& n, int a, uint32_t qv) { return (double)crh_u2f(n.w[a]) + (double)qv * (double)crh_quant_step(CRH_NODE_STEP_E(n.w[3], a)); };
+      for (uint32_t i = n_nodes; i-- > 0;) {
+        const uint32_t w3 = q[i].w[3], ni = CRH_NODE_NINNER(w3), nc = CRH_NODE_NCHILDREN(w3);
+        float* me = &tb[6 * (size_t)i];
+        for (int a = 0; a < 3; ++a) { me[a] = 3.0e38f; me[3 + a] = -3.0e38f; }
+        if (!reached[i]) continue;
         for (uint32_t k = 0; k < nc; ++k) {
-          double lo[3], hi[3];
-          for (int a = 0; a < 3; ++a) { lo[a] = plane(q[i], a, (q[i].w[4 + a] >> (8 * k)) & 0xffu); hi[a] = plane(q[i], a, (q[i].w[7 + a] >> (8 * k)) & 0xffu); }
-          if (k < ni) {
-            const uint32_t ch = q[i].w[10] + k;
-            if (reached[ch]) return fail(c, CRH_E_INVALID, "prebuilt node has two parents");
-            reached[ch] = 1; pend[ch] = (uint16_t)(pend[i] + (nc - 1u));
-            const uint32_t cw3 = q[ch].w[3], cnc = CRH_NODE_NCHILDREN(cw3);
-            for (int a = 0; a < 3 && cnc; ++a) {
-              uint32_t qmin = 255u, qmax = 0u;
-              for (uint32_t j = 0; j < cnc; ++j) { qmin = std::min(qmin, (q[ch].w[4 + a] >> (8 * j)) & 0xffu); qmax = std::max(qmax, (q[ch].w[7 + a] >> (8 * j)) & 0xffu); }
-              if (plane(q[ch], a, qmin) < lo[a] || plane(q[ch], a, qmax) > hi[a]) return fail(c, CRH_E_INVALID, "prebuilt child box does not contain the node below it");
-            }
-          } else {
+          float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+          if (k < ni) { const float* ch = &tb[6 * (size_t)(q[i].w[10] + k)]; for (int a = 0; a < 3; ++a) { lo[a] = ch[a]; hi[a] = ch[3 + a]; } }
+          else {
             const uint32_t t = prim_order[(q[i].w[11] & 0x0FFFFFFFu) + (k - ni)];
             for (int v = 0; v < 3; ++v) {
               const float* pv = &c->pos[3 * (size_t)c->tri[4 * (size_t)t + v]];
-              for (int a = 0; a < 3; ++a) if ((double)pv[a] < lo[a] || (double)pv[a] > hi[a]) return fail(c, CRH_E_INVALID, "prebuilt leaf box does not contain its triangle");
+              for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], pv[a]); hi[a] = std::max(hi[a], pv[a]); }
             }
+          }
+          for (int a = 0; a < 3; ++a) {
+            if (lo[a] > hi[a]) continue;                                   // an empty subtree holds nothing to miss
+            if (plane(q[i], a, (q[i].w[4 + a] >> (8 * k)) & 0xffu) > (double)lo[a] || plane(q[i], a, (q[i].w[7 + a] >> (8 * k)) & 0xffu) < (double)hi[a])
+              return fail(c, CRH_E_INVALID, "prebuilt child box does not contain what hangs below it");
+            me[a] = std::min(me[a], lo[a]); me[3 + a] = std::max(me[3 + a], hi[a]);
           }
         }
       }

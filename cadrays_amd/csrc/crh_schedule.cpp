@@ -23,7 +23,8 @@ namespace {
 // One batch: `ns` samples of `nt` tiles whose ids sit at d_tiles; seeds at d_seeds.
 // One wavefront schedule: `ns` samples of `nt` tiles (ids at d_tiles, seeds at d_seeds) on one stream and one slice of the path state.
 struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; bool donate = false;
-              bool frame = false; int grid_frame = 0; };      // frame: the whole batch in one launch of the frame kernel (k_frame.h) with grid_frame workgroups
+              bool frame = false; int grid_frame = 0;         // frame: the whole batch in one launch of the frame kernel (k_frame.h) with grid_frame workgroups
+              const uint32_t* h_seeds = nullptr; };           // ... whose <= 16 frame seeds travel by value (d_seeds == nullptr)
 
 // May this batch take the frame kernel?  Small, not counted, not timed per kernel, slots that fit the bits the kernel keeps them in.
 bool frame_ok(const crh_ctx* c, uint64_t total)
@@ -36,7 +37,7 @@ int frame_grid(const crh_ctx* c, const DScene& S, uint32_t share = 1u)
 }
 
 int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tiles, uint32_t nt, const uint32_t* d_seeds, uint32_t ns, int seed_per_tile,
-             bool accumulate, hipEvent_t before_accumulate = nullptr, hipEvent_t before_accumulate2 = nullptr)
+             bool accumulate, hipEvent_t before_accumulate = nullptr, hipEvent_t before_accumulate2 = nullptr, hipEvent_t before_accumulate3 = nullptr)
 {
   Launch L{ln.stream, ln.grid, c->counters_on};
   Launch LT{ln.stream, ln.grid_trace, c->counters_on, c->clamp_grid ? c->cus : 0, ln.donate && !c->counters_on};
@@ -48,7 +49,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     // the frame kernel: camera rays, every bounce's traversal, shading and shadow rays of this batch in ONE launch (k_frame.h); its two control words live behind
     // the queue counters of this lane (zero when allocated, left zero by every launch)
     Launch LF{ln.stream, ln.grid_frame, false, c->clamp_grid ? c->cus : 0};
-    launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->frame_low_water, c->frame_feeders, c->frame_claim_step, c->d_counters);
+    launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->frame_low_water, c->frame_feeders, c->frame_claim_step, c->frame_starve, c->d_counters, ln.h_seeds);
   } else {
   launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev);
   int qin = 0;
@@ -68,6 +69,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
   }
   if (accumulate && before_accumulate) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate, 0));      // samples are folded in in frame order
   if (accumulate && before_accumulate2) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate2, 0));    // ... and not while a read-back tone-maps the accumulator
+  if (accumulate && before_accumulate3) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate3, 0));    // ... and after a restart has zeroed it
   if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, ns, c->d_counters, ln.n_tiles_dev);
   CRH_HIP(hipGetLastError());
   return CRH_OK;
@@ -158,9 +160,19 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     int rc_u = stage_copy(c, c->d_tile_ids, tiles, sizeof(uint32_t) * nt); if (rc_u) return rc_u;
     c->h_tile_ids.assign(tiles, tiles + nt);
   }
-  const uint32_t cap_tiles = std::max<uint32_t>(1u, c->max_paths / tpp);
+  // path budget of this call: crh_set_path_budget's, cut to what the device has free when the state would have to grow (196 B per slot; a shared or smaller
+  // device gets the narrower batches the budget table of cadrays_hip.h prices at a few percent, not a hipMalloc error -- ADVICE r4)
+  uint32_t budget = c->max_paths;
+  if ((uint64_t)nt * tpp * ns > c->path_cap) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+      const uint64_t fit = (uint64_t)((double)(fr + (size_t)c->path_cap * 196u) * 0.85) / 196u;
+      if (fit < budget) budget = (uint32_t)std::max<uint64_t>(fit, std::min<uint64_t>(budget, 1u << 20));
+    }
+  }
+  const uint32_t cap_tiles = std::max<uint32_t>(1u, budget / tpp);
   uint32_t group = std::min(nt, cap_tiles);
-  uint32_t spb = std::max<uint32_t>(1u, std::min(ns, c->max_paths / (group * tpp)));
+  uint32_t spb = std::max<uint32_t>(1u, std::min(ns, budget / (group * tpp)));
   // A wide request that does not fit one batch is cut into TILE groups first and sample batches second: as many of the call's samples per batch as fit
   // (multiples of 64, so that a wavefront is 64 samples of one pixel and the camera rays walk as packets; at most kBatchSamples), the tiles per batch follow
   // (at least kBatchMinTiles).  The more samples of a pixel travel together, the more of their later bounces start from the same few triangles and the
@@ -171,11 +183,11 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   if (c->packets > 0 && c->packets <= 64 && !c->counters_on && ns >= 64u && (uint64_t)nt * tpp * ns > c->lane_max_paths) {
     uint32_t want = std::min<uint32_t>(ns & ~63u, kBatchSamples);
     const uint32_t min_group = std::min<uint32_t>(nt, kBatchMinTiles);
-    while (want > 64u && c->max_paths / (want * tpp) < min_group) want = (want / 2u) & ~63u;
-    if (want >= 64u && c->max_paths / (want * tpp) >= 1u) {
-      group = std::min(nt, c->max_paths / (want * tpp));
+    while (want > 64u && budget / (want * tpp) < min_group) want = (want / 2u) & ~63u;
+    if (want >= 64u && budget / (want * tpp) >= 1u) {
+      group = std::min(nt, budget / (want * tpp));
       spb = want;
-      if (group == nt) spb = std::max<uint32_t>(want, std::min(ns, c->max_paths / (group * tpp)) & ~63u);
+      if (group == nt) spb = std::max<uint32_t>(want, std::min(ns, budget / (group * tpp)) & ~63u);
     }
   }
   const uint64_t total = (uint64_t)nt * tpp * ns;
@@ -183,9 +195,11 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   // would get 187 instead of 225 (one schedule per frame is slower than two tile ranges when nothing overlaps it), so a
   // read-back / synchronisation since the last render selects the two-range schedule for this frame.
   const bool host_runs_ahead = !c->read_since_render;
-  if (c->pipeline && host_runs_ahead && !c->counters_on && !c->timing_on && !c->adaptive && group == nt && spb == ns && ns <= 16u && total >= (1u << 20) &&
+  // The frame kernel takes this path whether or not the host runs ahead: a lone frame costs the same here (one launch, the whole chip) and the next one --
+  // after a restart too: a camera drag restarts with every frame (AppViewer.cxx:979-984) -- can start tracing while this one's last paths finish.
+  const bool frame = frame_ok(c, total);
+  if (c->pipeline && (host_runs_ahead || frame) && !c->counters_on && !c->timing_on && !c->adaptive && group == nt && spb == ns && ns <= 16u && total >= (1u << 20) &&
       total <= c->lane_max_paths && (uint64_t)c->pipe_depth * total <= c->max_paths) {
-    const bool frame = frame_ok(c, total);
     const uint32_t depth = frame ? std::min(c->frame_pipe_depth, c->pipe_depth) : c->pipe_depth;      // frames in flight
     // ---- frame pipelining: this batch (one Redraw() worth) goes to pipeline stream k with its own half of the path state; it
     // starts as soon as the previous frame ON THAT STREAM is done and overlaps the frame on the other stream; its samples are
@@ -195,23 +209,30 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     const uint32_t k = c->pipe_seq % depth, prev = (c->pipe_seq + depth - 1u) % depth;      // this frame's stream, the previous frame's
     ++c->pipe_seq;
     const hipStream_t cs = c->stream_;                 // raw: no join
-    if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(cs, c->lane_join[k], 0));      // this stream's seed slot is free once its last frame is done
     uint32_t* d_seeds_k = c->d_pipe_seeds + 16u * k;
+    uint32_t seeds[16];
     {
-      std::vector<uint32_t> seeds(ns);
       uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;
       for (uint32_t i = 0; i < first + ns; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; if (i >= first) seeds[i - first] = hi >> 2; }
-      rc = stage_copy(c, d_seeds_k, seeds.data(), sizeof(uint32_t) * ns, cs); if (rc) return rc;
+    }
+    if (!frame) {                                       // the staged kernels read the seeds from HBM (the frame kernel takes them by value)
+      if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(cs, c->lane_join[k], 0));      // this stream's seed slot is free once its last frame is done
+      rc = stage_copy(c, d_seeds_k, seeds, sizeof(uint32_t) * ns, cs); if (rc) return rc;
     }
     DScene S; fill_scene(c, S);
-    CRH_HIP(hipEventRecord(c->lane_fork, cs));
+    // What this frame's TRACING must wait for: whatever was enqueued on the context's stream since the last frame forked -- scene uploads, a new tile list, a
+    // read-back's kernels.  A restart's memsets are not among them (do_reset): the frame kernel's first frame after crh_reset starts at once, only its
+    // accumulate waits (reset_ev below).  The staged kernels always fork (their seeds were just staged on that stream).
+    // Per pipeline stream: the frame after the one that forked runs on ANOTHER stream and must see the same uploads.
+    const bool fork = !frame || c->stream_uses != c->lane_stream_uses[k];
+    if (fork) { CRH_HIP(hipEventRecord(c->lane_fork, cs)); c->lane_stream_uses[k] = c->stream_uses; }
     Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false; ln.donate = c->donate;
     ln.grid = (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>((uint64_t)c->pipe_grid_min_shade, total / 2048u));
     // traversal grid of this frame: the chip's resident workgroups (6 per CU) shared among the frames that are in flight RIGHT NOW -- a host that runs far
     // ahead has pipe_depth of them (eight: 192 workgroups each), one that waits for every other frame's read-back has two or three (512 each); measured
     // optima at 3 / 4 / 6 / 8 frames in flight: 512 / 384 / 256 / 192-256 (profiles/r3/interactive_counters.txt)
     uint32_t in_flight = 1u;
-    for (uint32_t j = 0; j < 8u; ++j) if (j != k && c->pipe_pending[j] && hipEventQuery(c->lane_join[j]) == hipErrorNotReady) ++in_flight;
+    for (uint32_t j = 0; j < 8u; ++j) if (c->pipe_running[j]) { if (hipEventQuery(c->lane_join[j]) != hipErrorNotReady) c->pipe_running[j] = false; else if (j != k) ++in_flight; }
     {
       // a host that submitted the previous frame a moment ago is not waiting for anything: the pipeline is about to fill (counting what is in flight NOW
       // would give the first frames of a burst grids for a nearly empty chip: eight of them, 2900 workgroups)
@@ -221,30 +242,38 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     }
     const uint64_t share = std::min<uint64_t>(512u, std::max<uint64_t>((uint64_t)c->pipe_grid_min, (uint64_t)c->grid_trace / in_flight));
     ln.grid_trace = (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(share, total / (uint64_t)c->pipe_div));
-    ln.frame = frame; ln.grid_frame = frame ? frame_grid(c, S, std::min(in_flight, depth)) : 0;
+    // frame kernel: one workgroup fills a compute unit, so the frames in flight share the chip by compute units (every frame asking for all of them was
+    // measured: the second frame's workgroups then wait for whole workgroups of the first to leave -- 368 against 399 Redraw/s)
+    ln.frame = frame; ln.grid_frame = frame ? frame_grid(c, S, std::min(in_flight, depth)) : 0; ln.h_seeds = frame ? seeds : nullptr;
     const size_t base = (size_t)k * total;
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
     ln.P.thr[0] = P.thr[0] + base; ln.P.thr[1] = P.thr[1] + base; ln.P.hit = P.hit + base; ln.P.rad = P.rad + base;
     ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base; ln.P.stamp = next_stamp(c);      // this frame's own stamp
     ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.q2 = Q.q2 + base; ln.Q.q2_sh = Q.q2_sh + base; ln.Q.counts = c->d_lane_counts + kCounts * k;
-    CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
+    if (fork) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
+    if (c->lane_counter_epoch[k] != c->counter_epoch) {   // this stream's first frame of an accumulation: the counter block was zeroed one restart ago, stream-ordered
+      const hipEvent_t z = c->counters_zeroed[c->counter_epoch & 3u];
+      if (z) CRH_HIP(hipStreamWaitEvent(ln.stream, z, 0));
+      c->lane_counter_epoch[k] = c->counter_epoch;
+    }
     // the frames in flight own path-state slices [k * total, (k + 1) * total): a batch of ANOTHER size (crh_render_tiles with another
     // sample count or tile list) would lay its slice across theirs -- it starts only when they are all done
     // ... and so does the first frame after the number of frames in flight changed (frame kernel <-> staged form): stream k's predecessor is not frame n - 1 then
     if (total != c->pipe_total || depth != c->pipe_last_depth) {
-      for (int j = 0; j < 8; ++j) if (c->pipe_pending[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));
+      for (int j = 0; j < 8; ++j) if (c->pipe_running[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));      // (joined into the context's stream or not)
       c->pipe_total = total; c->pipe_last_depth = depth;
     }
     c->pending_n = 0;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);          // crh_stats.seconds: device time of this frame (frames in flight overlap)
     hipEventRecord(e0, ln.stream);
     const hipEvent_t guard = c->rb_guard_pending ? c->rb_guard : nullptr; c->rb_guard_pending = false;      // later frames are ordered behind this one's accumulate
-    rc = run_lane(c, ln, S, c->d_tile_ids, nt, d_seeds_k, ns, 0, true, c->pipe_pending[prev] ? c->lane_join[prev] : nullptr, guard); if (rc) return rc;
+    const hipEvent_t after_reset = c->reset_pending ? c->reset_ev : nullptr; c->reset_pending = false;      // (it followed the joins of every earlier frame)
+    rc = run_lane(c, ln, S, c->d_tile_ids, nt, frame ? nullptr : d_seeds_k, ns, 0, true, c->pipe_pending[prev] ? c->lane_join[prev] : nullptr, guard, after_reset); if (rc) return rc;
     hipEventRecord(e1, ln.stream);
     c->render_ev.emplace_back(e0, e1);
     CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
-    c->pipe_pending[k] = true;
+    c->pipe_pending[k] = true; c->pipe_running[k] = true;
     rc = trim_events(c);                                        // every 4096 frames: waits for the device once
     c->read_since_render = false;
     return rc;

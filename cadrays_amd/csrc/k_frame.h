@@ -20,17 +20,23 @@ constexpr int      kFrameMats  = 32;            // materials staged in LDS (4 KB
 #ifndef CRH_FRAME_BLOCK
 #define CRH_FRAME_BLOCK 1024                    // threads per workgroup of the frame kernel: ONE workgroup of 16 wavefronts per compute unit shares the rings, so that the
 #endif                                          // few rays of the late bounces gather in a few full wavefronts instead of trickling through all of them
+#ifndef CRH_FRAME_MINWAVES
+#define CRH_FRAME_MINWAVES 4                    // wavefronts per SIMD the register allocation must allow (4: 128 VGPRs, what the shading code needs)
+#endif
 constexpr int      kFrameBlock = CRH_FRAME_BLOCK;
-constexpr uint32_t kFrameRing  = 4u * kFrameBlock;      // entries of each ring = the most paths a workgroup may have alive (every live path is in at most one ring)
+constexpr uint32_t frame_pow2(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
+constexpr uint32_t kFrameRing  = frame_pow2(4u * kFrameBlock);      // entries of each ring (a power of two) = the most paths a workgroup may have alive (every live path is in at most one ring)
 
 struct FrameArgs {
   const uint32_t* tile_ids; uint32_t n_tiles; const uint32_t* n_tiles_dev;      // as k_raygen's
   const uint32_t* seeds; uint32_t n_samples; int seed_per_tile;
+  uint32_t seed_vals[16];     // seeds == nullptr: the frame seeds of the batch's <= 16 samples by value (a frame's tracing then reads nothing the host uploaded for it)
   uint32_t* ctl;              // [0] slot cursor, [1] workgroups finished (both zero at launch; the last workgroup to leave zeroes them again)
   uint32_t max_live;          // paths a workgroup keeps alive at most (<= kFrameRing)
   uint32_t gen_chunk;         // path slots a wavefront claims at a time (a multiple of 64)
   uint32_t low_water;         // a feeder wavefront claims the next chunk once fewer rays than this wait in the ring
   uint32_t n_feed;            // wavefronts of a workgroup that only shade and generate (the last ones)
+  uint32_t starve;            // a feeder shades fewer than a wavefront's worth of hits only while fewer rays than this wait in the ring (the tracers are about to starve)
   uint32_t claim_step;        // tracer wavefront w takes rays from the ring only while >= w * claim_step wait there: scarce rays go to the first wavefronts
 };
 
@@ -84,7 +90,7 @@ __device__ __forceinline__ void wave_sub(uint32_t* word, bool pred)          // 
 }
 
 template <bool TWO>
-__global__ __launch_bounds__(kFrameBlock, 4) void k_frame(DScene S, DPaths P, FrameArgs A, DCounters* C)
+__global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScene S, DPaths P, FrameArgs A, DCounters* C)
 {
   constexpr int kBlock = kFrameBlock;
   __shared__ uint32_t stk[kLdsStack * kBlock];
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(kFrameBlock, 4) void k_frame(DScene S, DPaths P, Fr
       if (valid) { slot_to_pixel_sample(pid, A.n_samples, local, s); valid = slot_pixel(S, A.tile_ids, local, px, py); }
       if (valid) {
         v3 o, d; uint32_t rng;
-        camera_ray(S, A.seeds, A.seed_per_tile, px, py, s, local, o, d, rng);
+        const uint32_t fseed = A.seeds ? (A.seed_per_tile ? A.seeds[local / (S.tile_size * S.tile_size)] : A.seeds[s]) : A.seed_vals[s & 15u];
+        camera_ray(S, fseed, px, py, o, d, rng);
         ray_o[pid] = mk4(o, __uint_as_float(rng));
         ray_d[pid] = mk4(d, __uint_as_float(pid << 1));               // bounce 0, outside
       }
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(kFrameBlock, 4) void k_frame(DScene S, DPaths P, Fr
     if (feeder) {
       if (ns >= 64u) act = 1;
       else if (nr < A.low_water && may_generate()) act = 2;
-      else if (ns != 0u) act = 1;                                    // nothing better to do: whatever waits is shaded now (the tracers get their rays sooner)
+      else if (ns != 0u && (nr < A.starve || nr == 0u)) act = 1;     // the tracers are about to starve: whatever waits is shaded now
     } else {
       if (nr != 0u && nr >= claim_min) act = 3;
       else if (ns >= 256u || (A.n_feed == 0u && ns != 0u && !(nr == 0u && may_generate()))) act = 1;      // the feeders have fallen behind (or there are none)

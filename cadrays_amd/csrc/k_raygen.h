@@ -46,13 +46,10 @@ __device__ __forceinline__ uint32_t pixel_sample_to_slot(uint32_t local, uint32_
 }
 
 // The camera ray of pixel (px, py), sample s of the batch (a2 / a14): rng seed, sub-pixel jitter, pinhole / orthographic / frustum-corner ray, thin lens.  Shared by
-// k_raygen and the frame kernel's own ray generation (k_frame.h).  `local` = the pixel's slot among the batch's tiles (adaptive passes seed per tile).
-__device__ __forceinline__ void camera_ray(const DScene& S, const uint32_t* __restrict__ seeds, const int seed_per_tile, const uint32_t px, const uint32_t py,
-                                           const uint32_t s, const uint32_t local, v3& o, v3& d, uint32_t& rng)
+// k_raygen and the frame kernel's own ray generation (k_frame.h).  fseed: the frame seed of the sample (whole-frame passes) or of the tile (adaptive passes).
+__device__ __forceinline__ void camera_ray(const DScene& S, const uint32_t fseed, const uint32_t px, const uint32_t py, v3& o, v3& d, uint32_t& rng)
 {
   const uint32_t pix = S.coherent ? ((py / 16u) * ((S.width + 15u) / 16u) + (px / 16u)) : (py * S.width + px);
-  // whole-frame passes share one frame seed per sample; adaptive passes give every tile its own sample index
-  const uint32_t fseed = seed_per_tile ? seeds[local / (S.tile_size * S.tile_size)] : seeds[s];
   rng = crh_rng_seed(pix, fseed);
   const float jx = crh_rng_next_mode(&rng, S.spec_u32), jy = crh_rng_next_mode(&rng, S.spec_u32);
   const float nx = CRH_FMA(((float)px + jx) / (float)S.width, 2.0f, -1.0f);
@@ -131,7 +128,8 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
     if (valid) { slot_to_pixel_sample(pid, n_samples, local, s); valid = slot_pixel(S, tile_ids, local, px, py); }
     if (valid) {
       v3 o, d; uint32_t rng;
-      camera_ray(S, seeds, seed_per_tile, px, py, s, local, o, d, rng);
+      // whole-frame passes share one frame seed per sample; adaptive passes give every tile its own sample index
+      camera_ray(S, seed_per_tile ? seeds[local / (S.tile_size * S.tile_size)] : seeds[s], px, py, o, d, rng);
       P.ray_o[0][pid] = mk4(o, __uint_as_float(rng));           // .w = rng state; position = path slot at bounce 0
       P.ray_d[0][pid] = mk4(d, __uint_as_float(pid << 1));      // .w = (path slot << 1) | inside-a-medium flag
       if (SPLIT) flagged = ray_touches_instances(S, o, d, CRH_MAXFLOAT);

@@ -24,6 +24,9 @@
 #if CRH_FRAME_STATS
 __device__ unsigned long long g_frame_stats[16];
 #endif
+#ifndef CRH_EXP_EARLY_TRI
+#define CRH_EXP_EARLY_TRI 0     // hunt scaffold only (tests/hunts/two_level_anyhit_counting.py)
+#endif
 #ifndef CRH_POOL_CHUNK
 #define CRH_POOL_CHUNK 256     // measured: 64 -> 2257, 128 -> 2305, 256 -> 2308, 512 -> 2266, 1024 -> 2136 Mrays/s (big pools starve late bounces)
 #endif
@@ -160,6 +163,11 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   };
   float4 hit = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   bool found = false;
+#if CRH_EXP_EARLY_TRI
+  // hunt scaffold (tests/hunts/two_level_anyhit_counting.py): round 4's early triangle fetch, compiled in behind a run-time switch that is never on
+  const bool early = gbox.w == -12345.0f;
+  float4 pre_a = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
   // donation state (DON): stack entries live in [sbase, sp); is_child: this lane walks a donated subtree, its total is absorbed by
   // its predecessor instead of stored; next: the lane that holds what comes right after this lane's part in traversal order;
   // chit / cfound: the folded totals of the successors absorbed so far (they come after everything this lane still walks)
@@ -427,7 +435,11 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     // one ray/triangle test of this lane against leaf-order triangle `ti`
     auto tri_step = [&](uint32_t ti) {
       const float4* tp = tris + kTriStride * ti;
+#if CRH_EXP_EARLY_TRI
+      const float4 a = early ? pre_a : tp[0], b = tp[1], c = tp[2];
+#else
       const float4 a = tp[0], b = tp[1], c = tp[2];
+#endif
       if (COUNT || (FRM && CRH_FRAME_STATS)) ++n_tris;
       // record = {v0 | n.x}, {e0 = v1 - v0 | n.y}, {e1 = v0 - v2 | n.z}: the two edges and n = e1 x e0 are evaluated ONCE per triangle on the host
       // with the inline arithmetic this function used to apply per test (crh_sub3 / crh_cross3, same bits) -- 15 VALU instructions per test
@@ -452,6 +464,9 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     for (int step_ = 0; step_ < CRH_INNER_STEPS && have && !(cur & kQLeafBit); ++step_) inner_step();
 #else
     while (have && !(cur & kQLeafBit)) inner_step();
+#endif
+#if CRH_EXP_EARLY_TRI
+    if (early && have && (cur & kQLeafBit) && cur != kDone && (cur & 0xF0000000u) != CRH_REF_INSTANCE_TAG) pre_a = tris[kTriStride * (cur & 0x0FFFFFFFu)];
 #endif
     // ------------------------------------------------------------------ (B) the leaf in hand
     if (TWO && have && (cur & 0xF0000000u) == CRH_REF_INSTANCE_TAG && cur < CRH_REF_SENTINEL) {

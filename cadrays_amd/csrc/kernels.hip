@@ -68,8 +68,9 @@ void launch_trace_nearest(const Launch& L, const DScene& S, const DPaths& P, con
                        Q.counts + count2_slot(bounce + 1u), Q.counts + 7, Q.q2, Q.counts + 11, C);
     else          hipLaunchKernelGGL(k_trace_packets<false>, dim3(grid), dim3(kBlock), 0, L.stream, S, P, S.nodes, S.nodes, S.tris, Q.q[qin], Q.counts + qin, Q.counts + 4, Q.counts + (1 - qin), Q.counts + 2,
                        Q.counts + count2_slot(bounce + 1u), Q.counts + 7, Q.q2, Q.counts + 11, C);
-    // (the donating instantiation: a handful of rays, each walked by a whole wavefront)
-    hipLaunchKernelGGL((k_trace_nearest<false, false, true, false, true>), dim3(64), dim3(kBlock), 0, L.stream, S, P, qin, Q.q2, Q.counts + 11, Q.counts + 4,
+    // (the donating instantiation: usually a handful of rays, each walked by a whole wavefront -- but coincident or duplicated faces, common in CAD assemblies,
+    // send every camera ray that meets them here: the grid is what is resident, and a workgroup that finds the list empty leaves at once)
+    hipLaunchKernelGGL((k_trace_nearest<false, false, true, false, true>), dim3(resident_grid<k_trace_nearest<false, false, true, false, true>>(L)), dim3(kBlock), 0, L.stream, S, P, qin, Q.q2, Q.counts + 11, Q.counts + 4,
                        Q.counts + (1 - qin), Q.counts + 2, Q.counts + count2_slot(bounce + 1u), Q.counts + 7, C);
     return;
   }
@@ -115,12 +116,13 @@ int frame_resident_grid(int cus, bool two_level)
   return (pc > 0 ? pc : 1024 / kFrameBlock) * (cus > 0 ? cus : 256);
 }
 void launch_frame(const Launch& L, const DScene& S, const DPaths& P, uint32_t* ctl, const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds,
-                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, uint32_t low_water, uint32_t n_feed, uint32_t claim_step, DCounters* C)
+                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, uint32_t low_water, uint32_t n_feed, uint32_t claim_step, uint32_t starve, DCounters* C, const uint32_t* h_seeds)
 {
   FrameArgs A;
   A.tile_ids = d_tile_ids; A.n_tiles = n_tiles; A.n_tiles_dev = d_n_tiles; A.seeds = d_seeds; A.n_samples = n_samples; A.seed_per_tile = seed_per_tile;
+  for (int i = 0; i < 16; ++i) A.seed_vals[i] = (h_seeds && (uint32_t)i < n_samples) ? h_seeds[i] : 0u;
   A.ctl = ctl; A.gen_chunk = min(max(gen_chunk & ~63u, 64u), kFrameRing); A.max_live = min(max(max_live, A.gen_chunk), kFrameRing); A.low_water = low_water;
-  A.n_feed = min(n_feed, (uint32_t)kFrameBlock / 64u - 1u); A.claim_step = claim_step;
+  A.n_feed = min(n_feed, (uint32_t)kFrameBlock / 64u - 1u); A.claim_step = claim_step; A.starve = starve;
   DScene S1 = S; S1.split = 0;                  // a split scene is walked in one go: static tree, then the top level (the two-pass form is a wavefront-schedule device)
   const int grid = min(L.grid, frame_resident_grid(L.cus, S.two_level != 0));
   if (S.two_level) hipLaunchKernelGGL(k_frame<true>, dim3(grid), dim3(kFrameBlock), 0, L.stream, S1, P, A, C);

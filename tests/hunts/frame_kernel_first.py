@@ -1,11 +1,11 @@
 import os, sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from cadrays_amd import scenes, abi
 from cadrays_amd.view import View
 from oracle.pyoracle import Oracle
 def bits(a): return np.ascontiguousarray(a, np.float32).view(np.uint32)
-from tests.test_two_level import moved_xforms, object_scene
+from test_two_level import moved_xforms, object_scene
 cases = {"cornell": (lambda: scenes.cornell_box(True, 128, 128), 6), "c3": (lambda: scenes.baseline_config("C3", 256, 144, n_tris=20000), 4),
          "c2": (lambda: scenes.baseline_config("C2", 256, 144, n_tris=20000), 4), "materials": (lambda: scenes.materials_scene(160, 120, 24, 12), 4),
          "two_level_moved": (lambda: object_scene(moved_xforms(8), 96, 96), 6), "two_level_identity": (lambda: object_scene(None, 96, 96), 6)}

@@ -1,0 +1,209 @@
+"""The frame kernel (cadrays_amd/csrc/k_frame.h, round 5): one Redraw() = +1 sample per pixel (reference AppViewer.cxx:1045-1047) in ONE launch -- every
+workgroup streams its own paths through ray generation, traversal and shading -- and the frame pipeline that lets the first frame after a restart
+(camera drag: AppViewer.cxx:979-984) start tracing while the last frame of the old accumulation finishes.  Nothing per path changes, so every frame
+must equal the staged schedule's (crh_set_schedule(CRH_SCHEDULE_STAGED): one launch per stage and bounce) and the CPU oracle's bit for bit, the
+ray counts included.  tests/test_timed_path_parity.py runs six scenes through all three schedules against the oracle; here: full-size frames, the
+application's call patterns (drag, display, restart with frames in flight), the kernel's knobs, two-level scenes mid-drag, adaptive iterations."""
+import dataclasses
+import math
+import os
+
+import numpy as np
+import pytest
+
+from cadrays_amd import abi, scenes
+
+from test_two_level import moved_xforms, object_scene, rigid
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def c3_1080p(n_tris=50_000):
+    sc = scenes.baseline_config("C3", n_tris=n_tris)
+    sc.env = scenes.procedural_sky(512, 256, 1)
+    return sc
+
+
+def orbit(cam0, i):
+    a = 0.01 * i
+    r = math.sqrt(sum(x * x for x in cam0.eye))
+    eye = (r * math.sin(a), -r * math.cos(a), 0.0)
+    return dataclasses.replace(cam0, eye=eye, dir=tuple(-x / r for x in eye))
+
+
+def test_full_size_frames_equal_the_staged_schedule_and_the_oracle(hip_lib, oracle_lib):
+    """1080p, 2 M paths per frame: what the application renders.  Three frames one by one: whole image == staged schedule, sampled tiles == oracle, counters equal."""
+    from cadrays_amd.view import View
+    sc = c3_1080p()
+    v = View(0).load_scene(sc)
+    for _ in range(3):
+        v.Redraw()
+    g, st = v.read_hdr(), v.stats()
+    assert st["nodes_nearest"] == 0                      # not the counting kernels
+    s = View(0).load_scene(sc); s.set_schedule(abi.SCHEDULE_STAGED)
+    for _ in range(3):
+        s.Redraw()
+    ref, sst = s.read_hdr(), s.stats()
+    assert np.array_equal(bits(g), bits(ref))
+    for k in ("rays_nearest", "rays_any", "shaded_hits", "samples"):
+        assert st[k] == sst[k], k
+    o = oracle_lib.Oracle().load_scene(sc)
+    sample = np.unique(np.linspace(0, o.n_tiles() - 1, 7).astype(np.uint32))
+    o.render_tiles(sample, 0, 3)
+    acc = o.read_accum(); mask = acc[..., 3] == 3
+    assert mask.sum() >= 5 * 32 * 32 and np.array_equal(bits(g[mask]), bits(acc[..., :3][mask]))
+    v.close(); s.close(); o.close()
+
+
+@pytest.mark.parametrize("scene", ["c3", "c2"])
+def test_drag_loop_every_displayed_frame_is_the_lone_frame_of_its_camera(hip_lib, scene):
+    """The application's drag (AppViewer.cxx:979-984): every GUI frame sets the camera, restarts and renders ONE sample; the frame is shown (asynchronous
+    LDR read-back, collected two frames later).  Frames overlap on the device; each displayed image must be what a fresh context renders for that camera,
+    and the counters after the loop are those of its last frame alone."""
+    from cadrays_amd.view import View
+    sc = c3_1080p(30_000) if scene == "c3" else scenes.baseline_config("C2", n_tris=30_000)
+    v = View(0).load_scene(sc)
+    shown = []
+    n = 7
+    for i in range(n):
+        v.set_camera(orbit(sc.camera, i)); v.reset(); v.Redraw()
+        if i >= 2:
+            shown.append(v.read_ldr_end())
+        v.read_ldr_begin()
+    shown.append(v.read_ldr_end()); shown.append(v.read_ldr_end())
+    st = v.stats()
+    hdr_last = v.read_hdr()
+    ref = View(0).load_scene(sc); ref.set_schedule(abi.SCHEDULE_STAGED)
+    for i in range(n):
+        ref.set_camera(orbit(sc.camera, i)); ref.reset(); ref.Redraw()
+        assert np.array_equal(shown[i], ref.read_ldr()), f"displayed frame {i} differs"
+    rst = ref.stats()
+    assert np.array_equal(bits(hdr_last), bits(ref.read_hdr()))
+    for k in ("rays_nearest", "rays_any", "shaded_hits", "samples"):
+        assert st[k] == rst[k], (k, st[k], rst[k])
+    v.close(); ref.close()
+
+
+def test_restart_with_frames_in_flight_counts_only_the_new_accumulation(hip_lib, oracle_lib):
+    """crh_reset while pipelined frames are still running: the accumulator and crh_stats afterwards hold the new frames and nothing else (the counters of an
+    accumulation live in their own block, crh_context.h) -- eight restarts in a row, then against the oracle"""
+    from cadrays_amd.view import View
+    sc = c3_1080p(20_000)
+    v = View(0).load_scene(sc)
+    per_frame = None
+    for rnd in range(8):
+        for _ in range(1 + rnd % 3):
+            v.Redraw()
+        v.reset()
+        k = 1 + (rnd * 5) % 4
+        for _ in range(k):
+            v.Redraw()
+        st = v.stats()
+        assert st["samples"] == k * sc.params.width * sc.params.height, (rnd, st["samples"])
+        if k == 1:
+            per_frame = per_frame or st["rays_nearest"]
+            assert st["rays_nearest"] == per_frame
+    v.reset(); v.Redraw(); v.Redraw()
+    g, st = v.read_hdr(), v.stats()
+    o = oracle_lib.Oracle().load_scene(sc)
+    sample = np.unique(np.linspace(0, o.n_tiles() - 1, 6).astype(np.uint32))
+    o.render_tiles(sample, 0, 2)
+    acc = o.read_accum(); mask = acc[..., 3] == 2
+    assert np.array_equal(bits(g[mask]), bits(acc[..., :3][mask]))
+    v.close(); o.close()
+
+
+def test_scene_change_between_pipelined_frames_is_seen_by_the_next_frame(hip_lib):
+    """materials / lights / environment uploaded between two free-running frames: the next frame's tracing waits for the upload (it forks from the context's
+    stream whenever something was enqueued there) -- same frames as a context that synchronises after every call"""
+    from cadrays_amd.view import View
+    sc = scenes.baseline_config("C2", n_tris=20_000)
+    a = View(0).load_scene(sc); b = View(0).load_scene(sc); b.set_schedule(abi.SCHEDULE_STAGED)
+    r = np.random.default_rng(4)
+    for step in range(6):
+        mats = [dataclasses.replace(sc.materials[0], Kd=r.uniform(0.1, 0.9, 3).astype(np.float32))]
+        for w in (a, b):
+            for _ in range(5):                             # a queue of frames in flight: the upload waits for them, the frames after it must wait for the upload --
+                w.Redraw()                                 # on BOTH pipeline streams (round 5: the second frame after the upload once started without it)
+            w.set_materials(mats); w.Redraw(); w.Redraw(); w.Redraw()
+        b.sync()
+        if step % 2:
+            env = scenes.procedural_sky(64, 32, step)
+            a.set_envmap(env); b.set_envmap(env)
+    assert np.array_equal(bits(a.read_hdr()), bits(b.read_hdr()))
+    a.close(); b.close()
+
+
+KNOBS = [dict(CRH_FRAME_LIVE="256", CRH_FRAME_CHUNK="64", CRH_FRAME_LOW="0", CRH_FRAME_FEED="0"),
+         dict(CRH_FRAME_LIVE="4096", CRH_FRAME_CHUNK="1024", CRH_FRAME_LOW="4096", CRH_FRAME_FEED="8", CRH_FRAME_STEP="64"),
+         dict(CRH_FRAME_LIVE="700", CRH_FRAME_CHUNK="192", CRH_FRAME_FEED="1", CRH_FRAME_GRID="7", CRH_FRAME_STARVE="0"),
+         dict(CRH_FRAME_FEED="15", CRH_FRAME_STEP="0", CRH_FRAME_GRID="3", CRH_FRAME_PIPE="4"),
+         dict(CRH_FRAME_PIPE="1", CRH_FRAME_LOW="64", CRH_FRAME_STARVE="64", CRH_FRAME_STEP="256")]
+
+
+@pytest.mark.parametrize("knobs", range(len(KNOBS)))
+def test_no_knob_changes_a_bit(hip_lib, oracle_lib, knobs, monkeypatch):
+    """live-path budget, chunk size, feeder wavefronts, claim thresholds, grid, pipeline depth: schedules, not results -- Cornell box (shadow rays behind every
+    hit), a glass / glossy soup and an all-moved two-level scene against the oracle, five frames each, the counters too"""
+    from cadrays_amd.view import View
+    for k, val in KNOBS[knobs].items():
+        monkeypatch.setenv(k, val)                       # read by crh_create
+    for mk, spp in ((lambda: scenes.cornell_box(True, 96, 96), 5), (lambda: dataclasses.replace(c3_1080p(8_000), params=dataclasses.replace(c3_1080p(8_000).params, width=200, height=120)), 5),
+                    (lambda: object_scene(moved_xforms(8), 80, 64), 4)):
+        sc = mk()
+        o = oracle_lib.Oracle().load_scene(sc); o.render(spp)
+        v = View(0).load_scene(sc)
+        for _ in range(spp):
+            v.Redraw()
+        assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), KNOBS[knobs]
+        vs, os_ = v.stats(), o.stats()
+        for k in ("rays_nearest", "rays_any", "shaded_hits", "samples"):
+            assert vs[k] == os_[k], (k, KNOBS[knobs])
+        v.close(); o.close()
+
+
+def test_moved_object_mid_drag_and_lookahead_batches(hip_lib, oracle_lib):
+    """a gizmo drag (ImRaytraceControls.cxx:64,88: crh_set_transforms every frame, accumulation restarted) and small look-ahead batches (4 / 16 samples per launch)
+    through the frame kernel: split scene (static tree + one moved object) walked in one go, == oracle"""
+    from cadrays_amd.view import View
+    sc = object_scene(None, 128, 96)
+    v = View(0).load_scene(sc); o = oracle_lib.Oracle().load_scene(sc)
+    n_obj = len(sc.obj_xform)
+    for i in range(4):
+        xf = np.tile(rigid(), (n_obj, 1))
+        xf[3] = rigid(10.0 * i, (0, 0, 1), (-0.05 * i, 0.02 * i, 0.01))      # the yellow box follows the gizmo; frame 3: a second object has moved too
+        if i == 3: xf[5] = rigid(0.0, (0, 0, 1), (0.1, 0.05, 0.1), 0.9)
+        v.set_transforms(xf); o.set_transforms(xf)
+        v.reset(); o.reset()
+        v.Redraw(); o.render(1)
+        assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), i
+    v.set_lookahead(4); v.reset(); o.reset()
+    for _ in range(6):
+        v.Redraw()
+    o.render(6)
+    assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr()))
+    v.set_lookahead(1); v.set_lookahead_auto(16); v.reset(); o.reset()
+    for _ in range(23):
+        v.Redraw()
+    o.render(23)
+    assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr()))
+    v.close(); o.close()
+
+
+def test_adaptive_iterations_take_the_frame_kernel_and_match_the_staged_ones(hip_lib):
+    """AdaptiveScreenSampling (SettingsWidget.cxx:427-477): the tile list is drawn on the device, the frame kernel reads its length there"""
+    from cadrays_amd.view import View
+    sc = dataclasses.replace(c3_1080p(10_000), params=dataclasses.replace(c3_1080p(10_000).params, width=320, height=200))
+    a = View(0).load_scene(sc); b = View(0).load_scene(sc); b.set_schedule(abi.SCHEDULE_STAGED)
+    for w in (a, b):
+        w.set_adaptive(True, 16)
+        for _ in range(12):
+            w.Redraw()
+    assert np.array_equal(bits(a.read_hdr()), bits(b.read_hdr()))
+    ea, ca = a.tile_stats(); eb, cb = b.tile_stats()
+    assert np.array_equal(ca, cb) and np.array_equal(bits(ea), bits(eb))
+    a.close(); b.close()

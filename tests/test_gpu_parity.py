@@ -596,7 +596,7 @@ def test_pipelined_frames_equal_unpipelined(view_cls, monkeypatch):
 def test_random_call_sequences_with_frames_in_flight(view_cls, monkeypatch, seed):
     """Random API sequences on a frame large enough to be pipelined (>= 1 M paths): bursts of Redraw()s with setters, resets,
     tile subsets, look-ahead and adaptive switches and read-outs in between.  Every read-out must be bit-identical to the same
-    sequence with CRH_PIPELINE=0 / CRH_DONATE=0 / one stream (the schedule the other tests tie to the oracle)."""
+    sequence with CRH_PIPELINE=0 / CRH_DONATE=0 / CRH_FRAME_KERNEL=0 / one stream (the staged schedule the other tests tie to the oracle)."""
     import dataclasses
     sc = scenes.cornell_box(True, 1216, 896)                       # 1064 tiles = 1.09 M paths per frame
     r0 = np.random.default_rng(seed)
@@ -633,10 +633,10 @@ def test_random_call_sequences_with_frames_in_flight(view_cls, monkeypatch, seed
         outs.append(v.read_hdr().copy())
         return outs
 
-    monkeypatch.setenv("CRH_PIPELINE", "0"); monkeypatch.setenv("CRH_DONATE", "0"); monkeypatch.setenv("CRH_LANES", "1")
+    monkeypatch.setenv("CRH_PIPELINE", "0"); monkeypatch.setenv("CRH_DONATE", "0"); monkeypatch.setenv("CRH_LANES", "1"); monkeypatch.setenv("CRH_FRAME_KERNEL", "0")
     ref = run(view_cls(0).load_scene(sc))
-    monkeypatch.delenv("CRH_PIPELINE"); monkeypatch.delenv("CRH_DONATE"); monkeypatch.delenv("CRH_LANES")
-    got = run(view_cls(0).load_scene(sc))
+    monkeypatch.delenv("CRH_PIPELINE"); monkeypatch.delenv("CRH_DONATE"); monkeypatch.delenv("CRH_LANES"); monkeypatch.delenv("CRH_FRAME_KERNEL")
+    got = run(view_cls(0).load_scene(sc))                              # round 5: the frame kernel, two frames in flight, restarts that do not wait
     assert len(got) == len(ref)
     for i, (a, b) in enumerate(zip(got, ref)):
         assert np.array_equal(bits(a), bits(b)), (seed, i)
@@ -766,8 +766,8 @@ def test_pipelined_batches_of_different_sizes_do_not_share_path_state(view_cls, 
         v.render_tiles(np.arange(0, v.n_tiles(), 2, dtype=np.uint32), 7, 2); v.Redraw(); v.render_tiles(tiles3, 50, 5)
         return v.read_hdr().copy()
 
-    monkeypatch.setenv("CRH_PIPELINE", "0"); monkeypatch.setenv("CRH_DONATE", "0"); monkeypatch.setenv("CRH_LANES", "1")
+    monkeypatch.setenv("CRH_PIPELINE", "0"); monkeypatch.setenv("CRH_DONATE", "0"); monkeypatch.setenv("CRH_LANES", "1"); monkeypatch.setenv("CRH_FRAME_KERNEL", "0")
     ref = run(view_cls(0).load_scene(sc))
-    monkeypatch.delenv("CRH_PIPELINE"); monkeypatch.delenv("CRH_DONATE"); monkeypatch.delenv("CRH_LANES")
-    got = run(view_cls(0).load_scene(sc))
+    monkeypatch.delenv("CRH_PIPELINE"); monkeypatch.delenv("CRH_DONATE"); monkeypatch.delenv("CRH_LANES"); monkeypatch.delenv("CRH_FRAME_KERNEL")
+    got = run(view_cls(0).load_scene(sc))                              # round 5: the frame kernel, two frames in flight, restarts that do not wait
     assert np.array_equal(bits(got), bits(ref))

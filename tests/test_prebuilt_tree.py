@@ -67,6 +67,34 @@ def test_prebuilt_tree_is_validated(hip_lib):
     nb = nodes.copy().view(np.uint32); nb[0, 3] |= 7 << 28
     attempt(nb.view(np.float32), order)                               # seven children
     attempt(nodes[:0], order)                                         # no nodes
+    # a child box that does not hold what hangs below it (silently wrong images) ...
+    nb = nodes.copy().view(np.uint32)
+    wide = [i for i in range(len(nb)) if (nb[i, 3] >> 28) & 7 >= 1 and any(((nb[i, 7 + x] >> 0) & 0xff) - ((nb[i, 4 + x] >> 0) & 0xff) >= 4 for x in range(3))][0]
+    ax = [x for x in range(3) if ((nb[wide, 7 + x]) & 0xff) - ((nb[wide, 4 + x]) & 0xff) >= 4][0]
+    nb[wide, 7 + ax] = (nb[wide, 7 + ax] & ~np.uint32(0xff)) | (((nb[wide, 7 + ax] & 0xff) - 3) & 0xff)      # slot 0's upper plane pulled in by three grid steps
+    attempt(nb.view(np.float32), order)
+    # ... and a tree deeper than the traversal stack (kLdsStack + kOvfStack = 128 pending entries): a forward chain of 4-wide nodes, three leaves and one inner
+    # child per level, every box spanning the scene (the planes 0 .. 255 of the real root's grid)
+    def chain(levels):
+        scn = scenes.baseline_config("C2", 64, 64, n_tris=3 * (levels - 1) + 4)
+        b = View(0).load_scene(scn); root = b.export_tree()[0].view(np.uint32)[0].copy(); b.close()
+        cn = np.zeros((levels, abi.NODE_DWORDS), np.uint32)
+        for lvl in range(levels):
+            last = lvl == levels - 1
+            cn[lvl, :3] = root[:3]
+            cn[lvl, 3] = (root[3] & 0x00ffffff) | ((0 if last else 1) << 24) | (4 << 28)
+            cn[lvl, 4:7] = 0; cn[lvl, 7:10] = 0xffffffff
+            cn[lvl, 10] = 0 if last else lvl + 1
+            cn[lvl, 11] = 0x80000000 | ((3 * lvl) if last else (3 * lvl))      # slots: [inner child,] three (last level: four) consecutive leaves
+        return scn, cn.view(np.float32), np.arange(3 * (levels - 1) + 4, dtype=np.uint32)
+    scn, cn, od = chain(45)                                           # 44 levels x 3 pending siblings + 3 > 128
+    with pytest.raises(BackendError, match="deeper than the traversal stack"):
+        v.load_scene(scn, prebuilt=(cn, od))
+    scn, cn, od = chain(40)                                           # 39 x 3 + 3 = 120: fits, and renders what its own tree renders
+    w = View(0).load_scene(scn, prebuilt=(cn, od)); w.render(2)
+    own = View(0).load_scene(scn); own.render(2)
+    assert np.array_equal(bits(w.read_hdr()), bits(own.read_hdr()))
+    w.close(); own.close()
     two = scenes.baseline_config("C2", 64, 64, n_tris=2_000)
     two = dataclasses.replace(two, tri_object=np.zeros(len(two.tri), np.int32), obj_xform=np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]], np.float32))
     attempt(nodes, order, two)                                        # two-level scenes build their own trees
