@@ -51,7 +51,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     Launch LF{ln.stream, ln.grid_frame, false, c->clamp_grid ? c->cus : 0};
     launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->frame_low_water, c->frame_feeders, c->frame_claim_step, c->frame_starve, c->d_counters, ln.h_seeds);
   } else {
-  launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev);
+  launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, ln.h_seeds);
   int qin = 0;
   for (uint32_t b = 0; b < S.max_depth; ++b) {
     const Launch& T = LT;
@@ -195,56 +195,56 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   // would get 187 instead of 225 (one schedule per frame is slower than two tile ranges when nothing overlaps it), so a
   // read-back / synchronisation since the last render selects the two-range schedule for this frame.
   const bool host_runs_ahead = !c->read_since_render;
-  // The frame kernel takes this path whether or not the host runs ahead: a lone frame costs the same here (one launch, the whole chip) and the next one --
-  // after a restart too: a camera drag restarts with every frame (AppViewer.cxx:979-984) -- can start tracing while this one's last paths finish.
-  const bool frame = frame_ok(c, total);
-  if (c->pipeline && (host_runs_ahead || frame) && !c->counters_on && !c->timing_on && !c->adaptive && group == nt && spb == ns && ns <= 16u && total >= (1u << 20) &&
+  // Small whole-frame batches -- one Redraw() each -- are pipelined: frame n + 1 starts tracing on another stream and another slice of the path state while frame n
+  // finishes; accumulation stays in frame order.  Two kinds of frame travel through the same pipeline:
+  //   * the FRAME KERNEL (k_frame.h, one launch): the fastest way through a chip that is empty or nearly so -- a lone frame (2.98 ms against 4.26 staged on C3),
+  //     and the frames of a host that shows every frame or restarts with every frame (AppViewer.cxx:979-984: the camera drag);
+  //   * the STAGED form (a launch per stage and bounce, 6 wavefronts per SIMD in the traversal launches): the higher throughput once the host runs far ahead --
+  //     eight frames in flight, 467 Redraw/s against 406-426 with frame kernels only.
+  // A frame takes the frame kernel when fewer than frame_pipe_depth frames are still running at its submission.  Neither kind waits for the context's stream
+  // unless something was enqueued there that its tracing reads (seeds travel by value, a restart's memsets gate the accumulate only).
+  const bool frame_able = frame_ok(c, total);
+  if (c->pipeline && (host_runs_ahead || frame_able) && !c->counters_on && !c->timing_on && !c->adaptive && group == nt && spb == ns && ns <= 16u && total >= (1u << 20) &&
       total <= c->lane_max_paths && (uint64_t)c->pipe_depth * total <= c->max_paths) {
-    const uint32_t depth = frame ? std::min(c->frame_pipe_depth, c->pipe_depth) : c->pipe_depth;      // frames in flight
-    // ---- frame pipelining: this batch (one Redraw() worth) goes to pipeline stream k with its own half of the path state; it
-    // starts as soon as the previous frame ON THAT STREAM is done and overlaps the frame on the other stream; its samples are
-    // folded in after that frame's.  Nothing is joined into the context's stream here -- cstream() does that on demand.
+    const uint32_t depth = c->pipe_depth;               // streams / path-state slices the frames rotate through
     int rc = ensure_paths(c, (uint32_t)(c->pipe_depth * total)); if (rc) return rc;
     rc = ensure_lanes(c); if (rc) return rc;
     const uint32_t k = c->pipe_seq % depth, prev = (c->pipe_seq + depth - 1u) % depth;      // this frame's stream, the previous frame's
     ++c->pipe_seq;
     const hipStream_t cs = c->stream_;                 // raw: no join
-    uint32_t* d_seeds_k = c->d_pipe_seeds + 16u * k;
     uint32_t seeds[16];
     {
       uint32_t hi = c->par.seed, lo = c->par.seed ^ 0x49616E42u;
       for (uint32_t i = 0; i < first + ns; ++i) { hi = (hi >> 2) + (hi << 2); hi += lo; lo += hi; if (i >= first) seeds[i - first] = hi >> 2; }
     }
-    if (!frame) {                                       // the staged kernels read the seeds from HBM (the frame kernel takes them by value)
-      if (c->pipe_pending[k]) CRH_HIP(hipStreamWaitEvent(cs, c->lane_join[k], 0));      // this stream's seed slot is free once its last frame is done
-      rc = stage_copy(c, d_seeds_k, seeds, sizeof(uint32_t) * ns, cs); if (rc) return rc;
-    }
     DScene S; fill_scene(c, S);
-    // What this frame's TRACING must wait for: whatever was enqueued on the context's stream since the last frame forked -- scene uploads, a new tile list, a
-    // read-back's kernels.  A restart's memsets are not among them (do_reset): the frame kernel's first frame after crh_reset starts at once, only its
-    // accumulate waits (reset_ev below).  The staged kernels always fork (their seeds were just staged on that stream).
-    // Per pipeline stream: the frame after the one that forked runs on ANOTHER stream and must see the same uploads.
-    const bool fork = !frame || c->stream_uses != c->lane_stream_uses[k];
+    // What this frame's TRACING must wait for: whatever was enqueued on the context's stream since this pipeline stream last forked from it -- scene uploads, a new
+    // tile list, a read-back's kernels.  A restart's memsets are not among them (do_reset): the first frame after crh_reset starts at once, only its accumulate
+    // waits (reset_ev below).  Per pipeline stream: the frame after the one that forked runs on ANOTHER stream and must see the same uploads.
+    const bool fork = c->stream_uses != c->lane_stream_uses[k];
     if (fork) { CRH_HIP(hipEventRecord(c->lane_fork, cs)); c->lane_stream_uses[k] = c->stream_uses; }
-    Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false; ln.donate = c->donate;
+    // frames still running right now (this stream's own last frame included: this one queues behind it)
+    uint32_t running = 0u;
+    for (uint32_t j = 0; j < 8u; ++j) if (c->pipe_running[j]) { if (hipEventQuery(c->lane_join[j]) != hipErrorNotReady) c->pipe_running[j] = false; else ++running; }
+    const bool frame = frame_able && (running < c->frame_pipe_depth || !host_runs_ahead);
+    Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false; ln.donate = c->donate; ln.h_seeds = seeds;
     ln.grid = (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>((uint64_t)c->pipe_grid_min_shade, total / 2048u));
-    // traversal grid of this frame: the chip's resident workgroups (6 per CU) shared among the frames that are in flight RIGHT NOW -- a host that runs far
+    // staged traversal grid of this frame: the chip's resident workgroups (6 per CU) shared among the frames that are in flight RIGHT NOW -- a host that runs far
     // ahead has pipe_depth of them (eight: 192 workgroups each), one that waits for every other frame's read-back has two or three (512 each); measured
     // optima at 3 / 4 / 6 / 8 frames in flight: 512 / 384 / 256 / 192-256 (profiles/r3/interactive_counters.txt)
-    uint32_t in_flight = 1u;
-    for (uint32_t j = 0; j < 8u; ++j) if (c->pipe_running[j]) { if (hipEventQuery(c->lane_join[j]) != hipErrorNotReady) c->pipe_running[j] = false; else if (j != k) ++in_flight; }
+    uint32_t in_flight = 1u + running - ((c->pipe_running[k]) ? 1u : 0u);
     {
       // a host that submitted the previous frame a moment ago is not waiting for anything: the pipeline is about to fill (counting what is in flight NOW
       // would give the first frames of a burst grids for a nearly empty chip: eight of them, 2900 workgroups)
       const auto now = std::chrono::steady_clock::now();
-      if (c->pipe_last_submit.time_since_epoch().count() != 0 && now - c->pipe_last_submit < std::chrono::microseconds(300)) in_flight = std::max(in_flight, depth);
+      if (!frame && c->pipe_last_submit.time_since_epoch().count() != 0 && now - c->pipe_last_submit < std::chrono::microseconds(300)) in_flight = std::max(in_flight, depth);
       c->pipe_last_submit = now;
     }
     const uint64_t share = std::min<uint64_t>(512u, std::max<uint64_t>((uint64_t)c->pipe_grid_min, (uint64_t)c->grid_trace / in_flight));
     ln.grid_trace = (int)std::min<uint64_t>((uint64_t)c->grid_trace, std::max<uint64_t>(share, total / (uint64_t)c->pipe_div));
     // frame kernel: one workgroup fills a compute unit, so the frames in flight share the chip by compute units (every frame asking for all of them was
     // measured: the second frame's workgroups then wait for whole workgroups of the first to leave -- 368 against 399 Redraw/s)
-    ln.frame = frame; ln.grid_frame = frame ? frame_grid(c, S, std::min(in_flight, depth)) : 0; ln.h_seeds = frame ? seeds : nullptr;
+    ln.frame = frame; ln.grid_frame = frame ? frame_grid(c, S, std::min(in_flight, std::max(1u, c->frame_pipe_depth))) : 0;
     const size_t base = (size_t)k * total;
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;
@@ -252,16 +252,21 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     ln.P.sh_o = P.sh_o + base; ln.P.sh_d = P.sh_d + base; ln.P.sh_c = P.sh_c + base; ln.P.stamp = next_stamp(c);      // this frame's own stamp
     ln.Q.q[0] = Q.q[0] + base; ln.Q.q[1] = Q.q[1] + base; ln.Q.q_sh = Q.q_sh + base; ln.Q.q2 = Q.q2 + base; ln.Q.q2_sh = Q.q2_sh + base; ln.Q.counts = c->d_lane_counts + kCounts * k;
     if (fork) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_fork, 0));
+    // a frame kernel wants compute units of its own: at most frame_pipe_depth of them run at a time (the frame submitted that many frames ago comes first;
+    // measured with three in flight on halves of the chip: 272 against 379 frames/s in the drag loop)
+    if (frame && c->frame_pipe_depth < depth) {
+      const uint32_t j = (k + depth - std::max(1u, c->frame_pipe_depth)) % depth;
+      if (c->pipe_running[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));
+    }
     if (c->lane_counter_epoch[k] != c->counter_epoch) {   // this stream's first frame of an accumulation: the counter block was zeroed one restart ago, stream-ordered
       const hipEvent_t z = c->counters_zeroed[c->counter_epoch & 3u];
       if (z) CRH_HIP(hipStreamWaitEvent(ln.stream, z, 0));
       c->lane_counter_epoch[k] = c->counter_epoch;
     }
     // the frames in flight own path-state slices [k * total, (k + 1) * total): a batch of ANOTHER size (crh_render_tiles with another
-    // sample count or tile list) would lay its slice across theirs -- it starts only when they are all done
-    // ... and so does the first frame after the number of frames in flight changed (frame kernel <-> staged form): stream k's predecessor is not frame n - 1 then
+    // sample count or tile list) would lay its slice across theirs -- it starts only when they are all done (joined into the context's stream or not)
     if (total != c->pipe_total || depth != c->pipe_last_depth) {
-      for (int j = 0; j < 8; ++j) if (c->pipe_running[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));      // (joined into the context's stream or not)
+      for (int j = 0; j < 8; ++j) if (c->pipe_running[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));
       c->pipe_total = total; c->pipe_last_depth = depth;
     }
     c->pending_n = 0;
@@ -269,7 +274,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     hipEventRecord(e0, ln.stream);
     const hipEvent_t guard = c->rb_guard_pending ? c->rb_guard : nullptr; c->rb_guard_pending = false;      // later frames are ordered behind this one's accumulate
     const hipEvent_t after_reset = c->reset_pending ? c->reset_ev : nullptr; c->reset_pending = false;      // (it followed the joins of every earlier frame)
-    rc = run_lane(c, ln, S, c->d_tile_ids, nt, frame ? nullptr : d_seeds_k, ns, 0, true, c->pipe_pending[prev] ? c->lane_join[prev] : nullptr, guard, after_reset); if (rc) return rc;
+    rc = run_lane(c, ln, S, c->d_tile_ids, nt, nullptr, ns, 0, true, c->pipe_pending[prev] ? c->lane_join[prev] : nullptr, guard, after_reset); if (rc) return rc;
     hipEventRecord(e1, ln.stream);
     c->render_ev.emplace_back(e0, e1);
     CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));

@@ -78,6 +78,9 @@ __device__ __forceinline__ void camera_ray(const DScene& S, const uint32_t fseed
   }
 }
 
+// frame seeds by value: a small batch (<= 16 samples) whose seeds the host did not stage in HBM (`seeds` == nullptr) -- the batch's tracing then reads nothing that
+// was uploaded for it and need not wait for the context's stream (the frame pipeline, crh_schedule.cpp)
+struct SeedVals { uint32_t v[16]; };
 // SPLIT: the instantiation for split scenes (static tree + moved objects) also lists the rays that touch a moved object; the plain one carries none of it
 template <bool SPLIT>
 __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t* __restrict__ q, uint32_t* __restrict__ count,
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
                                                     uint32_t* __restrict__ cursors,
                                                     const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
                                                     const uint32_t* __restrict__ seeds, uint32_t n_samples, int seed_per_tile,
-                                                    const uint32_t* __restrict__ n_tiles_dev)
+                                                    const uint32_t* __restrict__ n_tiles_dev, SeedVals sv)
 {
   if (n_tiles_dev) n_tiles = *n_tiles_dev;          // the tile list was drawn on the device (adaptive sampling): its length lives there too
   // Queue space is reserved ONCE per chunk of kGenIters x 256 slots: pass 1 counts the slots that map to a pixel
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(DScene S, DPaths P, uint32_t*
     if (valid) {
       v3 o, d; uint32_t rng;
       // whole-frame passes share one frame seed per sample; adaptive passes give every tile its own sample index
-      camera_ray(S, seed_per_tile ? seeds[local / (S.tile_size * S.tile_size)] : seeds[s], px, py, o, d, rng);
+      camera_ray(S, seeds ? (seed_per_tile ? seeds[local / (S.tile_size * S.tile_size)] : seeds[s]) : sv.v[s & 15u], px, py, o, d, rng);
       P.ray_o[0][pid] = mk4(o, __uint_as_float(rng));           // .w = rng state; position = path slot at bounce 0
       P.ray_d[0][pid] = mk4(d, __uint_as_float(pid << 1));      // .w = (path slot << 1) | inside-a-medium flag
       if (SPLIT) flagged = ray_touches_instances(S, o, d, CRH_MAXFLOAT);

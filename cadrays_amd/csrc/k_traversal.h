@@ -460,8 +460,10 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     };
     // ------------------------------------------------------------------ (A) inner nodes until a leaf is in hand
 #if CRH_INNER_STEPS > 0
+    // (the frame kernel's rays -- every bounce mixed in one wavefront -- hold leaves less often: three inner steps per turn there, lone frame 3.15 -> 3.05 ms on C3)
+    constexpr int kInnerSteps = FRM ? CRH_INNER_STEPS + 1 : CRH_INNER_STEPS;
 #pragma unroll 1
-    for (int step_ = 0; step_ < CRH_INNER_STEPS && have && !(cur & kQLeafBit); ++step_) inner_step();
+    for (int step_ = 0; step_ < kInnerSteps && have && !(cur & kQLeafBit); ++step_) inner_step();
 #else
     while (have && !(cur & kQLeafBit)) inner_step();
 #endif

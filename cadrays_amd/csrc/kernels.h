@@ -16,7 +16,8 @@ struct Launch {
 // camera rays for n_samples x n_tiles x tile^2 path slots; fills queue `qsel` and its count
 void launch_raygen(const Launch&, const DScene&, const DPaths&, const DQueues&, int qsel,
                    const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_frame_seeds, uint32_t n_samples,
-                   int seed_per_tile = 0, const uint32_t* d_n_tiles = nullptr /* tile count in HBM (device-drawn tile list) */);
+                   int seed_per_tile = 0, const uint32_t* d_n_tiles = nullptr /* tile count in HBM (device-drawn tile list) */,
+                   const uint32_t* h_seeds = nullptr /* with d_frame_seeds == nullptr: the <= 16 frame seeds on the host, passed by value */);
 // nearest-hit traversal of queue `qin`; also zeroes the other queue's count and the shadow count
 void launch_trace_nearest(const Launch&, const DScene&, const DPaths&, const DQueues&, int qin, uint32_t bounce, DCounters*);
 // emission, NEE, BSDF sampling, Russian roulette; survivors -> queue 1-qin, shadow rays -> q_sh

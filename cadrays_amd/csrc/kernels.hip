@@ -35,12 +35,14 @@ namespace {
 // ================================================================== launch wrappers
 void launch_raygen(const Launch& L, const DScene& S, const DPaths& P, const DQueues& Q, int qsel,
                    const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds, uint32_t n_samples, int seed_per_tile,
-                   const uint32_t* d_n_tiles)
+                   const uint32_t* d_n_tiles, const uint32_t* h_seeds)
 {
+  SeedVals sv;
+  for (int i = 0; i < 16; ++i) sv.v[i] = (h_seeds && (uint32_t)i < n_samples) ? h_seeds[i] : 0u;
   hipMemsetAsync(Q.counts + qsel, 0, sizeof(uint32_t), L.stream);
   if (S.split) hipMemsetAsync(Q.counts + 3, 0, sizeof(uint32_t), L.stream);                 // second-pass count of bounce 0 (even parity)
-  if (S.split) hipLaunchKernelGGL(k_raygen<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.q2, Q.counts + 3, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile, d_n_tiles);
-  else         hipLaunchKernelGGL(k_raygen<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.q2, Q.counts + 3, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile, d_n_tiles);
+  if (S.split) hipLaunchKernelGGL(k_raygen<true>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.q2, Q.counts + 3, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile, d_n_tiles, sv);
+  else         hipLaunchKernelGGL(k_raygen<false>, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, Q.q[qsel], Q.counts + qsel, Q.q2, Q.counts + 3, Q.counts + 4, d_tile_ids, n_tiles, d_seeds, n_samples, seed_per_tile, d_n_tiles, sv);
 }
 // A persistent traversal grid larger than what the register budget keeps resident leaves workgroups queued behind the first
 // wave of them, i.e. a second, nearly empty round at the end of every launch: clamp the grid to occupancy x compute units.
