@@ -190,9 +190,9 @@ static void read_env(crh_ctx* c)
   if (const char* e = getenv("CRH_PIPELINE")) c->pipeline = atoi(e) != 0;
   if (const char* e = getenv("CRH_PIPE_DEPTH")) { int v = atoi(e); if (v >= 2 && v <= (int)pipeline_capacity()) c->pipe_depth = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_KERNEL")) c->frame_kernel = c->auto_frame_kernel = atoi(e) != 0;
-  if (const char* e = getenv("CRH_FRAME_LIVE")) { int v = atoi(e); if (v >= 64 && v <= 4096) c->frame_live = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_LIVE")) { int v = atoi(e); if (v >= 64 && v <= 16384) c->frame_live = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 1024) c->frame_chunk = (uint32_t)v & ~63u; }
-  if (const char* e = getenv("CRH_FRAME_LOW")) { int v = atoi(e); if (v >= 0 && v <= 4096) c->frame_low_water = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_LOW")) { int v = atoi(e); if (v >= 0 && v <= 16384) c->frame_low_water = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_FEED")) { int v = atoi(e); if (v >= 0 && v <= 15) c->frame_feeders = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_STARVE")) { int v = atoi(e); if (v >= 0) c->frame_starve = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_STEP")) { int v = atoi(e); if (v >= 0 && v <= 256) c->frame_claim_step = (uint32_t)v; }

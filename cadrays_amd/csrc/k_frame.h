@@ -25,7 +25,10 @@ constexpr int      kFrameMats  = 32;            // materials staged in LDS (4 KB
 #endif
 constexpr int      kFrameBlock = CRH_FRAME_BLOCK;
 constexpr uint32_t frame_pow2(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
-constexpr uint32_t kFrameRing  = frame_pow2(4u * kFrameBlock);      // entries of each ring (a power of two) = the most paths a workgroup may have alive (every live path is in at most one ring)
+#ifndef CRH_FRAME_RING_MUL
+#define CRH_FRAME_RING_MUL 4
+#endif
+constexpr uint32_t kFrameRing  = frame_pow2((uint32_t)CRH_FRAME_RING_MUL * kFrameBlock);      // entries of each ring (a power of two) = the most paths a workgroup may have alive (every live path is in at most one ring)
 
 struct FrameArgs {
   const uint32_t* tile_ids; uint32_t n_tiles; const uint32_t* n_tiles_dev;      // as k_raygen's
