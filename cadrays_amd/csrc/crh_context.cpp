@@ -160,7 +160,7 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_FRAME_LOW",          "frame kernel: the feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring (default 128)"},
   {"CRH_FRAME_FEED",         "frame kernel: wavefronts of a workgroup that only shade and generate, 0 .. 15 (default 3 of 16)"},
   {"CRH_FRAME_STARVE",       "frame kernel: a feeder shades fewer than 64 waiting hits only while fewer rays than this wait in the ring"},
-  {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 16)"},
+  {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 0: every tracer takes what is there)"},
   {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident, 4 per CU)"},
   {"CRH_FRAME_PIPE",         "frame kernel: frames in flight of free-running Redraw()s, 1 .. 8 (default 2)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
@@ -253,7 +253,6 @@ void crh_destroy(crh_ctx* c)
   if (c->reset_ev) hipEventDestroy(c->reset_ev);
   for (hipEvent_t e : c->counters_zeroed) if (e) hipEventDestroy(e);
   if (c->d_lane_counts) hipFree(c->d_lane_counts);
-  if (c->d_pipe_seeds) hipFree(c->d_pipe_seeds);
   if (c->rb_stream) { hipStreamSynchronize(c->rb_stream); hipStreamDestroy(c->rb_stream); }
   for (int k = 0; k < 2; ++k) { if (c->d_rb[k]) hipFree(c->d_rb[k]); if (c->h_rb[k]) hipHostFree(c->h_rb[k]); if (c->rb_tm[k]) hipEventDestroy(c->rb_tm[k]); if (c->rb_done[k]) hipEventDestroy(c->rb_done[k]); }
   if (c->rb_fork) hipEventDestroy(c->rb_fork);

@@ -134,7 +134,7 @@ struct ScheduleState {
   // frame pipelining: consecutive small whole batches (one Redraw() each) run on alternating streams and path-state halves, so
   // the drain-bound late bounces of frame n overlap the throughput-bound first bounces of frame n + 1; accumulation stays in
   // frame order (an event between the two accumulate launches)
-  bool pipeline = true; bool pipe_pending[8] = {false, false, false, false, false, false, false, false}; uint32_t pipe_seq = 0; uint32_t* d_pipe_seeds = nullptr; int pipe_div = 4096;
+  bool pipeline = true; bool pipe_pending[8] = {false, false, false, false, false, false, false, false}; uint32_t pipe_seq = 0; int pipe_div = 4096;
   uint64_t pipe_total = 0;         // batch size of the frames in flight (their path-state slices are laid out by it)
   uint32_t pipe_last_depth = 0;    // frames in flight the last pipelined frame was submitted with
   std::chrono::steady_clock::time_point pipe_last_submit{};      // when the previous pipelined frame was submitted
@@ -153,7 +153,8 @@ struct ScheduleState {
   uint32_t frame_live = 4096, frame_chunk = 256;    // paths a workgroup (16 wavefronts, one per compute unit) keeps alive at most; path slots a wavefront claims at a time
   uint32_t frame_low_water = 512;                   // a feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring
   uint32_t frame_starve = 1u << 20;                 // a feeder shades fewer than 64 hits only while fewer rays than this wait in the ring
-  uint32_t frame_feeders = 3, frame_claim_step = 16;   // wavefronts that only shade and generate; tracer w takes rays only while >= w * claim_step wait
+  uint32_t frame_feeders = 3, frame_claim_step = 0;    // wavefronts that only shade and generate (2 / 3 / 4 -> 3.33 / 2.98 / 2.99 ms, lone frame on C3); tracer w takes rays only
+                                                       // while >= w * claim_step wait: 0 / 16 / 32 / 64 -> 2.90 / 2.95 / 3.13 / 3.46 ms -- the shared rings gather the late bounces by themselves
   int frame_grid = 0;                               // workgroups of a lone frame (0: what is resident, 4 per CU)
   uint32_t frame_pipe_depth = 2;                    // frames in flight of free-running Redraw()s on the frame kernel (a frame keeps the chip busy but for its tail)
   int schedule = CRH_SCHEDULE_AUTO; uint32_t auto_lane_max_paths = 12u << 20; bool auto_donate = true, auto_pipeline = true;   // crh_set_schedule

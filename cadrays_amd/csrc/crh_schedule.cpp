@@ -83,7 +83,6 @@ int ensure_lanes(crh_ctx* c)
     CRH_HIP(hipEventCreateWithFlags(&c->lane_join[k], hipEventDisableTiming));
   }
   CRH_HIP(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
-  CRH_HIP(hipMalloc((void**)&c->d_pipe_seeds, 8 * 16 * sizeof(uint32_t)));
   CRH_HIP(hipMalloc((void**)&c->d_lane_counts, kCounts * sizeof(uint32_t) * 8));
   CRH_HIP(hipMemsetAsync(c->d_lane_counts, 0, kCounts * sizeof(uint32_t) * 8, cstream(c)));
   return CRH_OK;

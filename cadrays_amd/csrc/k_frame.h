@@ -119,8 +119,8 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
 
   // Who does what.  Shading and ray generation are what keeps the ray ring from running dry, and a wavefront can only turn to them when none of its lanes holds a
   // ray -- so the LAST n_feed wavefronts of the workgroup (the "feeders") never trace: they shade as soon as hits wait and claim the next chunk of slots when
-  // the ray ring runs low; asleep they cost no issue slot.  The others trace; tracer w takes rays from the ring only while >= w * claim_step of them wait, so
-  // when rays are scarce (the late bounces: fewer rays than lanes) they gather in the first wavefronts, which run full, instead of a few lanes of each.
+  // the ray ring runs low; asleep they cost no issue slot.  The others trace.  (claim_step > 0: tracer w takes rays from the ring only while >= w * claim_step
+  // of them wait, so that scarce rays gather in the first wavefronts -- measured, it does not pay: sixteen wavefronts sharing one ring gather them already.)
   const uint32_t wave = threadIdx.x >> 6, n_waves = (uint32_t)kBlock >> 6;
   const bool feeder = wave + A.n_feed >= n_waves;
   const uint32_t claim_min = feeder ? 0u : wave * A.claim_step;
