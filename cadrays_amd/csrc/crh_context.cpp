@@ -162,7 +162,7 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_FRAME_STARVE",       "frame kernel: a feeder shades fewer than 64 waiting hits only while fewer rays than this wait in the ring"},
   {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 0: every tracer takes what is there)"},
   {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident, 4 per CU)"},
-  {"CRH_FRAME_PIPE",         "frame kernel: frames in flight of free-running Redraw()s, 1 .. 8 (default 2)"},
+  {"CRH_FRAME_PIPE",         "frame pipeline: a frame takes the frame kernel while fewer than this many frames are running, and at most this many frame kernels run at a time, 1 .. 8 (default 2)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
   {"CRH_SPLIT_PASSES",       "split scenes (static tree + moved objects): 0 one walk in the two-level kernels, 1 two traversal passes, unset: by the number of moved objects"},
   {"CRH_REDUCE_RCCL_SINGLE", "crh_reduce sends even a one-context group through RCCL (exercises the library binding on a 1-GPU box)"},

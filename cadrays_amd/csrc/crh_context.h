@@ -156,7 +156,8 @@ struct ScheduleState {
   uint32_t frame_feeders = 3, frame_claim_step = 0;    // wavefronts that only shade and generate (2 / 3 / 4 -> 3.33 / 2.98 / 2.99 ms, lone frame on C3); tracer w takes rays only
                                                        // while >= w * claim_step wait: 0 / 16 / 32 / 64 -> 2.90 / 2.95 / 3.13 / 3.46 ms -- the shared rings gather the late bounces by themselves
   int frame_grid = 0;                               // workgroups of a lone frame (0: what is resident, 4 per CU)
-  uint32_t frame_pipe_depth = 2;                    // frames in flight of free-running Redraw()s on the frame kernel (a frame keeps the chip busy but for its tail)
+  uint32_t frame_pipe_depth = 2;                    // a pipelined frame takes the frame kernel while fewer than this many frames are running, and at most this many frame
+                                                    // kernels run at a time (they share the chip by compute units); beyond it the staged form carries the deeper pipeline
   int schedule = CRH_SCHEDULE_AUTO; uint32_t auto_lane_max_paths = 12u << 20; bool auto_donate = true, auto_pipeline = true;   // crh_set_schedule
 };
 

@@ -198,8 +198,8 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   // finishes; accumulation stays in frame order.  Two kinds of frame travel through the same pipeline:
   //   * the FRAME KERNEL (k_frame.h, one launch): the fastest way through a chip that is empty or nearly so -- a lone frame (2.98 ms against 4.26 staged on C3),
   //     and the frames of a host that shows every frame or restarts with every frame (AppViewer.cxx:979-984: the camera drag);
-  //   * the STAGED form (a launch per stage and bounce, 6 wavefronts per SIMD in the traversal launches): the higher throughput once the host runs far ahead --
-  //     eight frames in flight, 467 Redraw/s against 406-426 with frame kernels only.
+  //   * the STAGED form (a launch per stage and bounce; the stages of eight frames in flight overlap one another): the higher throughput once the host runs far
+  //     ahead -- 467-480 Redraw/s against 406-426 with frame kernels only.
   // A frame takes the frame kernel when fewer than frame_pipe_depth frames are still running at its submission.  Neither kind waits for the context's stream
   // unless something was enqueued there that its tracing reads (seeds travel by value, a restart's memsets gate the accumulate only).
   const bool frame_able = frame_ok(c, total);

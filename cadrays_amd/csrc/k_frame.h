@@ -4,11 +4,11 @@
 // Why.  The wavefront schedule (kernels.hip: k_raygen -> [k_trace_nearest -> k_shade -> k_trace_any] x depth) ends every launch with the longest rays of a few
 // wavefronts while the rest of the chip idles; a 512-sample batch hides that (25 ms per launch), a lone 1080p frame of 2 M paths is twenty such drains: 4.3 ms
 // for 1.2 ms of work at the batch rate, and the application restarts with a lone frame on every camera move (AppViewer.cxx:979-984).
-// What.  Every workgroup is a small streaming path tracer over its own paths: it claims path slots in chunks from ONE global cursor, generates their camera rays,
-// and keeps two rings in LDS -- rays to trace (nearest-hit and shadow rays mixed) and hit records to shade.  Its four wavefronts pick work by what is waiting:
-// a full wavefront of hits -> shade them (survivors and shadow rays go back into the ray ring), rays -> trace them with the persistent engine of k_traversal.h
-// (lanes refill from the ring as rays finish; when the ring is dry the idle lanes take over parts of the long rays' stacks, DON), nothing -> claim the next
-// chunk.  No stage ever waits for another workgroup, and a path's bounces follow each other without a launch boundary: the only drain is the end of the frame.
+// What.  Every workgroup -- ONE of 16 wavefronts per compute unit -- is a small streaming path tracer over its own paths: it claims path slots in chunks from ONE
+// global cursor, generates their camera rays, and keeps two rings in LDS -- rays to trace (nearest-hit and shadow rays mixed) and hit records to shade.  Thirteen
+// wavefronts trace with the persistent engine of k_traversal.h (lanes refill from the ring as rays finish; when the ring is dry the idle lanes take over parts of
+// the long rays' stacks, DON); the last three only shade (survivors and shadow rays go back into the ray ring) and claim the next chunk when the ray ring runs low.
+// No stage ever waits for another workgroup, and a path's bounces follow each other without a launch boundary: the only drain is the end of the frame.
 // Per path nothing changes: the same camera_ray / trace steps / shade_path in the same order, the shadow ray of bounce b is resolved BEFORE the ray of bounce
 // b + 1 is traced (the lane that finishes the shadow ray goes on with the continuation itself), so the radiance record receives its terms in the order of the
 // wavefront schedule and every frame is bit-identical to it.  A path lives at the position of its slot for its whole life (no compaction: a queue entry is the
@@ -22,6 +22,9 @@ constexpr int      kFrameMats  = 32;            // materials staged in LDS (4 KB
 #endif                                          // few rays of the late bounces gather in a few full wavefronts instead of trickling through all of them
 #ifndef CRH_FRAME_MINWAVES
 #define CRH_FRAME_MINWAVES 4                    // wavefronts per SIMD the register allocation must allow (4: 128 VGPRs, what the shading code needs)
+#endif
+#ifndef CRH_FRAME_DON
+#define CRH_FRAME_DON 1                         // the frame engine's idle lanes take over parts of the long rays' stacks once the ray ring is dry
 #endif
 constexpr int      kFrameBlock = CRH_FRAME_BLOCK;
 constexpr uint32_t frame_pow2(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
 {
   constexpr int kBlock = kFrameBlock;
   __shared__ uint32_t stk[kLdsStack * kBlock];
-  __shared__ uint32_t s_bound[kBlock];
+  __shared__ uint32_t s_bound[CRH_FRAME_DON ? kBlock : 1];
   __shared__ float4 s_mats[kFrameMats * 8];
   __shared__ uint32_t s_rq[kFrameRing], s_sq[kFrameRing];
   __shared__ uint32_t s_ctl[8];      // [0] ray head, [1] ray tail, [2] shade head, [3] shade tail, [4] live paths, [5] the slot cursor has run out
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
 
   auto trace_some = [&]() {
     uint32_t nn = 0, nt = 0;
-    trace_engine<false, false, TWO, true, true, kFrameBlock>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, t2, nullptr, 0u, &stk[threadIdx.x],
+    trace_engine<false, false, TWO, CRH_FRAME_DON != 0, true, kFrameBlock>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, t2, nullptr, 0u, &stk[threadIdx.x],
       [&](uint32_t ticket, v3& o, v3& d, float& tmax, uint32_t& tag, bool& any_l) {
         tag = ring_take(s_rq, ticket);
         any_l = (tag & kFrameAny) != 0u; tag &= ~kFrameAny;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
         }
         wave_sub(live, fin && any_l && !go_on);                      // a shadow ray with nothing behind it: the path is done
         return go_on;
-      }, nn, nt, &s_bound[threadIdx.x & ~63u],
+      }, nn, nt, CRH_FRAME_DON ? &s_bound[threadIdx.x & ~63u] : nullptr,
       [&](uint32_t want, uint32_t& base) -> uint32_t {
         if (ring_count(rq_head, rq_tail) < max(claim_min, 1u)) return 0u;      // scarce rays are left to the wavefronts before this one
         return ring_claim(rq_head, rq_tail, want, base);

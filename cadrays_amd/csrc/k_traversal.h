@@ -130,7 +130,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
                                              Load load, Store store, uint32_t& n_nodes, uint32_t& n_tris, uint32_t* bound = nullptr, Claim claim = Claim())
 {
   constexpr int kBlock = BS;      // threads of the calling workgroup = row stride of its LDS stack and world-ray columns (the frame kernel runs wider workgroups)
-  static_assert(!FRM || (DON && !COUNT), "the frame kernel's engine donates (its retire step lives there) and does not count visits");
+  static_assert(!FRM || !COUNT, "the frame kernel's engine does not count visits");
   // bound (DON): one word per lane of this wavefront in LDS -- the smallest hit distance any part of the ray that STARTED in that
   // lane has found so far (float bits; distances are >= 0, so unsigned order = float order).  Every part prunes BOXES with it
   // (a box entered later than the bound holds nothing that can win the fold; equality is kept, ties are decided by order);
@@ -529,7 +529,23 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           }
         }
       } else if (fin) { store(tag, hit, found); have = false; }
-    } else if constexpr (!FRM) { if (have && cur == kDone) { store(tag, hit, found); have = false; } }
+    } else if constexpr (FRM) {
+      const bool fin = have && cur == kDone;
+      float tmax = CRH_MAXFLOAT;
+      const bool go_on = store(fin, tag, hit, found, any_l, o, d, tmax);        // the whole wavefront calls; true: the lane's path continues with the ray in o, d
+      if (fin) {
+        have = go_on;
+        if (go_on) {
+          any_l = false;
+          ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
+          set_guard(gbox);
+          if (TWO) save_world();
+          best = tmax; found = false; sp = 0; cur = root;
+          if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, d, tmax)) { lds[0] = t2.root2; sp = 1; }
+          hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
+        }
+      }
+    } else { if (have && cur == kDone) { store(tag, hit, found); have = false; } }
   }
 #undef CRH_ISANY
 #if CRH_FRAME_STATS

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU-only variant of tests/hunts/big_seq_fuzz.py: the oracle's seat is taken by a second context of the product on the plain schedule
-(CRH_PIPELINE=0, CRH_DONATE=0, CRH_LANES=1: one stream, no frames in flight, no work donation), so the random call sequences of
+(CRH_PIPELINE=0, CRH_DONATE=0, CRH_LANES=1, CRH_FRAME_KERNEL=0: one stream, no frames in flight, no work donation, the staged launches), so the random call sequences of
 tests/test_gpu_fuzz.py run several times faster, two contexts share the GPU, and a crash or mismatch can only come from the HIP
 side.    python tools/big_seq_selfcheck.py [first] [last]"""
 import importlib.util, os, sys
@@ -12,8 +12,8 @@ from cadrays_amd.view import View
 
 class PlainView(View):
     def __init__(self):
-        keep = {k: os.environ.get(k) for k in ("CRH_PIPELINE", "CRH_DONATE", "CRH_LANES")}
-        os.environ.update(CRH_PIPELINE="0", CRH_DONATE="0", CRH_LANES="1")
+        keep = {k: os.environ.get(k) for k in ("CRH_PIPELINE", "CRH_DONATE", "CRH_LANES", "CRH_FRAME_KERNEL")}
+        os.environ.update(CRH_PIPELINE="0", CRH_DONATE="0", CRH_LANES="1", CRH_FRAME_KERNEL="0")
         try:
             super().__init__(0)
         finally:
