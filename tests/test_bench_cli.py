@@ -132,6 +132,39 @@ def test_counter_passes_of_this_run_replace_the_committed_bytes(tmp_path, monkey
     assert bench.being_profiled() and "profiler" in bench.live_traffic("C3")["error"]
 
 
+def test_every_leg_is_in_flat_keys_and_in_the_tail_of_the_line():
+    """verdict r4 item 3: the driver's record keeps top-level scalars, the scalars inside config / roofline, and the tail of stdout -- so every leg's rate,
+    fractions and gate result, the interactive figures and the measured ceilings are flat keys in all three places and once more in `legs_summary`, the
+    LAST key.  Checked on a committed line of round 4 (nested objects only) and on this round's."""
+    sys.path.insert(0, ROOT)
+    import bench
+    old = json.loads(open(os.path.join(ROOT, "profiles", "r4", "bench_default_steps20.json")).read().strip().splitlines()[-1])
+    assert "legs_summary" not in old and "c5_mrays" not in old
+    bench.flatten_line(old)
+    assert list(old)[-1] == "legs_summary" and len(json.dumps(old["legs_summary"])) < 1200
+    legs = old["config"]["other_configs_timed"]
+    for name in ("C5", "C2", "C1"):
+        k = name.lower()
+        for place in (old, old["config"], old["legs_summary"]):
+            assert place[f"{k}_mrays"] == legs[name]["value"] and place[f"{k}_ms_per_step"] == legs[name]["ms_per_step"]
+            assert place[f"{k}_parity_bit_exact"] is True and place[f"{k}_frac_counter"] == legs[name]["roofline"]["traffic_frac"]
+    assert old["c3_mrays"] == old["value"] and old["c3_parity_bit_exact"] is True
+    assert old["roofline"]["valu_issue"] == old["roofline"]["ceilings"]["valu_issue"] and old["roofline"]["lane_util"] == old["roofline"]["ceilings"]["lane_util"]
+    assert old["interactive_redraw_per_s"] == old["config"]["interactive"]["redraw_per_s_lookahead_1"]
+    # a gate that errored or failed is not reported as passed
+    broken = {"value": 1.0, "ms_per_step": 1.0, "config": {"workload": "C3: x"}, "roofline": {}, "parity": {"error": "boom"}, "parity_step0": {"bit_exact": True}}
+    bench.flatten_line(broken)
+    assert broken["c3_parity_bit_exact"] is None
+    failed = {"value": 1.0, "ms_per_step": 1.0, "config": {"workload": "C3: x"}, "roofline": {}, "parity": {"bit_exact": False}, "parity_step0": {"bit_exact": True}}
+    bench.flatten_line(failed)
+    assert failed["c3_parity_bit_exact"] is False
+    new = os.path.join(ROOT, "profiles", "r5", "bench_default_steps20.json")
+    if os.path.exists(new):
+        line = json.loads(open(new).read().strip().splitlines()[-1])
+        assert list(line)[-1] == "legs_summary" and line["legs_summary"]["c5_mrays"] == line["config"]["other_configs_timed"]["C5"]["value"]
+        assert line["interactive_drag_frames_per_s"] > 0 and line["interactive_first_frame_ms"] > 0
+
+
 def test_committed_counter_traffic_belongs_to_this_build():
     """profiles/pmc_traffic.json must be re-collected (profiles/pmc_collect.sh) whenever the traversal kernel or the node format
     changes: a stale file would silently report another kernel's traffic."""
