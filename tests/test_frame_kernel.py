@@ -207,3 +207,34 @@ def test_adaptive_iterations_take_the_frame_kernel_and_match_the_staged_ones(hip
     ea, ca = a.tile_stats(); eb, cb = b.tile_stats()
     assert np.array_equal(ca, cb) and np.array_equal(bits(ea), bits(eb))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("world,rank", [(8, 3), (4, 1)])
+def test_one_rank_of_a_weak_scaling_step_at_eight_and_four_gpus(hip_lib, oracle_lib, world, rank):
+    """The shape ONE rank of the driver's scaling run has (verdict r4 weak 9): the full 1080p frame, its Morton-interleaved 1 / world of the tiles, and
+    512 x world samples per pixel in ONE crh_render_tiles call (weak scaling: bench.py gives every rank spp x N) -- 255 tiles x 4096 samples at N = 8, cut by
+    the library into tile groups of up to 1024 samples.  No second device is needed to know that this call renders the right pixels: two of the rank's tiles
+    against the oracle, every other pixel of the frame untouched."""
+    from cadrays_amd import sharding
+    from cadrays_amd.view import View
+    sc = c3_1080p(40_000)
+    v = View(0).load_scene(sc)
+    tiles = sharding.tiles_for_rank(v.n_tiles(), rank, world, sharding.tiles_x_of(v))
+    assert len(tiles) == v.n_tiles() // world
+    spp = 512 * world
+    v.render_tiles(tiles, spp, spp)                       # the first timed step after one warm-up step
+    acc, _ = v.save_accum()
+    mine = np.zeros(v.n_tiles(), bool); mine[tiles] = True
+    tx = sharding.tiles_x_of(v)
+    count = acc[..., 3]
+    for t in range(v.n_tiles()):
+        y0, x0 = (t // tx) * 32, (t % tx) * 32
+        blk = count[y0:y0 + 32, x0:x0 + 32]
+        assert (blk == (spp if mine[t] else 0)).all(), (t, bool(mine[t]))
+    o = oracle_lib.Oracle().load_scene(sc)
+    whole = [t for t in tiles if t // tx < sc.params.height // 32]      # not the partial bottom row
+    pick = np.array([whole[len(whole) // 3], whole[-2]], np.uint32)
+    o.render_tiles(pick, spp, spp)
+    ref = o.read_accum(); mask = ref[..., 3] == spp
+    assert mask.sum() == 2 * 32 * 32 and np.array_equal(bits(acc[..., :3][mask]), bits(ref[..., :3][mask]))
+    v.close(); o.close()
