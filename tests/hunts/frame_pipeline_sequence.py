@@ -1,5 +1,5 @@
 import os, sys, dataclasses, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch
 from cadrays_amd import scenes
