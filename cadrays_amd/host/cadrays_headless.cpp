@@ -11,10 +11,19 @@
 // gpus > 1: one context per GPU (devices device .. device+gpus-1; CRH_HEADLESS_SHARE_DEVICE=1 keeps them all on `device`),
 // screen tiles interleaved across the contexts, one host thread per context, crh_reduce (RCCL over xGMI) assembles the
 // frame on context 0 -- bit-identical to the one-GPU image.
+// `--loop lone|drag|display` anywhere on the command line (one GPU): the application's own call patterns instead of nFrames back-to-back Redraw()s, timed from
+// this C++ host (the reference host is C++: no interpreter between the calls) --
+//   lone     nFrames times: crh_reset, wait, then crh_render(1) + crh_sync timed alone: the frame after a restart (AppViewer.cxx:979-984)
+//   drag     every frame: crh_set_camera (the eye orbits the scene centre) + crh_reset + crh_render(1) + crh_read_ldr_begin, the frame of two frames ago collected
+//            with crh_read_ldr_end: orbiting the model with the mouse held down, every frame shown (AppViewer.cxx:1099)
+//   display  every frame: crh_render(1) + the same asynchronous read-back: a still camera, every frame shown
+// (eight untimed warm-up frames come first in every loop mode)
+// The outputs are written from the state after the last frame as ever; the JSON line gains "loop", "loop_frames_per_s" / "lone_frame_ms_median".
 // A path ending in .tcl is the reference's own saved-scene format (model.tcl + meshes/ + textures/, what File > Export writes and
 // ImportSettingsEditor.cxx:378-380 sources back in): read by host/model_tcl.hpp at WxH (default 512x512).
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -40,7 +49,11 @@ int main(int argc, char** argv)
 {
   setenv("GPU_MAX_HW_QUEUES", "16", 0);      // before the first HIP call: eight frames in flight need more hardware queues than the runtime's default four (crh_set_pipeline_depth)
 
-  if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene | model.tcl> <nFrames> [device] [lookahead] [gpus] [WxH]\n", argv[0]); return 2; }
+  std::string loop;
+  for (int i = 1; i + 1 < argc; ++i)
+    if (std::string(argv[i]) == "--loop") { loop = argv[i + 1]; for (int j = i; j + 2 < argc; ++j) argv[j] = argv[j + 2]; argc -= 2; break; }
+  if (!loop.empty() && loop != "lone" && loop != "drag" && loop != "display") { fprintf(stderr, "--loop must be lone, drag or display\n"); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: %s <scene.crhscene | model.tcl> <nFrames> [device] [lookahead] [gpus] [WxH] [--loop lone|drag|display]\n", argv[0]); return 2; }
   const std::string path = argv[1];
   const int n_frames = atoi(argv[2]);
   const int device = argc > 3 ? atoi(argv[3]) : 0;
@@ -119,8 +132,46 @@ int main(int argc, char** argv)
   }
   crh_ctx* c = ctx[0];
 
-  const auto t0 = std::chrono::steady_clock::now();
-  if (n_gpus == 1) {
+  double lone_median_ms = 0.0;
+  auto t0 = std::chrono::steady_clock::now();
+  if (n_gpus == 1 && !loop.empty()) {
+    // eight untimed frames first: the path state is allocated, every pipeline stream has launched once (the first launch on a hardware queue sets its scratch up)
+    for (int k = 0; k < 8; ++k) if ((rc = crh_render(c, 1))) return die_all(c, "crh_render", rc);
+    if ((rc = crh_reset(c)) || (rc = crh_sync(c))) return die_all(c, "crh_reset", rc);
+    t0 = std::chrono::steady_clock::now();
+    std::vector<uint8_t> shown(3 * (size_t)par.width * par.height);
+    const crh_camera cam0 = cam;
+    auto orbit = [&](int i) {                                  // the eye turns about the z axis through the scene's origin, looking at it
+      crh_camera k = cam0;
+      const double a = 0.002 * i, r = std::sqrt((double)cam0.eye[0] * cam0.eye[0] + (double)cam0.eye[1] * cam0.eye[1]);
+      const double a0 = std::atan2((double)cam0.eye[1], (double)cam0.eye[0]);
+      k.eye[0] = (float)(r * std::cos(a0 + a)); k.eye[1] = (float)(r * std::sin(a0 + a));
+      const double dx = -k.eye[0], dy = -k.eye[1], dz = -k.eye[2], n = std::sqrt(dx * dx + dy * dy + dz * dz);
+      if (n > 0) { k.dir[0] = (float)(dx / n); k.dir[1] = (float)(dy / n); k.dir[2] = (float)(dz / n); }
+      return k;
+    };
+    if (loop == "lone") {
+      std::vector<double> ms;
+      for (int frame = 0; frame < n_frames; ++frame) {
+        if ((rc = crh_reset(c)) || (rc = crh_sync(c))) return die_all(c, "crh_reset", rc);
+        const auto a = std::chrono::steady_clock::now();
+        if ((rc = crh_render(c, 1)) || (rc = crh_sync(c))) return die_all(c, "crh_render", rc);
+        ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count());
+      }
+      std::sort(ms.begin(), ms.end()); lone_median_ms = ms[ms.size() / 2];
+    } else {
+      int begun = 0;
+      for (int frame = 0; frame < n_frames; ++frame) {
+        if (loop == "drag") { const crh_camera k = orbit(frame); if ((rc = crh_set_camera(c, &k)) || (rc = crh_reset(c))) return die_all(c, "crh_set_camera / crh_reset", rc); }
+        if ((rc = crh_render(c, 1))) return die_all(c, "crh_render", rc);
+        if (begun >= 2 && (rc = crh_read_ldr_end(c, shown.data()))) return die_all(c, "crh_read_ldr_end", rc);
+        if ((rc = crh_read_ldr_begin(c))) return die_all(c, "crh_read_ldr_begin", rc);
+        ++begun;
+      }
+      for (int k = 0; k < std::min(begun, 2); ++k) if ((rc = crh_read_ldr_end(c, shown.data()))) return die_all(c, "crh_read_ldr_end", rc);
+      if ((rc = crh_sync(c))) return die_all(c, "crh_sync", rc);
+    }
+  } else if (n_gpus == 1) {
     // the render loop of AppViewer::Run in test mode: one Redraw per frame until MaxFramesCount
     for (int frame = 0; frame < n_frames; ++frame)
       if ((rc = crh_render(c, 1))) return die_all(c, "crh_render", rc);
@@ -174,9 +225,11 @@ int main(int argc, char** argv)
     fclose(o);
   }
   if (FILE* o = fopen((base + ".txt").c_str(), "w")) { fprintf(o, "%g", fps); fclose(o); }
-  printf("{\"scene\": \"%s\", \"gpus\": %d, \"frames\": %d, \"fps\": %.4f, \"seconds\": %.6f, \"rays_nearest\": %llu, \"rays_any\": %llu, \"samples\": %llu, \"mrays_per_s\": %.3f}\n",
+  printf("{\"scene\": \"%s\", \"gpus\": %d, \"frames\": %d, \"fps\": %.4f, \"seconds\": %.6f, \"rays_nearest\": %llu, \"rays_any\": %llu, \"samples\": %llu, \"mrays_per_s\": %.3f",
          name.c_str(), n_gpus, n_frames, fps, secs, (unsigned long long)st.rays_nearest, (unsigned long long)st.rays_any, (unsigned long long)st.samples,
          (double)(st.rays_nearest + st.rays_any) / secs / 1e6);
+  if (!loop.empty()) printf(", \"loop\": \"%s\", \"loop_frames_per_s\": %.2f, \"lone_frame_ms_median\": %.4f", loop.c_str(), loop == "lone" ? 0.0 : fps, lone_median_ms);
+  printf("}\n");
   for (crh_ctx* x : ctx) crh_destroy(x);
   return 0;
 }

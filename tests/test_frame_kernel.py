@@ -238,3 +238,38 @@ def test_one_rank_of_a_weak_scaling_step_at_eight_and_four_gpus(hip_lib, oracle_
     ref = o.read_accum(); mask = ref[..., 3] == spp
     assert mask.sum() == 2 * 32 * 32 and np.array_equal(bits(acc[..., :3][mask]), bits(ref[..., :3][mask]))
     v.close(); o.close()
+
+
+def test_cpp_host_runs_the_applications_loops(hip_lib, oracle_lib, tmp_path):
+    """The reference host is C++ (AppViewer.cxx): cadrays_headless --loop drag | display | lone drives the same calls without an interpreter between them.  The
+    frame the drag ends on -- camera of the last GUI frame, one sample -- must be the oracle's; the display loop must accumulate like plain Redraw()s."""
+    import json, subprocess
+    from cadrays_amd.scene_io import save_scene
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "cadrays_amd", "host", "cadrays_headless")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    sc = scenes.cornell_box(True, 1216, 896)                           # > 1 M paths per frame: the frame pipeline
+    path = save_scene(sc, str(tmp_path / "cornell.crhscene"))
+
+    def pfm(n):
+        with open(tmp_path / f"Output_cornell_{n}.pfm", "rb") as f:
+            assert f.readline() == b"PF\n"; w, h = map(int, f.readline().split()); f.readline()
+            return np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]
+    n = 9
+    info = json.loads(subprocess.check_output([exe, path, str(n), "--loop", "drag"], text=True).strip().splitlines()[-1])
+    assert info["loop"] == "drag" and info["samples"] == 1216 * 896 and info["loop_frames_per_s"] > 0      # counters of the LAST accumulation alone
+    e = np.array(sc.camera.eye, np.float32).astype(np.float64)
+    a, r, a0 = 0.002 * (n - 1), math.sqrt(e[0] * e[0] + e[1] * e[1]), math.atan2(e[1], e[0])          # the host's orbit(), operation by operation
+    eye = (np.float32(r * math.cos(a0 + a)), np.float32(r * math.sin(a0 + a)), np.float32(e[2]))
+    dx, dy, dz = (-float(x) for x in eye)
+    nrm = math.sqrt(dx * dx + dy * dy + dz * dz)
+    cam = dataclasses.replace(sc.camera, eye=tuple(float(x) for x in eye), dir=tuple(float(np.float32(x / nrm)) for x in (dx, dy, dz)))
+    o = oracle_lib.Oracle().load_scene(dataclasses.replace(sc, camera=cam)); o.render(1)
+    assert np.array_equal(bits(pfm(n)), bits(o.read_hdr()))
+    info = json.loads(subprocess.check_output([exe, path, "6", "--loop", "display"], text=True).strip().splitlines()[-1])
+    assert info["loop"] == "display" and info["samples"] == 1216 * 896 * 6
+    o2 = oracle_lib.Oracle().load_scene(sc); o2.render(6)
+    assert np.array_equal(bits(pfm(6)), bits(o2.read_hdr()))
+    info = json.loads(subprocess.check_output([exe, path, "5", "--loop", "lone"], text=True).strip().splitlines()[-1])
+    assert info["loop"] == "lone" and info["lone_frame_ms_median"] > 0 and info["samples"] == 1216 * 896
+    o.close(); o2.close()
