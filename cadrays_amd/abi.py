@@ -49,7 +49,7 @@ class crh_spec(C.Structure):
     _fields_ = [("size", C.c_uint32), ("uniform_32bit", C.c_int32), ("texel_gamma2", C.c_int32), ("mis_single_lobe", C.c_int32),
                 ("eps_rule", C.c_int32), ("eta_no_dielectric", C.c_float),
                 ("rr_start_bounce", C.c_int32), ("rr_survival_cap", C.c_float), ("min_contribution", C.c_float), ("min_throughput", C.c_float),
-                ("raygen_bilinear", C.c_int32), ("env_orientation", C.c_int32)]
+                ("raygen_bilinear", C.c_int32), ("env_orientation", C.c_int32), ("display_gamma22", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "size"}
@@ -57,9 +57,9 @@ class crh_spec(C.Structure):
 
 _f32 = lambda x: C.c_float(x).value      # the defaults as the float32 fields hold them, so that get_spec() == SPEC_DEFAULTS
 SPEC_DEFAULTS = dict(uniform_32bit=0, texel_gamma2=0, mis_single_lobe=0, eps_rule=0, eta_no_dielectric=1.0,
-                     rr_start_bounce=3, rr_survival_cap=_f32(0.95), min_contribution=_f32(1.0e-2), min_throughput=_f32(1.0e-3), raygen_bilinear=0, env_orientation=0)
+                     rr_start_bounce=3, rr_survival_cap=_f32(0.95), min_contribution=_f32(1.0e-2), min_throughput=_f32(1.0e-3), raygen_bilinear=0, env_orientation=0, display_gamma22=0)
 
-assert C.sizeof(crh_bsdf) == 128 and C.sizeof(crh_light) == 32 and C.sizeof(crh_spec) == 48
+assert C.sizeof(crh_bsdf) == 128 and C.sizeof(crh_light) == 32 and C.sizeof(crh_spec) == 52
 
 SCHEDULE_AUTO, SCHEDULE_WIDE, SCHEDULE_SMALL, SCHEDULE_STAGED = 0, 1, 2, 3      # crh_set_schedule
 

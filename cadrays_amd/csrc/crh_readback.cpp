@@ -32,7 +32,7 @@ int crh_read_ldr(crh_ctx* c, uint8_t* out)
   int rc = ensure_scratch(c, 3 * (size_t)n); if (rc) return rc;
   const uint8_t* d_mask = overlay ? c->d_picked : nullptr;            // written by the device-side tile draw of the last iteration
   Launch L{cstream(c), c->grid, false};
-  launch_tonemap(L, c->assembled_valid ? c->d_assembled : c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, d_mask, c->par.width, ts);
+  launch_tonemap(L, c->assembled_valid ? c->d_assembled : c->d_accum, (uint8_t*)c->d_scratch, n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, c->spec.display_gamma22, d_mask, c->par.width, ts);
   CRH_HIP(hipMemcpyAsync(out, c->d_scratch, 3 * (size_t)n, hipMemcpyDeviceToHost, cstream(c)));
   CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;
@@ -72,7 +72,7 @@ static int read_begin(crh_ctx* c, bool hdr)
   else {
     const uint32_t ts = c->par.tile_size, n_tiles = ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts);
     const bool overlay = c->show_tiles && c->adaptive && c->picked_valid && c->d_picked && c->tile_stat_cap >= n_tiles;
-    launch_tonemap(L, src, c->d_rb[slot], n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, overlay ? c->d_picked : nullptr, c->par.width, ts);
+    launch_tonemap(L, src, c->d_rb[slot], n, c->par.tonemap_mode, c->par.exposure, c->par.white_point, c->spec.display_gamma22, overlay ? c->d_picked : nullptr, c->par.width, ts);
   }
   CRH_HIP(hipGetLastError());
   CRH_HIP(hipEventRecord(c->rb_tm[slot], c->rb_stream));

@@ -191,7 +191,7 @@ __device__ __forceinline__ float hable(float x)
   return (CRH_FMA(x, CRH_FMA(A, x, Cc * B), D * E) / CRH_FMA(x, CRH_FMA(A, x, B), D * F)) - E / F;
 }
 __global__ __launch_bounds__(kBlock) void k_tonemap(const float4* __restrict__ accum, uint8_t* __restrict__ out, uint32_t n,
-                                                     int mode, float exposure, float white_point,
+                                                     int mode, float exposure, float white_point, int gamma22,
                                                      const uint8_t* __restrict__ tile_mask, uint32_t width, uint32_t tile_size)
 {
   const uint32_t tiles_x = tile_mask ? (width + tile_size - 1u) / tile_size : 0u;
@@ -206,7 +206,8 @@ __global__ __launch_bounds__(kBlock) void k_tonemap(const float4* __restrict__ a
       if (!(x == x) || x < 0.f) x = 0.f;
       x = x * gain;
       if (mode == 1) x = hable(x) / wp;
-      x = crh_pow(crh_clamp(x, 0.f, 1.0f), 1.0f / 2.2f);
+      x = crh_clamp(x, 0.f, 1.0f);
+      x = gamma22 ? crh_pow(x, 1.0f / 2.2f) : crh_sqrt(x);      // crh_spec.h #15: gamma 2 is what the reference's icons show
       out[3u * i + k] = (uint8_t)(int)CRH_FMA(x, 255.0f, 0.5f);
     }
     if (tile_mask) {                                     // ShowSamplingTiles: red outline around the tiles just sampled

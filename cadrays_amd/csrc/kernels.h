@@ -44,7 +44,7 @@ void launch_adaptive_pick(const Launch&, const float* tile_err, const uint32_t* 
 // adaptive tile sampler: per-tile mean standard error and minimum per-pixel sample count (one workgroup per tile)
 void launch_tile_error(const Launch&, const DScene&, const float4* accum, const float* m2, float* tile_err,
                        uint32_t* tile_min_count, uint32_t n_tiles_total);
-void launch_tonemap(const Launch&, const float4* accum, uint8_t* out_rgb, uint32_t n_pixels, int mode, float exposure, float white_point,
+void launch_tonemap(const Launch&, const float4* accum, uint8_t* out_rgb, uint32_t n_pixels, int mode, float exposure, float white_point, int gamma22,
                     const uint8_t* tile_mask /* nullptr: no overlay */, uint32_t width, uint32_t tile_size);
 void launch_hdr(const Launch&, const float4* accum, float* out_rgb, uint32_t n_pixels);
 void launch_add4(const Launch&, float4* dst, const float4* src, uint32_t n_float4);

@@ -156,10 +156,10 @@ void launch_adaptive_pick(const Launch& L, const float* tile_err, const uint32_t
 {
   hipLaunchKernelGGL(k_adaptive_pick, dim3(1), dim3(kBlock), 0, L.stream, tile_err, tile_cnt, n_tiles_total, pick0, n_picks, seed, cdf, picked, tiles_out, seeds_out, n_out);
 }
-void launch_tonemap(const Launch& L, const float4* accum, uint8_t* out, uint32_t n, int mode, float exposure, float wp,
+void launch_tonemap(const Launch& L, const float4* accum, uint8_t* out, uint32_t n, int mode, float exposure, float wp, int gamma22,
                     const uint8_t* tile_mask, uint32_t width, uint32_t tile_size)
 {
-  hipLaunchKernelGGL(k_tonemap, dim3(L.grid), dim3(kBlock), 0, L.stream, accum, out, n, mode, exposure, wp, tile_mask, width, tile_size);
+  hipLaunchKernelGGL(k_tonemap, dim3(L.grid), dim3(kBlock), 0, L.stream, accum, out, n, mode, exposure, wp, gamma22, tile_mask, width, tile_size);
 }
 void launch_hdr(const Launch& L, const float4* accum, float* out, uint32_t n)
 {

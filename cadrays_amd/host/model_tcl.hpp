@@ -300,13 +300,26 @@ struct Bsdf {
   }
 };
 
-inline Bsdf stock_material(const std::string& name)     // stand-ins for OCCT's stock materials [OCCT-ext]
+// Stand-ins for OCCT's 24 stock materials [OCCT-ext], fitted in round 6 to the icons OCCT rendered for them (data/materials/*.png of the reference;
+// tests/golden/icon_features.json): the same table as cadrays_amd/scene_tcl.py (_STOCK_*), where the evidence for each group is written down.
+inline Bsdf stock_material(const std::string& name)
 {
   const std::string n = lower(name);
-  auto in = [&](std::initializer_list<const char*> l) { for (const char* s : l) if (n == s) return true; return false; };
-  if (in({"glass", "diamond", "transparent", "water"})) return Bsdf::glass(1.f, 1, 1, 1, 0.f, n == "diamond" ? 2.42 : n == "water" ? 1.33 : 1.5);
-  if (in({"brass", "bronze", "copper", "gold", "silver", "steel", "aluminium", "aluminum", "chrome", "pewter", "metalized"})) return Bsdf::metallic(1.f, fr_schlick(0.8, 0.8, 0.8), 0.1f);
-  if (in({"plastic", "shiny_plastic", "satin", "jade", "obsidian", "neon_gnc", "neon_phc"})) { Bsdf b = Bsdf::metallic(0.5f, fr_schlick(0.8, 0.8, 0.8), 0.1f); b.Kd[0] = b.Kd[1] = b.Kd[2] = 0.5f; return b; }
+  struct Metal { const char* name; float r, g, b, rough; };
+  static const Metal metals[] = {{"brass", 0.63f, 0.46f, 0.2f, 0.02f}, {"bronze", 0.7f, 0.39f, 0.16f, 0.02f}, {"copper", 0.94f, 0.64f, 0.47f, 0.045f}, {"gold", 0.97f, 0.75f, 0.3f, 0.05f}, {"pewter", 0.65f, 0.63f, 0.54f, 0.04f}, {"silver", 0.95f, 0.9f, 0.75f, 0.065f}, {"steel", 0.57f, 0.53f, 0.45f, 0.035f}, {"chrome", 0.59f, 0.57f, 0.49f, 0.04f}, {"aluminium", 0.9f, 0.87f, 0.75f, 0.06f}, {"aluminum", 0.9f, 0.87f, 0.75f, 0.06f}, {"metalized", 0.25f, 0.25f, 0.22f, 0.02f}};
+  struct Glass { const char* name; float r, g, b, coeff; double ior; };
+  static const Glass glasses[] = {{"glass", 0.75f, 0.95f, 0.9f, 0.05f, 1.62}, {"water", 0.7f, 0.75f, 0.85f, 0.05f, 1.33}, {"diamond", 0.95f, 0.95f, 0.95f, 0.05f, 2.42}};
+  struct Matte { const char* name; float r, g, b, ks, rough; };
+  static const Matte mattes[] = {{"plaster", 0.53f, 0.52f, 0.49f, 0.0f, 0.0f}, {"stone", 0.28f, 0.27f, 0.26f, 0.0f, 0.0f}, {"charcoal", 0.12f, 0.12f, 0.115f, 0.0f, 0.0f}, {"satin", 0.66f, 0.65f, 0.62f, 0.04f, 0.35f}, {"plastic", 0.22f, 0.22f, 0.21f, 0.04f, 0.2f}, {"shiny_plastic", 0.33f, 0.33f, 0.31f, 0.05f, 0.08f}, {"jade", 0.25f, 0.45f, 0.24f, 0.04f, 0.2f}, {"obsidian", 0.035f, 0.014f, 0.033f, 0.05f, 0.1f}, {"neon_gnc", 0.32f, 0.33f, 0.36f, 0.05f, 0.1f}};
+  for (const Glass& g : glasses) if (n == g.name) return Bsdf::glass(1.f, g.r, g.g, g.b, g.coeff, g.ior);
+  if (n == "transparent") { Bsdf b = Bsdf::diffuse(0.15f); b.Kt[0] = b.Kt[1] = b.Kt[2] = 0.8f; return b; }      // index-matched: the icon's tile edges run straight through the ball
+  for (const Metal& m : metals) if (n == m.name) return Bsdf::metallic(1.f, fr_schlick(m.r, m.g, m.b), m.rough);
+  if (n == "neon_phc") { Bsdf b; b.Kd[0] = 0.f; b.Kd[1] = 0.3f; b.Kd[2] = 0.2f; b.Le[0] = 0.f; b.Le[1] = 0.9f; b.Le[2] = 0.55f; return b; }      // the one emissive preset
+  for (const Matte& d : mattes) if (n == d.name) {
+    Bsdf b; b.Kd[0] = d.r; b.Kd[1] = d.g; b.Kd[2] = d.b;
+    if (d.ks > 0.f) { b.Ks[0] = b.Ks[1] = b.Ks[2] = d.ks; b.Ks[3] = d.rough; b.base = fr_constant(1.0); }
+    return b;
+  }
   return Bsdf::diffuse(0.8f);
 }
 
@@ -537,7 +550,7 @@ inline bool read_model_tcl(const std::string& path, uint32_t width, uint32_t hei
     else out.unsupported.push_back("vtextureenv: " + e2);
   }
   crh_params& p = out.par; memset(&p, 0, sizeof p);      // Graphic3d_RenderingParams defaults of the Python mirror (cadrays_amd/scenes.py Params)
-  p.width = width; p.height = height; p.max_depth = (uint32_t)depth; p.two_sided = 1; p.seed = 1; p.tile_size = 32; p.white_point = 1.0f; p.env_as_background = 1; p.russian_roulette = 1;
+  p.width = width; p.height = height; p.max_depth = (uint32_t)depth; p.two_sided = 1; p.seed = 1; p.tile_size = 32; p.white_point = 1.0f; p.env_as_background = 0 /* OCCT's default; the reference's icons show it (scene_tcl.py snapshot) */; p.russian_roulette = 1;
   return true;
 }
 

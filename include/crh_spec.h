@@ -40,6 +40,12 @@
  *                                                                                    when the host uploads unit vectors): rays bend towards the image centre
  * 14  crh_spec.env_orientation       lat-long lookup u = (atan2(d.y, d.x) + pi) /   1: Appendix A's FetchEnvironment: u = atan2(d.y, d.x) / (2 pi) (wraps),
  *                                     (2 pi), v = acos(d.z) / pi (row 0 = zenith)    v = acos(-d.z) / pi -- the map turned by half a turn and upside down
+ *  -- round 6: the first switch whose default is backed by an OUTPUT OF THE REAL RENDERER (the icons under data/materials, tests/golden/icon_features.json) --
+ * 15  crh_spec.display_gamma22       display value = sqrt(v): gamma 2.  The 25      1: v ^ (1 / 2.2), this project's default up to round 5 (SURVEY Appendix A's
+ *                                     icons OCCT rendered from preview.tcl show a    recollection of Display.fs).  The icons refute it: 2.2 would put the tile
+ *                                     lit 0.85 tile over its 0.45 neighbour at       ratio at 1.335
+ *                                     1.365 .. 1.382 = (0.85 / 0.45) ^ (1 / gamma)
+ *                                     with gamma 1.97 .. 2.04 on every icon
  *
  * Reference evidence that these are the knobs that matter: the only numbers CADRays itself pins are the BSDF / light / camera /
  * parameter vectors of its input contract (cadrays_hip.h cites them line by line); everything in the table is arithmetic inside
@@ -65,10 +71,13 @@ typedef struct crh_spec {
   float    min_throughput;      /* #12: >= 0; default 1e-3 */
   int32_t  raygen_bilinear;     /* #13: 0 tan form, 1 blend of unnormalised corners, 2 blend of normalised corners */
   int32_t  env_orientation;     /* #14: 0 / 1 */
+  /* ---- round 6 (size 48 -> 52) */
+  int32_t  display_gamma22;     /* #15: 0 = sqrt (gamma 2, what the reference's icons show), 1 = v^(1/2.2) */
 } crh_spec;
 
-#define CRH_SPEC_DEFAULTS {(uint32_t)sizeof(crh_spec), 0, 0, 0, 0, 1.0f, 3, 0.95f, 1.0e-2f, 1.0e-3f, 0, 0}
+#define CRH_SPEC_DEFAULTS {(uint32_t)sizeof(crh_spec), 0, 0, 0, 0, 1.0f, 3, 0.95f, 1.0e-2f, 1.0e-3f, 0, 0, 0}
 #define CRH_SPEC_SIZE_R3 24u    /* the struct of round 3: {size .. eta_no_dielectric} */
+#define CRH_SPEC_SIZE_R5 48u    /* rounds 4 - 5: {.. env_orientation} */
 
 /* What crh_set_spec (product) and the oracle's twin both do with a caller's struct: copy the first min(in->size, sizeof) bytes over the defaults,
  * check the ranges, turn the flags into 0 / 1.  Returns 0, or -1 with *why (a static string) set.  Input contract, shared like the structs. */
@@ -87,6 +96,7 @@ static inline int crh_spec_normalise(const crh_spec* in, crh_spec* out, const ch
   if (!(s.min_contribution >= 0.f && s.min_contribution <= 3.0e38f) || !(s.min_throughput >= 0.f && s.min_throughput <= 3.0e38f)) { *why = "min_contribution / min_throughput must be finite and >= 0"; return -1; }
   if (s.raygen_bilinear < 0 || s.raygen_bilinear > 2) { *why = "raygen_bilinear must be 0, 1 or 2"; return -1; }
   if (s.env_orientation < 0 || s.env_orientation > 1) { *why = "env_orientation must be 0 or 1"; return -1; }
+  s.display_gamma22 = s.display_gamma22 != 0;
   s.uniform_32bit = s.uniform_32bit != 0; s.texel_gamma2 = s.texel_gamma2 != 0; s.mis_single_lobe = s.mis_single_lobe != 0; s.eps_rule = s.eps_rule != 0;
   *out = s;
   return 0;
@@ -94,13 +104,16 @@ static inline int crh_spec_normalise(const crh_spec* in, crh_spec* out, const ch
 
 /* What crh_get_spec (product) and the oracle's twin do: `out->size` is IN / OUT -- the caller sets it to sizeof(crh_spec) AS IT KNOWS THE STRUCT
  * (24 for a caller built against round 3's header) and exactly that many bytes are written: the switches the caller's struct has room for, nothing
- * past it; size stays the caller's.  A size that is neither this library's nor an older struct's (below CRH_SPEC_SIZE_R3, above sizeof(crh_spec),
- * not a multiple of 4 -- which includes an unset 0) is refused and nothing is written.  Returns 0 / -1 with *why set. */
+ * past it; size stays the caller's.  size == 0 -- a zero-initialised struct, which round 3's contract allowed -- means "the oldest struct":
+ * CRH_SPEC_SIZE_R3 bytes are written (every struct this header ever declared has room for them) and size is SET to 24 so that the caller can see
+ * how far the answer goes.  Any other size that is neither this library's nor an older struct's (below CRH_SPEC_SIZE_R3, above sizeof(crh_spec),
+ * not a multiple of 4) is refused and nothing is written.  Returns 0 / -1 with *why set. */
 static inline int crh_spec_export(const crh_spec* have, crh_spec* out, const char** why)
 {
   const char* dummy; if (!why) why = &dummy;
   if (!have || !out) { *why = "null spec"; return -1; }
-  const uint32_t n = out->size;
+  uint32_t n = out->size;
+  if (n == 0u) n = out->size = CRH_SPEC_SIZE_R3;
   if (n < CRH_SPEC_SIZE_R3 || n > (uint32_t)sizeof(crh_spec) || (n & 3u)) { *why = "crh_spec.size must hold the caller's sizeof(crh_spec) before crh_get_spec (24 .. this library's, a multiple of 4)"; return -1; }
   { const unsigned char* src = (const unsigned char*)have; unsigned char* dst = (unsigned char*)out; for (uint32_t i = 4; i < n; ++i) dst[i] = src[i]; }
   return 0;

@@ -1171,12 +1171,13 @@ static float hable(float x)
   const float A = 0.22f, B = 0.30f, C = 0.10f, D = 0.20f, E = 0.01f, F = 0.30f;
   return (CRH_FMA(x, CRH_FMA(A, x, C * B), D * E) / CRH_FMA(x, CRH_FMA(A, x, B), D * F)) - E / F;
 }
-static uint8_t to_ldr(const crh_params* p, float v)
+static uint8_t to_ldr(const crh_params* p, int gamma22, float v)
 {
   if (!(v == v) || v < 0.f) v = 0.f;
   v = v * crh_exp(p->exposure * 0.69314718056f);
   if (p->tonemap_mode == 1) v = hable(v) / hable(p->white_point > 0.f ? p->white_point : 1.0f);
-  v = crh_pow(crh_clamp(v, 0.f, 1.0f), 1.0f / 2.2f);
+  v = crh_clamp(v, 0.f, 1.0f);
+  v = gamma22 ? crh_pow(v, 1.0f / 2.2f) : crh_sqrt(v);      /* crh_spec.h #15 */
   return (uint8_t)(int)CRH_FMA(v, 255.0f, 0.5f);
 }
 
@@ -1428,7 +1429,7 @@ ORC_API int orc_read_ldr(orc_ctx* c, uint8_t* out)
 {
   if (!c || !c->accum) return CRH_E_INVALID;
   size_t n = (size_t)c->par.width * c->par.height;
-  for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) out[3 * i + k] = to_ldr(&c->par, c->accum[4 * i + k]);
+  for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) out[3 * i + k] = to_ldr(&c->par, c->spec.display_gamma22, c->accum[4 * i + k]);
   uint32_t ts = c->par.tile_size, tx = (c->par.width + ts - 1) / ts, ty = (c->par.height + ts - 1) / ts;
   if (c->show_tiles && c->adaptive && c->last_picked && c->last_picked_n == tx * ty)
     for (uint32_t y = 0; y < c->par.height; ++y) for (uint32_t x = 0; x < c->par.width; ++x) {

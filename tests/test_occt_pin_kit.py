@@ -49,7 +49,7 @@ def test_compare_ranks_the_setting_the_other_renderer_agrees_with(tmp_path):
     for n in names[1:4]:
         for k, v in pin_kit.SETTINGS[n].items():
             assert rec["spec"][k] == v
-    assert rec["c_initialiser"].startswith("#define CRH_SPEC_DEFAULTS {(uint32_t)sizeof(crh_spec), ") and rec["c_initialiser"].count(",") == 11
+    assert rec["c_initialiser"].startswith("#define CRH_SPEC_DEFAULTS {(uint32_t)sizeof(crh_spec), ") and rec["c_initialiser"].count(",") == 12
     import io, contextlib
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):

@@ -27,7 +27,9 @@ SWITCHES = {
     "raygen_unit_corners": dict(raygen_bilinear=2),
     "env_orientation": dict(env_orientation=1),
 }
-ALL_FLIPPED = {k: v for d in SWITCHES.values() for k, v in d.items()}
+# round 6: a switch of the DISPLAY transform (crh_spec.h #15): the HDR image does not move, the LDR bytes do
+DISPLAY_SWITCHES = {"display_gamma22": dict(display_gamma22=1)}
+ALL_FLIPPED = {k: v for d in list(SWITCHES.values()) + list(DISPLAY_SWITCHES.values()) for k, v in d.items()}
 
 
 def bits(a):
@@ -52,7 +54,7 @@ def test_spec_struct_round_trips_and_validates(oracle_lib):
     assert o.get_spec() == abi.SPEC_DEFAULTS
     o.set_spec(**ALL_FLIPPED)
     assert o.get_spec() == dict(uniform_32bit=1, texel_gamma2=1, mis_single_lobe=1, eps_rule=1, eta_no_dielectric=1.5, rr_start_bounce=1, rr_survival_cap=0.25,
-                                min_contribution=0.25, min_throughput=0.125, raygen_bilinear=2, env_orientation=1)
+                                min_contribution=0.25, min_throughput=0.125, raygen_bilinear=2, env_orientation=1, display_gamma22=1)
     o.set_spec()
     assert o.get_spec() == abi.SPEC_DEFAULTS
     from cadrays_amd.binding import BackendError
@@ -68,7 +70,7 @@ def test_spec_struct_round_trips_and_validates(oracle_lib):
     old = abi.crh_spec(size=24, uniform_32bit=1, eta_no_dielectric=1.25, rr_start_bounce=9, env_orientation=1)      # the tail is NOT read at size 24
     o._call("set_spec", C.byref(old))
     assert o.get_spec() == dict(abi.SPEC_DEFAULTS, uniform_32bit=1, eta_no_dielectric=1.25)
-    for size in (0, 20, 26, 52):
+    for size in (0, 20, 26, 56):
         with pytest.raises(BackendError):
             o._call("set_spec", C.byref(abi.crh_spec(size=size, eta_no_dielectric=1.0)))
     o.set_spec()
@@ -92,7 +94,15 @@ def check_get_spec_honours_the_callers_size(b):
     b._call("get_spec", C.byref(old))
     assert (old.size, old.uniform_32bit, old.texel_gamma2, old.eps_rule, old.eta_no_dielectric) == (24, 1, 0, 0, 1.25)
     assert [old.canary[i] for i in range(8)] == [0xC0FFEE00 + i for i in range(8)], "get_spec wrote past a 24-byte struct"
-    for size in (0, 20, 26, C.sizeof(abi.crh_spec) + 4):
+    zero = Old()                                       # a zero-initialised struct (round 3's contract) gets the oldest struct's 24 bytes, and is told so
+    for i in range(8):
+        zero.canary[i] = 0xC0FFEE00 + i
+    b._call("get_spec", C.byref(zero))
+    assert (zero.size, zero.uniform_32bit, zero.eta_no_dielectric) == (24, 1, 1.25) and [zero.canary[i] for i in range(8)] == [0xC0FFEE00 + i for i in range(8)]
+    r5 = abi.crh_spec(size=48, display_gamma22=-5)     # a caller built against round 5's 48-byte struct: its 11 switches, not a byte of the round-6 field behind them
+    b._call("get_spec", C.byref(r5))
+    assert r5.size == 48 and r5.env_orientation == 1 and r5.display_gamma22 == -5
+    for size in (20, 26, C.sizeof(abi.crh_spec) + 4):
         bad = Old(size=size, eta_no_dielectric=-7.0)
         with pytest.raises(BackendError):
             b._call("get_spec", C.byref(bad))
@@ -114,6 +124,14 @@ def test_defaults_are_the_frozen_spec_and_every_switch_is_real(oracle_lib):
         assert not np.array_equal(bits(img), bits(base)), f"switch {name} changes nothing in a scene built to exercise it"
         # every setting is still the same estimator up to what the switch models: the image mean moves by a bounded amount
         assert abs(img.mean() - base.mean()) < 0.6 * base.mean() + 1e-3, (name, img.mean(), base.mean())
+    base_ldr = o.read_ldr()
+    for name, kw in DISPLAY_SWITCHES.items():
+        img, d = render(oracle_lib.Oracle(), sc, **kw)
+        assert np.array_equal(bits(img), bits(base)) and not np.array_equal(d.read_ldr(), base_ldr), name
+    # crh_spec.h #15 in numbers: the default display value is round(255 * sqrt(v)) (gamma 2, what the reference's icons show), the alternative v^(1/2.2)
+    lin = np.clip(base.astype(np.float64), 0, 1)
+    assert np.abs(base_ldr.astype(np.int32) - np.floor(np.sqrt(lin) * 255 + 0.5).astype(np.int32)).max() <= 1
+    assert np.abs(d.read_ldr().astype(np.int32) - np.floor(lin ** (1 / 2.2) * 255 + 0.5).astype(np.int32)).max() <= 1
     # a scene handed over with the switches in it (Scene.spec) is the same thing
     img, _ = render(oracle_lib.Oracle(), sc, **SWITCHES["mis_single_lobe"])
     o2 = oracle_lib.Oracle().load_scene(dataclasses.replace(sc, spec=SWITCHES["mis_single_lobe"])); o2.render(3)
@@ -155,10 +173,10 @@ def test_furnace_holds_under_every_switch(oracle_lib):
 
 # ------------------------------------------------------------------------------------------------ GPU: product == oracle under every switch
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(SWITCHES) + ["all", "defaults"])
+@pytest.mark.parametrize("name", sorted(SWITCHES) + sorted(DISPLAY_SWITCHES) + ["all", "defaults"])
 def test_hip_equals_oracle_with_switch_flipped(hip_lib, oracle_lib, name):
     from cadrays_amd.view import View
-    kw = ALL_FLIPPED if name == "all" else ({} if name == "defaults" else SWITCHES[name])
+    kw = ALL_FLIPPED if name == "all" else ({} if name == "defaults" else {**SWITCHES, **DISPLAY_SWITCHES}[name])
     sc = switch_scene(96, 80)
     ref, o = render(oracle_lib.Oracle(), sc, spp=4, **kw)
     v = View(0)
@@ -189,11 +207,13 @@ def test_random_scenes_with_random_switches(hip_lib, oracle_lib, seed):
               rr_start_bounce=int(r.choice([3, 0, 1, 2, 5])), rr_survival_cap=float(r.choice([0.95, 1.0, 0.5, 0.25])),
               min_contribution=float(r.choice([1e-2, 0.0, 0.1, 0.5])), min_throughput=float(r.choice([1e-3, 0.0, 0.05, 0.2])),
               raygen_bilinear=int(r.integers(0, 3)), env_orientation=int(r.integers(0, 2)))
+    kw["display_gamma22"] = seed & 1
     sc = dataclasses.replace(random_scene(300 + seed), spec=kw)
     v = View(0).load_scene(sc); v.enable_counters(True); v.reset()
     o = oracle_lib.Oracle().load_scene(sc)
     v.render(2); o.render(2)
     assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr())), (seed, kw)
+    assert np.array_equal(v.read_ldr(), o.read_ldr()), (seed, kw)
     gs, cs = v.stats(), o.stats()
     for k in ("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "nodes_any", "tris_any", "shaded_hits", "samples"):
         assert gs[k] == cs[k], (seed, k)
