@@ -67,7 +67,7 @@ NODE_DWORDS = 16          # CRH_NODE_DWORDS of include/crh_bvh_format.h: 4-wide 
 
 # every symbol include/cadrays_hip.h declares (tests check the built library exports them all)
 EXPORTS = [
-    "crh_create", "crh_destroy", "crh_last_error", "crh_set_geometry", "crh_set_transforms", "crh_set_materials",
+    "crh_create", "crh_destroy", "crh_last_error", "crh_set_geometry", "crh_set_transforms", "crh_set_visibility", "crh_add_object", "crh_set_materials",
     "crh_set_lights", "crh_set_envmap", "crh_set_texture", "crh_set_camera", "crh_set_params", "crh_set_spec", "crh_get_spec", "crh_spec_order_exact", "crh_spec_anyhit_slot_order", "crh_build", "crh_reset",
     "crh_render", "crh_render_tiles", "crh_set_adaptive", "crh_set_show_tiles", "crh_set_lookahead", "crh_set_lookahead_auto", "crh_set_schedule", "crh_set_pipeline_depth", "crh_set_path_budget", "crh_get_tile_stats", "crh_sync", "crh_read_hdr", "crh_read_ldr", "crh_read_ldr_begin", "crh_read_ldr_end", "crh_read_hdr_begin", "crh_read_hdr_end",
     "crh_save_accum", "crh_load_accum", "crh_accum_device_ptr", "crh_reduce", "crh_enable_counters", "crh_get_stats", "crh_trace_nearest",

@@ -100,6 +100,22 @@ class Backend:
         xf = np.ascontiguousarray(obj_xform, np.float32).reshape(-1, 12)
         self._call("set_transforms", _fp(xf), C.c_uint32(len(xf)))
 
+    def set_visibility(self, visible):
+        """Display / Erase without a rebuild (DataNode.cxx:304-344): one flag per object"""
+        v = np.ascontiguousarray(np.asarray(visible) != 0, np.uint8)
+        self._call("set_visibility", v.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint32(len(v)))
+
+    def add_object(self, pos, nrm, tri, xform, uv=None):
+        """a new object into the built scene (an instance until the next full build); returns its object index"""
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+        tri = np.ascontiguousarray(tri, np.int32).reshape(-1, 4)
+        uv = None if uv is None else np.ascontiguousarray(uv, np.float32)
+        xf = np.ascontiguousarray(xform, np.float32).reshape(12)
+        out = C.c_uint32(0)
+        self._call("add_object", _fp(pos), _fp(nrm), _fp(uv), C.c_uint32(len(pos)), tri.ctypes.data_as(_i32p), C.c_uint32(len(tri)), _fp(xf), C.byref(out))
+        return int(out.value)
+
     def get_tlas(self):
         r, n, b = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         self._call("get_tlas", C.byref(r), C.byref(n), C.byref(b))

@@ -50,11 +50,12 @@ struct HostInputs {
 struct TwoLevelState {
   bool two_level = false; uint32_t nO = 0;
   std::vector<float> xf; std::vector<int32_t> tri_obj;
+  std::vector<uint8_t> hidden;            // per object: 1 = erased from the view (crh_set_visibility); empty = all displayed
   std::vector<float> xf0, pos_w, nrm_w;   // the transforms the scene was built with; per vertex: position / unit normal under its object's build-time transform (what the static tree holds)
   struct Inst { float fwd[12], inv[12], bmin[3], bmax[3]; uint32_t root, obj; };
   std::vector<Inst> inst;                 // the objects rendered as instances RIGHT NOW, ascending object index (empty: the scene is one world-space tree)
   uint32_t n_blas_nodes = 0, root = 0;    // nodes of the static tree + the object trees built so far (the top-level tree follows them); entry point of the walk
-  struct Obj { bool static0 = false, built = false, is_inst = false; uint32_t root = 0, first = 0, ntri = 0; float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}; };
+  struct Obj { bool static0 = false, built = false, is_inst = false, in_static = false; uint32_t root = 0, first = 0, ntri = 0; float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}; };
   std::vector<Obj> objs; std::vector<uint32_t> obj_tris, static_pos, pos_obj;   // pos_obj: object of the triangle at a leaf position >= n_static
   uint32_t n_static = 0, n_static_live = 0, n_pos = 0; float sbmin[3] = {0, 0, 0}, sbmax[3] = {0, 0, 0};
   uint32_t root2 = 0xFFFFFFFFu; float tlas_lo[3] = {0, 0, 0}, tlas_hi[3] = {0, 0, 0};

@@ -266,7 +266,7 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
   c->pos.assign(pos, pos + 3 * (size_t)nV); c->nrm.assign(nrm, nrm + 3 * (size_t)nV);
   if (uv) c->uv.assign(uv, uv + 2 * (size_t)nV); else c->uv.clear();
   c->tri.assign(tri, tri + 4 * (size_t)nT);
-  c->two_level = false; c->nO = 0; c->xf.clear(); c->tri_obj.clear();
+  c->two_level = false; c->nO = 0; c->xf.clear(); c->tri_obj.clear(); c->hidden.clear();      // a new scene: everything displayed
   if (tri_obj && xf && nO) {
     // two-level mode: vertices stay in object space; every object gets its own tree (crh_build), the top-level tree
     // over the instances carries the transforms (crh_set_transforms rebuilds only that)
@@ -277,52 +277,56 @@ int crh_set_geometry(crh_ctx* c, const float* pos, const float* nrm, const float
   return CRH_OK;
 }
 
-int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
+// Bring every object to the state its transform and its visibility ask for, touching nothing else (the body crh_set_transforms had up to round 5, now
+// shared with crh_set_visibility and crh_add_object).  A displayed object at its build-time placement lives in the static tree; a displayed object off it
+// -- or added after the build (static0 = false) -- is an instance with an object tree of its own, built the first time and appended behind the trees built
+// so far; an erased object is neither: its records in the static tree are disabled exactly like a moved object's (a scatter of all-zero records) and it
+// stays out of the top level.  Then the top-level tree over the instances of this moment is rebuilt on the host and only the new nodes, the patched
+// records and the instance table travel, stream-ordered.  Nothing big is ever rebuilt here.
+// `xf` (may be null: keep the transforms) and `hidden` (may be null: keep the flags) are the caller's new values; they are taken over only after the
+// capacity check, so that a refusal leaves the context as it was.
+static int apply_objects(crh_ctx* c, const float* xf, const uint8_t* visible)
 {
-  if (!c || !xf) return fail(c, CRH_E_INVALID, "null transforms");
-  if (!c->two_level || nO != c->nO) return fail(c, CRH_E_INVALID, "crh_set_transforms needs a two-level scene with the same object count");
-  if (!all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return fail(c, CRH_E_INVALID, "transform holds a NaN / Inf");
-  CRH_HIP(hipSetDevice(c->device));
-  if (!c->built) { c->xf.assign(xf, xf + 12 * (size_t)nO); return do_reset(c); }
-  // The manipulator calls this every frame (ImRaytraceControls.cxx:58-89).  Nothing big is ever rebuilt here: an object of the static tree that
-  // leaves the identity has its triangles THERE disabled (a scatter of all-zero records) and, the first time, gets an object tree of its own,
-  // appended behind the trees built so far; back at the identity its triangles are restored and the instance dropped.  Then the top-level tree
-  // over the instances of this moment is rebuilt on the host and only the new nodes and the instance table travel, stream-ordered.
+  const uint32_t nO = c->nO;
   const int threads = build_threads_env();
   const uint32_t old_nodes = c->n_blas_nodes, old_pos = c->n_pos;
+  auto moved_now = [&](uint32_t ob) { const float* m = xf ? &xf[12 * (size_t)ob] : &c->xf[12 * (size_t)ob]; return !c->objs[ob].static0 || std::memcmp(m, &c->xf0[12 * (size_t)ob], 12 * sizeof(float)) != 0; };
+  auto shown_now = [&](uint32_t ob) { return visible ? visible[ob] != 0 : (c->hidden.empty() || !c->hidden[ob]); };
   {
-    // leaf positions the object trees built by THIS call will take: checked before anything is touched, so that a refusal leaves the context as it was
-    // (after the loop below the host state has moved on while nothing has been uploaded: ADVICE r3)
     uint64_t extra = 0;
     for (uint32_t ob = 0; ob < nO; ++ob) {
       const crh_ctx::Obj& o = c->objs[ob];
-      if (o.ntri && !o.built && !o.is_inst && std::memcmp(&xf[12 * (size_t)ob], &c->xf0[12 * (size_t)ob], 12 * sizeof(float)) != 0) extra += o.ntri;
+      if (o.ntri && !o.built && shown_now(ob) && moved_now(ob)) extra += o.ntri;
     }
     if ((uint64_t)c->n_pos + extra > c->cap_pos || (uint64_t)c->n_pos + extra >= (1ull << 28)) return fail(c, CRH_E_NOMEM, "leaf positions exhausted (object trees of moved objects)");
   }
-  c->xf.assign(xf, xf + 12 * (size_t)nO);
+  if (xf) c->xf.assign(xf, xf + 12 * (size_t)nO);
+  if (visible) { c->hidden.resize(nO); for (uint32_t ob = 0; ob < nO; ++ob) c->hidden[ob] = visible[ob] ? 0 : 1; }
   c->bvh.nodes.resize(c->n_blas_nodes);
   std::vector<uint32_t> ppos; std::vector<float> prec;
   for (uint32_t ob = 0; ob < nO; ++ob) {
     TwoLevelState::Obj& o = c->objs[ob];
     if (!o.ntri) continue;
-    const bool want = std::memcmp(&xf[12 * (size_t)ob], &c->xf0[12 * (size_t)ob], 12 * sizeof(float)) != 0;      // off its build-time placement: an instance
-    if (want == o.is_inst) continue;
-    // static0 object changing sides: its records in the static tree die / come back
-    for (uint32_t i = 0; i < o.ntri; ++i) {
-      const uint32_t t = c->obj_tris[o.first + i], p = c->static_pos[t];
-      float* q = &c->h_tris[12 * (size_t)p];
-      if (want) { std::memset(q, 0, 48); std::memcpy(&q[3], &t, 4); }
-      else {
-        for (int k = 0; k < 3; ++k) { const int32_t vi = c->tri[4 * t + k]; for (int a = 0; a < 3; ++a) q[4 * k + a] = c->pos_w[3 * vi + a]; q[4 * k + 3] = 0.f; }
-        std::memcpy(&q[3], &t, 4);
+    const bool shown = shown_now(ob), moved = moved_now(ob);
+    const bool want_static = shown && !moved, want_inst = shown && moved;
+    if (want_static != o.in_static) {
+      // the object's records in the static tree die / come back
+      for (uint32_t i = 0; i < o.ntri; ++i) {
+        const uint32_t t = c->obj_tris[o.first + i], p = c->static_pos[t];
+        float* q = &c->h_tris[12 * (size_t)p];
+        if (!want_static) { std::memset(q, 0, 48); std::memcpy(&q[3], &t, 4); }
+        else {
+          for (int k = 0; k < 3; ++k) { const int32_t vi = c->tri[4 * t + k]; for (int a = 0; a < 3; ++a) q[4 * k + a] = c->pos_w[3 * vi + a]; q[4 * k + 3] = 0.f; }
+          std::memcpy(&q[3], &t, 4);
+        }
+        float d[16]; device_tri_record(q, d);
+        ppos.push_back(p); prec.insert(prec.end(), d, d + 12);
       }
-      float d[16]; device_tri_record(q, d);
-      ppos.push_back(p); prec.insert(prec.end(), d, d + 12);
+      if (want_static) c->n_static_live += o.ntri; else c->n_static_live -= o.ntri;
+      o.in_static = want_static;
     }
-    if (want) { c->n_static_live -= o.ntri; if (!o.built) build_object_tree(c, ob, threads); }
-    else c->n_static_live += o.ntri;
-    o.is_inst = want;
+    if (want_inst && !o.built) build_object_tree(c, ob, threads);
+    o.is_inst = want_inst;
   }
   c->n_blas_nodes = (uint32_t)c->bvh.nodes.size();
   int rc;
@@ -368,6 +372,84 @@ int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
     else { CRH_HIP(hipMemcpyAsync(dst, c->bvh.nodes.data() + old_nodes, bytes, hipMemcpyHostToDevice, cstream(c))); CRH_HIP(hipStreamSynchronize(cstream(c))); }
   }
   return do_reset(c);
+}
+
+int crh_set_transforms(crh_ctx* c, const float* xf, uint32_t nO)
+{
+  if (!c || !xf) return fail(c, CRH_E_INVALID, "null transforms");
+  if (!c->two_level || nO != c->nO) return fail(c, CRH_E_INVALID, "crh_set_transforms needs a two-level scene with the same object count");
+  if (!all_finite(xf, 12 * (size_t)nO, 1.0e30f)) return fail(c, CRH_E_INVALID, "transform holds a NaN / Inf");
+  CRH_HIP(hipSetDevice(c->device));
+  if (!c->built) { c->xf.assign(xf, xf + 12 * (size_t)nO); return do_reset(c); }
+  // The manipulator calls this every frame (ImRaytraceControls.cxx:58-89).
+  return apply_objects(c, xf, nullptr);
+}
+
+int crh_set_visibility(crh_ctx* c, const uint8_t* visible, uint32_t nO)
+{
+  if (!c || !visible) return fail(c, CRH_E_INVALID, "null visibility flags");
+  if (!c->two_level || nO != c->nO) return fail(c, CRH_E_INVALID, "crh_set_visibility needs a scene handed over with objects, and one flag per object");
+  CRH_HIP(hipSetDevice(c->device));
+  if (!c->built) { c->hidden.resize(nO); for (uint32_t ob = 0; ob < nO; ++ob) c->hidden[ob] = visible[ob] ? 0 : 1; return do_reset(c); }
+  return apply_objects(c, nullptr, visible);
+}
+
+// Grow a leaf-ordered device array to `cap` positions, keeping the first `keep`: a new allocation, a device-to-device copy, the old one freed.
+static int grow_positions(crh_ctx* c, float4*& d, size_t rec_float4, size_t keep, size_t cap)
+{
+  float4* n = nullptr;
+  CRH_HIP(hipMalloc((void**)&n, cap * rec_float4 * sizeof(float4)));
+  if (d && keep) CRH_HIP(hipMemcpyAsync(n, d, keep * rec_float4 * sizeof(float4), hipMemcpyDeviceToDevice, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
+  if (d) CRH_HIP(hipFree(d));
+  d = n;
+  return CRH_OK;
+}
+
+int crh_add_object(crh_ctx* c, const float* pos, const float* nrm, const float* uv, uint32_t nV, const int32_t* tri, uint32_t nT,
+                   const float* xform, uint32_t* object_out)
+{
+  if (!c) return CRH_E_INVALID;
+  if (!pos || !nrm || !tri || !xform || !nV || !nT) return fail(c, CRH_E_INVALID, "crh_add_object: null or empty geometry");
+  if (!c->built) return fail(c, CRH_E_NOTBUILT, "crh_build has not been called");
+  if (!c->two_level) return fail(c, CRH_E_INVALID, "crh_add_object needs a scene handed over with objects");
+  for (uint32_t t = 0; t < nT; ++t)
+    for (int k = 0; k < 3; ++k)
+      if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) { char b[96]; snprintf(b, sizeof b, "triangle %u index out of range", t); return fail(c, CRH_E_INVALID, b); }
+  if (!all_finite(pos, 3 * (size_t)nV, 1.0e30f) || !all_finite(nrm, 3 * (size_t)nV) || (uv && !all_finite(uv, 2 * (size_t)nV)) || !all_finite(xform, 12, 1.0e30f))
+    return fail(c, CRH_E_INVALID, "geometry holds a NaN / Inf (or a coordinate beyond 1e30)");
+  const uint32_t T0 = (uint32_t)(c->tri.size() / 4), V0 = (uint32_t)(c->pos.size() / 3), ob = c->nO;
+  if ((uint64_t)T0 + nT >= (1u << 28) || (uint64_t)c->n_pos + nT >= (1u << 28)) return fail(c, CRH_E_INVALID, "too many triangles (limit 2^28)");
+  CRH_HIP(hipSetDevice(c->device));
+  // room for the new object's leaf positions (and as many again: the next additions should not reallocate 64 B x 3 per triangle of the whole scene each time)
+  if ((size_t)c->n_pos + nT > c->cap_pos) {
+    const size_t cap = (size_t)c->n_pos + 2 * (size_t)nT + c->cap_pos / 4;
+    int rc;
+    CRH_HIP(hipStreamSynchronize(cstream(c)));
+    for (int k = 0; k < 8; ++k) if (c->pipe_pending[k]) CRH_HIP(hipEventSynchronize(c->lane_join[k]));      // frames in flight still read the old arrays
+    if ((rc = grow_positions(c, c->d_tris, kTriStride, c->n_pos, cap))) return rc;
+    if ((rc = grow_positions(c, c->d_shade, 4, c->n_pos, cap))) return rc;
+    if (c->d_uvs && (rc = grow_positions(c, c->d_uvs, 2, c->n_pos, cap))) return rc;
+    if ((rc = grow_positions(c, c->d_verts, 3, c->n_pos, cap))) return rc;
+    c->cap_pos = cap;
+  }
+  // host arrays: the new object's vertices and triangles behind the scene's own (vertex indices shifted), one more object
+  c->pos.insert(c->pos.end(), pos, pos + 3 * (size_t)nV); c->nrm.insert(c->nrm.end(), nrm, nrm + 3 * (size_t)nV);
+  c->pos_w.insert(c->pos_w.end(), pos, pos + 3 * (size_t)nV); c->nrm_w.insert(c->nrm_w.end(), nrm, nrm + 3 * (size_t)nV);
+  if (!c->uv.empty()) { if (uv) c->uv.insert(c->uv.end(), uv, uv + 2 * (size_t)nV); else c->uv.resize(c->uv.size() + 2 * (size_t)nV, 0.f); }
+  c->tri.resize(4 * ((size_t)T0 + nT)); c->tri_obj.resize((size_t)T0 + nT); c->obj_tris.resize((size_t)T0 + nT); c->static_pos.resize((size_t)T0 + nT, 0u);
+  for (uint32_t t = 0; t < nT; ++t) {
+    for (int k = 0; k < 3; ++k) c->tri[4 * ((size_t)T0 + t) + k] = tri[4 * t + k] + (int32_t)V0;
+    c->tri[4 * ((size_t)T0 + t) + 3] = tri[4 * t + 3];
+    c->tri_obj[T0 + t] = (int32_t)ob; c->obj_tris[T0 + t] = T0 + t;
+  }
+  c->xf.insert(c->xf.end(), xform, xform + 12); c->xf0.insert(c->xf0.end(), xform, xform + 12);
+  TwoLevelState::Obj o{}; o.first = T0; o.ntri = nT; o.static0 = false; o.in_static = false;
+  c->objs.push_back(o);
+  if (!c->hidden.empty()) c->hidden.push_back(0);
+  c->nO = ob + 1;
+  if (object_out) *object_out = ob;
+  return apply_objects(c, nullptr, nullptr);
 }
 
 int crh_get_tlas(crh_ctx* c, uint32_t* root, uint32_t* n_inst, uint32_t* n_blas)
@@ -509,7 +591,7 @@ static int build_scene(crh_ctx* c, const QNode* pre_nodes, uint32_t pre_n_nodes,
     // order); every other non-empty object gets an object-space tree (triangles in input order); then the top-level tree over the instances
     c->objs.assign(c->nO, TwoLevelState::Obj{}); c->obj_tris.resize(nT ? nT : 1); c->static_pos.assign(nT ? nT : 1, 0u);
     for (uint32_t t = 0; t < nT; ++t) c->objs[c->tri_obj[t]].ntri++;
-    { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { TwoLevelState::Obj& o = c->objs[ob]; o.first = acc; acc += o.ntri; o.ntri = 0; o.static0 = true; } }
+    { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { TwoLevelState::Obj& o = c->objs[ob]; o.first = acc; acc += o.ntri; o.ntri = 0; o.static0 = true; o.in_static = true; } }
     for (uint32_t t = 0; t < nT; ++t) { TwoLevelState::Obj& o = c->objs[c->tri_obj[t]]; c->obj_tris[o.first + o.ntri++] = t; }
     // bake: every vertex under the transform its object has NOW (each vertex belongs to one object; an object at the identity keeps its bits) -- a
     // loaded scene whose objects all carry a location (vlocation lines of model.tcl) renders as ONE tree at the single-level rate until one is dragged
@@ -645,6 +727,7 @@ static int build_scene(crh_ctx* c, const QNode* pre_nodes, uint32_t pre_n_nodes,
     launch_scatter_tris(L, c->d_tris, (const uint32_t*)c->d_patch, (const float4*)c->d_patch, 0);
     CRH_HIP(hipGetLastError());
   }
+  if (c->two_level && !c->hidden.empty()) { if (c->hidden.size() != c->nO) c->hidden.assign(c->nO, 0); if ((rc = apply_objects(c, nullptr, nullptr))) return rc; }      // objects erased before the build: baked like the rest, then disabled
   rc = do_reset(c); if (rc) return rc;
   CRH_HIP(hipStreamSynchronize(cstream(c)));
   return CRH_OK;

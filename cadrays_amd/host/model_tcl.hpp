@@ -15,7 +15,8 @@
 //   vcamera -orthographic | -perspective | -fovy a | -distance d      vviewparams -proj|-up|-at|-eye x y z | -size s
 //   vtextureenv on <image>        vlight clear | add directional direction x y z | add positional position x y z ... smoothness s
 //   intensity i [head 1]          rtlight <id> -color r g b           vrenderparams ... -rayDepth n
-//   rtmodel / rtdisplay / vupdate ...                        accepted, no effect on the path
+//   rtdisplay / rterase <node>                               like vdisplay / verase
+//   rtmodel / vupdate ...                                    accepted, no effect on the path
 //
 // Numbers are parsed as double and narrowed to float where the Python reader narrows them, so both hosts hand the same bytes
 // to the boundary (tests/test_scene_tcl.py::test_cpp_driver_reads_model_tcl_like_the_python_reader).
@@ -389,7 +390,8 @@ inline bool read_model_tcl(const std::string& path, uint32_t width, uint32_t hei
       if (!read_ply(a[0], o.mesh, e2, smooth)) return fail(ln, e2);
       o.displayed = true;
       objs[a[1]] = std::move(o); order.push_back(a[1]);
-    } else if (cmd == "vdisplay" || cmd == "verase") { for (const std::string& n : a) { auto it = objs.find(n); if (it != objs.end()) it->second.displayed = cmd == "vdisplay"; } }
+    } else if (cmd == "vdisplay" || cmd == "verase" || cmd == "rtdisplay" || cmd == "rterase") {      // rtdisplay / rterase: the data model's Show / Hide (ImportExportPlugin.cxx:373-425)
+      for (const std::string& n : a) { auto it = objs.find(n); if (it != objs.end()) it->second.displayed = cmd == "vdisplay" || cmd == "rtdisplay"; } }
     else if (cmd == "vclear") { for (auto& kv : objs) kv.second.displayed = false; }
     else if (cmd == "vsetmaterial") { if (a.size() < 2 || !objs.count(a[0])) return fail(ln, "vsetmaterial: unknown object"); objs[a[0]].bsdf = stock_material(a[1]); }
     else if (cmd == "vbsdf") {
@@ -478,7 +480,7 @@ inline bool read_model_tcl(const std::string& path, uint32_t width, uint32_t hei
       if (a.size() >= 5 && lower(a[1]) == "-color") { const int idx = atoi(a[0].c_str()); double v[3];
         if (idx >= 0 && (size_t)idx < lights.size() && num(a[2], v[0]) && num(a[3], v[1]) && num(a[4], v[2])) memcpy(lights[(size_t)idx].color, v, sizeof v); }
     } else if (cmd == "vrenderparams") { for (size_t i = 0; i + 1 < a.size(); ++i) if (lower(a[i]) == "-raydepth") depth = atoi(a[i + 1].c_str()); }
-    else if (cmd == "rtmodel" || cmd == "rtdisplay" || cmd == "rtgroup" || cmd == "vupdate" || cmd == "vrepaint" || cmd == "vsetdispmode" || cmd == "vaspects" || cmd == "vvbo" ||
+    else if (cmd == "rtmodel" || cmd == "rtgroup" || cmd == "vupdate" || cmd == "vrepaint" || cmd == "vsetdispmode" || cmd == "vaspects" || cmd == "vvbo" ||
              cmd == "vfit" || cmd == "vselect" || cmd == "vzbufftrihedron" || cmd == "vsetcolor" || cmd == "vinit" || cmd == "pload") { /* no effect on the path */ }
     else out.unsupported.push_back(cmd + " (line " + std::to_string(ln) + ")");
   }

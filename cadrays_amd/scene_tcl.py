@@ -952,7 +952,8 @@ class SceneBuilder:
 
     cmd_incmesh = _noop                                       # B-Rep tessellation: the primitives here are born as meshes
     cmd_vsetdispmode = cmd_vaspects = cmd_vvbo = cmd_rtmodel = cmd_rtgroup = cmd_vtop = cmd_vaxo = _noop
-    cmd_vzbufftrihedron = cmd_vsetcolor = cmd_vselect = cmd_vupdate = cmd_vrepaint = cmd_rtdisplay = _noop
+    cmd_vzbufftrihedron = cmd_vsetcolor = cmd_vselect = cmd_vupdate = cmd_vrepaint = _noop
+    cmd_rtdisplay, cmd_rterase = cmd_vdisplay, cmd_verase     # the data model's Show / Hide of a node (ImportExportPlugin.cxx:373-425 -> DataNode.cxx:304-344): Display / Erase
 
     # ---- result
     def snapshot(self, width=512, height=512, name="tcl_scene"):

@@ -149,6 +149,23 @@ CRH_API int crh_set_geometry(crh_ctx* ctx,
  * millisecond per thousand triangles, and kept; when it returns to its build-time transform its triangles are restored and the instance is
  * dropped.  The result depends on the transforms given to crh_build and on the current ones, not on the calls in between. */
 CRH_API int crh_set_transforms(crh_ctx* ctx, const float* obj_xform /* 12*nO */, uint32_t n_objects);
+/* == AIS_InteractiveContext::Display / Erase of objects already in the scene: the eye icons of the GUI's scene tree and `rtdisplay` / `rterase`
+ * (src/ImportExport/DataNode.cxx:304-344, ImportExportPlugin.cxx:373-425).  visible[i] != 0: object i is displayed.  No tree is rebuilt except the
+ * top level: an erased object's triangle records in the static tree are disabled in place -- what crh_set_transforms does for a moved object -- and
+ * its instance, if it is one, is dropped from the top level; displaying it again restores them.  `Remove` is Erase for good: hide the object and leave
+ * it out of the arrays of the next crh_set_geometry.  Restarts accumulation.  Before crh_build the flags are kept and applied by the build (every
+ * object is baked, the erased ones are then disabled: showing one later costs nothing).  The image equals, bit for bit, that of the scene built
+ * without the erased objects for as long as they sat at their build-time placement (same triangle arithmetic, another tree: only visit counters and
+ * the winner among hits at EQUAL distance can differ).  Needs a scene handed over with objects; a new crh_set_geometry displays everything again. */
+CRH_API int crh_set_visibility(crh_ctx* ctx, const uint8_t* visible /* n_objects */, uint32_t n_objects);
+/* == AIS_InteractiveContext::Display of a NEW object in a running viewer (`rtmeshread` into a loaded scene, ImportExportPlugin.cxx:132-354; the clone
+ * button, main.cxx:117): the object's arrays (vertex indices local to it, material ids into the table of crh_set_materials -- extend that first) are
+ * appended to the scene's, it gets an object-space tree and enters the top level as an instance under `xform` (3x4 row-major).  Cost: the object's
+ * own tree (about a millisecond per thousand triangles) + the top level; nothing of the built scene is touched.  *object_out (may be NULL) = its index:
+ * crh_set_transforms / crh_set_visibility take n_objects + 1 entries from now on.  The next full crh_build bakes it into the static tree like every
+ * other object.  Restarts accumulation.  Needs a BUILT scene handed over with objects (CRH_E_NOTBUILT / CRH_E_INVALID otherwise). */
+CRH_API int crh_add_object(crh_ctx* ctx, const float* pos, const float* nrm, const float* uv /* or NULL */, uint32_t n_vertices,
+                   const int32_t* tri /* 4*nT: i0,i1,i2,material */, uint32_t n_triangles, const float* xform /* 12 */, uint32_t* object_out);
 /* == Graphic3d_MaterialAspect::SetBSDF + SynchronizeAspects (MaterialEditor.cxx:331-337, Utils.cxx:57-93) */
 CRH_API int crh_set_materials(crh_ctx* ctx, const crh_bsdf* m, uint32_t n);
 /* == V3d_Viewer::SetLightOn/UpdateLights (LightSourcesEditor.cxx:47-87, 401-413) */

@@ -68,7 +68,9 @@ typedef struct orc_instance { float fwd[12], inv[12]; float bmin[3], bmax[3]; fl
  * the transform it has when the scene is built (static0 = 1 for every non-empty object); is_inst = rendered through its own object tree + the
  * top level right now, i.e. while its transform differs from the build-time one -- its triangles in the static tree are disabled meanwhile;
  * the object tree is built the first time it is needed and kept */
-typedef struct orc_object { uint8_t static0, built, is_inst; uint32_t root, first, ntri; float bmin[3], bmax[3]; } orc_object;
+typedef struct orc_object { uint8_t static0, built, is_inst, in_static; uint32_t root, first, ntri; float bmin[3], bmax[3]; } orc_object;
+/* round 6 (crh_set_visibility / crh_add_object): in_static = the object's records in the static tree are live right now (static0, visible, at its
+ * build-time placement); an object ADDED to a built scene has static0 = 0 until the next full build bakes it: always an instance while visible */
 
 typedef struct orc_ctx {
   /* inputs */
@@ -89,6 +91,7 @@ typedef struct orc_ctx {
   orc_object* obj; uint32_t* obj_tris;   /* per object; its triangles (input order) at obj_tris[first .. first + ntri) */
   uint32_t* static_pos;          /* leaf position of triangle t in the static tree */
   float* xf0;                    /* the transforms the scene was built with (12 * nO) */
+  uint8_t* hidden;               /* per object: 1 = erased from the view (crh_set_visibility); NULL = all displayed */
   float* pos_w; float* nrm_w;    /* per vertex: position / unit normal under its object's build-time transform = what the static tree holds */
   uint32_t n_static, n_static_live; float sbmin[3], sbmax[3];   /* triangles in the static tree, those not disabled; its bounds */
   uint32_t root2;                /* top-level root to walk AFTER the static tree (QBVH_EMPTY: none) and the bounds of the instances */
@@ -418,6 +421,27 @@ static void set_static_triangles(orc_ctx* c, uint32_t ob, int live)
   if (live) c->n_static_live += o->ntri; else c->n_static_live -= o->ntri;
 }
 
+/* Bring every object to the state its transform and its visibility ask for, touching nothing else: a displayed object at its build-time placement lives
+ * in the static tree; a displayed object off it (or added after the build) is an instance with a tree of its own, built the first time; an erased object
+ * is neither -- its records in the static tree are disabled exactly like a moved object's, and it stays out of the top level.  Then the top-level tree
+ * of this moment.  (AIS_InteractiveContext::Display / Erase / SetLocation of src/ImportExport/DataNode.cxx:239-242, 304-344.) */
+static void apply_objects(orc_ctx* c)
+{
+  collapser C; C.qn = c->nodes; C.nq = c->nBlasNodes; C.capq = c->capNodes;
+  for (uint32_t ob = 0; ob < c->nO; ++ob) {
+    orc_object* o = &c->obj[ob];
+    if (!o->ntri) continue;
+    const int shown = !(c->hidden && c->hidden[ob]);
+    const int moved = !o->static0 || memcmp(&c->xf[12 * ob], &c->xf0[12 * ob], 12 * sizeof(float)) != 0;
+    const int want_static = shown && !moved, want_inst = shown && moved;
+    if (want_static != o->in_static) { set_static_triangles(c, ob, want_static); o->in_static = (uint8_t)want_static; }
+    if (want_inst && !o->built) build_object_tree(c, &C, ob);
+    o->is_inst = (uint8_t)want_inst;
+  }
+  c->nodes = C.qn; c->nBlasNodes = C.nq; c->capNodes = C.capq;
+  build_tlas(c);
+}
+
 static int do_build(orc_ctx* c)
 {
   uint32_t n = c->nT;
@@ -444,7 +468,7 @@ static int do_build(orc_ctx* c)
   c->obj_tris = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
   c->static_pos = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
   for (uint32_t t = 0; t < n; ++t) c->obj[c->tri_obj[t]].ntri++;
-  { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { c->obj[ob].first = acc; acc += c->obj[ob].ntri; c->obj[ob].ntri = 0; c->obj[ob].static0 = 1; } }
+  { uint32_t acc = 0; for (uint32_t ob = 0; ob < c->nO; ++ob) { c->obj[ob].first = acc; acc += c->obj[ob].ntri; c->obj[ob].ntri = 0; c->obj[ob].static0 = 1; c->obj[ob].in_static = 1; } }
   for (uint32_t t = 0; t < n; ++t) { orc_object* o = &c->obj[c->tri_obj[t]]; c->obj_tris[o->first + o->ntri++] = t; }
   /* bake: every vertex under the transform its object has NOW (each vertex belongs to one object); an object at the identity keeps its bits */
   free(c->xf0); free(c->pos_w); free(c->nrm_w);
@@ -492,6 +516,7 @@ static int do_build(orc_ctx* c)
   }
   c->nodes = C.qn; c->nBlasNodes = C.nq; c->nNodes = C.nq; c->capNodes = C.capq;
   build_tlas(c);
+  if (c->hidden) apply_objects(c);      /* objects erased before the build: baked like the rest, then disabled */
   return 0;
 }
 
@@ -1195,7 +1220,7 @@ ORC_API void orc_destroy(orc_ctx* c)
 {
   if (!c) return;
   free(c->pos); free(c->nrm); free(c->uv); free(c->tri); free(c->mats); free(c->lights); free(c->env);
-  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->last_picked); free(c->xf); free(c->tri_obj); free(c->inst); free(c->tlas_order); free(c->obj); free(c->obj_tris); free(c->static_pos); free(c->xf0); free(c->pos_w); free(c->nrm_w); free(c);
+  free(c->nodes); free(c->qtris); free(c->l_vec); free(c->l_par); free(c->accum); free(c->m2); free(c->last_picked); free(c->xf); free(c->tri_obj); free(c->inst); free(c->tlas_order); free(c->obj); free(c->obj_tris); free(c->static_pos); free(c->xf0); free(c->pos_w); free(c->nrm_w); free(c->hidden); free(c);
 }
 ORC_API const char* orc_last_error(orc_ctx* c) { return c ? c->err : "null ctx"; }
 
@@ -1214,6 +1239,7 @@ ORC_API int orc_set_geometry(orc_ctx* c, const float* pos, const float* nrm, con
   if (!all_finite(pos, 3 * (size_t)nV, 1.0e30f) || !all_finite(nrm, 3 * (size_t)nV, 3.0e38f) || (uv && !all_finite(uv, 2 * (size_t)nV, 3.0e38f)) ||
       (xf && !all_finite(xf, 12 * (size_t)nO, 1.0e30f))) { snprintf(c->err, sizeof c->err, "geometry holds a NaN / Inf (or a coordinate beyond 1e30)"); return CRH_E_INVALID; }
   free(c->pos); free(c->nrm); free(c->xf); free(c->tri_obj); c->xf = NULL; c->tri_obj = NULL; c->two_level = 0; c->nO = 0;
+  free(c->hidden); c->hidden = NULL;                /* a new scene: everything displayed */
   c->pos = (float*)dup_mem(pos, sizeof(float) * 3 * nV); c->nrm = (float*)dup_mem(nrm, sizeof(float) * 3 * nV);
   if (tri_obj && xf && nO) {
     /* two-level mode: vertices stay in object space; each object gets its own tree, instances carry the transforms */
@@ -1242,19 +1268,60 @@ ORC_API int orc_set_transforms(orc_ctx* c, const float* xf, uint32_t nO)
   memcpy(c->xf, xf, sizeof(float) * 12 * nO);
   if (c->built) {
     /* static / moved split: the static tree and the object trees built so far are never rebuilt.  An object of the static tree that
-     * leaves the identity gets its triangles there disabled and (the first time) an object tree of its own; back at the identity, its
+     * leaves its build-time placement gets its triangles there disabled and (the first time) an object tree of its own; back there, its
      * triangles are restored and the instance is dropped.  Then the top-level tree over the instances of this moment. */
-    collapser C; C.qn = c->nodes; C.nq = c->nBlasNodes; C.capq = c->capNodes;
-    for (uint32_t ob = 0; ob < nO; ++ob) {
-      orc_object* o = &c->obj[ob];
-      if (!o->ntri) continue;
-      const int want = memcmp(&xf[12 * ob], &c->xf0[12 * ob], 12 * sizeof(float)) != 0;      /* off its build-time placement: an instance */
-      if (want && !o->is_inst) { set_static_triangles(c, ob, 0); if (!o->built) build_object_tree(c, &C, ob); o->is_inst = 1; }
-      else if (!want && o->is_inst) { set_static_triangles(c, ob, 1); o->is_inst = 0; }
-    }
-    c->nodes = C.qn; c->nBlasNodes = C.nq; c->capNodes = C.capq;
-    build_tlas(c);
+    apply_objects(c);
   }
+  return orc_reset(c);
+}
+/* crh_set_visibility: AIS_InteractiveContext::Display / Erase of one or more objects (DataNode.cxx:304-344; the GUI's eye icons, `rtdisplay` / `rterase`
+ * of ImportExportPlugin.cxx:373-425) without a rebuild */
+ORC_API int orc_set_visibility(orc_ctx* c, const uint8_t* visible, uint32_t nO)
+{
+  if (!c || !visible || !c->two_level || nO != c->nO) return CRH_E_INVALID;
+  if (!c->hidden) c->hidden = (uint8_t*)calloc(nO ? nO : 1, 1);
+  for (uint32_t ob = 0; ob < nO; ++ob) c->hidden[ob] = visible[ob] ? 0 : 1;
+  if (c->built) apply_objects(c);
+  return orc_reset(c);
+}
+/* crh_add_object: AIS_InteractiveContext::Display of a NEW object in a built scene (ImportExportPlugin.cxx:132-354 `rtmeshread` into a running viewer):
+ * the arrays grow, the object gets an object-space tree and enters the top level as an instance; the next full build bakes it like the rest */
+ORC_API int orc_add_object(orc_ctx* c, const float* pos, const float* nrm, const float* uv, uint32_t nV, const int32_t* tri, uint32_t nT,
+                           const float* xform, uint32_t* object_out)
+{
+  if (!c || !pos || !nrm || !tri || !xform || !nV || !nT) return CRH_E_INVALID;
+  if (!c->built) return CRH_E_NOTBUILT;
+  if (!c->two_level) { snprintf(c->err, sizeof c->err, "crh_add_object needs a scene handed over with objects"); return CRH_E_INVALID; }
+  for (uint32_t t = 0; t < nT; ++t) for (int k = 0; k < 3; ++k) if (tri[4 * t + k] < 0 || (uint32_t)tri[4 * t + k] >= nV) { snprintf(c->err, sizeof c->err, "triangle %u index out of range", t); return CRH_E_INVALID; }
+  if (!all_finite(pos, 3 * (size_t)nV, 1.0e30f) || !all_finite(nrm, 3 * (size_t)nV, 3.0e38f) || (uv && !all_finite(uv, 2 * (size_t)nV, 3.0e38f)) || !all_finite(xform, 12, 1.0e30f)) {
+    snprintf(c->err, sizeof c->err, "geometry holds a NaN / Inf (or a coordinate beyond 1e30)"); return CRH_E_INVALID; }
+  if ((uint64_t)c->nT + nT >= (1u << 28)) return CRH_E_INVALID;
+  const uint32_t V0 = c->nV, T0 = c->nT, ob = c->nO;
+  c->pos = (float*)realloc(c->pos, sizeof(float) * 3 * (V0 + nV)); memcpy(c->pos + 3 * (size_t)V0, pos, sizeof(float) * 3 * nV);
+  c->nrm = (float*)realloc(c->nrm, sizeof(float) * 3 * (V0 + nV)); memcpy(c->nrm + 3 * (size_t)V0, nrm, sizeof(float) * 3 * nV);
+  c->pos_w = (float*)realloc(c->pos_w, sizeof(float) * 3 * (V0 + nV)); memcpy(c->pos_w + 3 * (size_t)V0, pos, sizeof(float) * 3 * nV);
+  c->nrm_w = (float*)realloc(c->nrm_w, sizeof(float) * 3 * (V0 + nV)); memcpy(c->nrm_w + 3 * (size_t)V0, nrm, sizeof(float) * 3 * nV);
+  if (c->uv) {                                   /* a scene with texture coordinates keeps one pair per vertex (zeros when the new object brings none) */
+    c->uv = (float*)realloc(c->uv, sizeof(float) * 2 * (V0 + nV));
+    if (uv) memcpy(c->uv + 2 * (size_t)V0, uv, sizeof(float) * 2 * nV); else memset(c->uv + 2 * (size_t)V0, 0, sizeof(float) * 2 * nV);
+  }
+  c->tri = (int32_t*)realloc(c->tri, sizeof(int32_t) * 4 * (T0 + nT));
+  c->tri_obj = (int32_t*)realloc(c->tri_obj, sizeof(int32_t) * (T0 + nT));
+  c->obj_tris = (uint32_t*)realloc(c->obj_tris, sizeof(uint32_t) * (T0 + nT));
+  c->static_pos = (uint32_t*)realloc(c->static_pos, sizeof(uint32_t) * (T0 + nT));
+  for (uint32_t t = 0; t < nT; ++t) {
+    for (int k = 0; k < 3; ++k) c->tri[4 * (size_t)(T0 + t) + k] = tri[4 * t + k] + (int32_t)V0;
+    c->tri[4 * (size_t)(T0 + t) + 3] = tri[4 * t + 3];
+    c->tri_obj[T0 + t] = (int32_t)ob; c->obj_tris[T0 + t] = T0 + t; c->static_pos[T0 + t] = 0;
+  }
+  c->xf = (float*)realloc(c->xf, sizeof(float) * 12 * (ob + 1)); memcpy(c->xf + 12 * (size_t)ob, xform, sizeof(float) * 12);
+  c->xf0 = (float*)realloc(c->xf0, sizeof(float) * 12 * (ob + 1)); memcpy(c->xf0 + 12 * (size_t)ob, xform, sizeof(float) * 12);
+  c->obj = (orc_object*)realloc(c->obj, sizeof(orc_object) * (ob + 1)); memset(&c->obj[ob], 0, sizeof(orc_object));
+  c->obj[ob].first = T0; c->obj[ob].ntri = nT;
+  if (c->hidden) { c->hidden = (uint8_t*)realloc(c->hidden, ob + 1); c->hidden[ob] = 0; }
+  c->nV = V0 + nV; c->nT = T0 + nT; c->nO = ob + 1;
+  apply_objects(c);
+  if (object_out) *object_out = ob;
   return orc_reset(c);
 }
 ORC_API int orc_get_tlas(orc_ctx* c, uint32_t* root, uint32_t* n_instances, uint32_t* n_blas_nodes)
