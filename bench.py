@@ -299,6 +299,34 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT touching the HIP runtime or importing torch (the parent of spawned ranks never does): the KFD topology of
+    the ROCm driver, cut by the *_VISIBLE_DEVICES lists.  None when it cannot be told from here (the ranks then check for themselves after importing torch)."""
+    import re
+    if not os.path.exists("/dev/kfd"):
+        return 0                                             # no ROCm device node at all
+    n = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for d in os.listdir(base):
+            m = re.search(r"^simd_count\s+(\d+)", open(os.path.join(base, d, "properties")).read(), re.M)
+            if m and int(m.group(1)) > 0:
+                n += 1
+    except OSError:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
+def refuse_without_enough_gpus(wanted, have):
+    sys.exit(f"bench.py: --gpus {wanted} needs {wanted} GPUs on this node, {have} visible -- nothing was started "
+             "(CRH_BENCH_SHARE_DEVICE=1 CRH_BENCH_BACKEND=gloo rehearses the N-rank flow on one GPU)")
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` outside a launcher: start N fresh rank processes (this parent has not imported torch nor
     touched the HIP runtime, and never does) and wait for them.  Rank 0 prints the JSON line on the inherited stdout."""
@@ -332,7 +360,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "CAD1M"])
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (one crh_render_tiles call); 0 = 512 for C3, 256 for C5 and C2, 1024 for C1, 4096 for C4")
     ap.add_argument("--tris", type=int, default=0, help="override triangle count (debug)")
@@ -366,20 +394,24 @@ def parse_args(argv=None):
         args.steps = 1 if args.config == "C4" else 4
     if args.other_configs is None:
         plain = args.gpus == 1 and args.config == "C3" and not (args.tris or args.width or args.height or args.spp)
-        args.other_configs = "C5,C2,C1" if plain else "none"
+        args.other_configs = "C5,C2,C1,CAD1M" if plain else "none"
     if args.live_traffic is None:
         plain = args.gpus == 1 and args.config == "C3" and not (args.tris or args.width or args.height or args.spp) and args.other_configs != "none"
         args.live_traffic = "on" if plain else "off"
     args.other_list = [c for c in args.other_configs.split(",") if c and c != "none"]
     for c in args.other_list:
-        if c not in ("C1", "C2", "C3", "C5"):
+        if c not in ("C1", "C2", "C3", "C5", "CAD1M"):
             ap.error(f"--other-configs: unknown config {c}")
     return args
 
 
 def main():
     args = parse_args()
+    rehearsal = os.environ.get("CRH_BENCH_SHARE_DEVICE") == "1" or os.environ.get("CRH_BENCH_RANK_PROBE") == "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        have = None if rehearsal else visible_gpu_count()
+        if have is not None and have < args.gpus:
+            refuse_without_enough_gpus(args.gpus, have)         # one line, at once: not N ranks waiting for each other in a rendezvous (round-5 verdict, item 6)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))          # nothing GPU-related has been imported yet
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -414,6 +446,9 @@ def main():
         backend = os.environ.get("CRH_BENCH_BACKEND", "nccl")     # "gloo" + CRH_BENCH_SHARE_DEVICE=1: rehearsal of the N > 1 flow on one GPU
         if os.environ.get("CRH_BENCH_SHARE_DEVICE") == "1":
             local = 0
+        elif torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", str(world))):
+            # under a launcher (torchrun) nobody checked: EVERY rank sees the same count and leaves before the rendezvous, so none waits for another
+            refuse_without_enough_gpus(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch.cuda.device_count())
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
@@ -475,7 +510,7 @@ def flatten_line(out):
     line): every leg's rate, gate and fractions, the interactive figures and the measured ceilings are therefore ALSO written as flat scalar keys -- at the top level,
     inside `config` and `roofline` -- and once more as one small object, `legs_summary`, the LAST key of the line (verdict r4 item 3)."""
     cfg, roof = out.get("config") or {}, out.get("roofline") or {}
-    flat = {}
+    flat, wide = {}, {}          # flat: top level + config + legs_summary (the tail); wide: top level + config only
     def gate(o):
         ps = [p for p in (o.get("parity"), o.get("parity_step0")) if p is not None]
         return None if not ps or any("error" in p for p in ps) else all(bool(p.get("bit_exact")) for p in ps)
@@ -485,6 +520,12 @@ def flatten_line(out):
         flat[f"{tag}_parity_bit_exact"] = gate(o)
         c = r.get("ceilings") or {}
         flat[f"{tag}_valu_issue"] = c.get("valu_issue"); flat[f"{tag}_lane_util"] = c.get("lane_util")
+        # round 6: what the CAD-like leg is there to show -- kept out of the 2000-character tail for the soup legs (`wide` = flat keys only)
+        ff = o.get("first_frame_after_a_restart_ms", ((o.get("config") or {}).get("interactive") or {}).get("first_frame_after_a_restart_ms"))
+        for k, val in (("nodes_per_ray", r.get("nodes_per_ray")), ("tris_per_ray", r.get("tris_per_ray")), ("packet_fallback_fraction", r.get("packet_fallback_fraction")),
+                       ("first_frame_ms", ff if tag != head else None)):
+            if val is not None:
+                (flat if tag.startswith("cad") else wide)[f"{tag}_{k}"] = val
     head = (cfg.get("workload") or "C?").split(":")[0].lower()
     leg(head, out, roof)
     for name, o in (cfg.get("other_configs_timed") or {}).items():
@@ -495,16 +536,28 @@ def flatten_line(out):
     it = cfg.get("interactive") or {}
     for k_src, k_dst in (("redraw_per_s_lookahead_1", "interactive_redraw_per_s"), ("first_frame_after_a_restart_ms", "interactive_first_frame_ms"),
                          ("drag_frames_per_s", "interactive_drag_frames_per_s"), ("displayed_frames_per_s", "interactive_displayed_frames_per_s"),
-                         ("redraw_per_s_lookahead_64", "interactive_redraw_per_s_lookahead_64")):
+                         ("redraw_per_s_lookahead_64", "interactive_redraw_per_s_lookahead_64"),
+                         ("displayed_grays_per_s", "interactive_displayed_grays_per_s"), ("first_frame_grays_per_s", "interactive_first_frame_grays_per_s")):
         if k_src in it:
             flat[k_dst] = it[k_src]
+    if "drag_grays_per_s" in it:
+        wide["interactive_drag_grays_per_s"] = it["drag_grays_per_s"]
+    g = it.get("gates") or {}
+    if g:
+        flat["interactive_gates_bit_exact"] = None if "error" in g else bool(g.get("drag_last_frame_bit_exact") and g.get("displayed_frame_bit_exact"))
+    # the only TRUE HBM fraction of the run: C5's scene (0.97 GB) does not fit the caches, so its counter fraction is the HBM-resident figure; the headline
+    # config's own `frac` is that of a cache-resident scene (round-5 verdict, item 8)
+    c5 = ((cfg.get("other_configs_timed") or {}).get("C5") or {}).get("roofline") or {}
+    if c5.get("traffic_frac") is not None:
+        roof["hbm_resident_frac"] = c5["traffic_frac"]
+        roof["hbm_resident_frac_note"] = "C5 leg of this run (10 M triangles, 4K): memory-side counter traffic / 8 TB/s, leg average over its traversal launches"
     ceil = roof.get("ceilings") or {}
     for k in ("valu_issue", "lane_util", "hbm", "l2"):
         if k in ceil and isinstance(ceil[k], (int, float)):
             roof[k if k in ("valu_issue", "lane_util") else k + "_frac_ceiling"] = ceil[k]
-    cfg.update(flat)
+    cfg.update(wide); cfg.update(flat)
     out.pop("legs_summary", None)
-    out.update(flat)
+    out.update(wide); out.update(flat)
     out["legs_summary"] = flat          # last key: the tail of the line carries every leg
 
 
@@ -516,12 +569,14 @@ def compact_leg(o):
     return {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
             "spp_per_step": o["config"]["spp_per_step_per_rank"], "msamples_per_s": o["config"]["msamples_per_s"], "build_upload_s": o["config"]["build_upload_s"],
             "parity": keep(o.get("parity")), "parity_step0": keep(o.get("parity_step0")),
+            "first_frame_after_a_restart_ms": (o["config"].get("interactive") or {}).get("first_frame_after_a_restart_ms"),
             "roofline": {"kernel": r.get("kernel"), "avg_launch_ms": r.get("avg_launch_ms"), "launches": r.get("launches"), "kernel_time_share": r.get("kernel_time_share"),
                          "scene_bytes": r.get("scene_bytes"), "alg_gbps": r.get("alg_gbps"), "alg_frac": r.get("alg_frac_of_hbm_peak"),
                          "traffic_gbps": r.get("traffic_gbps"), "traffic_frac": r.get("traffic_frac_of_peak"), "traffic_measured": r.get("traffic_measured"),
                          "traffic": r.get("traffic"), "traffic_this_run_over_committed": r.get("traffic_this_run_over_committed"), "traffic_live_error": r.get("traffic_live_error"),
                          "traffic_reason": r.get("traffic_reason"), "frac": r.get("frac"), "achieved_basis": r.get("achieved_basis"),
                          "nodes_per_ray": r.get("nodes_per_ray"), "tris_per_ray": r.get("tris_per_ray"),
+                         "packet_rays": r.get("packet_rays"), "packet_fallback_rays": r.get("packet_fallback_rays"), "packet_fallback_fraction": r.get("packet_fallback_fraction"),
                          "ceilings": {k: ceil.get(k) for k in ("hbm", "l2", "valu_issue", "lane_util", "binding") if k in ceil} or None,
                          "limited_by": r.get("limited_by")}}
 
@@ -558,7 +613,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
         # samples of a pixel travel together: crh_schedule.cpp), so a step is given enough samples for that to matter: 512 at 1080p (C3: two batches of
         # 1024 tiles), 256 at 4K (C5: four batches of 2048 tiles), C4 its named 4096; C2 its named 256 (one batch of 2040 tiles; it does not care: 128 / 256 / 512 give 5572 / 5576 / 5585), C1 1024 as in round 3.  A workload
         # overridden on the command line gets what fills 2^28 slots, in multiples of 64.
-        named = {"C3": 512, "C4": 4096, "C5": 256, "C2": 256, "C1": 1024}
+        named = {"C3": 512, "C4": 4096, "C5": 256, "C2": 256, "C1": 1024, "CAD1M": 512}
         if config in named and not (ov and (args.tris or args.width or args.height)):
             spp = named[config]
         else:
@@ -644,6 +699,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     v.enable_kernel_timing(False)
     kt = v.kernel_timing()
     st = v.stats()
+    pk = v.packet_stats()                                     # camera rays of the timed steps walked as packets / handed to the per-ray fall-back pass
     # what the TIMED steps themselves accumulated (rank 0, N = 1): the parity gate below compares exactly these pixels with the oracle
     timed_hdr = v.read_hdr() if (rank == 0 and world == 1 and not args.no_parity) else None
     if rank == 0 and world > 1 and not args.no_parity and assembled[0] is not None:
@@ -685,15 +741,18 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
         # the memory-side counters of THIS run (two child passes under rocprofv3, after the timed region; the parent idles meanwhile)
         live = None
         if world == 1 and args.live_traffic == "on" and not modified:          # the headline and every other-config leg
+            budget_was = v.get_path_budget()                                    # restored as it was (the library's default or the caller's), not as a constant
             v.set_path_budget(1 << 20)                                          # the child holds a full path budget of its own (up to 105 GB): this process's goes first
             live = live_traffic(config)
-            v.set_path_budget(512 << 20)
+            v.set_path_budget(budget_was)
         roof = roofline_report(config if world == 1 else f"{config}@{world}", spp_step, modified,
                                alg_bytes / launches, avg_ms, mem["nodes"] + mem["triangles"], live=live, extra={
             "launches": int(launches),
             "kernel_time_share": round(kt["trace_nearest_ms_total"] / max(kt["render_ms_total"], 1e-9), 3),
             "nodes_per_ray": round(cs["nodes_nearest"] / max(cs["rays_nearest"], 1), 2),
             "tris_per_ray": round(cs["tris_nearest"] / max(cs["rays_nearest"], 1), 2),
+            "packet_rays": pk["packet_rays"], "packet_fallback_rays": pk["fallback_rays"],
+            "packet_fallback_fraction": round(pk["fallback_rays"] / pk["packet_rays"], 6) if pk["packet_rays"] else None,
             "camera_rays": ("bounce 0 of a wide batch is walked by k_trace_packets (one packet per wavefront: 64 samples of a pixel share the node fetches) + the per-ray "
                             "fall-back pass for rays that met two triangles at exactly the same distance; it is one of the `launches`, timed like the others; "
                             "nodes_per_ray / tris_per_ray / alg_bytes are those of the spec's per-ray walk (counting pass), which the packet walk does not exceed per ray") if wide_batch else None,
@@ -711,6 +770,15 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     interactive = None
     if headline and rank == 0 and world == 1 and not args.no_interactive:
         interactive = interactive_figures(v, sc.camera)
+    elif rank == 0 and world == 1 and not args.no_interactive:
+        # the other legs: the lone frame after a restart only (crh_reset + crh_render(1) + crh_sync, median of 9) -- what a user of THIS scene waits for
+        import statistics
+        ts = []
+        for _ in range(10):
+            v.reset(); v.sync()
+            t1 = time.perf_counter(); v.Redraw(); v.sync()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        interactive = {"first_frame_after_a_restart_ms": round(statistics.median(ts[1:]), 3), "first_frame_after_a_restart_ms_min": round(min(ts[1:]), 3)}
 
     v.close()                                                 # the path state (up to 105 GB) and the scene go before the next leg / the CPU legs
 
@@ -743,6 +811,42 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
             if p is not None and "error" not in p and not (p["pixels"] > 0 and p["rel_l2"] <= 1e-4):
                 failed = True                                   # differing pixels -- or no pixel compared at all
 
+    # ---- the gates of the interactive figures: the drag's last frame and a displayed frame, whole 1080p frames against the oracle
+    if interactive and "_frames_for_gates" in interactive:
+        fg = interactive.pop("_frames_for_gates")
+        if not args.no_parity:
+            try:
+                import dataclasses as _dc
+                import numpy as np
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_redraw
+                from oracle import pyoracle
+                Or = pyoracle.oracle_class("parity"); Or.set_threads(usable_cpus())
+                t1 = time.perf_counter()
+                o = Or().load_scene(_dc.replace(sc, camera=bench_redraw.drag_camera(sc.camera, fg["drag_camera_index"])))
+                o.render(1)
+                drag_ok = bool(np.array_equal(o.read_hdr().view(np.uint32), fg["drag_hdr"].view(np.uint32)))
+                o.set_camera(sc.camera); o.reset(); o.render(fg["displayed_frame"] + 1)
+                shown_ok = bool(np.array_equal(o.read_ldr(), fg["displayed_ldr"]))
+                o.close()
+                interactive["gates"] = {"drag_last_frame_bit_exact": drag_ok, "displayed_frame_bit_exact": shown_ok,
+                                        "what": f"whole {sc.params.width}x{sc.params.height} frames: the drag loop's frame {fg['drag_camera_index']} (HDR, 1 sample) and displayed frame "
+                                                f"{fg['displayed_frame']} of the still camera (LDR through crh_read_ldr_begin / _end, {fg['displayed_frame'] + 1} samples) against the CPU oracle, "
+                                                f"{time.perf_counter() - t1:.1f} s"}
+                if not (drag_ok and shown_ok):
+                    failed = True
+            except Exception as e:
+                errors.append(f"{config} interactive gates: {type(e).__name__}: {e}")
+                interactive["gates"] = {"error": f"{type(e).__name__}: {e}"}
+        rpf = interactive.get("rays_per_1spp_frame") or 0
+        if rpf:
+            if interactive.get("displayed_frames_per_s"):
+                interactive["displayed_grays_per_s"] = round(interactive["displayed_frames_per_s"] * rpf / 1e9, 3)
+            if interactive.get("first_frame_after_a_restart_ms"):
+                interactive["first_frame_grays_per_s"] = round(rpf / (interactive["first_frame_after_a_restart_ms"] * 1e-3) / 1e9, 3)
+            if interactive.get("drag_frames_per_s"):
+                interactive["drag_grays_per_s"] = round(interactive["drag_frames_per_s"] * rpf / 1e9, 3)
+
     # ---- CPU baseline: the oracle (a port, not the reference: OCCT has no CPU path tracer) on this box's cores
     cpu = None
     if headline and rank == 0 and not args.no_cpu and world == 1:          # reported on rank 0 at N = 1 only
@@ -754,7 +858,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     out = None
     if rank == 0:
         mrays = (rays_n + rays_a) / dt / 1e6
-        cfgd = {"workload": f"{config}: {len(sc.tri)} {'triangles of the Cornell box (CornellBox.tcl without the spheres)' if scene_cfg == 'C1' else 'random triangles'}, {len(sc.materials)} BSDF(s), "
+        cfgd = {"workload": f"{config}: {len(sc.tri)} {'triangles of the Cornell box (CornellBox.tcl without the spheres)' if scene_cfg == 'C1' else ('triangles of a tessellated CAD-like assembly (scenes.gen_cad_like: shared vertices, long thin triangles, coincident faces)' if scene_cfg == 'CAD1M' else 'random triangles')}, {len(sc.materials)} BSDF(s), "
                             f"{'HDR sky env' if sc.env is not None else 'constant env'}, {len(sc.lights)} light(s), "
                             f"{sc.params.width}x{sc.params.height}, depth {sc.params.max_depth}",
                 "spp_per_step_per_rank": spp_step, "spp_per_step_whole_frame": spp_step if scaling == "strong" or world == 1 else spp,
@@ -809,6 +913,22 @@ def interactive_figures(v, cam0):
     import bench_redraw
     interactive.update(bench_redraw.measure(v, cam0, frames=96, trials=9))
     interactive.pop("free_running_redraw_per_s", None)          # = redraw_per_s_lookahead_1 above
+    # ---- what the gates of the interactive figures compare (round-5 verdict, item 8): the LAST frame of the drag loop above (camera of frame 95, one
+    # sample) and a DISPLAYED frame of the still camera (the fourth: 4 samples, through the asynchronous LDR read-back) -- the oracle renders both after
+    # the view is closed (run_leg); rays of a 1-sample frame turn the frame rates into Grays/s
+    v.set_camera(bench_redraw.drag_camera(cam0, 95)); v.reset(); v.Redraw()
+    frames_for_gates = {"drag_hdr": v.read_hdr(), "drag_camera_index": 95}
+    v.set_camera(cam0); v.reset(); v.sync()
+    shown = []
+    for i in range(4):
+        v.Redraw()
+        if i >= 2: shown.append(v.read_ldr_end())
+        v.read_ldr_begin()
+    shown.append(v.read_ldr_end()); shown.append(v.read_ldr_end())
+    frames_for_gates["displayed_ldr"] = shown[3]; frames_for_gates["displayed_frame"] = 3
+    v.reset(); v.Redraw(); s1 = v.stats()
+    interactive["rays_per_1spp_frame"] = int(s1["rays_nearest"] + s1["rays_any"])
+    interactive["_frames_for_gates"] = frames_for_gates
     v.reset()
     import cadrays_amd
     frames, queues = cadrays_amd.pipeline_capacity()

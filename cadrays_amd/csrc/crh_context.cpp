@@ -268,6 +268,13 @@ int crh_reset(crh_ctx* c) { if (!c) return CRH_E_INVALID; return do_reset(c); }
 
 int crh_sync(crh_ctx* c) { if (!c) return CRH_E_INVALID; c->read_since_render = true; CRH_HIP(hipSetDevice(c->device)); CRH_HIP(hipStreamSynchronize(cstream(c))); return CRH_OK; }
 
+int crh_get_path_budget(crh_ctx* c, uint64_t* max_paths)
+{
+  if (!c || !max_paths) return fail(c, CRH_E_INVALID, "null argument");
+  *max_paths = c->max_paths;
+  return CRH_OK;
+}
+
 int crh_set_path_budget(crh_ctx* c, uint64_t max_paths)
 {
   if (!c || max_paths < 1024u || max_paths > (1ull << 30)) return fail(c, CRH_E_INVALID, "path budget must be in 1024 .. 2^30 slots");

@@ -149,6 +149,20 @@ int crh_get_stats(crh_ctx* c, crh_stats* out)
   return CRH_OK;
 }
 
+int crh_get_packet_stats(crh_ctx* c, uint64_t* packet_rays, uint64_t* fallback_rays)
+{
+  if (!c) return CRH_E_INVALID;
+  CRH_HIP(hipSetDevice(c->device));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
+  drain_events(c);
+  DCounters h;
+  CRH_HIP(hipMemcpyAsync(&h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, cstream(c)));
+  CRH_HIP(hipStreamSynchronize(cstream(c)));
+  if (packet_rays) *packet_rays = h.packet_rays;
+  if (fallback_rays) *fallback_rays = h.packet_fallback;
+  return CRH_OK;
+}
+
 int crh_get_kernel_timing(crh_ctx* c, double* trace_ms_total, uint64_t* trace_launches, double* all_ms_total)
 {
   if (!c) return CRH_E_INVALID;

@@ -162,7 +162,8 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   // path budget of this call: crh_set_path_budget's, cut to what the device has free when the state would have to grow (196 B per slot; a shared or smaller
   // device gets the narrower batches the budget table of cadrays_hip.h prices at a few percent, not a hipMalloc error -- ADVICE r4)
   uint32_t budget = c->max_paths;
-  if ((uint64_t)nt * tpp * ns > c->path_cap) {
+  const uint64_t slots_wanted = (uint64_t)nt * tpp * ns * ((c->pipeline && ns <= 16u && (uint64_t)nt * tpp * ns <= c->lane_max_paths) ? c->pipe_depth : 1u);      // a pipelined frame holds pipe_depth slices
+  if (slots_wanted > c->path_cap) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
       const uint64_t fit = (uint64_t)((double)(fr + (size_t)c->path_cap * 196u) * 0.85) / 196u;
@@ -204,7 +205,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   // unless something was enqueued there that its tracing reads (seeds travel by value, a restart's memsets gate the accumulate only).
   const bool frame_able = frame_ok(c, total);
   if (c->pipeline && (host_runs_ahead || frame_able) && !c->counters_on && !c->timing_on && !c->adaptive && group == nt && spb == ns && ns <= 16u && total >= (1u << 20) &&
-      total <= c->lane_max_paths && (uint64_t)c->pipe_depth * total <= c->max_paths) {
+      total <= c->lane_max_paths && (uint64_t)c->pipe_depth * total <= budget) {      // `budget`: the device's free memory counts here too
     const uint32_t depth = c->pipe_depth;               // streams / path-state slices the frames rotate through
     int rc = ensure_paths(c, (uint32_t)(c->pipe_depth * total)); if (rc) return rc;
     rc = ensure_lanes(c); if (rc) return rc;

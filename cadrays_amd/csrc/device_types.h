@@ -94,6 +94,7 @@ struct DPaths {
 
 struct DCounters {          // device-side mirror of crh_stats
   unsigned long long rays_nearest, rays_any, nodes_nearest, tris_nearest, nodes_any, tris_any, shaded_hits, samples;
+  unsigned long long packet_rays, packet_fallback;      // device only (crh_get_packet_stats): camera rays walked as packets, those of them handed to the per-ray fall-back pass
 };
 
 struct DQueues {

