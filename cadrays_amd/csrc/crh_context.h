@@ -270,6 +270,7 @@ uint32_t frame_seed(uint32_t seed, uint32_t n);
 
 // ---- crh_reduce.cpp
 void release_comms(crh_ctx* c);
+int reduce_fake_devices(crh_ctx* const* ctxs, uint32_t n, uint32_t root);      // crh_reduce.cpp: the RCCL branch of crh_reduce on contexts that share a device (test hook)
 
 }  // namespace api
 }  // namespace crh

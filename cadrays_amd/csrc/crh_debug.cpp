@@ -53,6 +53,14 @@ int crh_bench_trace(crh_ctx* c, const float* rays, uint32_t n, int any_hit, uint
   return CRH_OK;
 }
 
+// Test hook (never called by a product path): crh_reduce's RCCL branch -- communicators kept on the root, one group of ncclReduce calls on the contexts' own
+// streams, the assembled frame's lifetime -- on contexts that share ONE device, the only kind a 1-GPU pool has (crh_reduce.cpp explains what is replaced)
+int crh_debug_reduce_fake_devices(crh_ctx* const* ctxs, uint32_t n, uint32_t root)
+{
+  if (!ctxs || n == 0 || root >= n || !ctxs[root]) return CRH_E_INVALID;
+  return crh::api::reduce_fake_devices(ctxs, n, root);
+}
+
 int crh_debug_math(crh_ctx* c, int fn, const float* a, const float* b, float* out, float* out2, uint32_t n)
 {
   if (!c || !a || !b || !out || !out2 || !n) return fail(c, CRH_E_INVALID, "bad debug_math arguments");

@@ -63,7 +63,8 @@ namespace {
       char b_[512]; snprintf(b_, sizeof b_, "%s failed: %s", #call, R->GetErrorString ? R->GetErrorString(r_) : "rccl error"); \
       c->err = b_; return CRH_E_DEVICE; } } while (0)
 
-int reduce_impl(crh_ctx* const* ctxs, uint32_t n, uint32_t root)
+// fake_devices: the test hook of crh_debug_reduce_fake_devices (crh_debug.cpp) -- never set by crh_reduce
+int reduce_impl(crh_ctx* const* ctxs, uint32_t n, uint32_t root, bool fake_devices)
 {
   crh_ctx* c = ctxs[root];                                   // errors are reported on the root
   const uint32_t W = c->par.width, H = c->par.height;
@@ -87,8 +88,34 @@ int reduce_impl(crh_ctx* const* ctxs, uint32_t n, uint32_t root)
   for (uint32_t i = 0; i < n; ++i) { CRH_HIP(hipSetDevice(ctxs[i]->device)); CRH_HIP(hipStreamSynchronize(cstream(ctxs[i]))); }
 
   // CRH_REDUCE_RCCL_SINGLE=1 sends even a one-context group through RCCL (exercises the library binding on a 1-GPU box)
-  RcclApi* R = (distinct && (n > 1 || getenv("CRH_REDUCE_RCCL_SINGLE"))) ? rccl() : nullptr;
-  if (R) {
+  RcclApi* R = ((distinct && (n > 1 || getenv("CRH_REDUCE_RCCL_SINGLE"))) || fake_devices) ? rccl() : nullptr;
+  if (fake_devices && !R) return fail(c, CRH_E_DEVICE, "crh_debug_reduce_fake_devices: librccl could not be loaded");
+  if (R && fake_devices) {
+    // TEST HOOK (round-5 verdict, item 6): a 1-GPU pool can never run the branch below with n > 1.  Here the contexts -- all on ONE device -- take the same
+    // steps with what one device allows: a communicator per context (each a single-rank group of its own: ncclCommInitAll over n copies of the same device
+    // is refused), the same bookkeeping of communicators on the root, ONE group of n ncclReduce calls on the contexts' own streams (rank 0 of a
+    // single-rank group: the root's accumulator lands in d_assembled, the others reduce in place), the same synchronisation -- and the sum over the
+    // contexts, which the single-rank groups cannot do, by the add kernel of the same-device branch.
+    if (c->comm_ctxs.size() != n || !std::equal(c->comm_ctxs.begin(), c->comm_ctxs.end(), ctxs)) {
+      release_comms(c);
+      c->comms.assign(n, nullptr);
+      for (uint32_t i = 0; i < n; ++i) CRH_NCCL(R->CommInitAll(&c->comms[i], 1, &devs[i]));
+      c->comm_ctxs.assign(ctxs, ctxs + n);
+    }
+    CRH_NCCL(R->GroupStart());
+    for (uint32_t i = 0; i < n; ++i) {
+      hipSetDevice(ctxs[i]->device);
+      ncclResult_t r = R->Reduce(ctxs[i]->d_accum, i == root ? (void*)c->d_assembled : (void*)ctxs[i]->d_accum, 4 * n4, ncclFloat, ncclSum, 0, c->comms[i], cstream(ctxs[i]));
+      if (r != ncclSuccess) { R->GroupEnd(); c->err = "ncclReduce failed"; return CRH_E_DEVICE; }
+    }
+    CRH_NCCL(R->GroupEnd());
+    for (uint32_t i = 0; i < n; ++i) { CRH_HIP(hipSetDevice(ctxs[i]->device)); CRH_HIP(hipStreamSynchronize(cstream(ctxs[i]))); }
+    CRH_HIP(hipSetDevice(c->device));
+    Launch L{cstream(c), c->grid, false};
+    for (uint32_t i = 0; i < n; ++i) if (i != root) launch_add4(L, c->d_assembled, ctxs[i]->d_accum, (uint32_t)n4);
+    CRH_HIP(hipGetLastError());
+    CRH_HIP(hipStreamSynchronize(cstream(c)));
+  } else if (R) {
     // one process, one communicator per context, a single grouped ncclReduce: on xGMI the peers' contributions arrive
     // over distinct links; message = W*H*16 B (33 MB at 1080p, 133 MB at 4K)
     if (c->comm_ctxs.size() != n || !std::equal(c->comm_ctxs.begin(), c->comm_ctxs.end(), ctxs)) {
@@ -132,12 +159,18 @@ int reduce_impl(crh_ctx* const* ctxs, uint32_t n, uint32_t root)
 
 }  // namespace
 
+namespace crh {
+namespace api {
+int reduce_fake_devices(crh_ctx* const* ctxs, uint32_t n, uint32_t root) { return reduce_impl(ctxs, n, root, true); }
+}  // namespace api
+}  // namespace crh
+
 extern "C" {
 
 int crh_reduce(crh_ctx* const* ctxs, uint32_t n, uint32_t root)
 {
   if (!ctxs || n == 0 || root >= n || !ctxs[root]) return CRH_E_INVALID;
-  return reduce_impl(ctxs, n, root);
+  return reduce_impl(ctxs, n, root, false);
 }
 
 }  // extern "C"

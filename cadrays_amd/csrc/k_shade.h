@@ -150,6 +150,33 @@ __device__ __forceinline__ void shade_path(const DScene& S, const DPaths& P, con
   }
 }
 
+#if CRH_COHERENCE_STATS
+// Instrumented builds only (tools/ab_build.sh coh "-DCRH_COHERENCE_STATS=1"; tools/coherence_vote.py; round-5 verdict item 2): would the rays of bounce
+// >= 1 form packets?  The survivors / shadow rays of a chunk are written in rank order, so 64 consecutive ranks ARE the wavefront that traces them next.
+// Per bounce: [0] groups of 64 consecutive continuation rays with >= 48 entries, [1] those in which >= 48 entries leave the SAME triangle, [2] ... through a
+// delta lobe, [3] continuation rays; [4] groups of shadow rays, [5] those with >= 48 entries from the same triangle, [6] shadow rays, [7] -.
+__device__ unsigned long long g_coherence[32 * 8];
+__device__ __forceinline__ void coherence_vote(const uint32_t* keys, uint32_t n, unsigned long long* out, bool with_delta)
+{
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  for (uint32_t g = wave; g * 64u < n; g += (uint32_t)kBlock / 64u) {
+    const uint32_t i = g * 64u + lane; const bool valid = i < n;
+    const uint32_t key = valid ? keys[i] : 0xFFFFFFFFu;
+    const uint32_t nv = (uint32_t)__popcll(__ballot(valid));
+    uint32_t best = 0, best_key = 0;
+    for (int c = 0; c < 64; c += 21) {                      // three candidates: a key that >= 48 of 64 entries share is behind one of them with probability 0.98
+      const uint32_t kk = (uint32_t)__shfl((int)key, c);
+      const uint32_t m = (uint32_t)__popcll(__ballot(valid && key == kk));
+      if (m > best) { best = m; best_key = kk; }
+    }
+    if (lane == 0 && nv >= 48u) {
+      atomicAdd(&out[0], 1ull);
+      if (best >= 48u) { atomicAdd(&out[1], 1ull); if (with_delta && (best_key >> 31)) atomicAdd(&out[2], 1ull); }
+    }
+  }
+}
+#endif
+
 template <bool SPLIT>
 __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t bounce,
                                                    const uint32_t* __restrict__ q_in, const uint32_t* __restrict__ count_in,
@@ -165,6 +192,9 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
   // split scenes: those of them that touch a moved object, for the second traversal pass
   __shared__ uint32_t s_q2c[SPLIT ? kShadeIters * kBlock : 1], s_q2s[SPLIT ? kShadeIters * kBlock : 1];
   __shared__ uint32_t s_base, s_nc, s_ns, s_gc, s_gs, s_n2c, s_n2s, s_g2c, s_g2s;
+#if CRH_COHERENCE_STATS
+  __shared__ uint32_t s_kc[kShadeIters * kBlock], s_ks[kShadeIters * kBlock];
+#endif
   if (blockIdx.x == 0 && threadIdx.x == 0) { cursors[0] = 0u; cursors[4] = 0u; }     // nearest-hit cursors (both passes) of the next bounce
   const bool mats_in_lds = S.n_mats <= (uint32_t)kLdsMats;
   if (mats_in_lds) {
@@ -189,9 +219,15 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
     const uint32_t i = base + it * kBlock + threadIdx.x;
     bool cont = false, shadow = false;
     float4 n_o = zero4, n_d = zero4, n_t = zero4, s_o = zero4, s_d = zero4, s_c = zero4;     // successor ray / shadow ray, stored after the ranks are known
+#if CRH_COHERENCE_STATS
+    uint32_t coh_tri = 0u;
+#endif
     if (i < n) {
       const uint32_t pos = q_in[i];
       const float4 o4 = in_o[pos], d4 = in_d[pos], h = P.hit[pos];
+#if CRH_COHERENCE_STATS
+      coh_tri = __float_as_uint(h.w) & 0x7FFFFFFFu;
+#endif
       const float4 t4 = first ? make_float4(1.0f, 1.0f, 1.0f, CRH_MAXFLOAT) : in_t[pos];     // k_raygen leaves thr / rad unwritten
       const uint32_t pid = __float_as_uint(d4.w) >> 1;                              // the path's slot (radiance record, pixel)
       shade_path<SPLIT>(S, P, s_mats, mats_in_lds, bounce, first, last, o4, d4, t4, h, pid, cont, shadow, n_o, n_d, n_t, s_o, s_d, s_c, n_shaded);
@@ -202,16 +238,29 @@ __global__ CRH_SHADE_BOUNDS void k_shade(DScene S, DPaths P, int cur, uint32_t b
       const uint32_t r = lds_rank(shadow, &s_ns);
       uint32_t ps = 0u;
       if (shadow) { ps = q_in[base + r]; s_qs[r] = ps; P.sh_o[ps] = s_o; P.sh_d[ps] = s_d; P.sh_c[ps] = s_c; }
+#if CRH_COHERENCE_STATS
+      if (shadow) s_ks[r] = coh_tri;
+#endif
       if (SPLIT) lds_append(shadow && s_d.w != 0.f, ps, s_q2s, &s_n2s);
     }
     {
       const uint32_t r = lds_rank(cont, &s_nc);
       uint32_t pn = 0u;
       if (cont) { pn = q_in[base + r]; s_qc[r] = pn; out_o[pn] = n_o; out_d[pn] = n_d; out_t[pn] = n_t; }
+#if CRH_COHERENCE_STATS
+      if (cont) s_kc[r] = coh_tri | (n_t.w == CRH_MAXFLOAT ? 0x80000000u : 0u);      // the successor left through a delta lobe
+#endif
       if (SPLIT) lds_append(cont && ray_touches_instances(S, xyz(n_o), xyz(n_d), CRH_MAXFLOAT), pn, s_q2c, &s_n2c);
     }
     }
     __syncthreads();
+#if CRH_COHERENCE_STATS
+    if (bounce < 32u) {
+      coherence_vote(s_kc, s_nc, &g_coherence[8u * bounce], true);
+      coherence_vote(s_ks, s_ns, &g_coherence[8u * bounce + 4u], false);
+      if (threadIdx.x == 0) { atomicAdd(&g_coherence[8u * bounce + 3u], (unsigned long long)s_nc); atomicAdd(&g_coherence[8u * bounce + 6u], (unsigned long long)s_ns); }
+    }
+#endif
     if (threadIdx.x == 0) {
       s_gc = s_nc ? atomicAdd(count_out, s_nc) : 0u; s_gs = s_ns ? atomicAdd(count_sh, s_ns) : 0u;
       if (SPLIT) { s_g2c = s_n2c ? atomicAdd(count2, s_n2c) : 0u; s_g2s = s_n2s ? atomicAdd(count2_sh, s_n2s) : 0u; }

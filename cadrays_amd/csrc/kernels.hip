@@ -130,6 +130,17 @@ void launch_frame(const Launch& L, const DScene& S, const DPaths& P, uint32_t* c
   if (S.two_level) hipLaunchKernelGGL(k_frame<true>, dim3(grid), dim3(kFrameBlock), 0, L.stream, S1, P, A, C);
   else             hipLaunchKernelGGL(k_frame<false>, dim3(grid), dim3(kFrameBlock), 0, L.stream, S1, P, A, C);
 }
+#if CRH_COHERENCE_STATS
+}  // namespace crh
+// instrumented builds only (tools/ab_build.sh coh "-DCRH_COHERENCE_STATS=1"): k_shade's vote counters per bounce since the last call (k_shade.h)
+extern "C" __attribute__((visibility("default"))) int crh_exp_coherence(unsigned long long* out256)
+{
+  static unsigned long long zero[256] = {0};
+  if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(crh::g_coherence), sizeof zero) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(crh::g_coherence), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+namespace crh {
+#endif
 #if CRH_FRAME_STATS
 }  // namespace crh
 // instrumented builds only (tools/ab_build.sh NAME "-DCRH_FRAME_STATS=1"): what the frame kernel's engines counted since the last call

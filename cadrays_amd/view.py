@@ -127,13 +127,15 @@ class View(Backend):
         return p.value, n.value
 
     @staticmethod
-    def reduce(views, root=0):
+    def reduce(views, root=0, fake_devices=False):
         """crh_reduce: assemble the tile-sharded frame of `views` (one context per GPU) on views[root]; that view's
-        read_hdr / read_ldr / save_accum return the assembled frame until it renders again"""
+        read_hdr / read_ldr / save_accum return the assembled frame until it renders again.  fake_devices: the test hook
+        crh_debug_reduce_fake_devices (the RCCL branch on contexts that share a device)"""
         lib = views[root]._lib
         arr = (C.c_void_p * len(views))(*[v._ctx.value for v in views])
-        lib.crh_reduce.restype = C.c_int
-        rc = lib.crh_reduce(arr, C.c_uint32(len(views)), C.c_uint32(int(root)))
+        fn = lib.crh_debug_reduce_fake_devices if fake_devices else lib.crh_reduce
+        fn.restype = C.c_int
+        rc = fn(arr, C.c_uint32(len(views)), C.c_uint32(int(root)))
         if rc != 0:
             msg = views[root]._fn("last_error")(views[root]._ctx)
             raise BackendError(f"crh_reduce -> {rc}: {msg.decode() if msg else ''}")

@@ -155,8 +155,9 @@ CRH_API int crh_set_transforms(crh_ctx* ctx, const float* obj_xform /* 12*nO */,
  * its instance, if it is one, is dropped from the top level; displaying it again restores them.  `Remove` is Erase for good: hide the object and leave
  * it out of the arrays of the next crh_set_geometry.  Restarts accumulation.  Before crh_build the flags are kept and applied by the build (every
  * object is baked, the erased ones are then disabled: showing one later costs nothing).  The image equals, bit for bit, that of the scene built
- * without the erased objects for as long as they sat at their build-time placement (same triangle arithmetic, another tree: only visit counters and
- * the winner among hits at EQUAL distance can differ).  Needs a scene handed over with objects; a new crh_set_geometry displays everything again. */
+ * without the erased objects for as long as they sat at their build-time placement AND the scene's bounds are the same without them (an erased object
+ * keeps its place in the static tree: the bounds, hence the ray offset and the guard band of the box test, stay what they were) -- same triangle
+ * arithmetic, another tree: only visit counters and the winner among hits at EQUAL distance can differ.  Needs a scene handed over with objects; a new crh_set_geometry displays everything again. */
 CRH_API int crh_set_visibility(crh_ctx* ctx, const uint8_t* visible /* n_objects */, uint32_t n_objects);
 /* == AIS_InteractiveContext::Display of a NEW object in a running viewer (`rtmeshread` into a loaded scene, ImportExportPlugin.cxx:132-354; the clone
  * button, main.cxx:117): the object's arrays (vertex indices local to it, material ids into the table of crh_set_materials -- extend that first) are
@@ -356,6 +357,9 @@ CRH_API int crh_debug_math(crh_ctx* ctx, int fn, const float* a, const float* b,
  *                                                  out[8i..] = wi.xyz, weight.xyz, flags (1 alive | 2 delta | 4 inside after), rng after
  *   fn 3  b unused;                                out[3i..] = Fresnel(a[3i], m->FresnelCoat) */
 CRH_API int crh_debug_bsdf(crh_ctx* ctx, int fn, const crh_bsdf* m, const float* a, const float* b, float* out, uint32_t n, int two_sided);
+/* TEST HOOK, not for hosts: crh_reduce's RCCL branch (communicator bookkeeping, one group of ncclReduce calls on the contexts' streams, the assembled
+ * frame) executed on contexts that share one device -- a 1-GPU pool cannot run that branch otherwise.  Same result as crh_reduce. */
+CRH_API int crh_debug_reduce_fake_devices(crh_ctx* const* ctxs, uint32_t n, uint32_t root);
 CRH_API int crh_enable_kernel_timing(crh_ctx* ctx, int on);
 CRH_API int crh_get_kernel_timing(crh_ctx* ctx, double* trace_ms_total, uint64_t* trace_launches,
                           double* all_ms_total);

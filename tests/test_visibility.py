@@ -138,9 +138,11 @@ def pair(oracle_lib, sc):
     return v, oracle_lib.Oracle().load_scene(sc)
 
 
-def same(v, o, spp=3):
+def same(v, o, spp=3, stats=True):
     v.render(spp); o.render(spp)
     assert np.array_equal(bits(v.read_hdr()), bits(o.read_hdr()))
+    if not stats:
+        return
     gs, cs = v.stats(), o.stats()
     for k in ("rays_nearest", "rays_any", "nodes_nearest", "tris_nearest", "nodes_any", "tris_any", "shaded_hits", "samples"):
         assert gs[k] == cs[k], k
@@ -158,9 +160,11 @@ def test_hip_visibility_matches_oracle_and_rebuilt_scene(hip_lib, oracle_lib):
         same(v, o)
         assert np.array_equal(v.get_bvh()[0].view(np.uint32)[:len(nodes0)], nodes0)
         assert np.array_equal(v.get_bvh()[1].view(np.uint32), o.get_bvh()[1].view(np.uint32))          # the patched leaf records
-        if hidden and len(hidden) < 7:
+        if hidden in ([3], [3, 5], [6]):
+            # == the scene REBUILT without them -- for objects INSIDE the room: an erased object keeps its place in the static tree, so the scene's bounds (and
+            # with them the ray offset 1e-5 x diagonal and the slab guard band) stay what they were; a scene rebuilt without a wall has smaller bounds
             r = View(0).load_scene(without_objects(sc, hidden)); r.render(3)
-            assert np.array_equal(bits(v.read_hdr()), bits(r.read_hdr())), hidden                     # == the scene REBUILT without them
+            assert np.array_equal(bits(v.read_hdr()), bits(r.read_hdr())), hidden
     rays = probe_rays(6000)
     assert np.array_equal(v.trace_nearest(rays).view(np.uint32), o.trace_nearest(rays).view(np.uint32))
     assert np.array_equal(v.trace_any(rays), o.trace_any(rays))
@@ -237,26 +241,33 @@ def test_hip_fuzz_visibility_transforms_adaptive_checkpoint(hip_lib, oracle_lib,
     sc = object_scene(w=64, h=48)
     v, o = pair(oracle_lib, sc)
     n = 7
+    adaptive = False
+    stats_ok = True                    # a checkpoint restore restarts the product's counters, not the oracle's: counters are compared again after the next restart of both
     for step in range(10):
         k = int(r.integers(0, 6))
         if k == 0:
             f = (r.random(n) > 0.3).astype(np.uint8)
             for b in (v, o): b.set_visibility(f)
+            stats_ok = True
         elif k == 1:
             xf = np.tile(rigid(), (n, 1))
             for ob in r.choice(n, int(r.integers(1, 3)), replace=False):
                 xf[ob] = rigid(float(r.uniform(-40, 40)), r.normal(size=3), r.uniform(-0.15, 0.15, 3), float(r.uniform(0.8, 1.2)))
             for b in (v, o): b.set_transforms(xf)
+            stats_ok = True
         elif k == 2 and n < 10:
             src = int(r.integers(3, 7))
             args = one_object(sc, src) + (rigid(float(r.uniform(0, 90)), (0, 0, 1), r.uniform(-0.2, 0.2, 3), 0.5),)
             assert v.add_object(*args) == o.add_object(*args) == n
             n += 1
+            stats_ok = True
         elif k == 3:
-            on = bool(r.integers(0, 2))
-            for b in (v, o): b.set_adaptive(on, 4)
-        elif k == 4:
+            adaptive = bool(r.integers(0, 2))
+            for b in (v, o): b.set_adaptive(adaptive, 4)
+            stats_ok = True
+        elif k == 4 and not adaptive:                       # (a checkpoint does not carry the adaptive sampler's second moments: refused there)
             v.render(2); o.render(2)
             rgba, done = v.save_accum()
             v.reset(); v.load_accum(rgba, done)
-        same(v, o, int(r.integers(1, 4)))
+            stats_ok = False
+        same(v, o, int(r.integers(1, 4)), stats=stats_ok)

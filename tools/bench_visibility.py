@@ -39,6 +39,9 @@ for G in Gs:
     victim = (nO // 2)                                                      # the object in the middle of the cloud
     t0 = time.perf_counter(); v = View(0).load_scene(two); v.sync(); t_build = time.perf_counter() - t0
     v.render(1); v.sync()
+    lone = []
+    for _ in range(8):                                                       # the lone frame of the untouched scene, for scale
+        v.reset(); v.sync(); t0 = time.perf_counter(); v.Redraw(); v.sync(); lone.append(time.perf_counter() - t0)
     vis = np.ones(nO, np.uint8)
     calls = {"hide": [], "show": []}; dev = {"hide": [], "show": []}; frame = {"hide": [], "show": []}
     for rep in range(6):
@@ -63,7 +66,10 @@ for G in Gs:
     t0 = time.perf_counter(); w.add_object(two.pos[vid], two.nrm[vid], tri1, I12); t1 = time.perf_counter(); w.sync(); t2 = time.perf_counter()
     r_added = rate(w)
     med = lambda a: round(float(np.median(a)) * 1e3, 3)
-    print(json.dumps({"objects": nO, "triangles_of_the_object": int((~keep).sum()), "scene_hand_over_and_build_s": round(t_build, 3),
+    lone_hidden = []
+    for _ in range(8):
+        v.reset(); v.sync(); t0 = time.perf_counter(); v.Redraw(); v.sync(); lone_hidden.append(time.perf_counter() - t0)
+    print(json.dumps({"objects": nO, "lone_frame_ms_untouched": round(float(np.median(lone[1:])) * 1e3, 3), "lone_frame_ms_with_the_object_hidden": round(float(np.median(lone_hidden[1:])) * 1e3, 3), "triangles_of_the_object": int((~keep).sum()), "scene_hand_over_and_build_s": round(t_build, 3),
                       "rebuild_without_the_object_s": round(t_rebuild, 3),
                       "hide_call_ms": med(calls["hide"]), "show_call_ms": med(calls["show"]),
                       "hide_until_on_device_ms": med(dev["hide"]), "show_until_on_device_ms": med(dev["show"]),

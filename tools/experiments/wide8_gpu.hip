@@ -12,6 +12,11 @@
 // Children of a node: inner children first (consecutive node indices), then leaves (consecutive leaf-order triangles), one
 // triangle per leaf -- the product's implicit references.  Child order: sorted by entry distance (4: 5-comparator network,
 // 8: 19-comparator network), or for W=8 optionally octant-ordered slots walked without a sort (mode "oct").
+// Round 6 (round-5 verdict, item 2): MODE 4 / 5 of the 4-wide walk -- the child planes as FP8 (E4M3) numbers converted TWO per instruction
+// (v_cvt_pk_f32_fp8) instead of bytes converted one at a time (v_cvt_f32_ubyteN): 12 converts per visit instead of 24.  MODE 5: both planes as offsets from the
+// node's minimum corner (lower planes rounded down, upper planes rounded up to the next E4M3 number); MODE 4: corner-relative -- lower planes from the minimum
+// corner, upper planes from the MAXIMUM corner, both rounded down, so that the planes near either corner are exact (tools/experiments/fp8_planes_visits.py is
+// the CPU estimate of this variant; it needs the maximum corner in the node's fourth quarter: 64 B fetched per visit instead of 48).
 // The program checks that both widths return bit-identical hit distances for every ray, then prints rate, visits per ray and
 // (under rocprofv3 --pmc FETCH_SIZE) lets the memory-side bytes be read per kernel name.
 #include <hip/hip_runtime.h>
@@ -208,6 +213,16 @@ __device__ __forceinline__ void st_stream(float4* p, float4 v) { const f32x4 w =
 __device__ __forceinline__ float inv_dir(float d) { return 1.0f / (fabsf(d) < kDirEps ? (d < 0.f ? -kDirEps : kDirEps) : d); }
 #define CE(a, b) { const uint32_t lo_ = min(a, b); const uint32_t hi_ = max(a, b); a = lo_; b = hi_; }
 
+// what the hardware makes of the 256 FP8 codes (gfx950: OCP E4M3): the host encoder rounds against THIS table, so it is right whatever the format is
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__global__ void k_fp8_table(float* out)
+{
+  const uint32_t c = threadIdx.x;                              // 256 threads
+  const f32x2_t v = __builtin_amdgcn_cvt_pk_f32_fp8((int)(c | (c << 8)), false);
+  out[c] = v.x;
+}
+
+// MODE 4 / 5 (W = 4 only): FP8 planes, two per convert (see the head of the file);
 // MODE 0: W children sorted by entry distance;  MODE 1 (W = 8 only): octant slots, walked in order of (slot ^ ray octant), no sort;
 // MODE 2 (W = 4 only): MODE 0 on the treelet-pair numbering of collapse4_pairs
 template <int W, int MODE, bool COUNT, int LDS_STACK>
@@ -283,7 +298,55 @@ __global__ __launch_bounds__(kBlock) void k_trace(const float4* __restrict__ nod
         const int bits = max(__float_as_int(tmin), 0);                                                     \
         key[K] = ((VALID) && tmin <= tmx) ? (((uint32_t)bits & ~(uint32_t)(KEYBITS)) | (uint32_t)(K)) : 0xFFFFFFFFu; \
       }
-      if constexpr (W == 4) {
+      if constexpr (W == 4 && (MODE == 4 || MODE == 5)) {
+        // node: {origin | exponents, counts}, {x01 x23 y01 y23}, {z01 z23 child_base leaf_base}, MODE 4: {maximum corner | -}; a plane word holds
+        // [lo_k, hi_k, lo_k+1, hi_k+1] as FP8 codes.  A ray that runs DOWN an axis swaps the bytes of every half word (one v_perm_b32 per word, where the byte
+        // walk has one v_cndmask per word), so that a half word is always {near plane, far plane} and one packed convert feeds one packed fma.
+        const float4 n1 = np[1], n2 = np[2];
+        const uint32_t ni = (ew >> 24) & 7u, nch = (ew >> 28) & 7u;
+        const uint32_t base_inner = __float_as_uint(n2.z), base_leaf = __float_as_uint(n2.w) - ni;
+        const uint32_t px = sx ? 0x02030001u : 0x03020100u, py = sy ? 0x02030001u : 0x03020100u, pz = sz ? 0x02030001u : 0x03020100u;
+        const uint32_t wx0 = __builtin_amdgcn_perm(0u, __float_as_uint(n1.x), px), wx1 = __builtin_amdgcn_perm(0u, __float_as_uint(n1.y), px);
+        const uint32_t wy0 = __builtin_amdgcn_perm(0u, __float_as_uint(n1.z), py), wy1 = __builtin_amdgcn_perm(0u, __float_as_uint(n1.w), py);
+        const uint32_t wz0 = __builtin_amdgcn_perm(0u, __float_as_uint(n2.x), pz), wz1 = __builtin_amdgcn_perm(0u, __float_as_uint(n2.y), pz);
+        f32x2 Ax, Ay, Az, Bx, By, Bz;
+        if constexpr (MODE == 5) { Ax = ax2; Ay = ay2; Az = az2; Bx = bx2; By = by2; Bz = bz2; }
+        else {
+          const float4 n3 = np[3];
+          const float elx = ddx * ix, ely = ddy * iy, elz = ddz * iz, ehx = (n3.x - ox) * ix, ehy = (n3.y - oy) * iy, ehz = (n3.z - oz) * iz;
+          // up an axis: {lower offset * A + entry at the minimum corner, upper offset * (-A) + exit at the maximum corner}; down an axis the pair is
+          // {upper offset, lower offset}: {upper * (-A) + entry at the maximum corner, lower * A + exit at the minimum corner} -- A < 0 there
+          Ax = sx ? (f32x2){-ax, ax} : (f32x2){ax, -ax}; Ay = sy ? (f32x2){-ay, ay} : (f32x2){ay, -ay}; Az = sz ? (f32x2){-az, az} : (f32x2){az, -az};
+          Bx = sx ? (f32x2){ehx - gx, elx + gx} : (f32x2){elx - gx, ehx + gx};
+          By = sy ? (f32x2){ehy - gy, ely + gy} : (f32x2){ely - gy, ehy + gy};
+          Bz = sz ? (f32x2){ehz - gz, elz + gz} : (f32x2){elz - gz, ehz + gz};
+        }
+        uint32_t key[4];
+#define CHILDP(K, WX, WY, WZ)                                                                               \
+        {                                                                                                   \
+          const f32x2 tx = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)(WX), ((K) & 1) != 0), Ax, Bx); \
+          const f32x2 ty = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)(WY), ((K) & 1) != 0), Ay, By); \
+          const f32x2 tz = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_fp8((int)(WZ), ((K) & 1) != 0), Az, Bz); \
+          const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);                                   \
+          const float tmx = fminf(fminf(fminf(tx.y, ty.y), tz.y), best);                                   \
+          const int bits = max(__float_as_int(tmin), 0);                                                   \
+          key[K] = (((uint32_t)(K) < nch) && tmin <= tmx) ? (((uint32_t)bits & ~3u) | (uint32_t)(K)) : 0xFFFFFFFFu; \
+        }
+        CHILDP(0, wx0, wy0, wz0) CHILDP(1, wx0, wy0, wz0) CHILDP(2, wx1, wy1, wz1) CHILDP(3, wx1, wy1, wz1)
+#undef CHILDP
+        CE(key[0], key[1]) CE(key[2], key[3]) CE(key[0], key[2]) CE(key[1], key[3]) CE(key[1], key[2])
+#define REF(KEY) (((((KEY) & 3u) < ni) ? base_inner : base_leaf) + ((KEY) & 3u))
+        const uint32_t r0 = REF(key[0]), r1 = REF(key[1]), r2 = REF(key[2]), r3 = REF(key[3]);
+#undef REF
+        const int nh = 4 + ((((int)key[0] >> 31) + ((int)key[1] >> 31)) + (((int)key[2] >> 31) + ((int)key[3] >> 31)));
+        if (__builtin_expect(sp <= LDS_STACK - 3, 1)) {
+          uint32_t* top = lds + sp * kBlock;
+          const int p1 = max(nh, 2) - 2, p2 = (nh == 3) ? 0 : 1, p3 = (nh == 4) ? 0 : 2;
+          top[p3 * kBlock] = r3; top[p2 * kBlock] = r2; top[p1 * kBlock] = r1;
+          sp += max(nh, 1) - 1;
+        } else { if (nh == 4) push(r3); if (nh >= 3) push(r2); if (nh >= 2) push(r1); }
+        if (nh >= 1) cur = r0; else pop();
+      } else if constexpr (W == 4) {
         const float4 n1 = deep ? ld_stream(np + 1) : np[1], n2 = deep ? ld_stream(np + 2) : np[2];
         const uint32_t ni = (ew >> 24) & 7u, nch = (ew >> 28) & 7u;
         const uint32_t fav = (ew >> 27) & 1u;                                     // MODE 2: slot 0 lives in the other half of this node's line
@@ -396,6 +459,45 @@ __global__ __launch_bounds__(kBlock) void k_trace(const float4* __restrict__ nod
 }
 
 
+// the 4-wide byte-plane tree with its planes re-coded as FP8 (decode table `tab` read from the device): corner = true -> MODE 4, false -> MODE 5
+static Wide to_fp8(const Wide& w4, const float* tab, bool corner, double* grow_out)
+{
+  // every finite non-negative code, ascending by value
+  std::vector<std::pair<float, uint32_t>> codes;
+  for (uint32_t c = 0; c < 128; ++c) if (std::isfinite(tab[c]) && tab[c] >= 0.f) codes.push_back({tab[c], c});
+  std::sort(codes.begin(), codes.end());
+  auto enc_floor = [&](float x) { uint32_t best = codes[0].second; for (auto& pc : codes) { if (pc.first <= x) best = pc.second; else break; } return best; };
+  auto enc_ceil = [&](float x) { for (auto& pc : codes) if (pc.first >= x) return pc.second; fprintf(stderr, "fp8: %g has no code above it\n", x); exit(1); return 0u; };
+  Wide out = w4;
+  double grow = 0; uint64_t boxes = 0;
+  for (uint32_t i = 0; i < w4.n_nodes; ++i) {
+    const uint32_t* o = &w4.words[(size_t)i * 16]; uint32_t* q = &out.words[(size_t)i * 16];
+    const uint32_t ns = (o[3] >> 28) & 7u;
+    if (ns == 0) continue;
+    float org[3]; memcpy(org, o, 12);
+    uint32_t planes[6] = {0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < 3; ++a) {
+      const float step = crh_quant_step((o[3] >> (8 * a)) & 0xffu);
+      uint32_t ext = 0; for (uint32_t k = 0; k < ns; ++k) ext = std::max(ext, (o[7 + a] >> (8 * k)) & 0xffu);
+      if (corner) { float hc = org[a] + (float)ext * step; q[12 + a] = __builtin_bit_cast(uint32_t, hc); }
+      for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t cl = 0, ch = 0;
+        if (k < ns) {
+          const uint32_t ql = (o[4 + a] >> (8 * k)) & 0xffu, qh = (o[7 + a] >> (8 * k)) & 0xffu;
+          cl = enc_floor((float)ql);
+          ch = corner ? enc_floor((float)(ext - qh)) : enc_ceil((float)qh);
+          const float lo = tab[cl], hi = corner ? (float)ext - tab[ch] : tab[ch];
+          if (qh > ql) { grow += (double)(hi - lo) / (double)(qh - ql); ++boxes; }
+        }
+        planes[2 * a + (k >> 1)] |= (cl | (ch << 8)) << (16 * (k & 1));
+      }
+    }
+    for (int w = 0; w < 6; ++w) q[4 + w] = planes[w];
+  }
+  if (grow_out) *grow_out = boxes ? grow / (double)boxes : 0.0;
+  return out;
+}
+
 // bounds of (triangle ∩ box): Sutherland-Hodgman against the six planes (double precision; experiment only)
 static bool clip_bounds(const float* tri, const float* blo, const float* bhi, float* olo, float* ohi)
 {
@@ -442,7 +544,7 @@ static void run(const char* name, const Wide& wd, const float4* d_tris, const fl
   k_trace<W, MODE, true, LDS_STACK><<<grid, kBlock>>>(d_nodes, d_tris, d_rays, d_hits, d_cursor, n_rays, gbox, d_cnt);
   unsigned long long cnt[2]; HIPCHECK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
   const double avg = sum_ms / reps, vis = (double)cnt[0] / n_rays, tr = (double)cnt[1] / n_rays;
-  const double node_b = W == 4 ? 48.0 : 72.0, line_b = W == 4 ? 64.0 : 128.0;
+  const double node_b = W == 4 ? (MODE == 4 ? 64.0 : 48.0) : 72.0, line_b = W == 4 ? 64.0 : 128.0;
   printf("%-34s nodes %9u (%.1f MB, fill %.2f/%d)  occupancy %d WG/CU (max %d)  avg %.3f ms  best %.3f ms  %.0f Mrays/s  visits/ray %.2f  tris/ray %.2f  hit %.3f  "
          "fetched B/ray %.0f  sectors B/ray %.0f\n", name, wd.n_nodes, wd.words.size() * 4 / 1e6, wd.fill, W, wg_per_cu, per_cu, avg, best_ms, n_rays / avg * 1e-3, vis, tr,
          (double)nhit / n_rays, vis * node_b + tr * 48.0 + 48.0, vis * line_b + tr * 64.0 + 48.0);
@@ -499,6 +601,23 @@ int main(int argc, char** argv)
   printf("%u triangles, %u rays (origin on a random triangle, random direction)\n", n, n_rays);
   std::vector<float> t4, t8, t8o;
   float4* d_t = upload_tris(w4);  run<4, 0, 16>("4-wide 64-B node, sorted", w4, d_t, d_rays, n_rays, gbox, waves4, t4); HIPCHECK(hipFree(d_t));
+  {
+    float* d_tab; float tab[256]; HIPCHECK(hipMalloc(&d_tab, 1024)); k_fp8_table<<<1, 256>>>(d_tab); HIPCHECK(hipMemcpy(tab, d_tab, 1024, hipMemcpyDeviceToHost)); HIPCHECK(hipFree(d_tab));
+    printf("FP8 decode as this GPU does it: code 0x08 -> %g, 0x38 -> %g, 0x40 -> %g, 0x78 -> %g, largest finite %g\n", tab[0x08], tab[0x38], tab[0x40], tab[0x78],
+           *std::max_element(tab, tab + 128, [](float a, float b) { return (std::isfinite(a) ? a : -1.f) < (std::isfinite(b) ? b : -1.f); }));
+    double g5 = 0, g4 = 0;
+    const Wide w5 = to_fp8(w4, tab, false, &g5), w4c = to_fp8(w4, tab, true, &g4);
+    printf("mean child-box edge against the byte planes: FP8 from the minimum corner x %.4f, corner-relative x %.4f\n", g5, g4);
+    std::vector<float> t5, t4c;
+    d_t = upload_tris(w5);  run<4, 5, 16>("4-wide, FP8 planes (min corner)", w5, d_t, d_rays, n_rays, gbox, waves4, t5); HIPCHECK(hipFree(d_t));
+    d_t = upload_tris(w4c); run<4, 4, 16>("4-wide, FP8 planes (corner-relative)", w4c, d_t, d_rays, n_rays, gbox, waves4, t4c); HIPCHECK(hipFree(d_t));
+    uint64_t b5 = 0, b4 = 0; for (uint32_t i = 0; i < n_rays; ++i) { b5 += memcmp(&t4[i], &t5[i], 4) != 0; b4 += memcmp(&t4[i], &t4c[i], 4) != 0; }
+    printf("hit distances differing from the byte-plane walk: FP8 min-corner %llu, FP8 corner-relative %llu\n", (unsigned long long)b5, (unsigned long long)b4);
+    if (b5 || b4) return 2;
+    // the same walk on the byte planes once more, so that drift between the first and the last measurement of this process shows
+    std::vector<float> t4b; d_t = upload_tris(w4); run<4, 0, 16>("4-wide 64-B node, sorted (again)", w4, d_t, d_rays, n_rays, gbox, waves4, t4b); HIPCHECK(hipFree(d_t));
+  }
+  if (getenv("WIDE8_ONLY_FP8")) return 0;
   d_t = upload_tris(w8);          run<8, 0, 24>("8-wide 128-B node, sorted", w8, d_t, d_rays, n_rays, gbox, waves8, t8); HIPCHECK(hipFree(d_t));
   d_t = upload_tris(w8o);         run<8, 1, 24>("8-wide 128-B node, octant order", w8o, d_t, d_rays, n_rays, gbox, waves8, t8o); HIPCHECK(hipFree(d_t));
   if (presplit > 0) {
