@@ -136,6 +136,7 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
     if (n == 0u) return;
     const bool mine = lane < n;
 #if CRH_FRAME_STATS
+    const unsigned long long fs_t0 = (unsigned long long)clock64();
     if (lane == 0) { atomicAdd(&g_frame_stats[7], 1ull); atomicAdd(&g_frame_stats[8], (unsigned long long)n); }
 #endif
     uint32_t pos = 0;
@@ -143,6 +144,15 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");          // the hit record and the path state were written by another wavefront of this workgroup
     bool cont = false, shadow = false;
     float4 n_o = zero4, n_d = zero4, n_t = zero4, s_o = zero4, s_d = zero4, s_c = zero4;
+#if CRH_FRAME_STATS
+    {   // lanes of the batch in its largest class: miss (environment) / material 0 / material 1 / any other material
+      int cls = -1;
+      if (mine) { const int hk = __float_as_int(P.hit[pos].w); cls = hk < 0 ? 0 : 1 + min(__float_as_int(S.shade[4u * (uint32_t)hk].w), 2); }
+      uint32_t big = 0;
+      for (int c = 0; c < 4; ++c) big = max(big, (uint32_t)__popcll(__ballot(cls == c)));
+      if (lane == 0) atomicAdd(&g_frame_stats[15], (unsigned long long)big);
+    }
+#endif
     if (mine) {
       const float4 o4 = ray_o[pos], d4 = ray_d[pos], h = P.hit[pos];
       const uint32_t dw = __float_as_uint(d4.w), bounce = dw >> kFrameBounceShift;
@@ -160,9 +170,15 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
     ring_push(s_rq, rq_tail, cont && !shadow, pos);
     wave_sub(live, mine && !cont && !shadow);                        // the path ends here
     n_any += (uint32_t)__popcll(__ballot(shadow)); n_near += (uint32_t)__popcll(__ballot(cont));
+#if CRH_FRAME_STATS
+    if (lane == 0) atomicAdd(&g_frame_stats[21], (unsigned long long)clock64() - fs_t0);
+#endif
   };
 
   auto generate = [&]() -> bool {
+#if CRH_FRAME_STATS
+    const unsigned long long fs_t0 = (unsigned long long)clock64();
+#endif
     uint32_t ok = 0, cbase = 0;
     if (lane == 0 && load_u(cursor_out) == 0u) {
       const uint32_t before = atomicAdd(live, A.gen_chunk);             // counted BEFORE the slots are claimed: nobody sees "no paths, no slots" in between
@@ -194,6 +210,9 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
     }
     if (lane == 0 && made != A.gen_chunk) atomicSub(live, A.gen_chunk - made);      // slots past the end or outside the image (edge tiles are partial)
     n_near += made;
+#if CRH_FRAME_STATS
+    if (lane == 0) atomicAdd(&g_frame_stats[22], (unsigned long long)clock64() - fs_t0);
+#endif
     return true;
   };
 
@@ -235,6 +254,9 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
       });
   };
 
+#if CRH_FRAME_STATS
+  const unsigned long long fs_start = (unsigned long long)clock64();
+#endif
   for (;;) {
     const uint32_t nr = ring_count(rq_head, rq_tail), ns = ring_count(sq_head, sq_tail);
     // one call site per stage (each is a few thousand instructions, inlined): decide first, then act
@@ -258,6 +280,9 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
 #endif
     __builtin_amdgcn_s_sleep(4);
   }
+#if CRH_FRAME_STATS
+  if (lane == 0) atomicAdd(&g_frame_stats[feeder ? 25 : 24], (unsigned long long)clock64() - fs_start);      // wave cycles from start to leaving the loop
+#endif
   if (lane == 0) {
     if (n_near) atomicAdd(&C->rays_nearest, (unsigned long long)n_near);
     if (n_any) atomicAdd(&C->rays_any, (unsigned long long)n_any);

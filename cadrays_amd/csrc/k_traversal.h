@@ -22,7 +22,7 @@
 #define CRH_FRAME_STATS 0      // 1: an instrumented build (tools/ab_build.sh): the frame kernel's engine counts its turns, active rays, dry turns and step executions
 #endif
 #if CRH_FRAME_STATS
-__device__ unsigned long long g_frame_stats[16];
+__device__ unsigned long long g_frame_stats[32];      // tools/frame_stats.py names the entries
 #endif
 #ifndef CRH_EXP_EARLY_TRI
 #define CRH_EXP_EARLY_TRI 0     // hunt scaffold only (tests/hunts/two_level_anyhit_counting.py)
@@ -186,7 +186,12 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   bool exhausted = false;
 
 #if CRH_FRAME_STATS
-  uint32_t fs_turns = 0, fs_have = 0, fs_dry = 0, fs_inner_w = 0, fs_tri_w = 0, fs_don = 0;
+  uint32_t fs_turns = 0, fs_have = 0, fs_dry = 0, fs_inner_w = 0, fs_tri_w = 0, fs_don = 0, fs_store_w = 0, fs_fin = 0;
+  unsigned long long fc_refill = 0, fc_don = 0, fc_inner = 0, fc_leaf = 0, fc_retire = 0, fc_mark = 0;      // wave cycles by phase (s_memtime at the phase borders)
+#define CRH_FS_MARK(ACC) if (FRM) { const unsigned long long now_ = (unsigned long long)clock64(); ACC += now_ - fc_mark; fc_mark = now_; }
+  if (FRM) fc_mark = (unsigned long long)clock64();
+#else
+#define CRH_FS_MARK(ACC)
 #endif
   for (;;) {
     // ------------------------------------------------------------------ refill idle lanes
@@ -244,6 +249,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
 #if CRH_FRAME_STATS
     if (FRM) { ++fs_turns; fs_have += (uint32_t)__popcll(__ballot(have)); fs_dry += exhausted ? 1u : 0u; }
 #endif
+    CRH_FS_MARK(fc_refill)
 
     if (DON && (exhausted || thin)) {
       // ---------------------------------------------------------------- donation: bottom stack entries -> idle lanes
@@ -300,6 +306,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       }
     }
 
+    CRH_FS_MARK(fc_don)
     auto read_top = [&]() {
       --sp;
       if (__builtin_expect(sp < kLdsStack, 1)) cur = lds[sp * kBlock];
@@ -320,6 +327,9 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float4* np = nodes + (uint32_t)(CRH_NODE_DWORDS / 4) * cur;
       const float4 n0 = np[0], n1 = np[1], n2 = np[2];
       if (COUNT || (FRM && CRH_FRAME_STATS)) ++n_nodes;
+#if CRH_FRAME_STATS
+      if (FRM && lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) ++fs_inner_w;      // once per execution by the wavefront (the lanes in it: n_nodes)
+#endif
       // per-node grid: face t = fma(q, step * inv_d, fma(origin - o, inv_d, -+ guard)).  The difference is taken BEFORE the
       // multiplication: fma(origin, inv_d, -o * inv_d) cancels catastrophically when |o * inv_d| >> t (a ray grazing a box
       // corner was culled by 2e-5 of t); the guard is the per-ray constant above.
@@ -441,6 +451,9 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       const float4 a = tp[0], b = tp[1], c = tp[2];
 #endif
       if (COUNT || (FRM && CRH_FRAME_STATS)) ++n_tris;
+#if CRH_FRAME_STATS
+      if (FRM && lane == (uint32_t)__ffsll((long long)__ballot(true)) - 1u) ++fs_tri_w;
+#endif
       // record = {v0 | n.x}, {e0 = v1 - v0 | n.y}, {e1 = v0 - v2 | n.z}: the two edges and n = e1 x e0 are evaluated ONCE per triangle on the host
       // with the inline arithmetic this function used to apply per test (crh_sub3 / crh_cross3, same bits) -- 15 VALU instructions per test
       // fewer in a kernel that runs at the VALU issue limit
@@ -470,6 +483,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
 #if CRH_EXP_EARLY_TRI
     if (early && have && (cur & kQLeafBit) && cur != kDone && (cur & 0xF0000000u) != CRH_REF_INSTANCE_TAG) pre_a = tris[kTriStride * (cur & 0x0FFFFFFFu)];
 #endif
+    CRH_FS_MARK(fc_inner)
     // ------------------------------------------------------------------ (B) the leaf in hand
     if (TWO && have && (cur & 0xF0000000u) == CRH_REF_INSTANCE_TAG && cur < CRH_REF_SENTINEL) {
       // top-level leaf: enter the object (ray := M^-1 ray), mark the stack, continue at the object's root
@@ -491,7 +505,11 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       pop();
     }
 
+    CRH_FS_MARK(fc_leaf)
     // ------------------------------------------------------------------ (C) retire finished rays
+#if CRH_FRAME_STATS
+    if (FRM) { const unsigned long long fm_ = __ballot(have && cur == kDone); if (fm_ != 0ull) { ++fs_store_w; fs_fin += (uint32_t)__popcll(fm_); } }
+#endif
     if (DON) {
       // own part walked and no successor left: fold what was absorbed behind the own hit (left-biased minimum: a later part
       // wins only with a strictly smaller t); helpers then wait to be absorbed by their predecessor, the head stores
@@ -546,6 +564,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         }
       }
     } else { if (have && cur == kDone) { store(tag, hit, found); have = false; } }
+    CRH_FS_MARK(fc_retire)
   }
 #undef CRH_ISANY
 #if CRH_FRAME_STATS
@@ -555,9 +574,15 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       atomicAdd(&g_frame_stats[0], (unsigned long long)fs_turns); atomicAdd(&g_frame_stats[1], (unsigned long long)fs_have); atomicAdd(&g_frame_stats[2], (unsigned long long)fs_dry);
       atomicAdd(&g_frame_stats[3], (unsigned long long)li); atomicAdd(&g_frame_stats[4], (unsigned long long)lt); atomicAdd(&g_frame_stats[5], (unsigned long long)fs_don);
       atomicAdd(&g_frame_stats[6], 1ull);
+      atomicAdd(&g_frame_stats[13], (unsigned long long)fs_store_w); atomicAdd(&g_frame_stats[14], (unsigned long long)fs_fin);
+      atomicAdd(&g_frame_stats[16], fc_refill); atomicAdd(&g_frame_stats[17], fc_don); atomicAdd(&g_frame_stats[18], fc_inner); atomicAdd(&g_frame_stats[19], fc_leaf);
+      atomicAdd(&g_frame_stats[20], fc_retire);
     }
+    const uint32_t wi = wave_sum(fs_inner_w), wt = wave_sum(fs_tri_w);
+    if (lane == 0) { atomicAdd(&g_frame_stats[11], (unsigned long long)wi); atomicAdd(&g_frame_stats[12], (unsigned long long)wt); }
   }
 #endif
+#undef CRH_FS_MARK
 }
 
 // P2: the SECOND pass of a split scene (static tree + moved objects).  The first pass is the single-level instantiation over the

@@ -144,10 +144,10 @@ namespace crh {
 #if CRH_FRAME_STATS
 }  // namespace crh
 // instrumented builds only (tools/ab_build.sh NAME "-DCRH_FRAME_STATS=1"): what the frame kernel's engines counted since the last call
-extern "C" __attribute__((visibility("default"))) int crh_exp_frame_stats(unsigned long long* out16)
+extern "C" __attribute__((visibility("default"))) int crh_exp_frame_stats(unsigned long long* out32)
 {
-  unsigned long long zero[16] = {0};
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(crh::g_frame_stats), sizeof zero) != hipSuccess) return -1;
+  unsigned long long zero[32] = {0};
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(crh::g_frame_stats), sizeof zero) != hipSuccess) return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(crh::g_frame_stats), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 namespace crh {

@@ -64,6 +64,7 @@ for G in Gs:
     t = two.tri[~keep]; vid, inv = np.unique(t[:, :3], return_inverse=True)
     tri1 = np.concatenate([inv.reshape(-1, 3).astype(np.int32), t[:, 3:4]], 1)
     t0 = time.perf_counter(); w.add_object(two.pos[vid], two.nrm[vid], tri1, I12); t1 = time.perf_counter(); w.sync(); t2 = time.perf_counter()
+    add_call_ms, add_dev_ms = (t1 - t0) * 1e3, (t2 - t0) * 1e3
     r_added = rate(w)
     med = lambda a: round(float(np.median(a)) * 1e3, 3)
     lone_hidden = []
@@ -76,6 +77,6 @@ for G in Gs:
                       "hide_plus_first_frame_ms": med(frame["hide"]), "show_plus_first_frame_ms": med(frame["show"]),
                       "mrays_hidden": round(r_hidden, 1), "mrays_rebuilt_without_it": round(r_rebuilt, 1), "hidden_over_rebuilt": round(r_hidden / r_rebuilt, 4),
                       "image_bit_identical_to_rebuilt": same,
-                      "add_object_call_ms": round((t1 - t0) * 1e3, 2), "add_object_until_on_device_ms": round((t2 - t0) * 1e3, 2),
+                      "add_object_call_ms": round(add_call_ms, 2), "add_object_until_on_device_ms": round(add_dev_ms, 2),
                       "mrays_with_added_instance": round(r_added, 1)}), flush=True)
     v.close(); w.close()
