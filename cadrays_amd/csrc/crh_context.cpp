@@ -10,6 +10,20 @@ namespace api {
 
 int fail(crh_ctx* c, int code, const char* msg) { if (c) c->err = msg; return code; }
 
+// The device error word (d_api_cursor[8]): raised by a frame-kernel workgroup whose spin loop gave up (k_frame.h, kFrameSpinLimit) -- never in a healthy run.
+// Read where the host has just synchronised anyway (crh_sync, crh_get_stats, the synchronous read-backs): one 4-byte copy.
+int check_device_error(crh_ctx* c)
+{
+  uint32_t e = 0;
+  if (!c->d_api_cursor || hipMemcpyAsync(&e, c->d_api_cursor + 8, sizeof e, hipMemcpyDeviceToHost, cstream(c)) != hipSuccess || hipStreamSynchronize(cstream(c)) != hipSuccess) return CRH_OK;
+  if (e == 0u) return CRH_OK;
+  hipMemsetAsync(c->d_api_cursor + 8, 0, sizeof e, cstream(c));
+  char b[160]; snprintf(b, sizeof b, "frame kernel gave up: a workgroup's %s%s%sloop did not end (code %u); the frame is incomplete -- crh_reset and render again",
+                        (e & 1u) ? "ring-take " : "", (e & 2u) ? "ring-push " : "", (e & 4u) ? "idle " : "", e);
+  c->err = b;
+  return CRH_E_DEVICE;
+}
+
 // The boundary takes finite numbers only (coordinates additionally |x| <= 1e30, so that box centres and extents stay finite):
 // NaN / Inf would otherwise reach the BVH builder's binning and the kernels' float -> int conversions.
 bool all_finite(const float* v, size_t n, float limit)
@@ -155,13 +169,13 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_PIPELINE",           "0: free-running Redraw()s are not pipelined across streams (reference schedule of the sequence tests)"},
   {"CRH_PIPE_DEPTH",         "frames in flight of free-running Redraw()s, 2 .. 8; the same knob as crh_set_pipeline_depth (crh_query_pipeline_capacity says what the process supports)"},
   {"CRH_FRAME_KERNEL",       "0: small batches take the staged small-batch schedule (one launch per stage and bounce) instead of the frame kernel (reference schedule of the sequence tests)"},
-  {"CRH_FRAME_LIVE",         "frame kernel: paths a workgroup keeps alive at most, 64 .. 1024 (default 512)"},
+  {"CRH_FRAME_LIVE",         "frame kernel: paths a workgroup (16 wavefronts, one per compute unit) keeps alive at most, 64 .. 16384, cut to the ring size 4096 (default 4096)"},
   {"CRH_FRAME_CHUNK",        "frame kernel: path slots a wavefront claims at a time, multiples of 64 up to 1024 (default 256)"},
-  {"CRH_FRAME_LOW",          "frame kernel: the feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring (default 128)"},
+  {"CRH_FRAME_LOW",          "frame kernel: a feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring (default 512)"},
   {"CRH_FRAME_FEED",         "frame kernel: wavefronts of a workgroup that only shade and generate, 0 .. 15 (default 3 of 16)"},
-  {"CRH_FRAME_STARVE",       "frame kernel: a feeder shades fewer than 64 waiting hits only while fewer rays than this wait in the ring"},
+  {"CRH_FRAME_STARVE",       "frame kernel: a feeder shades fewer than 64 waiting hits only while fewer rays than this wait in the ring (default 2^20: always)"},
   {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 0: every tracer takes what is there)"},
-  {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident, 4 per CU)"},
+  {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident = ONE 1024-thread workgroup per compute unit); never fewer than min(resident, 32), never more than resident"},
   {"CRH_FRAME_PIPE",         "frame pipeline: a frame takes the frame kernel while fewer than this many frames are running, and at most this many frame kernels run at a time, 1 .. 8 (default 2)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
   {"CRH_SPLIT_PASSES",       "split scenes (static tree + moved objects): 0 one walk in the two-level kernels, 1 two traversal passes, unset: by the number of moved objects"},
@@ -217,7 +231,7 @@ crh_ctx* crh_create(int device_ordinal)
   crh_ctx* c = new crh_ctx();
   c->device = device_ordinal;
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&c->d_counters_ring, 4 * sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemsetAsync(c->d_counters_ring, 0, 4 * sizeof(DCounters), cstream(c)) != hipSuccess ||
+      hipMalloc((void**)&c->d_counters_ring, 4 * sizeof(DCounters)) != hipSuccess || hipMalloc((void**)&c->d_api_cursor, 64) != hipSuccess || hipMemsetAsync(c->d_counters_ring, 0, 4 * sizeof(DCounters), cstream(c)) != hipSuccess || hipMemsetAsync(c->d_api_cursor, 0, 64, cstream(c)) != hipSuccess ||
       hipStreamSynchronize(cstream(c)) != hipSuccess) {
     fprintf(stderr, "crh_create: HIP initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
     delete c; return nullptr;
@@ -266,7 +280,7 @@ const char* crh_last_error(crh_ctx* c) { return c ? c->err.c_str() : "null conte
 
 int crh_reset(crh_ctx* c) { if (!c) return CRH_E_INVALID; return do_reset(c); }
 
-int crh_sync(crh_ctx* c) { if (!c) return CRH_E_INVALID; c->read_since_render = true; CRH_HIP(hipSetDevice(c->device)); CRH_HIP(hipStreamSynchronize(cstream(c))); return CRH_OK; }
+int crh_sync(crh_ctx* c) { if (!c) return CRH_E_INVALID; c->read_since_render = true; CRH_HIP(hipSetDevice(c->device)); CRH_HIP(hipStreamSynchronize(cstream(c))); return check_device_error(c); }
 
 int crh_get_path_budget(crh_ctx* c, uint64_t* max_paths)
 {

@@ -219,6 +219,7 @@ bool all_finite(const float* v, size_t n, float limit = 3.0e38f);
 int stage_copy(crh_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t on = nullptr);
 hipEvent_t get_event(crh_ctx* c);
 void drain_events(crh_ctx* c);
+int check_device_error(crh_ctx* c);      // CRH_E_DEVICE + message if a frame-kernel workgroup gave up (crh_context.cpp)
 int trim_events(crh_ctx* c);
 void discard_events(crh_ctx* c);
 int ensure_paths(crh_ctx* c, uint32_t need);

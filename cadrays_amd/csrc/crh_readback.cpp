@@ -146,7 +146,7 @@ int crh_get_stats(crh_ctx* c, crh_stats* out)
   out->rays_nearest = h.rays_nearest; out->rays_any = h.rays_any; out->nodes_nearest = h.nodes_nearest; out->tris_nearest = h.tris_nearest;
   out->nodes_any = h.nodes_any; out->tris_any = h.tris_any; out->shaded_hits = h.shaded_hits; out->samples = h.samples;
   out->seconds = c->seconds_acc;
-  return CRH_OK;
+  return check_device_error(c);
 }
 
 int crh_get_packet_stats(crh_ctx* c, uint64_t* packet_rays, uint64_t* fallback_rays)

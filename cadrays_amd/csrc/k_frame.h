@@ -28,11 +28,19 @@ constexpr int      kFrameMats  = 32;            // materials staged in LDS (4 KB
 #endif
 constexpr int      kFrameBlock = CRH_FRAME_BLOCK;
 constexpr uint32_t frame_pow2(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
+#ifndef CRH_FRAME_MISS_RING
+#define CRH_FRAME_MISS_RING 0                   // round 6 experiment: rays that hit nothing wait in a ring of their own, so that a shading batch is either all misses (environment /
+#endif                                          // implicit light, the path ends: a few hundred instructions) or all surface hits (the BSDF code) -- profiles/r6/lone_frame.md
 #ifndef CRH_FRAME_RING_MUL
 #define CRH_FRAME_RING_MUL 4
 #endif
 constexpr uint32_t kFrameRing  = frame_pow2((uint32_t)CRH_FRAME_RING_MUL * kFrameBlock);      // entries of each ring (a power of two) = the most paths a workgroup may have alive (every live path is in at most one ring)
 
+// the three spin loops of the kernel end on two invariants (the live count never undercounts; a workgroup never holds more paths than ring entries).
+// Should a future change break one, a loop that has spun ~0.5 s (legitimate waits are microseconds) raises the workgroup's error flag: the workgroup leaves, the
+// code lands in the context's device error word (crh_sync / crh_get_stats / the read-backs report CRH_E_DEVICE "frame kernel gave up: ...") -- no hung GPU.
+constexpr uint32_t kFrameSpinLimit = 1u << 23;
+constexpr uint32_t kFrameErrTake = 1u, kFrameErrPush = 2u, kFrameErrIdle = 4u;
 struct FrameArgs {
   const uint32_t* tile_ids; uint32_t n_tiles; const uint32_t* n_tiles_dev;      // as k_raygen's
   const uint32_t* seeds; uint32_t n_samples; int seed_per_tile;
@@ -44,6 +52,7 @@ struct FrameArgs {
   uint32_t n_feed;            // wavefronts of a workgroup that only shade and generate (the last ones)
   uint32_t starve;            // a feeder shades fewer than a wavefront's worth of hits only while fewer rays than this wait in the ring (the tracers are about to starve)
   uint32_t claim_step;        // tracer wavefront w takes rays from the ring only while >= w * claim_step wait there: scarce rays go to the first wavefronts
+  uint32_t* err;              // the context's device error word (never touched in a healthy run)
 };
 
 // ---- rings: multi-producer / multi-consumer inside one workgroup.  head / tail are tickets; a slot holds kFrameEmpty until its producer has written it and is
@@ -64,14 +73,17 @@ __device__ __forceinline__ uint32_t ring_claim(uint32_t* head, uint32_t* tail, u
   base = __shfl(b, 0);
   return __shfl(n, 0);
 }
-__device__ __forceinline__ uint32_t ring_take(uint32_t* slots, uint32_t ticket)
+__device__ __forceinline__ uint32_t ring_take(uint32_t* slots, uint32_t ticket, uint32_t* wg_err)
 {
   uint32_t* p = slots + (ticket & (kFrameRing - 1u));
-  uint32_t v;
-  while ((v = atomicExch(p, kFrameEmpty)) == kFrameEmpty) __builtin_amdgcn_s_sleep(1);      // its producer holds the ticket and is about to write
+  uint32_t v, spins = 0;
+  while ((v = atomicExch(p, kFrameEmpty)) == kFrameEmpty) {                                  // its producer holds the ticket and is about to write
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins >= kFrameSpinLimit || __hip_atomic_load(wg_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { atomicOr(wg_err, kFrameErrTake); return 0u; }
+  }
   return v;
 }
-__device__ __forceinline__ void ring_push(uint32_t* slots, uint32_t* tail, bool pred, uint32_t value)      // whole wavefront
+__device__ __forceinline__ void ring_push(uint32_t* slots, uint32_t* tail, bool pred, uint32_t value, uint32_t* wg_err)      // whole wavefront
 {
   const unsigned long long m = __ballot(pred);
   if (m == 0ull) return;
@@ -81,7 +93,11 @@ __device__ __forceinline__ void ring_push(uint32_t* slots, uint32_t* tail, bool 
   base = __shfl(base, leader);
   if (pred) {
     uint32_t* p = slots + ((base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (kFrameRing - 1u));
-    while (atomicCAS(p, kFrameEmpty, value) != kFrameEmpty) __builtin_amdgcn_s_sleep(1);                  // the consumer of the entry a lap ago is about to empty it
+    uint32_t spins = 0;
+    while (atomicCAS(p, kFrameEmpty, value) != kFrameEmpty) {                                             // the consumer of the entry a lap ago is about to empty it
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins >= kFrameSpinLimit || __hip_atomic_load(wg_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) { atomicOr(wg_err, kFrameErrPush); break; }
+    }
   }
 }
 __device__ __forceinline__ uint32_t ring_count(uint32_t* head, uint32_t* tail)
@@ -103,11 +119,18 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
   __shared__ uint32_t s_bound[CRH_FRAME_DON ? kBlock : 1];
   __shared__ float4 s_mats[kFrameMats * 8];
   __shared__ uint32_t s_rq[kFrameRing], s_sq[kFrameRing];
-  __shared__ uint32_t s_ctl[8];      // [0] ray head, [1] ray tail, [2] shade head, [3] shade tail, [4] live paths, [5] the slot cursor has run out
+#if CRH_FRAME_MISS_RING
+  __shared__ uint32_t s_mq[kFrameRing];      // hit records that are misses
+#endif
+  __shared__ uint32_t s_ctl[12];     // [0] ray head, [1] ray tail, [2] shade head, [3] shade tail, [4] live paths, [5] the slot cursor has run out, [6] error, [8] miss head, [9] miss tail
   uint32_t* const rq_head = &s_ctl[0]; uint32_t* const rq_tail = &s_ctl[1]; uint32_t* const sq_head = &s_ctl[2]; uint32_t* const sq_tail = &s_ctl[3];
-  uint32_t* const live = &s_ctl[4]; uint32_t* const cursor_out = &s_ctl[5];
+  uint32_t* const live = &s_ctl[4]; uint32_t* const cursor_out = &s_ctl[5]; uint32_t* const wg_err = &s_ctl[6];      // [6]: a spin loop of this workgroup gave up
   for (uint32_t i = threadIdx.x; i < kFrameRing; i += (uint32_t)kBlock) { s_rq[i] = kFrameEmpty; s_sq[i] = kFrameEmpty; }
-  if (threadIdx.x < 8u) s_ctl[threadIdx.x] = 0u;
+#if CRH_FRAME_MISS_RING
+  for (uint32_t i = threadIdx.x; i < kFrameRing; i += (uint32_t)kBlock) s_mq[i] = kFrameEmpty;
+  uint32_t* const mq_head = &s_ctl[8]; uint32_t* const mq_tail = &s_ctl[9];
+#endif
+  if (threadIdx.x < 12u) s_ctl[threadIdx.x] = 0u;
   const bool mats_in_lds = S.n_mats <= (uint32_t)kFrameMats;
   if (mats_in_lds) for (uint32_t i = threadIdx.x; i < S.n_mats * 8u; i += (uint32_t)kBlock) s_mats[i] = S.mats[i];
   __syncthreads();
@@ -130,9 +153,15 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
   auto load_u = [](uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   auto may_generate = [&]() { return load_u(cursor_out) == 0u && load_u(live) + A.gen_chunk <= A.max_live; };
 
-  auto shade_some = [&]() {
+  auto shade_some = [&](bool misses) {
     uint32_t base = 0;
+#if CRH_FRAME_MISS_RING
+    uint32_t* const q_slots = misses ? s_mq : s_sq;
+    const uint32_t n = ring_claim(misses ? mq_head : sq_head, misses ? mq_tail : sq_tail, 64u, base);
+#else
+    uint32_t* const q_slots = s_sq; (void)misses;
     const uint32_t n = ring_claim(sq_head, sq_tail, 64u, base);
+#endif
     if (n == 0u) return;
     const bool mine = lane < n;
 #if CRH_FRAME_STATS
@@ -140,7 +169,7 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
     if (lane == 0) { atomicAdd(&g_frame_stats[7], 1ull); atomicAdd(&g_frame_stats[8], (unsigned long long)n); }
 #endif
     uint32_t pos = 0;
-    if (mine) pos = ring_take(s_sq, base + lane);
+    if (mine) pos = ring_take(q_slots, base + lane, wg_err);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");          // the hit record and the path state were written by another wavefront of this workgroup
     bool cont = false, shadow = false;
     float4 n_o = zero4, n_d = zero4, n_t = zero4, s_o = zero4, s_d = zero4, s_c = zero4;
@@ -166,8 +195,8 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
       if (shadow) { s_c.w = cont ? 1.0f : 0.f; P.sh_o[pos] = s_o; P.sh_d[pos] = s_d; P.sh_c[pos] = s_c; }      // .w: a camera-path ray waits behind this shadow ray
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    ring_push(s_rq, rq_tail, shadow, pos | kFrameAny);
-    ring_push(s_rq, rq_tail, cont && !shadow, pos);
+    ring_push(s_rq, rq_tail, shadow, pos | kFrameAny, wg_err);
+    ring_push(s_rq, rq_tail, cont && !shadow, pos, wg_err);
     wave_sub(live, mine && !cont && !shadow);                        // the path ends here
     n_any += (uint32_t)__popcll(__ballot(shadow)); n_near += (uint32_t)__popcll(__ballot(cont));
 #if CRH_FRAME_STATS
@@ -205,7 +234,7 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
         ray_d[pid] = mk4(d, __uint_as_float(pid << 1));               // bounce 0, outside
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      ring_push(s_rq, rq_tail, valid, pid);
+      ring_push(s_rq, rq_tail, valid, pid, wg_err);
       made += (uint32_t)__popcll(__ballot(valid));
     }
     if (lane == 0 && made != A.gen_chunk) atomicSub(live, A.gen_chunk - made);      // slots past the end or outside the image (edge tiles are partial)
@@ -220,7 +249,7 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
     uint32_t nn = 0, nt = 0;
     trace_engine<false, false, TWO, CRH_FRAME_DON != 0, true, kFrameBlock>(S.nodes, S.tris, S.inst_leaf, S.root, S.guard_box, t2, nullptr, 0u, &stk[threadIdx.x],
       [&](uint32_t ticket, v3& o, v3& d, float& tmax, uint32_t& tag, bool& any_l) {
-        tag = ring_take(s_rq, ticket);
+        tag = ring_take(s_rq, ticket, wg_err);
         any_l = (tag & kFrameAny) != 0u; tag &= ~kFrameAny;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const float4 o4 = any_l ? P.sh_o[tag] : ray_o[tag], d4 = any_l ? P.sh_d[tag] : ray_d[tag];
@@ -243,7 +272,13 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
         if (to_shade) P.hit[tag] = h;
         if (__ballot(to_shade) != 0ull) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          ring_push(s_sq, sq_tail, to_shade, tag);
+#if CRH_FRAME_MISS_RING
+          const bool miss = __float_as_int(h.w) < 0;
+          ring_push(s_sq, sq_tail, to_shade && !miss, tag, wg_err);
+          ring_push(s_mq, mq_tail, to_shade && miss, tag, wg_err);
+#else
+          ring_push(s_sq, sq_tail, to_shade, tag, wg_err);
+#endif
         }
         wave_sub(live, fin && any_l && !go_on);                      // a shadow ray with nothing behind it: the path is done
         return go_on;
@@ -257,12 +292,22 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
 #if CRH_FRAME_STATS
   const unsigned long long fs_start = (unsigned long long)clock64();
 #endif
+  uint32_t idle_spins = 0;
   for (;;) {
-    const uint32_t nr = ring_count(rq_head, rq_tail), ns = ring_count(sq_head, sq_tail);
+    const uint32_t nr = ring_count(rq_head, rq_tail);
+#if CRH_FRAME_MISS_RING
+    const uint32_t nh = ring_count(sq_head, sq_tail), nm = ring_count(mq_head, mq_tail), ns = nh + nm;
+    // which ring a shading batch comes from: a full batch of surface hits first (they refill the ray ring), then a full batch of misses, else the fuller one
+    const bool from_misses = nh >= 64u ? false : (nm >= 64u ? true : nm > nh);
+    const bool full_batch = nh >= 64u || nm >= 64u;
+#else
+    const uint32_t ns = ring_count(sq_head, sq_tail);
+    const bool from_misses = false, full_batch = ns >= 64u;
+#endif
     // one call site per stage (each is a few thousand instructions, inlined): decide first, then act
     int act = 0;                                                     // 0 idle, 1 shade, 2 generate, 3 trace
     if (feeder) {
-      if (ns >= 64u) act = 1;
+      if (full_batch) act = 1;
       else if (nr < A.low_water && may_generate()) act = 2;
       else if (ns != 0u && (nr < A.starve || nr == 0u)) act = 1;     // the tracers are about to starve: whatever waits is shaded now
     } else {
@@ -270,11 +315,13 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
       else if (ns >= 256u || (A.n_feed == 0u && ns != 0u && !(nr == 0u && may_generate()))) act = 1;      // the feeders have fallen behind (or there are none)
       else if (nr == 0u && may_generate()) act = 2;
     }
-    if (act == 1) { shade_some(); continue; }
-    if (act == 2) { if (generate()) continue; }
-    if (act == 3) { trace_some(); continue; }
+    if (act == 1) { shade_some(from_misses); idle_spins = 0; continue; }
+    if (act == 2) { if (generate()) { idle_spins = 0; continue; } }
+    if (act == 3) { trace_some(); idle_spins = 0; continue; }
     // idle: other wavefronts of the workgroup still hold paths, or the frame is done
     if (load_u(cursor_out) != 0u && load_u(live) == 0u) break;
+    if (++idle_spins >= kFrameSpinLimit / 4u) atomicOr(wg_err, kFrameErrIdle);
+    if (load_u(wg_err) != 0u) break;
 #if CRH_FRAME_STATS
     if (lane == 0) atomicAdd(&g_frame_stats[feeder ? 9 : 10], 1ull);
 #endif
@@ -290,5 +337,6 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
   n_shaded = wave_sum(n_shaded);
   if (lane == 0 && n_shaded) atomicAdd(&C->shaded_hits, (unsigned long long)n_shaded);
   __syncthreads();
+  if (threadIdx.x == 0 && s_ctl[6] != 0u && A.err) atomicOr(A.err, s_ctl[6]);
   if (threadIdx.x == 0 && atomicAdd(A.ctl + 1, 1u) == gridDim.x - 1u) { A.ctl[0] = 0u; A.ctl[1] = 0u; }      // the last workgroup leaves the control words as it found them
 }

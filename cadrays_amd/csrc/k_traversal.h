@@ -15,6 +15,13 @@
 #ifndef CRH_POOL_DIV
 #define CRH_POOL_DIV 2
 #endif
+#ifndef CRH_POSTPONE_LEAF
+#define CRH_POSTPONE_LEAF 0    // round 6 experiment: 1 = the frame kernel's engine keeps descending with ONE triangle leaf postponed per lane (speculative while-while:
+#endif                         // a lane that reaches a leaf does not drop out of the inner steps of its wavefront), 2 = every non-counting single-level engine
+#ifndef CRH_HUNT_NOOP_CALLS
+#define CRH_HUNT_NOOP_CALLS 0  // 1 re-creates the build of round 6 in which k_trace_rays<ANY, COUNT, TWO> answered wrong: calls of a lambda whose body is `if (false && ..)`
+#endif                         // around the inner steps -- nothing at source level -- and hipcc 7.2's si-form-memory-clauses pass miscompiles that instantiation (DESIGN.md section 7,
+                               // profiles/r6/hunt_anyhit_found.md, tests/hunts/anyhit_split_min.py).  The default source has no such call.
 #ifndef CRH_REFILL_IDLE
 #define CRH_REFILL_IDLE 12     // refill a wavefront once this many of its 64 lanes have no ray
 #endif
@@ -143,6 +150,14 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
   bool any_l = ANY;                     // FRM: this lane's ray is an occlusion query (per lane); otherwise the template constant
 #define CRH_ISANY (FRM ? any_l : ANY)
   uint32_t cur = kDone, tag = 0;
+  // PL (CRH_POSTPONE_LEAF): a triangle leaf the lane has reached but not tested yet.  The lane goes on with the next stack entry and takes part in the inner steps
+  // of its wavefront instead of waiting for the triangle phase; the leaf is tested there, BEFORE any leaf reached later (one at a time), so triangles are tested in
+  // the walk's order.  Boxes visited in between are pruned with the `best` of before that test: more visits (never counted: not in COUNT instantiations), the
+  // same hit -- a triangle in a box the up-to-date `best` would have culled lies strictly behind it (boxes are conservative), so it can neither win nor tie.
+  // Single-level walks only: a postponed leaf of an object must not be tested with the world ray the lane holds again after popping the object's sentinel.
+  constexpr bool PL = CRH_POSTPONE_LEAF != 0 && !COUNT && !TWO && (FRM || CRH_POSTPONE_LEAF > 1);
+  uint32_t pleaf = kDone;               // kDone: none
+#define CRH_LANE_DONE (cur == kDone && (!PL || pleaf == kDone))
   int sp = 0;
   v3 o = crh_mk3(0.f, 0.f, 0.f), d = o;
   // TWO: the world-space ray {origin, direction, reciprocal direction} of every lane waits in LDS while the lane walks inside an object
@@ -208,7 +223,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
           set_guard(gbox);
           if (TWO) save_world();
-          best = tmax; found = false; sp = 0; cur = root; have = true;
+          best = tmax; found = false; sp = 0; cur = root; have = true; pleaf = kDone;
           if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, d, tmax)) { lds[0] = t2.root2; sp = 1; }
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
           if (DON) { sbase = 0; is_child = false; cfound = false; next = kNoLane; head = lane; bound[lane] = __float_as_uint(tmax); }
@@ -235,7 +250,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
           set_guard(gbox);
           if (TWO) save_world();
-          best = tmax; found = false; sp = 0; cur = root; have = true;
+          best = tmax; found = false; sp = 0; cur = root; have = true; pleaf = kDone;
           if (ANY && tmax < 0.f) cur = kDone;                      // second any-hit pass of a split scene: already occluded in the first (no visit, no test)
           if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, d, tmax)) { lds[0] = t2.root2; sp = 1; }
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
@@ -297,7 +312,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
             ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
             set_guard(gbox);
             if (TWO) save_world();
-            best = rbest; found = false; sbase = 0; sp = rcnt - 1; cur = lds[sp * kBlock]; have = true;      // the nearest of the entries received
+            best = rbest; found = false; sbase = 0; sp = rcnt - 1; cur = lds[sp * kBlock]; have = true; pleaf = kDone;      // the nearest of the entries received
             hit = make_float4(rbest, 0.f, 0.f, __int_as_float(-1));
             is_child = true; cfound = false; next = rnext; head = rhead;            // ... and before what the donor gave away earlier
             if (FRM) any_l = rany != 0;
@@ -475,8 +490,16 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
 #if CRH_INNER_STEPS > 0
     // (the frame kernel's rays -- every bounce mixed in one wavefront -- hold leaves less often: three inner steps per turn there, lone frame 3.15 -> 3.05 ms on C3)
     constexpr int kInnerSteps = FRM ? CRH_INNER_STEPS + 1 : CRH_INNER_STEPS;
+#if CRH_POSTPONE_LEAF || CRH_HUNT_NOOP_CALLS
+    // PL: a triangle leaf in hand moves aside (if none waits yet) and the lane descends on
+    auto postpone = [&]() { if (PL && have && (cur & kQLeafBit) && cur != kDone && pleaf == kDone) { pleaf = cur; pop(); } };
+    postpone();
+#pragma unroll 1
+    for (int step_ = 0; step_ < kInnerSteps && have && !(cur & kQLeafBit); ++step_) { inner_step(); postpone(); }
+#else
 #pragma unroll 1
     for (int step_ = 0; step_ < kInnerSteps && have && !(cur & kQLeafBit); ++step_) inner_step();
+#endif
 #else
     while (have && !(cur & kQLeafBit)) inner_step();
 #endif
@@ -500,7 +523,17 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       if (sp < kLdsStack) lds[sp * kBlock] = mark; else ovf[sp - kLdsStack] = mark;
       ++sp;
       cur = __float_as_uint(meta.x);
-    } else if (have && (cur & kQLeafBit) && cur != kDone) {
+    }
+#if CRH_POSTPONE_LEAF
+    else if (PL) {
+      if (have && pleaf != kDone) {
+        tri_step(pleaf & 0x0FFFFFFFu);                           // the postponed leaf first: triangles in the walk's order
+        pleaf = kDone;
+        if (CRH_ISANY && found) cur = kDone;                     // an occluder ends the walk (what pop() does in the plain form)
+      }
+    }
+#endif
+    else if (have && (cur & kQLeafBit) && cur != kDone) {
       tri_step(cur & 0x0FFFFFFFu);                               // one triangle per leaf (crh_bvh_format.h)
       pop();
     }
@@ -508,12 +541,12 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
     CRH_FS_MARK(fc_leaf)
     // ------------------------------------------------------------------ (C) retire finished rays
 #if CRH_FRAME_STATS
-    if (FRM) { const unsigned long long fm_ = __ballot(have && cur == kDone); if (fm_ != 0ull) { ++fs_store_w; fs_fin += (uint32_t)__popcll(fm_); } }
+    if (FRM) { const unsigned long long fm_ = __ballot(have && CRH_LANE_DONE); if (fm_ != 0ull) { ++fs_store_w; fs_fin += (uint32_t)__popcll(fm_); } }
 #endif
     if (DON) {
       // own part walked and no successor left: fold what was absorbed behind the own hit (left-biased minimum: a later part
       // wins only with a strictly smaller t); helpers then wait to be absorbed by their predecessor, the head stores
-      const bool finished = have && cur == kDone && next == kNoLane;
+      const bool finished = have && CRH_LANE_DONE && next == kNoLane;
       if (finished && cfound) { if (CRH_ISANY || !found || chit.x < hit.x) { hit = chit; found = true; } cfound = false; }
       const unsigned long long fin_children = __ballot(finished && is_child);
       if (fin_children != 0ull) {
@@ -528,7 +561,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         }
         if ((fin_children >> lane) & 1ull) { have = false; is_child = false; }           // absorbed: the lane is free again
       }
-      const bool fin = have && !is_child && cur == kDone && next == kNoLane;
+      const bool fin = have && !is_child && CRH_LANE_DONE && next == kNoLane;
       if (fin && cfound) { if (CRH_ISANY || !found || chit.x < hit.x) { hit = chit; found = true; } cfound = false; }
       if constexpr (FRM) {
         float tmax = CRH_MAXFLOAT;
@@ -540,7 +573,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
             ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
             set_guard(gbox);
             if (TWO) save_world();
-            best = tmax; found = false; sp = 0; cur = root;
+            best = tmax; found = false; sp = 0; cur = root; pleaf = kDone;
             if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, d, tmax)) { lds[0] = t2.root2; sp = 1; }
             hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
             sbase = 0; is_child = false; cfound = false; next = kNoLane; head = lane; bound[lane] = __float_as_uint(tmax);
@@ -548,7 +581,7 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
         }
       } else if (fin) { store(tag, hit, found); have = false; }
     } else if constexpr (FRM) {
-      const bool fin = have && cur == kDone;
+      const bool fin = have && CRH_LANE_DONE;
       float tmax = CRH_MAXFLOAT;
       const bool go_on = store(fin, tag, hit, found, any_l, o, d, tmax);        // the whole wavefront calls; true: the lane's path continues with the ray in o, d
       if (fin) {
@@ -558,15 +591,16 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
           ix = inv_dir(d.x); iy = inv_dir(d.y); iz = inv_dir(d.z);
           set_guard(gbox);
           if (TWO) save_world();
-          best = tmax; found = false; sp = 0; cur = root;
+          best = tmax; found = false; sp = 0; cur = root; pleaf = kDone;
           if (TWO && t2.root2 != kQEmpty && touches_instances(t2, o, d, tmax)) { lds[0] = t2.root2; sp = 1; }
           hit = make_float4(tmax, 0.f, 0.f, __int_as_float(-1));
         }
       }
-    } else { if (have && cur == kDone) { store(tag, hit, found); have = false; } }
+    } else { if (have && CRH_LANE_DONE) { store(tag, hit, found); have = false; } }
     CRH_FS_MARK(fc_retire)
   }
 #undef CRH_ISANY
+#undef CRH_LANE_DONE
 #if CRH_FRAME_STATS
   if (FRM) {
     const uint32_t li = wave_sum(n_nodes), lt = wave_sum(n_tris);

@@ -110,17 +110,29 @@ void launch_trace_any(const Launch& L, const DScene& S, const DPaths& P, const D
 // The frame kernel (k_frame.h): ray generation, every bounce's traversal and shading of a small batch in ONE launch.  `ctl`: two words, zero at launch (the kernel
 // leaves them zero).  The grid is what the register budget keeps resident (every workgroup is a persistent streaming path tracer), or less for a frame that
 // shares the chip with others in flight.
-int frame_resident_grid(int cus, bool two_level)
+// LDS of the frame kernel: stack 16 x 1024 x 4 B = 64 KB + two rings of kFrameRing x 4 B = 32 KB + bounds 4 KB + materials 4 KB = ~104 KB (two-level scenes: + 36 KB of
+// world rays = ~140 KB).  Only a part with gfx950's 160 KB of LDS per compute unit can launch it.
+static_assert((size_t)kLdsStack * kFrameBlock * 4 + (2 + CRH_FRAME_MISS_RING) * (size_t)kFrameRing * 4 + (size_t)kFrameBlock * 4 + (size_t)kFrameMats * 128 + 9 * (size_t)kFrameBlock * 4 <= 160 * 1024, "k_frame<true> does not fit the LDS of a gfx950 compute unit");
+static int frame_occupancy(bool two_level)
 {
   static int per_cu[2] = {0, 0};
   int& pc = per_cu[two_level ? 1 : 0];
   if (pc == 0) { int n = 0; pc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, two_level ? k_frame<true> : k_frame<false>, kFrameBlock, 0) == hipSuccess && n > 0) ? n : -1; }
+  return pc;
+}
+// on a device (or after a build-flag change) where not even one workgroup of the frame kernel is resident, small batches take the staged schedule
+// (crh_schedule.cpp frame_ok) -- bit-identical -- instead of a launch that fails
+bool frame_launchable(bool two_level) { return frame_occupancy(two_level) > 0; }
+int frame_resident_grid(int cus, bool two_level)
+{
+  const int pc = frame_occupancy(two_level);
   return (pc > 0 ? pc : 1024 / kFrameBlock) * (cus > 0 ? cus : 256);
 }
 void launch_frame(const Launch& L, const DScene& S, const DPaths& P, uint32_t* ctl, const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds,
-                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, uint32_t low_water, uint32_t n_feed, uint32_t claim_step, uint32_t starve, DCounters* C, const uint32_t* h_seeds)
+                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, uint32_t low_water, uint32_t n_feed, uint32_t claim_step, uint32_t starve, DCounters* C, const uint32_t* h_seeds, uint32_t* d_err)
 {
   FrameArgs A;
+  A.err = d_err;
   A.tile_ids = d_tile_ids; A.n_tiles = n_tiles; A.n_tiles_dev = d_n_tiles; A.seeds = d_seeds; A.n_samples = n_samples; A.seed_per_tile = seed_per_tile;
   for (int i = 0; i < 16; ++i) A.seed_vals[i] = (h_seeds && (uint32_t)i < n_samples) ? h_seeds[i] : 0u;
   A.ctl = ctl; A.gen_chunk = min(max(gen_chunk & ~63u, 64u), kFrameRing); A.max_live = min(max(max_live, A.gen_chunk), kFrameRing); A.low_water = low_water;
