@@ -170,11 +170,12 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_PIPE_DEPTH",         "frames in flight of free-running Redraw()s, 2 .. 8; the same knob as crh_set_pipeline_depth (crh_query_pipeline_capacity says what the process supports)"},
   {"CRH_FRAME_KERNEL",       "0: small batches take the staged small-batch schedule (one launch per stage and bounce) instead of the frame kernel (reference schedule of the sequence tests)"},
   {"CRH_FRAME_LIVE",         "frame kernel: paths a workgroup (16 wavefronts, one per compute unit) keeps alive at most, 64 .. 16384, cut to the ring size 4096 (default 4096)"},
-  {"CRH_FRAME_CHUNK",        "frame kernel: path slots a wavefront claims at a time, multiples of 64 up to 1024 (default 256)"},
+  {"CRH_FRAME_CHUNK",        "frame kernel: path slots a wavefront claims at a time, multiples of 64 up to 1024 (default 128)"},
   {"CRH_FRAME_LOW",          "frame kernel: a feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring (default 512)"},
-  {"CRH_FRAME_FEED",         "frame kernel: wavefronts of a workgroup that only shade and generate, 0 .. 15 (default 3 of 16)"},
+  {"CRH_FRAME_FEED",         "frame kernel: wavefronts of a workgroup that only shade and generate, 0 .. 15 (default 3 of 16; 4 pays on scenes with short walks: profiles/r6/lone_frame.md)"},
   {"CRH_FRAME_STARVE",       "frame kernel: a feeder shades fewer than 64 waiting hits only while fewer rays than this wait in the ring (default 2^20: always)"},
   {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 0: every tracer takes what is there)"},
+  {"CRH_FRAME_HELP",         "frame kernel: a tracer wavefront shades a batch itself once this many hit records wait in the workgroup's rings, 64 .. 4096 (default 256)"},
   {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident = ONE 1024-thread workgroup per compute unit); never fewer than min(resident, 32), never more than resident"},
   {"CRH_FRAME_PIPE",         "frame pipeline: a frame takes the frame kernel while fewer than this many frames are running, and at most this many frame kernels run at a time, 1 .. 8 (default 2)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
@@ -210,6 +211,7 @@ static void read_env(crh_ctx* c)
   if (const char* e = getenv("CRH_FRAME_FEED")) { int v = atoi(e); if (v >= 0 && v <= 15) c->frame_feeders = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_STARVE")) { int v = atoi(e); if (v >= 0) c->frame_starve = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_STEP")) { int v = atoi(e); if (v >= 0 && v <= 256) c->frame_claim_step = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_HELP")) { int v = atoi(e); if (v >= 64 && v <= 4096) c->frame_help = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_GRID")) { int v = atoi(e); if (v >= 1) c->frame_grid = v; }
   if (const char* e = getenv("CRH_FRAME_PIPE")) { int v = atoi(e); if (v >= 1 && v <= 8) c->frame_pipe_depth = (uint32_t)v; }
   if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }

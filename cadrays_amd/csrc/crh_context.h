@@ -151,11 +151,14 @@ struct ScheduleState {
   // launch boundary between bounces.  Takes the place of the staged small-batch schedule (lanes / pipelined launches per bounce) wherever a batch is small,
   // not counted and not timed per kernel; CRH_FRAME_KERNEL=0 or crh_set_schedule(CRH_SCHEDULE_STAGED) keeps the staged form (the reference of the sequence tests).
   bool frame_kernel = true, auto_frame_kernel = true;
-  uint32_t frame_live = 4096, frame_chunk = 256;    // paths a workgroup (16 wavefronts, one per compute unit) keeps alive at most; path slots a wavefront claims at a time
+  uint32_t frame_live = 4096, frame_chunk = 128;    // paths a workgroup (16 wavefronts, one per compute unit) keeps alive at most; path slots a wavefront claims at a time
+                                                    // (round 6, with the miss ring: chunk 128 / 192 / 256 / 512 -> lone frame on C3 2.85 / 2.97 / 2.95 / 3.46 ms, profiles/r6/lone_frame.md)
   uint32_t frame_low_water = 512;                   // a feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring
   uint32_t frame_starve = 1u << 20;                 // a feeder shades fewer than 64 hits only while fewer rays than this wait in the ring
-  uint32_t frame_feeders = 3, frame_claim_step = 0;    // wavefronts that only shade and generate (2 / 3 / 4 -> 3.33 / 2.98 / 2.99 ms, lone frame on C3); tracer w takes rays only
+  uint32_t frame_feeders = 3, frame_claim_step = 0;    // wavefronts that only shade and generate (round 6: 2 / 3 / 4 / 5 -> 3.07 / 2.85 / 2.92 / 3.39 ms lone frame on C3, 3.0 / 2.60 / 2.30 / 2.31 on the CAD-like scene,
+                                                    // whose short walks leave more shading and generating per traced ray: CRH_FRAME_FEED=4 there); tracer w takes rays only
                                                        // while >= w * claim_step wait: 0 / 16 / 32 / 64 -> 2.90 / 2.95 / 3.13 / 3.46 ms -- the shared rings gather the late bounces by themselves
+  uint32_t frame_help = 256;                        // a tracer wavefront shades a batch itself once this many hit records wait
   int frame_grid = 0;                               // workgroups of a lone frame (0: what is resident, 4 per CU)
   uint32_t frame_pipe_depth = 2;                    // a pipelined frame takes the frame kernel while fewer than this many frames are running, and at most this many frame
                                                     // kernels run at a time (they share the chip by compute units); beyond it the staged form carries the deeper pipeline

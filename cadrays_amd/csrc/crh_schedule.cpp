@@ -49,7 +49,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     // the frame kernel: camera rays, every bounce's traversal, shading and shadow rays of this batch in ONE launch (k_frame.h); its two control words live behind
     // the queue counters of this lane (zero when allocated, left zero by every launch)
     Launch LF{ln.stream, ln.grid_frame, false, c->clamp_grid ? c->cus : 0};
-    launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->frame_low_water, c->frame_feeders, c->frame_claim_step, c->frame_starve, c->d_counters, ln.h_seeds, c->d_api_cursor + 8);      // + 8: the context's device error word (crh_context.cpp check_device_error)
+    launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->frame_low_water, c->frame_feeders, c->frame_claim_step, c->frame_starve, c->d_counters, ln.h_seeds, c->d_api_cursor + 8, c->frame_help);      // + 8: the context's device error word (crh_context.cpp check_device_error)
   } else {
   launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, ln.h_seeds);
   int qin = 0;

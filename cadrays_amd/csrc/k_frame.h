@@ -29,7 +29,7 @@ constexpr int      kFrameMats  = 32;            // materials staged in LDS (4 KB
 constexpr int      kFrameBlock = CRH_FRAME_BLOCK;
 constexpr uint32_t frame_pow2(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
 #ifndef CRH_FRAME_MISS_RING
-#define CRH_FRAME_MISS_RING 0                   // round 6 experiment: rays that hit nothing wait in a ring of their own, so that a shading batch is either all misses (environment /
+#define CRH_FRAME_MISS_RING 1                   // round 6 experiment: rays that hit nothing wait in a ring of their own, so that a shading batch is either all misses (environment /
 #endif                                          // implicit light, the path ends: a few hundred instructions) or all surface hits (the BSDF code) -- profiles/r6/lone_frame.md
 #ifndef CRH_FRAME_RING_MUL
 #define CRH_FRAME_RING_MUL 4
@@ -52,6 +52,7 @@ struct FrameArgs {
   uint32_t n_feed;            // wavefronts of a workgroup that only shade and generate (the last ones)
   uint32_t starve;            // a feeder shades fewer than a wavefront's worth of hits only while fewer rays than this wait in the ring (the tracers are about to starve)
   uint32_t claim_step;        // tracer wavefront w takes rays from the ring only while >= w * claim_step wait there: scarce rays go to the first wavefronts
+  uint32_t help;              // a tracer wavefront shades a batch itself once this many hit records wait (the feeders have fallen behind)
   uint32_t* err;              // the context's device error word (never touched in a healthy run)
 };
 
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
       else if (ns != 0u && (nr < A.starve || nr == 0u)) act = 1;     // the tracers are about to starve: whatever waits is shaded now
     } else {
       if (nr != 0u && nr >= claim_min) act = 3;
-      else if (ns >= 256u || (A.n_feed == 0u && ns != 0u && !(nr == 0u && may_generate()))) act = 1;      // the feeders have fallen behind (or there are none)
+      else if (ns >= A.help || (A.n_feed == 0u && ns != 0u && !(nr == 0u && may_generate()))) act = 1;      // the feeders have fallen behind (or there are none)
       else if (nr == 0u && may_generate()) act = 2;
     }
     if (act == 1) { shade_some(from_misses); idle_spins = 0; continue; }

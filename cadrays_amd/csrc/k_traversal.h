@@ -22,6 +22,9 @@
 #define CRH_HUNT_NOOP_CALLS 0  // 1 re-creates the build of round 6 in which k_trace_rays<ANY, COUNT, TWO> answered wrong: calls of a lambda whose body is `if (false && ..)`
 #endif                         // around the inner steps -- nothing at source level -- and hipcc 7.2's si-form-memory-clauses pass miscompiles that instantiation (DESIGN.md section 7,
                                // profiles/r6/hunt_anyhit_found.md, tests/hunts/anyhit_split_min.py).  The default source has no such call.
+#ifndef CRH_FRAME_PARK
+#define CRH_FRAME_PARK 0       // round 6 experiment: the frame engine runs its triangle step only when at least this many lanes hold a leaf, or none can descend (0: every turn)
+#endif
 #ifndef CRH_REFILL_IDLE
 #define CRH_REFILL_IDLE 12     // refill a wavefront once this many of its 64 lanes have no ray
 #endif
@@ -524,6 +527,11 @@ __device__ __forceinline__ void trace_engine(const float4* __restrict__ nodes, c
       ++sp;
       cur = __float_as_uint(meta.x);
     }
+#if CRH_FRAME_PARK > 0
+    else if (FRM && !TWO && (uint32_t)__popcll(__ballot(have && (cur & kQLeafBit) && cur != kDone)) < (uint32_t)CRH_FRAME_PARK && __ballot(have && !(cur & kQLeafBit)) != 0ull) {
+      // parked: too few leaves in hand and somebody can still descend -- the leaves wait for the next turn
+    }
+#endif
 #if CRH_POSTPONE_LEAF
     else if (PL) {
       if (have && pleaf != kDone) {

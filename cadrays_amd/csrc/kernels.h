@@ -32,7 +32,7 @@ int frame_resident_grid(int cus, bool two_level);
 bool frame_launchable(bool two_level);      // at least one workgroup of the frame kernel is resident on this device
 void launch_frame(const Launch&, const DScene&, const DPaths&, uint32_t* ctl, const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_frame_seeds,
                   uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, uint32_t low_water, uint32_t n_feed, uint32_t claim_step, uint32_t starve, DCounters*,
-                  const uint32_t* h_seeds = nullptr /* with d_frame_seeds == nullptr: the <= 16 frame seeds on the host, passed by value */, uint32_t* d_err = nullptr /* the context's device error word */);
+                  const uint32_t* h_seeds = nullptr /* with d_frame_seeds == nullptr: the <= 16 frame seeds on the host, passed by value */, uint32_t* d_err = nullptr /* the context's device error word */, uint32_t help = 256u /* FrameArgs::help */);
 // clamp + running mean of the finished paths of batch samples [first_sample, first_sample + n_samples) into the float4
 // accumulator, sample by sample; batch_samples = the sample count the batch was generated with (it fixes the slot layout)
 void launch_accumulate(const Launch&, const DScene&, const DPaths&, float4* accum, float* m2 /* or nullptr */,

@@ -129,10 +129,10 @@ int frame_resident_grid(int cus, bool two_level)
   return (pc > 0 ? pc : 1024 / kFrameBlock) * (cus > 0 ? cus : 256);
 }
 void launch_frame(const Launch& L, const DScene& S, const DPaths& P, uint32_t* ctl, const uint32_t* d_tile_ids, uint32_t n_tiles, const uint32_t* d_seeds,
-                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, uint32_t low_water, uint32_t n_feed, uint32_t claim_step, uint32_t starve, DCounters* C, const uint32_t* h_seeds, uint32_t* d_err)
+                  uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, uint32_t low_water, uint32_t n_feed, uint32_t claim_step, uint32_t starve, DCounters* C, const uint32_t* h_seeds, uint32_t* d_err, uint32_t help)
 {
   FrameArgs A;
-  A.err = d_err;
+  A.err = d_err; A.help = help ? help : 256u;
   A.tile_ids = d_tile_ids; A.n_tiles = n_tiles; A.n_tiles_dev = d_n_tiles; A.seeds = d_seeds; A.n_samples = n_samples; A.seed_per_tile = seed_per_tile;
   for (int i = 0; i < 16; ++i) A.seed_vals[i] = (h_seeds && (uint32_t)i < n_samples) ? h_seeds[i] : 0u;
   A.ctl = ctl; A.gen_chunk = min(max(gen_chunk & ~63u, 64u), kFrameRing); A.max_live = min(max(max_live, A.gen_chunk), kFrameRing); A.low_water = low_water;
