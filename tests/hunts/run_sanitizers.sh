@@ -20,7 +20,7 @@ for k in $KINDS; do
   if [ $k != tsan ]; then       # libgomp is not TSan-instrumented: its barriers read as races; the oracle's OpenMP loops only touch disjoint pixels
     pre=$(gcc -print-file-name=lib${k}.so)
     env $env LD_PRELOAD=$pre CRH_ORACLE_LIB=$PWD/oracle/san/$k/libcrh_oracle.so ASAN_OPTIONS=detect_leaks=0 \
-      python -m pytest tests/test_oracle_kat.py tests/test_golden.py tests/test_node_quantiser.py tests/test_geometric_truth.py tests/test_adaptive.py tests/test_two_level.py tests/test_textures.py -x -q -m "not gpu" -k "not product_builder" >> $log 2>&1 \
+      python -m pytest tests/test_oracle_kat.py tests/test_golden.py tests/test_node_quantiser.py tests/test_geometric_truth.py tests/test_adaptive.py tests/test_two_level.py tests/test_textures.py tests/test_visibility.py tests/test_cad_like.py tests/test_icon_features.py -x -q -m "not gpu" -k "not product_builder" >> $log 2>&1 \
       || { echo "$k: oracle tests failed"; rc=1; }
   fi
   if grep -E "ERROR: (Address|Thread|Leak)Sanitizer|runtime error:|WARNING: ThreadSanitizer" $log > /dev/null; then echo "$k: sanitizer reports in $log"; rc=1; else echo "$k: clean"; fi

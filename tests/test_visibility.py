@@ -237,13 +237,18 @@ def test_hip_add_object_matches_oracle(hip_lib, oracle_lib):
 @pytest.mark.parametrize("seed", range(6))
 def test_hip_fuzz_visibility_transforms_adaptive_checkpoint(hip_lib, oracle_lib, seed):
     """random sequences mixing Display / Erase, manipulator moves, an added object, adaptive sampling and a checkpoint: the product follows the oracle"""
-    r = np.random.default_rng(4100 + seed)
+    visibility_sequence(oracle_lib, 4100 + seed)
+
+
+def visibility_sequence(oracle_lib, seed, steps=10):
+    """(tests/hunts/visibility_walks.py runs many more seeds of this)"""
+    r = np.random.default_rng(seed)
     sc = object_scene(w=64, h=48)
     v, o = pair(oracle_lib, sc)
     n = 7
     adaptive = False
     stats_ok = True                    # a checkpoint restore restarts the product's counters, not the oracle's: counters are compared again after the next restart of both
-    for step in range(10):
+    for step in range(steps):
         k = int(r.integers(0, 6))
         if k == 0:
             f = (r.random(n) > 0.3).astype(np.uint8)
