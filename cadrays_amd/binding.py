@@ -60,9 +60,7 @@ class Backend:
         return getattr(self._lib, self._p + name)
 
     def _call(self, name, *args):
-        f = self._fn(name)
-        f.restype = C.c_int
-        rc = f(self._ctx, *args)
+        rc = self._fn(name)(self._ctx, *args)                  # (restype of a ctypes function defaults to c_int)
         if rc != 0:
             msg = self._fn("last_error")(self._ctx)
             raise BackendError(f"{self._p}{name} -> {rc}: {msg.decode() if msg else ''}")
@@ -277,11 +275,17 @@ class Backend:
         self._call("read_ldr_begin")
         self._rb_shapes = getattr(self, "_rb_shapes", []) + [(self.height, self.width, 3)]
 
-    def read_ldr_end(self):
-        """the oldest begun read-back (crh_read_ldr_end)"""
-        shape = self._rb_shapes.pop(0) if getattr(self, "_rb_shapes", None) else (self.height, self.width, 3)
-        out = np.empty(shape, np.uint8)
+    def read_ldr_end(self, out=None):
+        """the oldest begun read-back (crh_read_ldr_end).  `out`: a C-contiguous uint8 array of the frame's shape to fill instead of a fresh one -- what a GUI
+        host does (one staging buffer for the texture upload, INTEGRATION.md `myLdr`): a fresh 6 MB array per 1080p frame is 1500 first-touch page faults"""
+        pending = getattr(self, "_rb_shapes", None)
+        shape = pending[0] if pending else (self.height, self.width, 3)
+        if out is None:
+            out = np.empty(shape, np.uint8)
+        elif out.dtype != np.uint8 or out.shape != tuple(shape) or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
+            raise ValueError(f"read_ldr_end(out=...): need a writeable C-contiguous uint8 array of shape {tuple(shape)}")
         self._call("read_ldr_end", out.ctypes.data_as(_u8p))
+        if pending: pending.pop(0)
         return out
 
     def read_hdr_begin(self):

@@ -686,6 +686,16 @@ def test_async_ldr_readback_returns_the_frame_of_its_begin(view_cls, Oracle, mon
         v.read_ldr_begin()                                           # at most two
     v.read_ldr_end(); v.read_ldr_end()
     assert np.array_equal(v.read_ldr(), want[-1]) and np.array_equal(bits(v.read_hdr()), bits(twin.read_hdr()))
+    # the host's own staging buffer (what a GUI does for its texture upload): filled in place, a wrong one refused before the call
+    staging = np.zeros((960, 1280, 3), np.uint8)
+    v.read_ldr_begin()
+    assert v.read_ldr_end(staging) is staging and np.array_equal(staging, want[-1])
+    v.read_ldr_begin()
+    for bad in (np.zeros((960, 1280, 4), np.uint8), np.zeros((960, 1280, 3), np.float32), staging[:, ::2]):
+        with pytest.raises(ValueError):
+            v.read_ldr_end(bad)
+    v.read_ldr_begin()                                               # (the refused calls took nothing out of flight: this is the second)
+    v.read_ldr_end(staging); v.read_ldr_end(staging)
 
 
 def test_async_hdr_readback_returns_the_frame_of_its_begin(view_cls):

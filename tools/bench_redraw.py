@@ -36,6 +36,8 @@ def measure(v, cam0, frames=128, trials=15):
     out["first_frame_after_a_restart_ms"] = round(statistics.median(ts), 3)
     out["first_frame_after_a_restart_ms_min"] = round(min(ts), 3)
 
+    import numpy as np
+    shown = np.empty((v.height, v.width, 3), np.uint8)          # the host's one staging buffer (INTEGRATION.md `myLdr`, cadrays_headless.cpp `shown`)
     # ---- the drag: camera change -> restart -> one frame -> shown
     def cam(i):
         return drag_camera(cam0, i)
@@ -45,9 +47,9 @@ def measure(v, cam0, frames=128, trials=15):
         t = time.perf_counter()
         for i in range(n):
             v.set_camera(cam(i)); v.reset(); v.Redraw()
-            if i >= 2: v.read_ldr_end()
+            if i >= 2: v.read_ldr_end(shown)
             v.read_ldr_begin()
-        v.read_ldr_end(); v.read_ldr_end(); v.sync()
+        v.read_ldr_end(shown); v.read_ldr_end(shown); v.sync()
         dt = time.perf_counter() - t
     out["drag_frames_per_s"] = round(frames / dt, 1)
     v.set_camera(cam0); v.reset()
@@ -59,9 +61,9 @@ def measure(v, cam0, frames=128, trials=15):
         t = time.perf_counter()
         for i in range(n):
             v.Redraw()
-            if i >= 2: v.read_ldr_end()
+            if i >= 2: v.read_ldr_end(shown)
             v.read_ldr_begin()
-        v.read_ldr_end(); v.read_ldr_end(); v.sync()
+        v.read_ldr_end(shown); v.read_ldr_end(shown); v.sync()
         dt = time.perf_counter() - t
     out["displayed_frames_per_s"] = round(frames / dt, 1)
 
@@ -81,13 +83,17 @@ if __name__ == "__main__":
     ap.add_argument("--config", default="C3")
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--trials", type=int, default=15)
+    ap.add_argument("--no-torch", action="store_true", help="do not import torch first: the process then runs on the HIP runtime the library was linked against (/opt/rocm), "
+                    "not on the one bundled with the torch wheel (round 6: the two differ in what a lone frame costs the host)")
     a = ap.parse_args()
-    import torch  # noqa: F401
+    if not a.no_torch:
+        import torch  # noqa: F401
     from cadrays_amd import scenes
     from cadrays_amd.view import View
     sc = scenes.baseline_config(a.config)
     v = View(0).load_scene(sc)
-    out = {"config": a.config, "env": {k: os.environ[k] for k in sorted(os.environ) if k.startswith("CRH_") or k == "GPU_MAX_HW_QUEUES"}}
+    out = {"config": a.config, "env": {k: os.environ[k] for k in sorted(os.environ) if k.startswith(("CRH_", "ROC_", "HSA_")) or k == "GPU_MAX_HW_QUEUES"},
+           "hip_runtime": [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][:1]}
     out.update(measure(v, sc.camera, a.frames, a.trials))
     st = v.stats()
     out["rays_per_frame"] = None
