@@ -421,9 +421,14 @@ int crh_add_object(crh_ctx* c, const float* pos, const float* nrm, const float* 
   const uint32_t T0 = (uint32_t)(c->tri.size() / 4), V0 = (uint32_t)(c->pos.size() / 3), ob = c->nO;
   if ((uint64_t)T0 + nT >= (1u << 28) || (uint64_t)c->n_pos + nT >= (1u << 28)) return fail(c, CRH_E_INVALID, "too many triangles (limit 2^28)");
   CRH_HIP(hipSetDevice(c->device));
-  // room for the new object's leaf positions (and as many again: the next additions should not reallocate 64 B x 3 per triangle of the whole scene each time)
-  if ((size_t)c->n_pos + nT > c->cap_pos) {
-    const size_t cap = (size_t)c->n_pos + 2 * (size_t)nT + c->cap_pos / 4;
+  // room for the new object's leaf positions BEHIND the room crh_build left for the object trees of the scene's own objects that have not moved yet (the new tree
+  // must not live on their reservation: a later crh_set_transforms would find the positions exhausted -- tests/hunts/visibility_walks.py found that), and as
+  // many again: the next additions should not reallocate 64 B x 3 per triangle of the whole scene each time
+  uint64_t reserved = 0;
+  for (const TwoLevelState::Obj& o : c->objs) if (!o.built) reserved += o.ntri;
+  if ((uint64_t)c->n_pos + reserved + nT >= (1ull << 28)) return fail(c, CRH_E_INVALID, "too many triangles (limit 2^28)");
+  if ((size_t)c->n_pos + reserved + nT > c->cap_pos) {
+    const size_t cap = (size_t)c->n_pos + (size_t)reserved + 2 * (size_t)nT + c->cap_pos / 4;
     int rc;
     CRH_HIP(hipStreamSynchronize(cstream(c)));
     for (int k = 0; k < 8; ++k) if (c->pipe_pending[k]) CRH_HIP(hipEventSynchronize(c->lane_join[k]));      // frames in flight still read the old arrays

@@ -234,6 +234,24 @@ def test_hip_add_object_matches_oracle(hip_lib, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_hip_added_object_does_not_live_on_the_room_of_objects_that_move_later(hip_lib, oracle_lib):
+    """crh_build leaves leaf positions for the object tree of every object that has not moved yet; a small object added afterwards fits into that room -- and
+    used to take it: the crh_set_transforms that then moved every object of the scene found the positions exhausted (tests/hunts/visibility_walks.py)"""
+    sc = object_scene(w=64, h=48)
+    v, o = pair(oracle_lib, sc)
+    small = one_object(sc, 3)
+    for k in range(3):
+        place = rigid(20.0 * k, (0, 0, 1), (0.1 * k - 0.1, 0.05, 0.1), 0.5)
+        assert v.add_object(*small, place) == o.add_object(*small, place) == 7 + k
+    same(v, o)
+    xf = np.stack([rigid(5.0 + ob, (0, 0, 1), (0.01 * ob, 0.0, 0.02)) for ob in range(10)])            # every object off its build-time placement
+    for b in (v, o): b.set_transforms(xf)
+    same(v, o)
+    for b in (v, o): b.set_transforms(np.tile(rigid(), (10, 1)))
+    same(v, o)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(6))
 def test_hip_fuzz_visibility_transforms_adaptive_checkpoint(hip_lib, oracle_lib, seed):
     """random sequences mixing Display / Erase, manipulator moves, an added object, adaptive sampling and a checkpoint: the product follows the oracle"""

@@ -23,6 +23,10 @@ def mem():
     return (total - free) / 2**20, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024
 
 
+def rss_now():
+    return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2**20
+
+
 def burst(n):
     inflight = 0
     t0 = time.perf_counter()
@@ -35,6 +39,7 @@ def burst(n):
             mats = list(sc.materials); mats[0] = dataclasses.replace(mats[0], Kd=np.float32(r.random(3))); v.set_materials(mats)
         elif k == 3: v.set_adaptive(bool(r.integers(0, 2)), 32)
         elif k == 4: v.set_lookahead(int(r.choice([1, 4])))
+        elif k == 5 and not os.environ.get("SOAK_NO_VISIBILITY"): v.set_visibility((r.random(nO) > 0.2).astype(np.uint8))            # the eye icons of the scene tree (round 6)
         v.Redraw()
         if inflight == 2: v.read_ldr_end(); inflight -= 1
         v.read_ldr_begin(); inflight += 1
@@ -44,12 +49,12 @@ def burst(n):
 
 
 burst(2000)
-d0, h0 = mem(); rates = []
+d0, h0 = mem(); rates = []; rss = [round(rss_now(), 1)]
 for _ in range(max(1, frames // 5000)):
-    rates.append(round(burst(5000), 1))
+    rates.append(round(burst(5000), 1)); rss.append(round(rss_now(), 1))
 d1, h1 = mem()
 out = {"frames": 5000 * len(rates), "redraw_per_s_per_5000": rates, "device_MiB_before": round(d0, 1), "device_MiB_after": round(d1, 1),
-       "host_maxrss_MiB_before": round(h0, 1), "host_maxrss_MiB_after": round(h1, 1), "finite": bool(np.isfinite(v.read_hdr()).all())}
+       "host_rss_MiB_per_5000": rss, "host_maxrss_MiB_before": round(h0, 1), "host_maxrss_MiB_after": round(h1, 1), "finite": bool(np.isfinite(v.read_hdr()).all())}
 out["pass"] = abs(d1 - d0) < 64 and h1 - h0 < 64 and min(rates) > 0.7 * max(rates) and out["finite"]
 print(json.dumps(out))
 sys.exit(0 if out["pass"] else 1)
