@@ -172,10 +172,11 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_FRAME_LIVE",         "frame kernel: paths a workgroup (16 wavefronts, one per compute unit) keeps alive at most, 64 .. 16384, cut to the ring size 4096 (default 4096)"},
   {"CRH_FRAME_CHUNK",        "frame kernel: path slots a wavefront claims at a time, multiples of 64 up to 1024 (default 128)"},
   {"CRH_FRAME_LOW",          "frame kernel: a feeder wavefront claims the next chunk once fewer rays than this wait in the workgroup's ring (default 512)"},
-  {"CRH_FRAME_FEED",         "frame kernel: wavefronts of a workgroup that only shade and generate, 0 .. 15 (default 3 of 16; 4 pays on scenes with short walks: profiles/r6/lone_frame.md)"},
+  {"CRH_FRAME_FEED",         "frame kernel: wavefronts of a workgroup that only shade and generate, 0 .. 15 (default: 3 or 4 of 16, chosen by measurement after every crh_build -- 4 pays on scenes with short walks: profiles/r6/lone_frame.md)"},
   {"CRH_FRAME_STARVE",       "frame kernel: a feeder shades fewer than 64 waiting hits only while fewer rays than this wait in the ring (default 2^20: always)"},
   {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 0: every tracer takes what is there)"},
   {"CRH_FRAME_HELP",         "frame kernel: a tracer wavefront shades a batch itself once this many hit records wait in the workgroup's rings, 64 .. 4096 (default 256)"},
+  {"CRH_FRAME_HELP_LOW",     "frame kernel: a tracer wavefront prefers a full shading batch (64 waiting hits) to tracing while fewer rays than this wait in the ring, 0 .. 4096 (default 0: it traces whatever is there)"},
   {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident = ONE 1024-thread workgroup per compute unit); never fewer than min(resident, 32), never more than resident"},
   {"CRH_FRAME_PIPE",         "frame pipeline: a frame takes the frame kernel while fewer than this many frames are running, and at most this many frame kernels run at a time, 1 .. 8 (default 2)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
@@ -208,10 +209,11 @@ static void read_env(crh_ctx* c)
   if (const char* e = getenv("CRH_FRAME_LIVE")) { int v = atoi(e); if (v >= 64 && v <= 16384) c->frame_live = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 1024) c->frame_chunk = (uint32_t)v & ~63u; }
   if (const char* e = getenv("CRH_FRAME_LOW")) { int v = atoi(e); if (v >= 0 && v <= 16384) c->frame_low_water = (uint32_t)v; }
-  if (const char* e = getenv("CRH_FRAME_FEED")) { int v = atoi(e); if (v >= 0 && v <= 15) c->frame_feeders = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_FEED")) { int v = atoi(e); if (v >= 0 && v <= 15) { c->frame_feeders = (uint32_t)v; c->feed_tune.on = false; } }      // fixed: no tuning
   if (const char* e = getenv("CRH_FRAME_STARVE")) { int v = atoi(e); if (v >= 0) c->frame_starve = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_STEP")) { int v = atoi(e); if (v >= 0 && v <= 256) c->frame_claim_step = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_HELP")) { int v = atoi(e); if (v >= 64 && v <= 4096) c->frame_help = (uint32_t)v; }
+  if (const char* e = getenv("CRH_FRAME_HELP_LOW")) { int v = atoi(e); if (v >= 0 && v <= 4096) c->frame_help_low = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_GRID")) { int v = atoi(e); if (v >= 1) c->frame_grid = v; }
   if (const char* e = getenv("CRH_FRAME_PIPE")) { int v = atoi(e); if (v >= 1 && v <= 8) c->frame_pipe_depth = (uint32_t)v; }
   if (const char* e = getenv("CRH_LANES")) { int v = atoi(e); if (v >= 1 && v <= 8) c->n_lanes = (uint32_t)v; }
@@ -255,6 +257,8 @@ void crh_destroy(crh_ctx* c)
   hipSetDevice(c->device);
   hipStreamSynchronize(cstream(c));
   drain_events(c);
+  for (auto& q : c->feed_tune.pend) { c->ev_pool.push_back(q.e0); c->ev_pool.push_back(q.e1); }
+  c->feed_tune.pend.clear();
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {c->d_nodes, c->d_pnodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o[0], c->paths.ray_d[0], c->paths.ray_o[1], c->paths.ray_d[1], c->paths.thr[1],
                   c->paths.hit, c->paths.thr[0], c->paths.rad, c->paths.sh_o, c->paths.sh_d, c->paths.sh_c,
@@ -283,6 +287,15 @@ const char* crh_last_error(crh_ctx* c) { return c ? c->err.c_str() : "null conte
 int crh_reset(crh_ctx* c) { if (!c) return CRH_E_INVALID; return do_reset(c); }
 
 int crh_sync(crh_ctx* c) { if (!c) return CRH_E_INVALID; c->read_since_render = true; CRH_HIP(hipSetDevice(c->device)); CRH_HIP(hipStreamSynchronize(cstream(c))); return check_device_error(c); }
+
+int crh_get_frame_tuning(crh_ctx* c, uint32_t out[5])
+{
+  if (!c || !out) return fail(c, CRH_E_INVALID, "null argument");
+  const crh_ctx::FeedTune& ft = c->feed_tune;
+  out[0] = ft.on ? 1u : 0u; out[1] = ft.on ? ft.chosen : c->frame_feeders; out[2] = ft.n[0] + ft.n[1];
+  out[3] = ft.n[0] ? (uint32_t)(1.0e3 * ft.ms[0] / ft.n[0]) : 0u; out[4] = ft.n[1] ? (uint32_t)(1.0e3 * ft.ms[1] / ft.n[1]) : 0u;
+  return CRH_OK;
+}
 
 int crh_get_path_budget(crh_ctx* c, uint64_t* max_paths)
 {

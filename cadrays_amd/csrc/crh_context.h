@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <thread>
 #include <vector>
@@ -158,7 +159,18 @@ struct ScheduleState {
   uint32_t frame_feeders = 3, frame_claim_step = 0;    // wavefronts that only shade and generate (round 6: 2 / 3 / 4 / 5 -> 3.07 / 2.85 / 2.92 / 3.39 ms lone frame on C3, 3.0 / 2.60 / 2.30 / 2.31 on the CAD-like scene,
                                                     // whose short walks leave more shading and generating per traced ray: CRH_FRAME_FEED=4 there); tracer w takes rays only
                                                        // while >= w * claim_step wait: 0 / 16 / 32 / 64 -> 2.90 / 2.95 / 3.13 / 3.46 ms -- the shared rings gather the late bounces by themselves
+  // The feeder count is chosen by measurement (round 6) unless CRH_FRAME_FEED fixes it: scenes with short walks (tessellated parts, 13.6 node visits per ray) want 4
+  // feeders -- lone frame 2.62 -> 2.36 ms, drag 425 -> 507 frames/s on CAD1M -- triangle soups 3 (4 costs them 1 - 2 %).  After every crh_build (and a change of the
+  // target size or the depth) the first pipelined frame-kernel frames run in blocks of 6 -- a warm-up block, then 3 / 4 / 3 / 4 feeders; the device time of each
+  // frame KERNEL (its own event pair, first frame of a block left out) decides: 4 if that is >= 5 % faster, else 3 (CAD1M: 16 %; the soups: within +- 3 %).  No image depends on the count (tests/test_frame_kernel.py).
+  struct FeedTune {
+    bool on = true; uint32_t chosen = 0, frames = 0, n[2] = {0, 0}; double ms[2] = {0.0, 0.0};
+    struct Pend { hipEvent_t e0, e1; int which; };
+    std::deque<Pend> pend;
+    void restart() { chosen = 0; frames = 0; n[0] = n[1] = 0; ms[0] = ms[1] = 0.0; for (Pend& q : pend) q.which = -1; }
+  } feed_tune;
   uint32_t frame_help = 256;                        // a tracer wavefront shades a batch itself once this many hit records wait
+  uint32_t frame_help_low = 0;                      // ... and prefers a full shading batch to tracing while fewer rays than this wait (CRH_FRAME_HELP_LOW)
   int frame_grid = 0;                               // workgroups of a lone frame (0: what is resident, 4 per CU)
   uint32_t frame_pipe_depth = 2;                    // a pipelined frame takes the frame kernel while fewer than this many frames are running, and at most this many frame
                                                     // kernels run at a time (they share the chip by compute units); beyond it the staged form carries the deeper pipeline

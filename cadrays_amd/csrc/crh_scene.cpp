@@ -290,6 +290,7 @@ static int apply_objects(crh_ctx* c, const float* xf, const uint8_t* visible)
   const uint32_t nO = c->nO;
   const int threads = build_threads_env();
   const uint32_t old_nodes = c->n_blas_nodes, old_pos = c->n_pos;
+  const bool had_instances = !c->inst.empty();
   auto moved_now = [&](uint32_t ob) { const float* m = xf ? &xf[12 * (size_t)ob] : &c->xf[12 * (size_t)ob]; return !c->objs[ob].static0 || std::memcmp(m, &c->xf0[12 * (size_t)ob], 12 * sizeof(float)) != 0; };
   auto shown_now = [&](uint32_t ob) { return visible ? visible[ob] != 0 : (c->hidden.empty() || !c->hidden[ob]); };
   {
@@ -363,6 +364,7 @@ static int apply_objects(crh_ctx* c, const float* xf, const uint8_t* visible)
     CRH_HIP(hipGetLastError());
   }
   if ((rc = build_tlas(c))) return rc;
+  if (had_instances != !c->inst.empty()) c->feed_tune.restart();      // the frame kernel's other instantiation (one walk / two levels): its feeder count is measured again
   const size_t tail = c->bvh.nodes.size() - old_nodes;
   if (c->bvh.nodes.size() * sizeof(QNode) > c->cap_nodes) {          // more object trees than crh_build left room for: the whole array again, with head-room
     if ((rc = dev_put(c, c->d_nodes, c->cap_nodes, c->bvh.nodes.data(), c->bvh.nodes.size() * sizeof(QNode), c->bvh.nodes.size() * sizeof(QNode) / 2 + (size_t)(4 * c->nO + 64) * sizeof(QNode)))) return rc;
@@ -540,6 +542,7 @@ int crh_set_params(crh_ctx* c, const crh_params* p)
   if (p->tile_size < 8 || (p->tile_size & 7u) || p->tile_size > 1024) return fail(c, CRH_E_INVALID, "tile_size must be a multiple of 8 in 8..1024");
   { const float f[] = {p->radiance_clamp, p->exposure, p->white_point, p->background[0], p->background[1], p->background[2], p->scene_epsilon};
     if (!all_finite(f, sizeof f / sizeof f[0])) return fail(c, CRH_E_INVALID, "params hold a NaN / Inf"); }
+  if (p->width != c->par.width || p->height != c->par.height || p->max_depth != c->par.max_depth) c->feed_tune.restart();      // another frame: measured again
   c->par = *p;
   return do_reset(c);
 }
@@ -715,7 +718,7 @@ static int build_scene(crh_ctx* c, const QNode* pre_nodes, uint32_t pre_n_nodes,
       CRH_HIP(hipMalloc(&c->d_patch, want_patch)); c->cap_patch = want_patch;
     }
   }
-  c->built = true;
+  c->built = true; c->feed_tune.restart();
   if (c->two_level && c->inst.empty()) {
     // Every object sits at the identity: the single-level kernels render this scene.  The first crh_set_transforms (the user has just grabbed the
     // gizmo) switches to the two-level instantiations and the record scatter -- launch each of them once now, on empty queues, so that their

@@ -24,7 +24,8 @@ namespace {
 // One wavefront schedule: `ns` samples of `nt` tiles (ids at d_tiles, seeds at d_seeds) on one stream and one slice of the path state.
 struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; bool donate = false;
               bool frame = false; int grid_frame = 0;         // frame: the whole batch in one launch of the frame kernel (k_frame.h) with grid_frame workgroups
-              const uint32_t* h_seeds = nullptr; };           // ... whose <= 16 frame seeds travel by value (d_seeds == nullptr)
+              const uint32_t* h_seeds = nullptr;              // ... whose <= 16 frame seeds travel by value (d_seeds == nullptr)
+              hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr; };   // ... bracketed by these two events when the feeder count is being tuned (crh_context.h FeedTune)
 
 // May this batch take the frame kernel?  Small, not counted, not timed per kernel, slots that fit the bits the kernel keeps them in.
 bool frame_ok(const crh_ctx* c, uint64_t total)
@@ -49,7 +50,9 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
     // the frame kernel: camera rays, every bounce's traversal, shading and shadow rays of this batch in ONE launch (k_frame.h); its two control words live behind
     // the queue counters of this lane (zero when allocated, left zero by every launch)
     Launch LF{ln.stream, ln.grid_frame, false, c->clamp_grid ? c->cus : 0};
-    launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->frame_low_water, c->frame_feeders, c->frame_claim_step, c->frame_starve, c->d_counters, ln.h_seeds, c->d_api_cursor + 8, c->frame_help);      // + 8: the context's device error word (crh_context.cpp check_device_error)
+    if (ln.tune_e0) hipEventRecord(ln.tune_e0, ln.stream);
+    launch_frame(LF, S, ln.P, ln.Q.counts + 12, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, c->frame_live, c->frame_chunk, c->frame_low_water, c->frame_feeders, c->frame_claim_step, c->frame_starve, c->d_counters, ln.h_seeds, c->d_api_cursor + 8, c->frame_help | (c->frame_help_low << 16));      // + 8: the context's device error word (crh_context.cpp check_device_error)
+    if (ln.tune_e1) hipEventRecord(ln.tune_e1, ln.stream);
   } else {
   launch_raygen(L, S, ln.P, ln.Q, 0, d_tiles, nt, d_seeds, ns, seed_per_tile, ln.n_tiles_dev, ln.h_seeds);
   int qin = 0;
@@ -245,6 +248,31 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     // frame kernel: one workgroup fills a compute unit, so the frames in flight share the chip by compute units (every frame asking for all of them was
     // measured: the second frame's workgroups then wait for whole workgroups of the first to leave -- 368 against 399 Redraw/s)
     ln.frame = frame; ln.grid_frame = frame ? frame_grid(c, S, std::min(in_flight, std::max(1u, c->frame_pipe_depth))) : 0;
+    if (frame && c->feed_tune.on) {
+      // the feeder count by measurement (crh_context.h FeedTune): collect the frame kernels that have finished, then either take the next measurement or the verdict
+      crh_ctx::FeedTune& ft = c->feed_tune;
+      while (!ft.pend.empty() && hipEventQuery(ft.pend.front().e1) != hipErrorNotReady) {
+        const crh_ctx::FeedTune::Pend q = ft.pend.front(); ft.pend.pop_front();
+        float ms = 0.f;
+        if (q.which >= 0 && hipEventElapsedTime(&ms, q.e0, q.e1) == hipSuccess) { ft.ms[q.which] += ms; ++ft.n[q.which]; }
+        c->ev_pool.push_back(q.e0); c->ev_pool.push_back(q.e1);
+      }
+      if (!ft.chosen && ft.n[0] >= 8u && ft.n[1] >= 8u) {
+        ft.chosen = ft.ms[1] / ft.n[1] < 0.95 * (ft.ms[0] / ft.n[0]) ? 4u : 3u;
+        for (crh_ctx::FeedTune::Pend& q : ft.pend) q.which = -1;
+      }
+      if (ft.chosen) c->frame_feeders = ft.chosen;
+      else {
+        const uint32_t block = ft.frames / 6u, which = (block + 1u) & 1u;      // blocks: warm-up (4, not measured), 3, 4, 3, 4, ...
+        c->frame_feeders = which ? 4u : 3u;
+        if (block != 0u && ft.frames % 6u != 0u && ft.pend.size() < 64u) {     // (the first frame of a block runs beside a frame of the other setting; the first block after
+                                                                               // a build touches the path state for the first time)
+          ln.tune_e0 = get_event(c); ln.tune_e1 = get_event(c);
+          ft.pend.push_back({ln.tune_e0, ln.tune_e1, (int)which});
+        }
+        ++ft.frames;
+      }
+    }
     const size_t base = (size_t)k * total;
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
     ln.P.ray_o[0] = P.ray_o[0] + base; ln.P.ray_o[1] = P.ray_o[1] + base; ln.P.ray_d[0] = P.ray_d[0] + base; ln.P.ray_d[1] = P.ray_d[1] + base;

@@ -53,6 +53,7 @@ struct FrameArgs {
   uint32_t starve;            // a feeder shades fewer than a wavefront's worth of hits only while fewer rays than this wait in the ring (the tracers are about to starve)
   uint32_t claim_step;        // tracer wavefront w takes rays from the ring only while >= w * claim_step wait there: scarce rays go to the first wavefronts
   uint32_t help;              // a tracer wavefront shades a batch itself once this many hit records wait (the feeders have fallen behind)
+  uint32_t help_low;          // ... and prefers a FULL shading batch to tracing while fewer rays than this wait in the ring (0: a tracer traces whatever is there)
   uint32_t* err;              // the context's device error word (never touched in a healthy run)
 };
 
@@ -215,7 +216,12 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
       if (before + A.gen_chunk > A.max_live) atomicSub(live, A.gen_chunk);
       else {
         cbase = atomicAdd(A.ctl, A.gen_chunk);
-        if (cbase >= total) { atomicSub(live, A.gen_chunk); __hip_atomic_store(cursor_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        if (cbase >= total) {
+          atomicSub(live, A.gen_chunk); __hip_atomic_store(cursor_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if CRH_FRAME_STATS || CRH_FRAME_TIMELINE
+          { const unsigned long long t = (unsigned long long)wall_clock64(); atomicMax(&g_frame_stats[27], ~t); atomicMax(&g_frame_stats[28], t); }
+#endif
+        }
         else ok = 1u;
       }
     }
@@ -293,6 +299,11 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
 #if CRH_FRAME_STATS
   const unsigned long long fs_start = (unsigned long long)clock64();
 #endif
+#if CRH_FRAME_STATS || CRH_FRAME_TIMELINE
+  // the frame's time line on the 100 MHz wall clock (one frame per read of the statistics): [26] earliest wavefront start, [27] / [28] the first / last workgroup to
+  // find the slot cursor exhausted, [29] / [30] the last / first wavefront to leave (minima are kept as maxima of the complement)
+  if (lane == 0) atomicMax(&g_frame_stats[26], ~(unsigned long long)wall_clock64());
+#endif
   uint32_t idle_spins = 0;
   for (;;) {
     const uint32_t nr = ring_count(rq_head, rq_tail);
@@ -312,7 +323,8 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
       else if (nr < A.low_water && may_generate()) act = 2;
       else if (ns != 0u && (nr < A.starve || nr == 0u)) act = 1;     // the tracers are about to starve: whatever waits is shaded now
     } else {
-      if (nr != 0u && nr >= claim_min) act = 3;
+      if (nr < A.help_low && full_batch) act = 1;                    // a handful of rays would run at a few lanes of 64: 64 waiting hits make 64 new rays first
+      else if (nr != 0u && nr >= claim_min) act = 3;
       else if (ns >= A.help || (A.n_feed == 0u && ns != 0u && !(nr == 0u && may_generate()))) act = 1;      // the feeders have fallen behind (or there are none)
       else if (nr == 0u && may_generate()) act = 2;
     }
@@ -330,6 +342,9 @@ __global__ __launch_bounds__(kFrameBlock, CRH_FRAME_MINWAVES) void k_frame(DScen
   }
 #if CRH_FRAME_STATS
   if (lane == 0) atomicAdd(&g_frame_stats[feeder ? 25 : 24], (unsigned long long)clock64() - fs_start);      // wave cycles from start to leaving the loop
+#endif
+#if CRH_FRAME_STATS || CRH_FRAME_TIMELINE
+  if (lane == 0) { const unsigned long long t = (unsigned long long)wall_clock64(); atomicMax(&g_frame_stats[29], t); atomicMax(&g_frame_stats[30], ~t); }
 #endif
   if (lane == 0) {
     if (n_near) atomicAdd(&C->rays_nearest, (unsigned long long)n_near);

@@ -31,7 +31,10 @@
 #ifndef CRH_FRAME_STATS
 #define CRH_FRAME_STATS 0      // 1: an instrumented build (tools/ab_build.sh): the frame kernel's engine counts its turns, active rays, dry turns and step executions
 #endif
-#if CRH_FRAME_STATS
+#ifndef CRH_FRAME_TIMELINE
+#define CRH_FRAME_TIMELINE 0   // 1: only the frame's time line (three wall-clock marks per workgroup: no measurable cost, unlike CRH_FRAME_STATS whose phase clocks slow a frame 3 x)
+#endif
+#if CRH_FRAME_STATS || CRH_FRAME_TIMELINE
 __device__ unsigned long long g_frame_stats[32];      // tools/frame_stats.py names the entries
 #endif
 #ifndef CRH_EXP_EARLY_TRI

@@ -132,7 +132,7 @@ void launch_frame(const Launch& L, const DScene& S, const DPaths& P, uint32_t* c
                   uint32_t n_samples, int seed_per_tile, const uint32_t* d_n_tiles, uint32_t max_live, uint32_t gen_chunk, uint32_t low_water, uint32_t n_feed, uint32_t claim_step, uint32_t starve, DCounters* C, const uint32_t* h_seeds, uint32_t* d_err, uint32_t help)
 {
   FrameArgs A;
-  A.err = d_err; A.help = help ? help : 256u;
+  A.err = d_err; A.help = (help & 0xFFFFu) ? (help & 0xFFFFu) : 256u; A.help_low = help >> 16;      // (the two tracer-helps-shading thresholds travel in one argument)
   A.tile_ids = d_tile_ids; A.n_tiles = n_tiles; A.n_tiles_dev = d_n_tiles; A.seeds = d_seeds; A.n_samples = n_samples; A.seed_per_tile = seed_per_tile;
   for (int i = 0; i < 16; ++i) A.seed_vals[i] = (h_seeds && (uint32_t)i < n_samples) ? h_seeds[i] : 0u;
   A.ctl = ctl; A.gen_chunk = min(max(gen_chunk & ~63u, 64u), kFrameRing); A.max_live = min(max(max_live, A.gen_chunk), kFrameRing); A.low_water = low_water;
@@ -153,7 +153,7 @@ extern "C" __attribute__((visibility("default"))) int crh_exp_coherence(unsigned
 }
 namespace crh {
 #endif
-#if CRH_FRAME_STATS
+#if CRH_FRAME_STATS || CRH_FRAME_TIMELINE
 }  // namespace crh
 // instrumented builds only (tools/ab_build.sh NAME "-DCRH_FRAME_STATS=1"): what the frame kernel's engines counted since the last call
 extern "C" __attribute__((visibility("default"))) int crh_exp_frame_stats(unsigned long long* out32)

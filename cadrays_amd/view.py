@@ -79,6 +79,12 @@ class View(Backend):
         self._call("get_path_budget", C.byref(n))
         return int(n.value)
 
+    def frame_tuning(self):
+        """crh_get_frame_tuning: the frame kernel's feeder count chosen by measurement after every build (no image depends on it)"""
+        out = (C.c_uint32 * 5)()
+        self._call("get_frame_tuning", out)
+        return {"enabled": bool(out[0]), "feeders": int(out[1]), "frames_measured": int(out[2]), "mean_us_3_feeders": int(out[3]), "mean_us_4_feeders": int(out[4])}
+
     def packet_stats(self):
         """camera rays walked as packets since the last restart, and those of them handed to the per-ray fall-back pass (ties at equal distance)"""
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -272,6 +272,10 @@ CRH_API const char* crh_env_table(void);
 CRH_API int crh_set_path_budget(crh_ctx* ctx, uint64_t max_paths);
 /* the budget in force (the default, CRH_MAX_PATHS or the last crh_set_path_budget): a host that lowers it for a while restores THIS value, not a constant */
 CRH_API int crh_get_path_budget(crh_ctx* ctx, uint64_t* max_paths);
+/* Round 6: the frame kernel's feeder count (wavefronts of a workgroup that shade and generate instead of tracing) is chosen by measurement after every crh_build
+ * unless CRH_FRAME_FEED fixes it -- no image depends on it.  out[0] = tuning enabled, out[1] = the count chosen (0: still measuring), out[2] = frames measured
+ * so far, out[3] / out[4] = mean frame-kernel time in microseconds with 3 / 4 feeders. */
+CRH_API int crh_get_frame_tuning(crh_ctx* ctx, uint32_t out[5]);
 /* Per-tile error estimate (mean standard error of the pixel luminance) and per-tile sample count; pass NULL
  * arrays to query n_tiles.  Needs adaptive mode for a meaningful error. */
 CRH_API int crh_get_tile_stats(crh_ctx* ctx, float* err, uint32_t* counts, uint32_t* n_tiles);

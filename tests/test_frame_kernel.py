@@ -273,3 +273,33 @@ def test_cpp_host_runs_the_applications_loops(hip_lib, oracle_lib, tmp_path):
     info = json.loads(subprocess.check_output([exe, path, "5", "--loop", "lone"], text=True).strip().splitlines()[-1])
     assert info["loop"] == "lone" and info["lone_frame_ms_median"] > 0 and info["samples"] == 1216 * 896
     o.close(); o2.close()
+
+
+def test_feeder_count_is_chosen_by_measurement_and_no_image_depends_on_it(hip_lib, oracle_lib, monkeypatch):
+    """Round 6: unless CRH_FRAME_FEED fixes it, the first pipelined frames after a build run in blocks with 3 / 4 feeder wavefronts and the frame kernels' own
+    device times decide (crh_get_frame_tuning).  The frames rendered WHILE the count alternates equal the staged schedule's bit for bit; a new build measures again."""
+    from cadrays_amd.view import View
+    sc = c3_1080p(20_000)
+    v = View(0).load_scene(sc)
+    t0 = v.frame_tuning()
+    assert t0["enabled"] and t0["feeders"] == 0 and t0["frames_measured"] == 0
+    for i in range(40):
+        v.Redraw()
+        if i < 36: v.sync()                              # a host that waits for every frame (each then takes the frame kernel); the finished ones are collected at the next submission
+    v.Redraw(); v.sync(); v.Redraw()
+    t = v.frame_tuning()
+    assert t["feeders"] in (3, 4) and t["frames_measured"] >= 16 and t["mean_us_3_feeders"] > 0 and t["mean_us_4_feeders"] > 0, t
+    print("frame tuning on the 20 k-triangle soup:", t)
+    s = View(0).load_scene(sc); s.set_schedule(abi.SCHEDULE_STAGED)
+    for _ in range(42):
+        s.Redraw()
+    assert np.array_equal(bits(v.read_hdr()), bits(s.read_hdr())) and v.stats()["rays_nearest"] == s.stats()["rays_nearest"]
+    v.build()                                            # the scene may be another one now: measured again
+    assert v.frame_tuning()["feeders"] == 0 and v.frame_tuning()["frames_measured"] == 0
+    v.close(); s.close()
+    monkeypatch.setenv("CRH_FRAME_FEED", "5")
+    w = View(0).load_scene(sc)
+    for _ in range(3):
+        w.Redraw()
+    assert w.frame_tuning() == {"enabled": False, "feeders": 5, "frames_measured": 0, "mean_us_3_feeders": 0, "mean_us_4_feeders": 0}
+    w.close()

@@ -26,6 +26,11 @@ def drag_camera(cam0, i):
 
 def measure(v, cam0, frames=128, trials=15):
     out = {}
+    # the first 30 frame-kernel frames after a build are the library's measurement of its feeder count (crh_get_frame_tuning): let it settle first
+    for _ in range(64):
+        if not v.frame_tuning()["enabled"] or v.frame_tuning()["feeders"]: break
+        v.reset(); v.Redraw(); v.sync()
+    out["frame_tuning"] = v.frame_tuning()
     # ---- a lone frame after a restart
     ts = []
     for _ in range(trials):

@@ -31,3 +31,11 @@ for i in range(3):
           f"retire / store {fin / max(store_w, 1):.1f} ({store_w} turns of {turns} retire something)   shading {sh_n / max(sh_b, 1):.1f} per batch, {big / max(sh_b, 1):.1f} of them in the batch's largest material class")
     print(f"   tracer wavefronts: {c_tr / 1e6:.1f} M wave cycles in the kernel, {tr_busy / 1e6:.1f} M inside the engine = refill / claim {c_refill / max(tr_busy, 1):.3f}  donation {c_don / max(tr_busy, 1):.3f}  inner steps {c_inner / max(tr_busy, 1):.3f}  "
           f"leaf {c_leaf / max(tr_busy, 1):.3f}  retire / store {c_retire / max(tr_busy, 1):.3f};   feeders: {c_fd / 1e6:.1f} M wave cycles, shading {c_shade / max(c_fd, 1):.3f} generating {c_gen / max(c_fd, 1):.3f} of them (tracers that shade or generate are in these two as well)")
+    # round 6: the frame's time line (100 MHz wall clock): start .. the slot cursor runs out (first / last workgroup to notice) .. first / last wavefront leaves
+    M = (1 << 64) - 1
+    if s[26] and s[29]:
+        t0 = M - s[26]; out_first = M - s[27]; out_last = s[28]; end_last = s[29]; end_first = M - s[30]
+        us = lambda t: (t - t0) / 100.0
+        print(f"   time line (us after the first wavefront's start): slot cursor exhausted {us(out_first):.0f} (first workgroup to see it) .. {us(out_last):.0f} (last);  wavefronts leave {us(end_first):.0f} .. {us(end_last):.0f}"
+              f"   => no new path after {us(out_first) / max(us(end_last), 1e-9):.2f} of the frame; the drain is {us(end_last) - us(out_first):.0f} us")
+
