@@ -889,6 +889,13 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
 
 def interactive_figures(v, cam0):
     interactive = {}
+    # the first 30 frame-kernel frames after a build are the library's measurement of its feeder count (crh_get_frame_tuning): a viewer passes them in the first
+    # tenth of a second; the figures below are those of the settled library
+    v.set_lookahead(1)
+    for _ in range(64):
+        if not v.frame_tuning()["enabled"] or v.frame_tuning()["feeders"]: break
+        v.reset(); v.Redraw(); v.sync()
+    interactive["frame_tuning"] = v.frame_tuning()
     for k in (1, 16, 64):
         v.set_lookahead(k); v.reset()
         for _ in range(max(8, 2 * k)):              # the frame pipeline (up to eight in flight) is full before the clock starts
