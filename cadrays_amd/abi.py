@@ -72,5 +72,5 @@ EXPORTS = [
     "crh_render", "crh_render_tiles", "crh_set_adaptive", "crh_set_show_tiles", "crh_set_lookahead", "crh_set_lookahead_auto", "crh_set_schedule", "crh_set_pipeline_depth", "crh_set_path_budget", "crh_get_tile_stats", "crh_sync", "crh_read_hdr", "crh_read_ldr", "crh_read_ldr_begin", "crh_read_ldr_end", "crh_read_hdr_begin", "crh_read_hdr_end",
     "crh_save_accum", "crh_load_accum", "crh_accum_device_ptr", "crh_reduce", "crh_enable_counters", "crh_get_stats", "crh_trace_nearest",
     "crh_trace_any", "crh_get_bvh", "crh_get_tlas", "crh_build_bvh_host", "crh_bench_trace", "crh_debug_math", "crh_debug_bsdf", "crh_enable_kernel_timing",
-    "crh_get_kernel_timing", "crh_get_packet_stats", "crh_debug_reduce_fake_devices", "crh_get_path_budget", "crh_get_frame_tuning", "crh_build_prebuilt", "crh_query_pipeline_capacity", "crh_env_table",
+    "crh_get_kernel_timing", "crh_get_packet_stats", "crh_debug_reduce_fake_devices", "crh_get_path_budget", "crh_get_frame_tuning", "crh_get_tile_order", "crh_build_prebuilt", "crh_query_pipeline_capacity", "crh_env_table",
 ]

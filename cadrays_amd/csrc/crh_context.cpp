@@ -140,6 +140,18 @@ int do_reset(crh_ctx* c)
   CRH_HIP(hipMemsetAsync(c->d_accum, 0, sizeof(float4) * (size_t)c->par.width * c->par.height, cs));
   CRH_HIP(hipMemsetAsync(c->d_m2, 0, sizeof(float) * (size_t)c->par.width * c->par.height, cs));
   c->adaptive_picks = 0; c->pending_n = 0; c->ramp_k = 1; c->picked_valid = false; c->assembled_valid = false;
+  {   // per-tile costs of the accumulation that ends here: to the host (pinned, asynchronous, behind the frames in flight), then zero for the next one
+    crh_ctx::TileOrder& to = c->tile_order;
+    // a host that restarts while frames are still running is dragging: it gets no new list (replacing the list waits for the frames that read it -- measured:
+    // drag loop -5 ... -10 % when every restart may do that); `streak` = crh_render calls in a row that found nothing in flight
+    if (to.on && to.d_cost && to.dirty && !to.pending && to.streak >= 2u) {
+      if (!to.copied) CRH_HIP(hipEventCreateWithFlags(&to.copied, hipEventDisableTiming));
+      CRH_HIP(hipMemcpyAsync(to.h_cost, to.d_cost, sizeof(uint32_t) * to.n, hipMemcpyDeviceToHost, cs));
+      CRH_HIP(hipMemsetAsync(to.d_cost, 0, sizeof(uint32_t) * to.n, cs));
+      CRH_HIP(hipEventRecord(to.copied, cs));
+      to.pending = true; to.dirty = false;
+    }
+  }
   if (!c->reset_ev) CRH_HIP(hipEventCreateWithFlags(&c->reset_ev, hipEventDisableTiming));
   CRH_HIP(hipEventRecord(c->reset_ev, cs)); c->reset_pending = true;
   {
@@ -177,6 +189,7 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 0: every tracer takes what is there)"},
   {"CRH_FRAME_HELP",         "frame kernel: a tracer wavefront shades a batch itself once this many hit records wait in the workgroup's rings, 64 .. 4096 (default 256)"},
   {"CRH_FRAME_HELP_LOW",     "frame kernel: a tracer wavefront prefers a full shading batch (64 waiting hits) to tracing while fewer rays than this wait in the ring, 0 .. 4096 (default 0: it traces whatever is there)"},
+  {"CRH_TILE_ORDER",         "1: a host whose frames start on an idle chip gets the image's tiles most-rays-of-the-last-accumulation-first from crh_render instead of row-major (lone frame -6 % on a model in front of a background, drag loop -2 %: opt-in; no pixel depends on the order)"},
   {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident = ONE 1024-thread workgroup per compute unit); never fewer than min(resident, 32), never more than resident"},
   {"CRH_FRAME_PIPE",         "frame pipeline: a frame takes the frame kernel while fewer than this many frames are running, and at most this many frame kernels run at a time, 1 .. 8 (default 2)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
@@ -213,6 +226,7 @@ static void read_env(crh_ctx* c)
   if (const char* e = getenv("CRH_FRAME_STARVE")) { int v = atoi(e); if (v >= 0) c->frame_starve = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_STEP")) { int v = atoi(e); if (v >= 0 && v <= 256) c->frame_claim_step = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_HELP")) { int v = atoi(e); if (v >= 64 && v <= 4096) c->frame_help = (uint32_t)v; }
+  if (const char* e = getenv("CRH_TILE_ORDER")) c->tile_order.on = atoi(e) != 0;
   if (const char* e = getenv("CRH_FRAME_HELP_LOW")) { int v = atoi(e); if (v >= 0 && v <= 4096) c->frame_help_low = (uint32_t)v; }
   if (const char* e = getenv("CRH_FRAME_GRID")) { int v = atoi(e); if (v >= 1) c->frame_grid = v; }
   if (const char* e = getenv("CRH_FRAME_PIPE")) { int v = atoi(e); if (v >= 1 && v <= 8) c->frame_pipe_depth = (uint32_t)v; }
@@ -258,6 +272,10 @@ void crh_destroy(crh_ctx* c)
   hipStreamSynchronize(cstream(c));
   drain_events(c);
   for (auto& q : c->feed_tune.pend) { c->ev_pool.push_back(q.e0); c->ev_pool.push_back(q.e1); }
+  if (c->d_tile_ids2) hipFree(c->d_tile_ids2);
+  if (c->tile_order.d_cost) hipFree(c->tile_order.d_cost);
+  if (c->tile_order.h_cost) hipHostFree(c->tile_order.h_cost);
+  if (c->tile_order.copied) hipEventDestroy(c->tile_order.copied);
   c->feed_tune.pend.clear();
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   void* ptrs[] = {c->d_nodes, c->d_pnodes, c->d_tris, c->d_shade, c->d_mats, c->d_lights, c->d_env, c->d_accum, c->paths.ray_o[0], c->paths.ray_d[0], c->paths.ray_o[1], c->paths.ray_d[1], c->paths.thr[1],
@@ -294,6 +312,18 @@ int crh_get_frame_tuning(crh_ctx* c, uint32_t out[5])
   const crh_ctx::FeedTune& ft = c->feed_tune;
   out[0] = ft.on ? 1u : 0u; out[1] = ft.on ? ft.chosen : c->frame_feeders; out[2] = ft.n[0] + ft.n[1];
   out[3] = ft.n[0] ? (uint32_t)(1.0e3 * ft.ms[0] / ft.n[0]) : 0u; out[4] = ft.n[1] ? (uint32_t)(1.0e3 * ft.ms[1] / ft.n[1]) : 0u;
+  return CRH_OK;
+}
+
+int crh_get_tile_order(crh_ctx* c, uint32_t* order, uint32_t* n_tiles, uint64_t counts[3])
+{
+  if (!c) return CRH_E_INVALID;
+  const uint32_t ts = c->par.tile_size;
+  const uint32_t nt = ts ? ((c->par.width + ts - 1) / ts) * ((c->par.height + ts - 1) / ts) : 0u;
+  const bool have = c->tile_order.on && c->tile_order.order.size() == nt;
+  if (order) for (uint32_t t = 0; t < nt; ++t) order[t] = have ? c->tile_order.order[t] : t;
+  if (n_tiles) *n_tiles = nt;
+  if (counts) { counts[0] = c->tile_order.reorders; counts[1] = c->tile_order.calls_sorted; counts[2] = c->tile_order.calls_row_major; }
   return CRH_OK;
 }
 

@@ -108,6 +108,7 @@ struct ScheduleState {
   DPaths paths{}; DQueues queues{}; uint32_t path_cap = 0;
   uint32_t stamp_counter = 0;        // DPaths::stamp of the last batch traced (never 0: the radiance buffer is zeroed when it is allocated)
   uint32_t* d_tile_ids = nullptr; uint32_t tile_cap = 0;
+  uint32_t* d_tile_ids2 = nullptr; uint32_t tile_cap2 = 0; int tile_list_last = 0;      // render_impl keeps two lists resident (round 6: row-major and sorted)
   uint32_t* d_seeds = nullptr; uint32_t seed_cap = 0;
   // Counters of the CURRENT accumulation (crh_stats counts since the last restart).  Four blocks, used in turn: crh_reset moves on to the next one -- zeroed one
   // restart earlier, stream-ordered -- instead of zeroing the one in use, so the first frame after a restart need not wait for the frames of the old accumulation
@@ -133,6 +134,7 @@ struct ScheduleState {
   uint32_t n_lanes = 2, lane_max_paths = 12u << 20;
   hipStream_t lane_stream[8] = {}; hipEvent_t lane_fork = nullptr, lane_join[8] = {}; uint32_t* d_lane_counts = nullptr;
   std::vector<uint32_t> h_tile_ids;      // what d_tile_ids holds (an unchanged tile list is not uploaded again)
+  std::vector<uint32_t> h_tile_ids2;     // ... and d_tile_ids2
   // frame pipelining: consecutive small whole batches (one Redraw() each) run on alternating streams and path-state halves, so
   // the drain-bound late bounces of frame n overlap the throughput-bound first bounces of frame n + 1; accumulation stays in
   // frame order (an event between the two accumulate launches)
@@ -169,6 +171,20 @@ struct ScheduleState {
     std::deque<Pend> pend;
     void restart() { chosen = 0; frames = 0; n[0] = n[1] = 0; ms[0] = ms[1] = 0.0; for (Pend& q : pend) q.which = -1; }
   } feed_tune;
+  // The ORDER in which a lone frame's tiles are claimed (round 6) -- OPT-IN, CRH_TILE_ORDER=1.  Whatever the frame kernel claims last runs out its bounces on an
+  // emptying chip (the drain is 0.43 of a lone frame); pixels do not depend on the order (the RNG is seeded per pixel).  k_accumulate sums the rays each tile's paths
+  // traced (frame-kernel frames only); a restart copies the sums to the host and zeroes them; crh_render then lists the tiles most-rays-first -- for a host whose
+  // frames start on an idle chip (three calls in a row with nothing in flight); otherwise row-major.  Both lists stay resident on the device (render_impl).
+  // Measured (profiles/r6/lone_frame.md 2c, tile_order_product_ab.txt): lone frame -6 % on CAD1M, -3 % on C2, +-1 % on C3; but the drag loop loses 2 - 3 % on every
+  // scene although its frames take the row-major list -- not understood, hence not the default.
+  struct TileOrder {
+    bool on = false;
+    uint32_t* d_cost = nullptr; uint32_t* h_cost = nullptr; uint32_t n = 0;     // per tile id: rays since the last restart (device), the last restart's copy (pinned host)
+    hipEvent_t copied = nullptr; bool pending = false, dirty = false;           // a copy is under way; frames have added to d_cost since the last copy
+    std::vector<uint8_t> cls; std::vector<uint32_t> order;                      // the classes the current list was made from; the list (empty: row-major)
+    uint64_t reorders = 0, calls_sorted = 0, calls_row_major = 0; uint32_t streak = 0;                                 // crh_render calls in a row that found no frame in flight
+  } tile_order;
+  uint32_t last_running = 0;                        // frames in flight when the last pipelined frame was submitted (render_impl)
   uint32_t frame_help = 256;                        // a tracer wavefront shades a batch itself once this many hit records wait
   uint32_t frame_help_low = 0;                      // ... and prefers a full shading batch to tracing while fewer rays than this wait (CRH_FRAME_HELP_LOW)
   int frame_grid = 0;                               // workgroups of a lone frame (0: what is resident, 4 per CU)

@@ -25,7 +25,8 @@ namespace {
 struct Lane { hipStream_t stream; DPaths P; DQueues Q; int grid, grid_trace; bool timed; const uint32_t* n_tiles_dev = nullptr; bool donate = false;
               bool frame = false; int grid_frame = 0;         // frame: the whole batch in one launch of the frame kernel (k_frame.h) with grid_frame workgroups
               const uint32_t* h_seeds = nullptr;              // ... whose <= 16 frame seeds travel by value (d_seeds == nullptr)
-              hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr; };   // ... bracketed by these two events when the feeder count is being tuned (crh_context.h FeedTune)
+              hipEvent_t tune_e0 = nullptr, tune_e1 = nullptr;      // ... bracketed by these two events when the feeder count is being tuned (crh_context.h FeedTune)
+              uint32_t* tile_cost = nullptr; };                     // ... and whose accumulate adds the rays its paths traced to the per-tile sums (crh_context.h TileOrder)
 
 // May this batch take the frame kernel?  Small, not counted, not timed per kernel, slots that fit the bits the kernel keeps them in.
 bool frame_ok(const crh_ctx* c, uint64_t total)
@@ -73,7 +74,7 @@ int run_lane(crh_ctx* c, const Lane& ln, const DScene& S, const uint32_t* d_tile
   if (accumulate && before_accumulate) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate, 0));      // samples are folded in in frame order
   if (accumulate && before_accumulate2) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate2, 0));    // ... and not while a read-back tone-maps the accumulator
   if (accumulate && before_accumulate3) CRH_HIP(hipStreamWaitEvent(ln.stream, before_accumulate3, 0));    // ... and after a restart has zeroed it
-  if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, ns, c->d_counters, ln.n_tiles_dev);
+  if (accumulate) launch_accumulate(L, S, ln.P, c->d_accum, c->adaptive ? c->d_m2 : nullptr, d_tiles, nt, 0, ns, ns, c->d_counters, ln.n_tiles_dev, ln.frame && ns == 1u ? ln.tile_cost : nullptr);
   CRH_HIP(hipGetLastError());
   return CRH_OK;
 }
@@ -158,9 +159,19 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   // tile ids + frame seeds to the device, stream-ordered behind any kernels still reading the old ones, through pinned staging:
   // a Redraw() does not wait for the previous one (an unchanged tile list is not sent again)
   if (nt > c->tile_cap) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_tile_ids) CRH_HIP(hipFree(c->d_tile_ids)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids, sizeof(uint32_t) * nt)); c->tile_cap = nt; c->h_tile_ids.clear(); }
-  if (c->h_tile_ids.size() != nt || std::memcmp(c->h_tile_ids.data(), tiles, sizeof(uint32_t) * nt) != 0) {
+  // Round 6: TWO lists stay on the device -- crh_render hands over the image's tiles either row-major or most-expensive-first (crh_context.h TileOrder), by what
+  // is in flight; switching between two resident lists costs nothing, and a frame in flight keeps reading the one it was launched with.  A third list replaces the
+  // one the previous call did not use (through the context's stream: behind every frame that still reads it).
+  uint32_t* d_list = nullptr;
+  if (c->h_tile_ids.size() == nt && std::memcmp(c->h_tile_ids.data(), tiles, sizeof(uint32_t) * nt) == 0) { d_list = c->d_tile_ids; c->tile_list_last = 0; }
+  else if (c->h_tile_ids2.size() == nt && std::memcmp(c->h_tile_ids2.data(), tiles, sizeof(uint32_t) * nt) == 0) { d_list = c->d_tile_ids2; c->tile_list_last = 1; }
+  else if (c->tile_list_last == 0 && !c->h_tile_ids.empty()) {      // the first list is the one in use: the new one goes to the second
+    if (nt > c->tile_cap2) { CRH_HIP(hipStreamSynchronize(cstream(c))); if (c->d_tile_ids2) CRH_HIP(hipFree(c->d_tile_ids2)); CRH_HIP(hipMalloc((void**)&c->d_tile_ids2, sizeof(uint32_t) * nt)); c->tile_cap2 = nt; }
+    int rc_u = stage_copy(c, c->d_tile_ids2, tiles, sizeof(uint32_t) * nt); if (rc_u) return rc_u;
+    c->h_tile_ids2.assign(tiles, tiles + nt); d_list = c->d_tile_ids2; c->tile_list_last = 1;
+  } else {
     int rc_u = stage_copy(c, c->d_tile_ids, tiles, sizeof(uint32_t) * nt); if (rc_u) return rc_u;
-    c->h_tile_ids.assign(tiles, tiles + nt);
+    c->h_tile_ids.assign(tiles, tiles + nt); d_list = c->d_tile_ids; c->tile_list_last = 0;
   }
   // path budget of this call: crh_set_path_budget's, cut to what the device has free when the state would have to grow (196 B per slot; a shared or smaller
   // device gets the narrower batches the budget table of cadrays_hip.h prices at a few percent, not a hipMalloc error -- ADVICE r4)
@@ -229,6 +240,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     // frames still running right now (this stream's own last frame included: this one queues behind it)
     uint32_t running = 0u;
     for (uint32_t j = 0; j < 8u; ++j) if (c->pipe_running[j]) { if (hipEventQuery(c->lane_join[j]) != hipErrorNotReady) c->pipe_running[j] = false; else ++running; }
+    c->last_running = running;
     const bool frame = frame_able && (running < c->frame_pipe_depth || !host_runs_ahead);
     Lane ln; ln.stream = c->lane_stream[k]; ln.timed = false; ln.donate = c->donate; ln.h_seeds = seeds;
     ln.grid = (int)std::min<uint64_t>((uint64_t)c->grid, std::max<uint64_t>((uint64_t)c->pipe_grid_min_shade, total / 2048u));
@@ -248,6 +260,20 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     // frame kernel: one workgroup fills a compute unit, so the frames in flight share the chip by compute units (every frame asking for all of them was
     // measured: the second frame's workgroups then wait for whole workgroups of the first to leave -- 368 against 399 Redraw/s)
     ln.frame = frame; ln.grid_frame = frame ? frame_grid(c, S, std::min(in_flight, std::max(1u, c->frame_pipe_depth))) : 0;
+    if (frame && c->tile_order.on && ns == 1u && true) {
+      // per-tile ray sums of this accumulation (crh_context.h TileOrder), indexed by tile id: allocated for the image's tiles
+      crh_ctx::TileOrder& to = c->tile_order;
+      const uint32_t ts_ = c->par.tile_size, all_tiles = ((c->par.width + ts_ - 1u) / ts_) * ((c->par.height + ts_ - 1u) / ts_);
+      if (to.n != all_tiles) {
+        CRH_HIP(hipStreamSynchronize(cstream(c)));
+        if (to.d_cost) CRH_HIP(hipFree(to.d_cost)); if (to.h_cost) CRH_HIP(hipHostFree(to.h_cost));
+        to.d_cost = nullptr; to.h_cost = nullptr;
+        CRH_HIP(hipMalloc((void**)&to.d_cost, sizeof(uint32_t) * all_tiles)); CRH_HIP(hipMemset(to.d_cost, 0, sizeof(uint32_t) * all_tiles));
+        CRH_HIP(hipHostMalloc((void**)&to.h_cost, sizeof(uint32_t) * all_tiles, hipHostMallocDefault));
+        to.n = all_tiles; to.pending = false; to.dirty = false; to.cls.clear(); to.order.clear();
+      }
+      if (to.streak >= 1u) { ln.tile_cost = to.d_cost; to.dirty = true; }      // (a host that keeps frames in flight gets no new list anyway: nothing is collected for it)
+    }
     if (frame && c->feed_tune.on) {
       // the feeder count by measurement (crh_context.h FeedTune): collect the frame kernels that have finished, then either take the next measurement or the verdict
       crh_ctx::FeedTune& ft = c->feed_tune;
@@ -302,7 +328,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     hipEventRecord(e0, ln.stream);
     const hipEvent_t guard = c->rb_guard_pending ? c->rb_guard : nullptr; c->rb_guard_pending = false;      // later frames are ordered behind this one's accumulate
     const hipEvent_t after_reset = c->reset_pending ? c->reset_ev : nullptr; c->reset_pending = false;      // (it followed the joins of every earlier frame)
-    rc = run_lane(c, ln, S, c->d_tile_ids, nt, nullptr, ns, 0, true, c->pipe_pending[prev] ? c->lane_join[prev] : nullptr, guard, after_reset); if (rc) return rc;
+    rc = run_lane(c, ln, S, d_list, nt, nullptr, ns, 0, true, c->pipe_pending[prev] ? c->lane_join[prev] : nullptr, guard, after_reset); if (rc) return rc;
     hipEventRecord(e1, ln.stream);
     c->render_ev.emplace_back(e0, e1);
     CRH_HIP(hipEventRecord(c->lane_join[k], ln.stream));
@@ -327,7 +353,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
   for (uint32_t t0 = 0; t0 < nt; t0 += group) {
     const uint32_t g = std::min(group, nt - t0);
     for (uint32_t s0 = 0; s0 < ns; s0 += spb) {
-      rc = run_batch(c, S, c->d_tile_ids + t0, g, c->d_seeds + s0, std::min(spb, ns - s0));
+      rc = run_batch(c, S, d_list + t0, g, c->d_seeds + s0, std::min(spb, ns - s0));
       if (rc) return rc;
     }
   }
@@ -475,6 +501,39 @@ int crh_render(crh_ctx* c, uint32_t n)
       c->pending_off += m; c->pending_n -= m; c->pending_first += m; c->frames_done += m; n -= m;
     }
     return CRH_OK;
+  }
+  // the order the tiles are claimed in (crh_context.h TileOrder): most rays of the last accumulation first -- for a host whose frames start on an idle chip (three
+  // calls in a row found nothing in flight: a viewer that waits for every frame).  With frames in flight the drain overlaps the next frame anyway, the row-major
+  // list keeps neighbouring tiles together (sorted: drag loop -4 % on C3 / C2) and a new list would wait for the frames that read the old one.
+  {
+    crh_ctx::TileOrder& to = c->tile_order;
+    if (to.on && to.n == nt) {
+      const bool busy = c->last_running != 0u;           // what the previous pipelined frame found in flight when it was submitted (no event queries of its own here:
+                                                         // four more hipEventQuery calls per frame cost the drag loop 2 - 3 %)
+      to.streak = busy ? 0u : std::min(to.streak + 1u, 1000u);
+      if (to.streak >= 3u && to.pending && hipEventQuery(to.copied) == hipSuccess) {
+        to.pending = false;
+        uint64_t sum = 0; for (uint32_t t = 0; t < nt; ++t) sum += to.h_cost[t];
+        if (sum) {
+          const double mean = (double)sum / nt;
+          std::vector<uint8_t> cls(nt);
+          for (uint32_t t = 0; t < nt; ++t) { const double x = to.h_cost[t] / mean; cls[t] = x >= 2.0 ? 0 : x >= 1.25 ? 1 : x >= 0.75 ? 2 : x >= 0.4 ? 3 : 4; }
+          if (cls != to.cls) {                                                  // (the classes only say WHEN to make a new list: noise between two frames of one view does not)
+            // most rays first, row-major among equals: a counting sort over 256 levels of the cost (five classes in row-major order inside each class gain nothing
+            // -- 2.27 against 2.30 ms on CAD1M -- the sorted list 2.16: profiles/r6/lone_frame.md 2c)
+            uint32_t top = 1; for (uint32_t t = 0; t < nt; ++t) top = std::max(top, to.h_cost[t]);
+            uint32_t at[258]; std::memset(at, 0, sizeof at);
+            auto level = [&](uint32_t t) { return 255u - (uint32_t)(((uint64_t)to.h_cost[t] * 255u) / top); };      // 0 = the most expensive
+            for (uint32_t t = 0; t < nt; ++t) ++at[level(t) + 1u];
+            for (int k = 1; k < 258; ++k) at[k] += at[k - 1];
+            to.order.resize(nt);
+            for (uint32_t t = 0; t < nt; ++t) to.order[at[level(t)]++] = t;
+            to.cls.swap(cls); ++to.reorders;
+          }
+        }
+      }
+      if (to.streak >= 3u && to.order.size() == nt) { all = to.order; ++to.calls_sorted; } else ++to.calls_row_major;
+    }
   }
   int rc = render_impl(c, all.data(), nt, c->frames_done, n);
   if (rc == CRH_OK) c->frames_done += n;

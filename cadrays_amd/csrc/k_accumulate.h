@@ -4,7 +4,7 @@
 __global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float4* __restrict__ accum, float* __restrict__ m2,
                                                         const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
                                                         uint32_t first_sample, uint32_t n_samples, uint32_t batch_samples, DCounters* C,
-                                                        const uint32_t* __restrict__ n_tiles_dev)
+                                                        const uint32_t* __restrict__ n_tiles_dev, uint32_t* __restrict__ tile_cost)
 {
   if (n_tiles_dev) n_tiles = *n_tiles_dev;
   // samples [first_sample, first_sample + n_samples) of the batch of batch_samples in the path buffer are folded in, in order
@@ -66,13 +66,20 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DScene S, DPaths P, float
     }
   } else {
     for (uint32_t local = blockIdx.x * kBlock + threadIdx.x; local < per_sample; local += gridDim.x * kBlock) {
-      uint32_t px, py;
-      if (!slot_pixel(S, tile_ids, local, px, py)) continue;
-      const size_t pi = (size_t)py * S.width + px;
-      a = accum[pi]; q = m2 ? m2[pi] : 0.f;
-      for (uint32_t s = first_sample; s < last; ++s) fold(P.rad[pixel_sample_to_slot(local, s, batch_samples)]);
-      accum[pi] = a;
-      if (m2) m2[pi] = q;
+      uint32_t px, py, bounces = 0u;
+      if (slot_pixel(S, tile_ids, local, px, py)) {
+        const size_t pi = (size_t)py * S.width + px;
+        a = accum[pi]; q = m2 ? m2[pi] : 0.f;
+        for (uint32_t s = first_sample; s < last; ++s) fold(P.rad[pixel_sample_to_slot(local, s, batch_samples)]);
+        accum[pi] = a;
+        if (m2) m2[pi] = q;
+        // a frame-kernel frame leaves the index of each path's last ray in its slot (k_frame.h: ray_d.w = bounce << 26 | ...): rays traced by this pixel's path
+        // (every pixel: a list made from one wavefront in eight lost the gain -- lone frame 2.20 instead of 2.13 ms on CAD1M, 2.92 instead of 2.85 on C3)
+        if (tile_cost) bounces = (__float_as_uint(P.ray_d[0][pixel_sample_to_slot(local, first_sample, batch_samples)].w) >> kFrameBounceShift) + 1u;
+      }
+      // per-tile cost of the frame (round 6: the host claims the expensive tiles first in the next lone frame, crh_schedule.cpp): the 64 slots of a wavefront lie in
+      // ONE tile (a tile is tile_size^2 consecutive slots, a multiple of 64), every lane of the wavefront runs the same number of rounds
+      if (tile_cost) { const uint32_t sum = wave_sum(bounces); if (lane_id() == 0 && sum) atomicAdd(&tile_cost[tile_ids[local / (S.tile_size * S.tile_size)]], sum); }
     }
   }
   done = wave_sum(done);

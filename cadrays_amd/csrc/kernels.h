@@ -37,7 +37,7 @@ void launch_frame(const Launch&, const DScene&, const DPaths&, uint32_t* ctl, co
 // accumulator, sample by sample; batch_samples = the sample count the batch was generated with (it fixes the slot layout)
 void launch_accumulate(const Launch&, const DScene&, const DPaths&, float4* accum, float* m2 /* or nullptr */,
                        const uint32_t* d_tile_ids, uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, uint32_t batch_samples, DCounters*,
-                       const uint32_t* d_n_tiles = nullptr);
+                       const uint32_t* d_n_tiles = nullptr, uint32_t* d_tile_cost = nullptr /* small batches of the frame kernel: + rays traced per tile */);
 // adaptive tile sampler, device side: running sum of the tile errors, n_picks inverse-CDF draws (radical inverse of pick0 + k),
 // the distinct tiles in ascending order with their per-tile frame seeds and their number -- all left in HBM
 void launch_adaptive_pick(const Launch&, const float* tile_err, const uint32_t* tile_cnt, uint32_t n_tiles_total, uint32_t pick0, uint32_t n_picks,

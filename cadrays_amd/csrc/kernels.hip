@@ -165,9 +165,9 @@ extern "C" __attribute__((visibility("default"))) int crh_exp_frame_stats(unsign
 namespace crh {
 #endif
 void launch_accumulate(const Launch& L, const DScene& S, const DPaths& P, float4* accum, float* m2, const uint32_t* d_tile_ids,
-                       uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, uint32_t batch_samples, DCounters* C, const uint32_t* d_n_tiles)
+                       uint32_t n_tiles, uint32_t first_sample, uint32_t n_samples, uint32_t batch_samples, DCounters* C, const uint32_t* d_n_tiles, uint32_t* d_tile_cost)
 {
-  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, m2, d_tile_ids, n_tiles, first_sample, n_samples, batch_samples, C, d_n_tiles);
+  hipLaunchKernelGGL(k_accumulate, dim3(L.grid), dim3(kBlock), 0, L.stream, S, P, accum, m2, d_tile_ids, n_tiles, first_sample, n_samples, batch_samples, C, d_n_tiles, d_tile_cost);
 }
 void launch_tile_error(const Launch& L, const DScene& S, const float4* accum, const float* m2, float* tile_err, uint32_t* tile_min_count,
                        uint32_t n_tiles_total)

@@ -85,6 +85,15 @@ class View(Backend):
         self._call("get_frame_tuning", out)
         return {"enabled": bool(out[0]), "feeders": int(out[1]), "frames_measured": int(out[2]), "mean_us_3_feeders": int(out[3]), "mean_us_4_feeders": int(out[4])}
 
+    def tile_order(self):
+        """crh_get_tile_order: the order crh_render lists the tiles in (no pixel depends on it), and how often it has been replaced"""
+        n, r = C.c_uint32(0), (C.c_uint64 * 3)()
+        self._call("get_tile_order", None, C.byref(n), r)
+        order = np.zeros(n.value, np.uint32)
+        self._call("get_tile_order", order.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n), r)
+        self.tile_order_calls = {"sorted": int(r[1]), "row_major": int(r[2])}
+        return order, int(r[0])
+
     def packet_stats(self):
         """camera rays walked as packets since the last restart, and those of them handed to the per-ray fall-back pass (ties at equal distance)"""
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -303,3 +303,38 @@ def test_feeder_count_is_chosen_by_measurement_and_no_image_depends_on_it(hip_li
         w.Redraw()
     assert w.frame_tuning() == {"enabled": False, "feeders": 5, "frames_measured": 0, "mean_us_3_feeders": 0, "mean_us_4_feeders": 0}
     w.close()
+
+
+def test_expensive_tiles_are_claimed_first_and_no_pixel_depends_on_it(hip_lib, oracle_lib, monkeypatch):
+    """Round 6, CRH_TILE_ORDER=1: crh_render lists the tiles most-rays-of-the-last-accumulation-first for a host that waits for every frame (k_accumulate sums the rays
+    per tile, a restart hands them to the host): what the frame kernel claims last -- the tail of a lone frame -- are then the cheap tiles.  The list changes
+    between restarts; the frames do not."""
+    from cadrays_amd.view import View
+    monkeypatch.setenv("CRH_TILE_ORDER", "1")                    # opt-in (the drag loop loses 2 - 3 % with it: profiles/r6/lone_frame.md 2c)
+    sc = scenes.baseline_config("CAD1M", n_tris=24_000)          # parts in front of a sky: tiles of 1 ray per pixel beside tiles of glass
+    sc.env = scenes.procedural_sky(256, 128, 1)
+    v = View(0).load_scene(sc)
+    order, n = v.tile_order()
+    assert n == 0 and np.array_equal(order, np.arange(v.n_tiles(), dtype=np.uint32))
+    for _ in range(5):                                           # lone frames, a restart before each: the second restart's costs are on the host by the fourth frame at the latest
+        v.reset(); v.Redraw(); v.sync()
+    order, n = v.tile_order()
+    assert n >= 1 and np.array_equal(np.sort(order), np.arange(v.n_tiles(), dtype=np.uint32)) and not np.array_equal(order, np.sort(order))
+    for _ in range(3):
+        v.Redraw()                                               # the accumulation goes on with the list it has
+    monkeypatch.setenv("CRH_TILE_ORDER", "0")
+    s = View(0).load_scene(sc); s.set_schedule(abi.SCHEDULE_STAGED)
+    for _ in range(4):
+        s.Redraw()
+    assert s.tile_order()[1] == 0
+    assert np.array_equal(bits(v.read_hdr()), bits(s.read_hdr()))
+    gs, ss = v.stats(), s.stats()
+    for k in ("rays_nearest", "rays_any", "shaded_hits", "samples"):
+        assert gs[k] == ss[k], k
+    # the first tiles of the list cost more than the last ones: rays per tile from the counted schedule
+    s.enable_counters(True); s.reset()
+    cost = []
+    for t in list(order[:12]) + list(order[-12:]):
+        before = s.stats()["rays_nearest"]; s.render_tiles(np.array([t], np.uint32), 0, 1); cost.append(s.stats()["rays_nearest"] - before)
+    assert np.mean(cost[:12]) > 1.5 * np.mean(cost[12:]), cost
+    v.close(); s.close()

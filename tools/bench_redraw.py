@@ -40,6 +40,7 @@ def measure(v, cam0, frames=128, trials=15):
         ts.append((time.perf_counter() - t) * 1e3)
     out["first_frame_after_a_restart_ms"] = round(statistics.median(ts), 3)
     out["first_frame_after_a_restart_ms_min"] = round(min(ts), 3)
+    out["tile_list_replaced_up_to_the_end_of_the_lone_frames"] = v.tile_order()[1]; out["tile_order_calls_up_to_the_end_of_the_lone_frames"] = dict(v.tile_order_calls)
 
     import numpy as np
     shown = np.empty((v.height, v.width, 3), np.uint8)          # the host's one staging buffer (INTEGRATION.md `myLdr`, cadrays_headless.cpp `shown`)
@@ -57,6 +58,7 @@ def measure(v, cam0, frames=128, trials=15):
         v.read_ldr_end(shown); v.read_ldr_end(shown); v.sync()
         dt = time.perf_counter() - t
     out["drag_frames_per_s"] = round(frames / dt, 1)
+    out["tile_list_replaced_up_to_the_end_of_the_drag"] = v.tile_order()[1]; out["tile_order_calls_up_to_the_end_of_the_drag"] = dict(v.tile_order_calls)
     v.set_camera(cam0); v.reset()
 
     # ---- a still camera, every frame displayed

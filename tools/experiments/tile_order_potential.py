@@ -48,4 +48,12 @@ ts = []
 for _ in range(a.trials):
     v.reset(); v.sync(); t0 = time.perf_counter(); v.Redraw(); v.sync(); ts.append((time.perf_counter() - t0) * 1e3)
 out["lone_frame_ms"]["Redraw() (the library's own tile list)"] = [round(statistics.median(ts[2:]), 3)]
+order, n_re = v.tile_order()
+q = nt // 4
+out["library_order"] = {"reorders": n_re, "mean_rays_first_quarter": float(rays[order[:q]].mean()), "mean_rays_last_quarter": float(rays[order[-q:]].mean()),
+                        "same_as_row_major": bool(np.array_equal(order, ids))}
+ts = []
+for _ in range(a.trials):
+    v.reset(); v.sync(); t0 = time.perf_counter(); v.render_tiles(order, 0, 1); v.sync(); ts.append((time.perf_counter() - t0) * 1e3)
+out["lone_frame_ms"]["crh_render_tiles with the library's list"] = [round(statistics.median(ts[2:]), 3)]
 print(json.dumps(out))
