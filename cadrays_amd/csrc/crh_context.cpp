@@ -189,7 +189,7 @@ static const EnvKnob kEnvKnobs[] = {
   {"CRH_FRAME_STEP",         "frame kernel: tracer wavefront w takes rays only while w x this many wait in the ring (default 0: every tracer takes what is there)"},
   {"CRH_FRAME_HELP",         "frame kernel: a tracer wavefront shades a batch itself once this many hit records wait in the workgroup's rings, 64 .. 4096 (default 256)"},
   {"CRH_FRAME_HELP_LOW",     "frame kernel: a tracer wavefront prefers a full shading batch (64 waiting hits) to tracing while fewer rays than this wait in the ring, 0 .. 4096 (default 0: it traces whatever is there)"},
-  {"CRH_TILE_ORDER",         "1: a host whose frames start on an idle chip gets the image's tiles most-rays-of-the-last-accumulation-first from crh_render instead of row-major (lone frame -6 % on a model in front of a background, drag loop -2 %: opt-in; no pixel depends on the order)"},
+  {"CRH_TILE_ORDER",         "0: crh_render lists the tiles row-major as up to round 5 (default 1: a host whose frames start on an idle chip gets the tiles that cost the most rays in the last accumulation first -- lone frame -6 % on a model in front of a background; no pixel depends on the order)"},
   {"CRH_FRAME_GRID",         "frame kernel: workgroups of a lone frame (default: what is resident = ONE 1024-thread workgroup per compute unit); never fewer than min(resident, 32), never more than resident"},
   {"CRH_FRAME_PIPE",         "frame pipeline: a frame takes the frame kernel while fewer than this many frames are running, and at most this many frame kernels run at a time, 1 .. 8 (default 2)"},
   {"CRH_LANES",              "tile ranges a small batch is cut into, 1 .. 8 (default 2); 1 = one stream (reference schedule of the sequence tests)"},
@@ -315,7 +315,7 @@ int crh_get_frame_tuning(crh_ctx* c, uint32_t out[5])
   return CRH_OK;
 }
 
-int crh_get_tile_order(crh_ctx* c, uint32_t* order, uint32_t* n_tiles, uint64_t counts[3])
+int crh_get_tile_order(crh_ctx* c, uint32_t* order, uint32_t* n_tiles, uint64_t counts[4])
 {
   if (!c) return CRH_E_INVALID;
   const uint32_t ts = c->par.tile_size;
@@ -323,7 +323,7 @@ int crh_get_tile_order(crh_ctx* c, uint32_t* order, uint32_t* n_tiles, uint64_t 
   const bool have = c->tile_order.on && c->tile_order.order.size() == nt;
   if (order) for (uint32_t t = 0; t < nt; ++t) order[t] = have ? c->tile_order.order[t] : t;
   if (n_tiles) *n_tiles = nt;
-  if (counts) { counts[0] = c->tile_order.reorders; counts[1] = c->tile_order.calls_sorted; counts[2] = c->tile_order.calls_row_major; }
+  if (counts) { counts[0] = c->tile_order.reorders; counts[1] = c->tile_order.calls_sorted; counts[2] = c->tile_order.calls_row_major; counts[3] = c->tile_order.frames_collected; }
   return CRH_OK;
 }
 

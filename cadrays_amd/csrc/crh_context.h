@@ -171,18 +171,18 @@ struct ScheduleState {
     std::deque<Pend> pend;
     void restart() { chosen = 0; frames = 0; n[0] = n[1] = 0; ms[0] = ms[1] = 0.0; for (Pend& q : pend) q.which = -1; }
   } feed_tune;
-  // The ORDER in which a lone frame's tiles are claimed (round 6) -- OPT-IN, CRH_TILE_ORDER=1.  Whatever the frame kernel claims last runs out its bounces on an
-  // emptying chip (the drain is 0.43 of a lone frame); pixels do not depend on the order (the RNG is seeded per pixel).  k_accumulate sums the rays each tile's paths
-  // traced (frame-kernel frames only); a restart copies the sums to the host and zeroes them; crh_render then lists the tiles most-rays-first -- for a host whose
-  // frames start on an idle chip (three calls in a row with nothing in flight); otherwise row-major.  Both lists stay resident on the device (render_impl).
-  // Measured (profiles/r6/lone_frame.md 2c, tile_order_product_ab.txt): lone frame -6 % on CAD1M, -3 % on C2, +-1 % on C3; but the drag loop loses 2 - 3 % on every
-  // scene although its frames take the row-major list -- not understood, hence not the default.
+  // The ORDER in which a lone frame's tiles are claimed (round 6; CRH_TILE_ORDER=0: row-major as up to round 5).  Whatever the frame kernel claims last runs out its
+  // bounces on an emptying chip (the drain is 0.43 of a lone frame); pixels do not depend on the order (the RNG is seeded per pixel).  k_accumulate sums the rays
+  // each tile's paths traced (frame-kernel frames of a host that waits for its frames only); a restart copies the sums to the host and zeroes them; crh_render
+  // then lists the tiles most-rays-first -- for a host whose frames start on an idle chip (three calls in a row with nothing in flight); otherwise row-major.
+  // Both lists stay resident on the device (render_impl).  Measured (profiles/r6/lone_frame.md 2c, tile_order_product_ab.txt): lone frame -6 % on CAD1M, -2 % on
+  // C2, +-1 % on C3; the drag, display and free-running loops unchanged.
   struct TileOrder {
-    bool on = false;
+    bool on = true;
     uint32_t* d_cost = nullptr; uint32_t* h_cost = nullptr; uint32_t n = 0;     // per tile id: rays since the last restart (device), the last restart's copy (pinned host)
     hipEvent_t copied = nullptr; bool pending = false, dirty = false;           // a copy is under way; frames have added to d_cost since the last copy
     std::vector<uint8_t> cls; std::vector<uint32_t> order;                      // the classes the current list was made from; the list (empty: row-major)
-    uint64_t reorders = 0, calls_sorted = 0, calls_row_major = 0; uint32_t streak = 0;                                 // crh_render calls in a row that found no frame in flight
+    uint64_t reorders = 0, calls_sorted = 0, calls_row_major = 0, frames_collected = 0; uint32_t streak = 0;                                 // crh_render calls in a row that found no frame in flight
   } tile_order;
   uint32_t last_running = 0;                        // frames in flight when the last pipelined frame was submitted (render_impl)
   uint32_t frame_help = 256;                        // a tracer wavefront shades a batch itself once this many hit records wait

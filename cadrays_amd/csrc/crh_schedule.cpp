@@ -268,11 +268,11 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
         CRH_HIP(hipStreamSynchronize(cstream(c)));
         if (to.d_cost) CRH_HIP(hipFree(to.d_cost)); if (to.h_cost) CRH_HIP(hipHostFree(to.h_cost));
         to.d_cost = nullptr; to.h_cost = nullptr;
-        CRH_HIP(hipMalloc((void**)&to.d_cost, sizeof(uint32_t) * all_tiles)); CRH_HIP(hipMemset(to.d_cost, 0, sizeof(uint32_t) * all_tiles));
+        CRH_HIP(hipMalloc((void**)&to.d_cost, sizeof(uint32_t) * all_tiles)); CRH_HIP(hipMemsetAsync(to.d_cost, 0, sizeof(uint32_t) * all_tiles, cstream(c)));      // (never the NULL stream: once it exists every launch on the context's streams pays for it -- the drag loop lost 2.3 % to one hipMemset here)
         CRH_HIP(hipHostMalloc((void**)&to.h_cost, sizeof(uint32_t) * all_tiles, hipHostMallocDefault));
         to.n = all_tiles; to.pending = false; to.dirty = false; to.cls.clear(); to.order.clear();
       }
-      if (to.streak >= 1u) { ln.tile_cost = to.d_cost; to.dirty = true; }      // (a host that keeps frames in flight gets no new list anyway: nothing is collected for it)
+      if (to.streak >= 1u) { ln.tile_cost = to.d_cost; to.dirty = true; ++to.frames_collected; }      // (a host that keeps frames in flight gets no new list anyway: nothing is collected for it)
     }
     if (frame && c->feed_tune.on) {
       // the feeder count by measurement (crh_context.h FeedTune): collect the frame kernels that have finished, then either take the next measurement or the verdict

@@ -306,11 +306,10 @@ def test_feeder_count_is_chosen_by_measurement_and_no_image_depends_on_it(hip_li
 
 
 def test_expensive_tiles_are_claimed_first_and_no_pixel_depends_on_it(hip_lib, oracle_lib, monkeypatch):
-    """Round 6, CRH_TILE_ORDER=1: crh_render lists the tiles most-rays-of-the-last-accumulation-first for a host that waits for every frame (k_accumulate sums the rays
+    """Round 6: crh_render lists the tiles most-rays-of-the-last-accumulation-first for a host that waits for every frame (k_accumulate sums the rays
     per tile, a restart hands them to the host): what the frame kernel claims last -- the tail of a lone frame -- are then the cheap tiles.  The list changes
     between restarts; the frames do not."""
     from cadrays_amd.view import View
-    monkeypatch.setenv("CRH_TILE_ORDER", "1")                    # opt-in (the drag loop loses 2 - 3 % with it: profiles/r6/lone_frame.md 2c)
     sc = scenes.baseline_config("CAD1M", n_tris=24_000)          # parts in front of a sky: tiles of 1 ray per pixel beside tiles of glass
     sc.env = scenes.procedural_sky(256, 128, 1)
     v = View(0).load_scene(sc)
