@@ -773,8 +773,9 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
     elif rank == 0 and world == 1 and not args.no_interactive:
         # the other legs: the lone frame after a restart only (crh_reset + crh_render(1) + crh_sync, median of 9) -- what a user of THIS scene waits for
         import statistics
-        for _ in range(64):                                   # the library's own measurement of its feeder count for this scene comes first (crh_get_frame_tuning: <= 30 frames)
-            if not v.frame_tuning()["enabled"] or v.frame_tuning()["feeders"]: break
+        for _ in range(96):                                   # the library's own measurements for this scene come first (crh_get_frame_tuning: <= 30 frames; crh_get_tile_order: ~ 16 more)
+            ft = v.frame_tuning(); v.tile_order()
+            if (not ft["enabled"] or ft["feeders"]) and v.tile_order_calls["verdict"] != 0: break
             v.reset(); v.Redraw(); v.sync()
         ts = []
         for _ in range(10):
@@ -782,7 +783,7 @@ def run_leg(args, ctxt, config, steps, warmup, spp_arg, headline):
             t1 = time.perf_counter(); v.Redraw(); v.sync()
             ts.append((time.perf_counter() - t1) * 1e3)
         interactive = {"first_frame_after_a_restart_ms": round(statistics.median(ts[1:]), 3), "first_frame_after_a_restart_ms_min": round(min(ts[1:]), 3),
-                       "frame_feeders": v.frame_tuning()["feeders"]}
+                       "frame_feeders": v.frame_tuning()["feeders"], "tile_order": dict(v.tile_order_calls)}
 
     v.close()                                                 # the path state (up to 105 GB) and the scene go before the next leg / the CPU legs
 
@@ -892,10 +893,11 @@ def interactive_figures(v, cam0):
     # the first 30 frame-kernel frames after a build are the library's measurement of its feeder count (crh_get_frame_tuning): a viewer passes them in the first
     # tenth of a second; the figures below are those of the settled library
     v.set_lookahead(1)
-    for _ in range(64):
-        if not v.frame_tuning()["enabled"] or v.frame_tuning()["feeders"]: break
+    for _ in range(96):                                       # (the feeder count, then whether the sorted tile list pays on this scene: crh_get_tile_order)
+        ft = v.frame_tuning(); v.tile_order()
+        if (not ft["enabled"] or ft["feeders"]) and v.tile_order_calls["verdict"] != 0: break
         v.reset(); v.Redraw(); v.sync()
-    interactive["frame_tuning"] = v.frame_tuning()
+    interactive["frame_tuning"] = v.frame_tuning(); interactive["tile_order"] = dict(v.tile_order_calls)
     for k in (1, 16, 64):
         v.set_lookahead(k); v.reset()
         for _ in range(max(8, 2 * k)):              # the frame pipeline (up to eight in flight) is full before the clock starts

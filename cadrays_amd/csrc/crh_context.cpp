@@ -272,6 +272,8 @@ void crh_destroy(crh_ctx* c)
   hipStreamSynchronize(cstream(c));
   drain_events(c);
   for (auto& q : c->feed_tune.pend) { c->ev_pool.push_back(q.e0); c->ev_pool.push_back(q.e1); }
+  for (auto& q : c->tile_order.pend) { hipEventDestroy(q.e0); hipEventDestroy(q.e1); }
+  c->tile_order.pend.clear();
   if (c->d_tile_ids2) hipFree(c->d_tile_ids2);
   if (c->tile_order.d_cost) hipFree(c->tile_order.d_cost);
   if (c->tile_order.h_cost) hipHostFree(c->tile_order.h_cost);
@@ -315,7 +317,7 @@ int crh_get_frame_tuning(crh_ctx* c, uint32_t out[5])
   return CRH_OK;
 }
 
-int crh_get_tile_order(crh_ctx* c, uint32_t* order, uint32_t* n_tiles, uint64_t counts[4])
+int crh_get_tile_order(crh_ctx* c, uint32_t* order, uint32_t* n_tiles, uint64_t counts[7])
 {
   if (!c) return CRH_E_INVALID;
   const uint32_t ts = c->par.tile_size;
@@ -323,7 +325,7 @@ int crh_get_tile_order(crh_ctx* c, uint32_t* order, uint32_t* n_tiles, uint64_t 
   const bool have = c->tile_order.on && c->tile_order.order.size() == nt;
   if (order) for (uint32_t t = 0; t < nt; ++t) order[t] = have ? c->tile_order.order[t] : t;
   if (n_tiles) *n_tiles = nt;
-  if (counts) { counts[0] = c->tile_order.reorders; counts[1] = c->tile_order.calls_sorted; counts[2] = c->tile_order.calls_row_major; counts[3] = c->tile_order.frames_collected; }
+  if (counts) { counts[0] = c->tile_order.reorders; counts[1] = c->tile_order.calls_sorted; counts[2] = c->tile_order.calls_row_major; counts[3] = c->tile_order.frames_collected; counts[4] = c->tile_order.on ? c->tile_order.verdict : 2u; counts[5] = c->tile_order.tn[0] ? (uint64_t)(1.0e3 * c->tile_order.tms[0] / c->tile_order.tn[0]) : 0; counts[6] = c->tile_order.tn[1] ? (uint64_t)(1.0e3 * c->tile_order.tms[1] / c->tile_order.tn[1]) : 0; }
   return CRH_OK;
 }
 

@@ -174,7 +174,7 @@ struct ScheduleState {
   // The ORDER in which a lone frame's tiles are claimed (round 6; CRH_TILE_ORDER=0: row-major as up to round 5).  Whatever the frame kernel claims last runs out its
   // bounces on an emptying chip (the drain is 0.43 of a lone frame); pixels do not depend on the order (the RNG is seeded per pixel).  k_accumulate sums the rays
   // each tile's paths traced (frame-kernel frames of a host that waits for its frames only); a restart copies the sums to the host and zeroes them; crh_render
-  // then lists the tiles most-rays-first -- for a host whose frames start on an idle chip (three calls in a row with nothing in flight); otherwise row-major.
+  // then lists the tiles most-rays-first -- for a host whose frames start on an idle chip (six calls in a row with nothing in flight); otherwise row-major.
   // Both lists stay resident on the device (render_impl).  Measured (profiles/r6/lone_frame.md 2c, tile_order_product_ab.txt): lone frame -6 % on CAD1M, -2 % on
   // C2, +-1 % on C3; the drag, display and free-running loops unchanged.
   struct TileOrder {
@@ -182,7 +182,14 @@ struct ScheduleState {
     uint32_t* d_cost = nullptr; uint32_t* h_cost = nullptr; uint32_t n = 0;     // per tile id: rays since the last restart (device), the last restart's copy (pinned host)
     hipEvent_t copied = nullptr; bool pending = false, dirty = false;           // a copy is under way; frames have added to d_cost since the last copy
     std::vector<uint8_t> cls; std::vector<uint32_t> order;                      // the classes the current list was made from; the list (empty: row-major)
-    uint64_t reorders = 0, calls_sorted = 0, calls_row_major = 0, frames_collected = 0; uint32_t streak = 0;                                 // crh_render calls in a row that found no frame in flight
+    uint64_t reorders = 0, calls_sorted = 0, calls_row_major = 0, frames_collected = 0; uint32_t streak = 0;
+    // ... and whether the sorted list pays on THIS scene is measured, once per crh_build (a soup that does not fit the caches loses more by the scattered tiles than
+    // the shorter drain gives back: C5's lone 4K frame 10.9 -> 12.1 ms): once a sorted list exists and the feeder count is settled, lone frames take the two lists
+    // in turn, each frame kernel between two events; sorted stays if its mean is >= 2 % shorter.  verdict: 0 measuring, 1 sorted, 2 row-major.
+    uint32_t verdict = 0, trials = 0, tn[2] = {0, 0}; double tms[2] = {0.0, 0.0}; int tag_next = -1;
+    struct Pend { hipEvent_t e0, e1; int which; };
+    std::deque<Pend> pend;
+    void remeasure() { verdict = 0; trials = 0; tn[0] = tn[1] = 0; tms[0] = tms[1] = 0.0; tag_next = -1; for (Pend& q : pend) q.which = -1; }                                 // crh_render calls in a row that found no frame in flight
   } tile_order;
   uint32_t last_running = 0;                        // frames in flight when the last pipelined frame was submitted (render_impl)
   uint32_t frame_help = 256;                        // a tracer wavefront shades a batch itself once this many hit records wait

@@ -543,7 +543,7 @@ int crh_set_params(crh_ctx* c, const crh_params* p)
   { const float f[] = {p->radiance_clamp, p->exposure, p->white_point, p->background[0], p->background[1], p->background[2], p->scene_epsilon};
     if (!all_finite(f, sizeof f / sizeof f[0])) return fail(c, CRH_E_INVALID, "params hold a NaN / Inf"); }
   if (p->width != c->par.width || p->height != c->par.height || p->max_depth != c->par.max_depth) c->feed_tune.restart();      // another frame: measured again
-  if (p->width != c->par.width || p->height != c->par.height || p->tile_size != c->par.tile_size) { c->tile_order.order.clear(); c->tile_order.cls.clear(); c->tile_order.pending = false; }      // other tiles
+  if (p->width != c->par.width || p->height != c->par.height || p->tile_size != c->par.tile_size) { c->tile_order.order.clear(); c->tile_order.cls.clear(); c->tile_order.pending = false; c->tile_order.remeasure(); }      // other tiles
   c->par = *p;
   return do_reset(c);
 }
@@ -719,7 +719,7 @@ static int build_scene(crh_ctx* c, const QNode* pre_nodes, uint32_t pre_n_nodes,
       CRH_HIP(hipMalloc(&c->d_patch, want_patch)); c->cap_patch = want_patch;
     }
   }
-  c->built = true; c->feed_tune.restart();
+  c->built = true; c->feed_tune.restart(); c->tile_order.remeasure();
   if (c->two_level && c->inst.empty()) {
     // Every object sits at the identity: the single-level kernels render this scene.  The first crh_set_transforms (the user has just grabbed the
     // gizmo) switches to the two-level instantiations and the record scatter -- launch each of them once now, on empty queues, so that their

@@ -272,7 +272,7 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
         CRH_HIP(hipHostMalloc((void**)&to.h_cost, sizeof(uint32_t) * all_tiles, hipHostMallocDefault));
         to.n = all_tiles; to.pending = false; to.dirty = false; to.cls.clear(); to.order.clear();
       }
-      if (to.streak >= 1u) { ln.tile_cost = to.d_cost; to.dirty = true; ++to.frames_collected; }      // (a host that keeps frames in flight gets no new list anyway: nothing is collected for it)
+      if (to.streak >= 2u && to.verdict != 2u) { ln.tile_cost = to.d_cost; to.dirty = true; ++to.frames_collected; }      // (a host that keeps frames in flight gets no new list anyway: nothing is collected for it)
     }
     if (frame && c->feed_tune.on) {
       // the feeder count by measurement (crh_context.h FeedTune): collect the frame kernels that have finished, then either take the next measurement or the verdict
@@ -298,6 +298,14 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
         }
         ++ft.frames;
       }
+    }
+    if (frame && c->tile_order.on && c->tile_order.tag_next >= 0) {      // this lone frame is a sample of the sorted-against-row-major measurement (crh_render decided which list it got)
+      crh_ctx::TileOrder& to = c->tile_order;
+      if (!ln.tune_e0 && running == 0u && to.pend.size() < 32u) {
+        ln.tune_e0 = get_event(c); ln.tune_e1 = get_event(c);
+        to.pend.push_back({ln.tune_e0, ln.tune_e1, to.tag_next});
+      }
+      to.tag_next = -1;
     }
     const size_t base = (size_t)k * total;
     const DPaths& P = c->paths; const DQueues& Q = c->queues;
@@ -502,8 +510,8 @@ int crh_render(crh_ctx* c, uint32_t n)
     }
     return CRH_OK;
   }
-  // the order the tiles are claimed in (crh_context.h TileOrder): most rays of the last accumulation first -- for a host whose frames start on an idle chip (three
-  // calls in a row found nothing in flight: a viewer that waits for every frame).  With frames in flight the drain overlaps the next frame anyway, the row-major
+  // the order the tiles are claimed in (crh_context.h TileOrder): most rays of the last accumulation first -- for a host whose frames start on an idle chip (six
+  // calls in a row found nothing in flight: a viewer that waits for every frame; a drag loop with a gap now and then does not get there).  With frames in flight the drain overlaps the next frame anyway, the row-major
   // list keeps neighbouring tiles together (sorted: drag loop -4 % on C3 / C2) and a new list would wait for the frames that read the old one.
   {
     crh_ctx::TileOrder& to = c->tile_order;
@@ -511,7 +519,7 @@ int crh_render(crh_ctx* c, uint32_t n)
       const bool busy = c->last_running != 0u;           // what the previous pipelined frame found in flight when it was submitted (no event queries of its own here:
                                                          // four more hipEventQuery calls per frame cost the drag loop 2 - 3 %)
       to.streak = busy ? 0u : std::min(to.streak + 1u, 1000u);
-      if (to.streak >= 3u && to.pending && hipEventQuery(to.copied) == hipSuccess) {
+      if (to.streak >= 6u && to.pending && hipEventQuery(to.copied) == hipSuccess) {
         to.pending = false;
         uint64_t sum = 0; for (uint32_t t = 0; t < nt; ++t) sum += to.h_cost[t];
         if (sum) {
@@ -532,7 +540,24 @@ int crh_render(crh_ctx* c, uint32_t n)
           }
         }
       }
-      if (to.streak >= 3u && to.order.size() == nt) { all = to.order; ++to.calls_sorted; } else ++to.calls_row_major;
+      bool sorted = false;
+      if (to.streak >= 6u && to.order.size() == nt) {
+        while (!to.pend.empty() && hipEventQuery(to.pend.front().e1) != hipErrorNotReady) {      // frame kernels of the measurement that have finished
+          const crh_ctx::TileOrder::Pend q = to.pend.front(); to.pend.pop_front();
+          float ms = 0.f;
+          if (q.which >= 0 && hipEventElapsedTime(&ms, q.e0, q.e1) == hipSuccess) { to.tms[q.which] += ms; ++to.tn[q.which]; }
+          c->ev_pool.push_back(q.e0); c->ev_pool.push_back(q.e1);
+        }
+        if (!to.verdict && to.tn[0] >= 5u && to.tn[1] >= 5u) {
+          to.verdict = to.tms[0] / to.tn[0] < 0.98 * (to.tms[1] / to.tn[1]) ? 1u : 2u;
+          for (crh_ctx::TileOrder::Pend& q : to.pend) q.which = -1;
+        }
+        to.tag_next = -1;
+        if (to.verdict) sorted = to.verdict == 1u;
+        else if (c->feed_tune.on && !c->feed_tune.chosen) sorted = true;      // one measurement at a time: the feeder count first
+        else { const uint32_t which = to.trials++ & 1u; sorted = which == 0u; to.tag_next = (int)which; }
+      }
+      if (sorted) { all = to.order; ++to.calls_sorted; } else ++to.calls_row_major;
     }
   }
   int rc = render_impl(c, all.data(), nt, c->frames_done, n);

@@ -139,9 +139,11 @@ int main(int argc, char** argv)
     for (int k = 0; k < 8; ++k) if ((rc = crh_render(c, 1))) return die_all(c, "crh_render", rc);
     // ... and up to 64 lone frames until the library has settled on its feeder count for this scene (crh_get_frame_tuning: the first 30 frame-kernel frames after a
     // build are measurements; a viewer passes them in the first tenth of a second)
-    for (int k = 0; k < 64; ++k) {
-      uint32_t tune[5] = {0, 0, 0, 0, 0};
-      if (crh_get_frame_tuning(c, tune) || !tune[0] || tune[1]) break;
+    for (int k = 0; k < 96; ++k) {
+      uint32_t tune[5] = {0, 0, 0, 0, 0}; uint64_t order[7] = {0, 0, 0, 0, 0, 0, 0};
+      const bool feeders_settled = crh_get_frame_tuning(c, tune) || !tune[0] || tune[1];
+      const bool order_settled = crh_get_tile_order(c, nullptr, nullptr, order) || order[4] != 0;      // (whether the sorted tile list pays on this scene: ~ 16 lone frames more)
+      if (feeders_settled && order_settled) break;
       if ((rc = crh_reset(c)) || (rc = crh_render(c, 1)) || (rc = crh_sync(c))) return die_all(c, "crh_render", rc);
     }
     if ((rc = crh_reset(c)) || (rc = crh_sync(c))) return die_all(c, "crh_reset", rc);
@@ -236,7 +238,8 @@ int main(int argc, char** argv)
          name.c_str(), n_gpus, n_frames, fps, secs, (unsigned long long)st.rays_nearest, (unsigned long long)st.rays_any, (unsigned long long)st.samples,
          (double)(st.rays_nearest + st.rays_any) / secs / 1e6);
   if (!loop.empty()) printf(", \"loop\": \"%s\", \"loop_frames_per_s\": %.2f, \"lone_frame_ms_median\": %.4f", loop.c_str(), loop == "lone" ? 0.0 : fps, lone_median_ms);
-  if (!loop.empty()) { uint32_t tune[5] = {0, 0, 0, 0, 0}; if (!crh_get_frame_tuning(c, tune)) printf(", \"frame_feeders\": %u, \"frame_us_3_4_feeders\": [%u, %u]", tune[1], tune[3], tune[4]); }
+  if (!loop.empty()) { uint32_t tune[5] = {0, 0, 0, 0, 0}; if (!crh_get_frame_tuning(c, tune)) printf(", \"frame_feeders\": %u, \"frame_us_3_4_feeders\": [%u, %u]", tune[1], tune[3], tune[4]);
+                       uint64_t order[7] = {0, 0, 0, 0, 0, 0, 0}; if (!crh_get_tile_order(c, nullptr, nullptr, order)) printf(", \"tile_order_verdict\": %llu, \"frame_us_sorted_row_major\": [%llu, %llu]", (unsigned long long)order[4], (unsigned long long)order[5], (unsigned long long)order[6]); }
   printf("}\n");
   for (crh_ctx* x : ctx) crh_destroy(x);
   return 0;

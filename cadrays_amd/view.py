@@ -87,11 +87,11 @@ class View(Backend):
 
     def tile_order(self):
         """crh_get_tile_order: the order crh_render lists the tiles in (no pixel depends on it), and how often it has been replaced"""
-        n, r = C.c_uint32(0), (C.c_uint64 * 4)()
+        n, r = C.c_uint32(0), (C.c_uint64 * 7)()
         self._call("get_tile_order", None, C.byref(n), r)
         order = np.zeros(n.value, np.uint32)
         self._call("get_tile_order", order.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n), r)
-        self.tile_order_calls = {"sorted": int(r[1]), "row_major": int(r[2]), "frames_collected": int(r[3])}
+        self.tile_order_calls = {"sorted": int(r[1]), "row_major": int(r[2]), "frames_collected": int(r[3]), "verdict": int(r[4]), "mean_us_sorted": int(r[5]), "mean_us_row_major": int(r[6])}
         return order, int(r[0])
 
     def packet_stats(self):

@@ -278,8 +278,9 @@ CRH_API int crh_get_path_budget(crh_ctx* ctx, uint64_t* max_paths);
 CRH_API int crh_get_frame_tuning(crh_ctx* ctx, uint32_t out[5]);
 /* Round 6: the order in which crh_render lists the image's tiles (the frame kernel claims them in that order: for a host that waits for its frames the tiles
  * that cost the most rays in the last accumulation first, else row-major; CRH_TILE_ORDER=0: always row-major).  No pixel depends on it.  order: n_tiles ids or NULL; counts (or NULL): how often the sorted list has been replaced, crh_render calls that
- * used the sorted list, calls that used the row-major one, frames whose accumulate added to the per-tile sums. */
-CRH_API int crh_get_tile_order(crh_ctx* ctx, uint32_t* order, uint32_t* n_tiles, uint64_t counts[4]);
+ * used the sorted list, calls that used the row-major one, frames whose accumulate added to the per-tile sums, the verdict of the library's own measurement
+ * on this scene (0 measuring, 1 the sorted list pays, 2 it does not: row-major), and the two measured means in microseconds (sorted, row-major). */
+CRH_API int crh_get_tile_order(crh_ctx* ctx, uint32_t* order, uint32_t* n_tiles, uint64_t counts[7]);
 /* Per-tile error estimate (mean standard error of the pixel luminance) and per-tile sample count; pass NULL
  * arrays to query n_tiles.  Needs adaptive mode for a meaningful error. */
 CRH_API int crh_get_tile_stats(crh_ctx* ctx, float* err, uint32_t* counts, uint32_t* n_tiles);

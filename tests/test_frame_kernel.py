@@ -315,7 +315,7 @@ def test_expensive_tiles_are_claimed_first_and_no_pixel_depends_on_it(hip_lib, o
     v = View(0).load_scene(sc)
     order, n = v.tile_order()
     assert n == 0 and np.array_equal(order, np.arange(v.n_tiles(), dtype=np.uint32))
-    for _ in range(5):                                           # lone frames, a restart before each: the second restart's costs are on the host by the fourth frame at the latest
+    for _ in range(10):                                          # lone frames, a restart before each: six calls in a row with nothing in flight make the host a "waiting" one
         v.reset(); v.Redraw(); v.sync()
     order, n = v.tile_order()
     assert n >= 1 and np.array_equal(np.sort(order), np.arange(v.n_tiles(), dtype=np.uint32)) and not np.array_equal(order, np.sort(order))

@@ -27,10 +27,13 @@ def drag_camera(cam0, i):
 def measure(v, cam0, frames=128, trials=15):
     out = {}
     # the first 30 frame-kernel frames after a build are the library's measurement of its feeder count (crh_get_frame_tuning): let it settle first
-    for _ in range(64):
-        if not v.frame_tuning()["enabled"] or v.frame_tuning()["feeders"]: break
+    def settled():
+        ft = v.frame_tuning(); v.tile_order()
+        return (not ft["enabled"] or ft["feeders"]) and v.tile_order_calls["verdict"] != 0
+    for _ in range(96):                                         # (the feeder count, then whether the sorted tile list pays on this scene: crh_get_tile_order)
+        if settled(): break
         v.reset(); v.Redraw(); v.sync()
-    out["frame_tuning"] = v.frame_tuning()
+    out["frame_tuning"] = v.frame_tuning(); out["tile_order"] = dict(v.tile_order_calls)
     # ---- a lone frame after a restart
     ts = []
     for _ in range(trials):
