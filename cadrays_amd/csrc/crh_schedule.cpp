@@ -515,7 +515,7 @@ int crh_render(crh_ctx* c, uint32_t n)
   // list keeps neighbouring tiles together (sorted: drag loop -4 % on C3 / C2) and a new list would wait for the frames that read the old one.
   {
     crh_ctx::TileOrder& to = c->tile_order;
-    if (to.on && to.n == nt) {
+    if (to.on && to.n == nt && n == 1u) {                  // (one sample per pixel: the frame kernel's regime; a wide batch keeps the row-major list -- its tile groups want neighbours)
       const bool busy = c->last_running != 0u;           // what the previous pipelined frame found in flight when it was submitted (no event queries of its own here:
                                                          // four more hipEventQuery calls per frame cost the drag loop 2 - 3 %)
       to.streak = busy ? 0u : std::min(to.streak + 1u, 1000u);
