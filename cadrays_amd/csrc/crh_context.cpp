@@ -274,6 +274,7 @@ void crh_destroy(crh_ctx* c)
   for (auto& q : c->feed_tune.pend) { c->ev_pool.push_back(q.e0); c->ev_pool.push_back(q.e1); }
   for (auto& q : c->tile_order.pend) { hipEventDestroy(q.e0); hipEventDestroy(q.e1); }
   c->tile_order.pend.clear();
+  if (c->pipe_resized) hipEventDestroy(c->pipe_resized);
   if (c->d_tile_ids2) hipFree(c->d_tile_ids2);
   if (c->tile_order.d_cost) hipFree(c->tile_order.d_cost);
   if (c->tile_order.h_cost) hipHostFree(c->tile_order.h_cost);

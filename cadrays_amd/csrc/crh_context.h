@@ -140,6 +140,7 @@ struct ScheduleState {
   // frame order (an event between the two accumulate launches)
   bool pipeline = true; bool pipe_pending[8] = {false, false, false, false, false, false, false, false}; uint32_t pipe_seq = 0; int pipe_div = 4096;
   uint64_t pipe_total = 0;         // batch size of the frames in flight (their path-state slices are laid out by it)
+  hipEvent_t pipe_resized = nullptr; bool pipe_resized_pending = false;      // complete when the last frame of the PREVIOUS batch size is done (render_impl)
   uint32_t pipe_last_depth = 0;    // frames in flight the last pipelined frame was submitted with
   std::chrono::steady_clock::time_point pipe_last_submit{};      // when the previous pipelined frame was submitted
   int pipe_grid_min = 192, pipe_grid_min_shade = 512;      // floors of a pipelined frame's traversal / streaming grids

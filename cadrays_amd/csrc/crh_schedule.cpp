@@ -330,6 +330,15 @@ int render_impl(crh_ctx* c, const uint32_t* tiles, uint32_t nt, uint32_t first, 
     if (total != c->pipe_total || depth != c->pipe_last_depth) {
       for (int j = 0; j < 8; ++j) if (c->pipe_running[j]) CRH_HIP(hipStreamWaitEvent(ln.stream, c->lane_join[j], 0));
       c->pipe_total = total; c->pipe_last_depth = depth;
+      // ... and so must every LATER frame of the new size: its slice may lie across a slice of the old size too, and it runs on another stream (round 6,
+      // tests/hunts/tile_order_sequences.py seed 166: crh_render(2) followed at once by three one-sample frames -- the third one's slice [6.5 M, 7.6 M) lay inside the
+      // two-sample frame's [6.5 M, 8.7 M) and nothing made it wait: a GPU memory fault).  One event, recorded behind the waits above, says "the old size is gone".
+      if (!c->pipe_resized) CRH_HIP(hipEventCreateWithFlags(&c->pipe_resized, hipEventDisableTiming));
+      CRH_HIP(hipEventRecord(c->pipe_resized, ln.stream));
+      c->pipe_resized_pending = true;
+    } else if (c->pipe_resized_pending) {
+      if (hipEventQuery(c->pipe_resized) == hipErrorNotReady) CRH_HIP(hipStreamWaitEvent(ln.stream, c->pipe_resized, 0));
+      else c->pipe_resized_pending = false;
     }
     c->pending_n = 0;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);          // crh_stats.seconds: device time of this frame (frames in flight overlap)

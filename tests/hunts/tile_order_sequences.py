@@ -29,24 +29,33 @@ sc = dataclasses.replace(base, pos=pos, nrm=nrm, tri=tri, tri_object=ob, obj_xfo
 bad = []
 for seed in range(a, b):
     r = np.random.default_rng(9000 + seed)
+    # (reproduction aids: HUNT_LOG=1 prints every step before it runs; HUNT_V="CRH_TILE_ORDER=0,CRH_FRAME_FEED=3" gives the first context that environment too)
+    LOG = os.environ.get("HUNT_LOG") == "1"
     for k in ("CRH_TILE_ORDER", "CRH_FRAME_FEED"): os.environ.pop(k, None)
+    for kv in filter(None, os.environ.get("HUNT_V", "").split(",")): os.environ[kv.split("=")[0]] = kv.split("=")[1]
     v = View(0).load_scene(sc)
     os.environ["CRH_TILE_ORDER"] = "0"; os.environ["CRH_FRAME_FEED"] = "3"
     w = View(0).load_scene(sc)
     for k in ("CRH_TILE_ORDER", "CRH_FRAME_FEED"): os.environ.pop(k, None)
+    if os.environ.get("HUNT_ONLY") in ("v", "w"):            # (reproduction aid: the other context is closed and replaced by the one that stays)
+        if os.environ["HUNT_ONLY"] == "v": w.close(); w = v
+        else: v.close(); v = w
     o = None
     cam = sc.camera; xf = np.tile(I12, (nO, 1)); vis = np.ones(nO, np.uint8)
     try:
         inflight = 0
         for step in range(40):
             k = int(r.integers(0, 10))
+            if LOG: print("seed", seed, "step", step, "op", k, file=sys.stderr, flush=True)
             if k <= 3:                                              # lone frames: restart, one frame, wait
                 for _ in range(int(r.integers(1, 12))):
                     for x in (v, w): x.reset(); x.Redraw(); x.sync()
             elif k == 4:                                            # a burst without waiting
                 n = int(r.integers(1, 9))
+                if LOG: print("   burst of", n, file=sys.stderr, flush=True)
                 for x in (v, w):
                     for _ in range(n): x.Redraw()
+                    if os.environ.get("HUNT_SYNC_AFTER_BURST"): x.sync(); print("   burst done on", "vw"[x is w], file=sys.stderr, flush=True)
             elif k == 5:                                            # a drag: restart every frame, frames in flight
                 for i in range(int(r.integers(2, 10))):
                     cam = dataclasses.replace(cam, eye=tuple(np.float32(cam.eye) + np.float32(r.normal(size=3) * 0.01)))
@@ -59,9 +68,12 @@ for seed in range(a, b):
                 for x in (v, w): x.set_transforms(xf)
             elif k == 8:                                            # a wide call in between
                 n = int(r.choice([2, 5, 16]))
+                if LOG: print("   render", n, file=sys.stderr, flush=True)
                 for x in (v, w): x.render(n)
             else:
                 assert np.array_equal(v.read_ldr(), w.read_ldr()), f"LDR differs at step {step}"
+            if os.environ.get("HUNT_SYNC_EVERY"):
+                for x in (v, w): x.sync(); print("   step", step, "done on", "vw"[x is w], file=sys.stderr, flush=True)
             if r.random() < 0.4:
                 assert np.array_equal(bits(v.read_hdr()), bits(w.read_hdr())), f"HDR differs at step {step} (op {k})"
         gv, gw = v.stats(), w.stats()
@@ -80,7 +92,8 @@ for seed in range(a, b):
     except AssertionError as e:
         bad.append(seed); print("seed", seed, "MISMATCH:", str(e)[:200], flush=True)
     finally:
-        v.close(); w.close()
+        v.close()
+        if w is not v: w.close()
         if o is not None: o.close()
 print(f"{b - a} sequences with the frame kernel's measurements on against off, mismatches: {bad}")
 sys.exit(1 if bad else 0)

@@ -345,3 +345,25 @@ def test_expensive_tiles_are_claimed_first_and_no_pixel_depends_on_it(hip_lib, o
         before = s.stats()["rays_nearest"]; s.render_tiles(np.array([t], np.uint32), 0, 1); cost.append(s.stats()["rays_nearest"] - before)
     assert np.mean(cost[:12]) > 1.5 * np.mean(cost[12:]), cost
     v.close(); s.close()
+
+
+def test_frames_of_another_size_wait_for_the_ones_in_flight(hip_lib):
+    """Found by tests/hunts/tile_order_sequences.py (round 6): pipelined frames own path-state slices [k * size, (k + 1) * size); after crh_render(2) the FIRST one-sample
+    frame waited for the two-sample frame, the third one -- on another stream, its slice inside the two-sample frame's -- did not: a GPU memory fault.  Mixed sizes back to
+    back, nothing waited for in between, against the staged schedule."""
+    from cadrays_amd.view import View
+    sc = c3_1080p(20_000)
+    v = View(0).load_scene(sc)
+    s = View(0).load_scene(sc); s.set_schedule(abi.SCHEDULE_STAGED)
+    for x in (v, s):
+        for rep in range(5):
+            for _ in range(4): x.Redraw()
+            x.render(2)
+            for _ in range(6): x.Redraw()
+            x.render(3)
+            for _ in range(3): x.Redraw()
+    assert np.array_equal(bits(v.read_hdr()), bits(s.read_hdr()))
+    gs, ss = v.stats(), s.stats()
+    for k in ("rays_nearest", "rays_any", "shaded_hits", "samples"):
+        assert gs[k] == ss[k], k
+    v.close(); s.close()
