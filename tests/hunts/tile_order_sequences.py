@@ -43,9 +43,9 @@ for seed in range(a, b):
     o = None
     cam = sc.camera; xf = np.tile(I12, (nO, 1)); vis = np.ones(nO, np.uint8)
     try:
-        inflight = 0
+        inflight = 0; adaptive_on = False
         for step in range(40):
-            k = int(r.integers(0, 10))
+            k = int(r.integers(0, 10 + (4 if os.environ.get("HUNT_MORE_OPS") else 0)))      # HUNT_MORE_OPS=1: + asynchronous read-backs, look-ahead, adaptive sampling, tile subsets
             if LOG: print("seed", seed, "step", step, "op", k, file=sys.stderr, flush=True)
             if k <= 3:                                              # lone frames: restart, one frame, wait
                 for _ in range(int(r.integers(1, 12))):
@@ -70,6 +70,26 @@ for seed in range(a, b):
                 n = int(r.choice([2, 5, 16]))
                 if LOG: print("   render", n, file=sys.stderr, flush=True)
                 for x in (v, w): x.render(n)
+            elif k == 10:                                           # every frame displayed: asynchronous read-backs two frames behind, compared as they arrive
+                n = int(r.integers(3, 10)); got = {id(v): [], id(w): []}
+                for x in (v, w):
+                    for i in range(n):
+                        x.Redraw()
+                        if i >= 2: got[id(x)].append(x.read_ldr_end())
+                        x.read_ldr_begin()
+                    got[id(x)].append(x.read_ldr_end()); got[id(x)].append(x.read_ldr_end())
+                assert all(np.array_equal(p, q) for p, q in zip(got[id(v)], got[id(w)])), f"displayed frames differ at step {step}"
+            elif k == 11:
+                la = int(r.choice([1, 1, 4, 16]))
+                for x in (v, w): x.set_lookahead(la)
+            elif k == 12:
+                on = bool(r.integers(0, 2)); per = int(r.choice([64, 128, 512]))
+                for x in (v, w): x.set_adaptive(on, per)
+                adaptive_on = on
+            elif k == 13:                                           # a tile subset with its own sample range (another batch size on the context's stream)
+                if not adaptive_on:
+                    sub = r.choice(v.n_tiles(), int(r.integers(1, 400)), replace=False).astype(np.uint32); ns_ = int(r.integers(1, 4))
+                    for x in (v, w): x.render_tiles(sub, 0, ns_)
             else:
                 assert np.array_equal(v.read_ldr(), w.read_ldr()), f"LDR differs at step {step}"
             if os.environ.get("HUNT_SYNC_EVERY"):
@@ -80,7 +100,7 @@ for seed in range(a, b):
         for key in ("rays_nearest", "rays_any", "shaded_hits", "samples"):
             assert gv[key] == gw[key], key
         # the oracle on the final state: sampled tiles of a fresh accumulation
-        for x in (v, w): x.reset(); x.Redraw(); x.Redraw()
+        for x in (v, w): x.set_adaptive(False, 128); x.set_lookahead(1); x.reset(); x.Redraw(); x.Redraw()
         o = pyoracle.Oracle().load_scene(sc); o.set_camera(cam); o.set_transforms(xf); o.set_visibility(vis)
         sample = np.unique(np.linspace(0, o.n_tiles() - 1, 9).astype(np.uint32))
         o.render_tiles(sample, 0, 2)
